@@ -1,0 +1,322 @@
+"""ORACLE (test infrastructure only): fp32 CPU restatement of the acoustic-model inference path.
+
+One utterance at a time (the reference's step="test" is batch-1 only, models.py:361-362), written
+as plain functions over a flat dict of FOLDED weights (artspeech_amd.weights.fold_state_dict).
+Each function cites the reference lines it restates.  Pinned against the reference itself through
+tests/golden/*.npz (tests/test_oracle_golden.py); tolerances are stated there.
+
+Tensors are torch CPU fp32, shaped [C, L] (1-D) or [C, H, W] (2-D) without a batch axis unless noted.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+SQRT2 = math.sqrt(2)
+LRELU = 0.2
+
+
+# ----------------------------------------------------------------------------------------------
+# Phoneme encoder (Utils/RelTransformerEnc.py)
+# ----------------------------------------------------------------------------------------------
+def channel_layernorm(x, gamma, beta, eps=1e-4):
+    """RelTransformerEnc.py:281-290: statistics over the channel axis of [C, L]."""
+    mean = x.mean(0, keepdim=True)
+    var = ((x - mean) ** 2).mean(0, keepdim=True)
+    x = (x - mean) * torch.rsqrt(var + eps)
+    return x * gamma[:, None] + beta[:, None]
+
+
+def conv1d(x, w, b=None, pad=0, stride=1, groups=1):
+    return F.conv1d(x[None], w, b, stride=stride, padding=pad, groups=groups)[0]
+
+
+def relpos_attention(W, p, x, n_heads=4, window=4):
+    """RelTransformerEnc.py:128-169 with the pad/reshape skew (:189-233) written as the +-window
+    band it equals: r = (j - i) + window indexes emb_rel_*[0]."""
+    C, N = x.shape
+    dk = C // n_heads
+    q = conv1d(x, W[p + ".conv_q.weight"], W[p + ".conv_q.bias"])
+    k = conv1d(x, W[p + ".conv_k.weight"], W[p + ".conv_k.bias"])
+    v = conv1d(x, W[p + ".conv_v.weight"], W[p + ".conv_v.bias"])
+    q = q.view(n_heads, dk, N).transpose(1, 2)            # [h, N, dk]
+    k = k.view(n_heads, dk, N).transpose(1, 2)
+    v = v.view(n_heads, dk, N).transpose(1, 2)
+    ek = W[p + ".emb_rel_k"][0]                            # [2w+1, dk]
+    ev = W[p + ".emb_rel_v"][0]
+    scale = math.sqrt(dk)
+    scores = torch.matmul(q, k.transpose(1, 2)) / scale    # :145
+    rel = torch.matmul(q, ek.t()) / scale                  # [h, N, 2w+1]   (:149-151)
+    for r in range(-window, window + 1):
+        i = torch.arange(max(0, -r), min(N, N - r))
+        if len(i):
+            scores[:, i, i + r] = scores[:, i, i + r] + rel[:, i, r + window]
+    pr = F.softmax(scores, dim=-1)                         # :161
+    out = torch.matmul(pr, v)                              # :163
+    for r in range(-window, window + 1):                   # :165-167
+        i = torch.arange(max(0, -r), min(N, N - r))
+        if len(i):
+            out[:, i, :] = out[:, i, :] + pr[:, i, i + r][..., None] * ev[r + window]
+    out = out.transpose(1, 2).contiguous().view(C, N)      # :168
+    return conv1d(out, W[p + ".conv_o.weight"], W[p + ".conv_o.bias"])
+
+
+def rel_encoder(W, p, tokens, n_layers):
+    """RelTransformerEncoder.forward (RelTransformerEnc.py:371-380); returns [C, N]."""
+    emb = W[p + ".emb.weight"]
+    C = emb.shape[1]
+    x = (emb[tokens] * math.sqrt(C)).t().contiguous()      # :373-374
+    x_org = x                                              # ConvReluNorm :318-325
+    for i in range(3):
+        x = conv1d(x, W[f"{p}.pre.conv_layers.{i}.weight"], W[f"{p}.pre.conv_layers.{i}.bias"], pad=2)
+        x = channel_layernorm(x, W[f"{p}.pre.norm_layers.{i}.gamma"], W[f"{p}.pre.norm_layers.{i}.beta"])
+        x = torch.relu(x)
+    x = x_org + conv1d(x, W[p + ".pre.proj.weight"], W[p + ".pre.proj.bias"])
+    e = p + ".encoder"
+    for i in range(n_layers):                              # Encoder.forward :66-90, pre_ln=True
+        y = channel_layernorm(x, W[f"{e}.norm_layers_1.{i}.gamma"], W[f"{e}.norm_layers_1.{i}.beta"])
+        x = x + relpos_attention(W, f"{e}.attn_layers.{i}", y)
+        y = channel_layernorm(x, W[f"{e}.norm_layers_2.{i}.gamma"], W[f"{e}.norm_layers_2.{i}.beta"])
+        f = f"{e}.ffn_layers.{i}"                          # FFN :261-269
+        y = torch.relu(conv1d(y, W[f + ".conv_1.weight"], W[f + ".conv_1.bias"], pad=4))
+        y = conv1d(y, W[f + ".conv_2.weight"], W[f + ".conv_2.bias"])
+        x = x + y
+    return channel_layernorm(x, W[e + ".last_ln.gamma"], W[e + ".last_ln.beta"])
+
+
+# ----------------------------------------------------------------------------------------------
+# AdaIN residual block (models.py:158-202, 230-240, 261-270)
+# ----------------------------------------------------------------------------------------------
+def instance_norm(x, eps=1e-5):
+    """nn.InstanceNorm1d(affine=False): biased variance over time, per channel."""
+    mean = x.mean(-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(-1, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps)
+
+
+def adain(W, p, x, s):
+    h = F.linear(s, W[p + ".fc.weight"], W[p + ".fc.bias"])       # models.py:237
+    C = x.shape[0]
+    gamma, beta = h[:C], h[C:]                                     # :239
+    return (1 + gamma[:, None]) * instance_norm(x) + beta[:, None]
+
+
+def adain_resblk1d(W, p, x, s, upsample=False):
+    din = x.shape[0]
+    r = F.leaky_relu(adain(W, p + ".norm1", x, s), LRELU)          # :190-191
+    if upsample:                                                   # :172,192 depthwise ConvTranspose1d
+        r = F.conv_transpose1d(r[None], W[p + ".pool.weight"], W[p + ".pool.bias"], stride=2,
+                               padding=1, output_padding=1, groups=din)[0]
+    r = conv1d(r, W[p + ".conv1.weight"], W[p + ".conv1.bias"], pad=1)
+    r = F.leaky_relu(adain(W, p + ".norm2", r, s), LRELU)
+    r = conv1d(r, W[p + ".conv2.weight"], W[p + ".conv2.bias"], pad=1)
+    sc = x
+    if upsample:                                                   # :184, nearest x2
+        sc = sc.repeat_interleave(2, dim=-1)
+    if (p + ".conv1x1.weight") in W:                               # :185-186
+        sc = conv1d(sc, W[p + ".conv1x1.weight"])
+    return (r + sc) / SQRT2                                        # :201
+
+
+# ----------------------------------------------------------------------------------------------
+# Style towers (models.py:19-156, 385-424)
+# ----------------------------------------------------------------------------------------------
+def _avgpool_down(x, kind):
+    """DownSample.forward, models.py:43-57 (x: [C,H,W])."""
+    if kind == "none":
+        return x
+    if x.shape[-1] % 2 != 0:
+        x = torch.cat([x, x[..., -1:]], dim=-1)
+    k = (1, 2) if kind == "channelpreserve" else (2, 2)
+    return F.avg_pool2d(x[None], k)[0]
+
+
+def _learned_down(W, p, x, kind):
+    """LearnedDownSample, models.py:19-36: depthwise strided conv."""
+    C = x.shape[0]
+    w, b = W[p + ".conv.weight"], W[p + ".conv.bias"]
+    if kind == "half":
+        return F.conv2d(x[None], w, b, stride=(2, 2), padding=1, groups=C)[0]
+    if kind == "channelpreserve":
+        return F.conv2d(x[None], w, b, stride=(1, 2), padding=(0, 1), groups=C)[0]
+    raise ValueError(kind)
+
+
+def resblk2d(W, p, x, kind):
+    """ResBlk.forward, models.py:79-100 (normalize=False)."""
+    sc = x
+    if (p + ".conv1x1.weight") in W:
+        sc = F.conv2d(sc[None], W[p + ".conv1x1.weight"])[0]
+    sc = _avgpool_down(sc, kind)
+    r = F.leaky_relu(x, LRELU)
+    r = F.conv2d(r[None], W[p + ".conv1.weight"], W[p + ".conv1.bias"], padding=1)[0]
+    r = _learned_down(W, p + ".downsample_res", r, kind)
+    r = F.leaky_relu(r, LRELU)
+    r = F.conv2d(r[None], W[p + ".conv2.weight"], W[p + ".conv2.bias"], padding=1)[0]
+    return (sc + r) / SQRT2
+
+
+def resblk1d(W, p, x):
+    """ResBlk1d.forward with downsample=True, models.py:127-156."""
+    C = x.shape[0]
+    sc = x
+    if (p + ".conv1x1.weight") in W:
+        sc = conv1d(sc, W[p + ".conv1x1.weight"])
+    if sc.shape[-1] % 2 != 0:
+        sc = torch.cat([sc, sc[..., -1:]], dim=-1)
+    sc = F.avg_pool1d(sc[None], 2)[0]
+    r = F.leaky_relu(x, LRELU)
+    r = conv1d(r, W[p + ".conv1.weight"], W[p + ".conv1.bias"], pad=1)
+    r = conv1d(r, W[p + ".pool.weight"], W[p + ".pool.bias"], pad=1, stride=2, groups=C)
+    r = F.leaky_relu(r, LRELU)
+    r = conv1d(r, W[p + ".conv2.weight"], W[p + ".conv2.bias"], pad=1)
+    return (sc + r) / SQRT2
+
+
+def tower2d(W, p, x, kinds, last_idx, last_stride):
+    """Mel_block / EMA_block / dur_block Sequentials (models.py:385-401, 530-537). x: [1,H,W]."""
+    x = F.conv2d(x[None], W[p + ".0.weight"], W[p + ".0.bias"], padding=1)[0]
+    for i, kind in enumerate(kinds):
+        x = resblk2d(W, f"{p}.{i + 1}", x, kind)
+    x = F.leaky_relu(x, LRELU)
+    x = F.conv2d(x[None], W[f"{p}.{last_idx}.weight"], W[f"{p}.{last_idx}.bias"], stride=last_stride)[0]
+    x = F.leaky_relu(x, LRELU)
+    return x.mean((1, 2))                                          # AdaptiveAvgPool2d(1)
+
+
+def tower1d(W, p, x):
+    """F0_block / energy_block (models.py:402-411). x: [1,T]."""
+    x = conv1d(x, W[p + ".0.weight"], W[p + ".0.bias"], pad=1)
+    for i in (1, 2, 3, 4):
+        x = resblk1d(W, f"{p}.{i}", x)
+    return F.leaky_relu(x, LRELU).mean(-1)
+
+
+def style_extractor(W, p, mel, ema, f0, n):
+    """StyleEncoder.style_extractor, models.py:417-424.  mel [80,T'], ema [10,T'], f0/n [1,T']."""
+    ms = F.linear(tower2d(W, p + ".Mel_block", mel[None], ["half"] * 4, 6, 1),
+                  W[p + ".Mellinear.weight"], W[p + ".Mellinear.bias"])
+    es = F.linear(tower2d(W, p + ".EMA_block", ema[None], ["channelpreserve"] * 2 + ["half"], 5, 2),
+                  W[p + ".EMAlinear.weight"], W[p + ".EMAlinear.bias"])
+    fs = F.linear(tower1d(W, p + ".F0_block", f0), W[p + ".F0linear.weight"], W[p + ".F0linear.bias"])
+    ns = F.linear(tower1d(W, p + ".energy_block", n), W[p + ".Energylinear.weight"], W[p + ".Energylinear.bias"])
+    return torch.cat([ms, es, fs, ns])
+
+
+def log_norm(mel, mean=-4.0, std=4.0):
+    """models.py:655-660 on mel [80,T] -> [1,T]."""
+    return torch.log(torch.exp(mel * std + mean).norm(dim=0, keepdim=True))
+
+
+def style_encoder(W, p, mel, f0_raw, ema_raw, dist):
+    """StyleEncoder.forward, models.py:426-472, with the frozen extractors' outputs (A14) supplied.
+    Returns (f0_ext [1,T], n_ext [1,T], ema_ext [10,T], Style [512])."""
+    n_ext = (log_norm(mel) - dist["energy_mean"]) / dist["energy_std"]            # :431,447
+    f0_ext = (f0_raw - dist["pitch_mean"]) / dist["pitch_std"]                    # :448
+    ema_ext = ((ema_raw.t() - dist["EMA_mean"]) / dist["EMA_std"]).t()            # :449
+    T = mel.shape[-1]
+    L = T - 1                                                                     # :459; start=randint(0,1)=0
+    style = style_extractor(W, p, mel[:, :L], ema_ext[:, :L], f0_ext[:, :L], n_ext[:, :L])
+    return f0_ext, n_ext, ema_ext, style
+
+
+# ----------------------------------------------------------------------------------------------
+# LSTM (torch.nn.LSTM semantics: gate order i,f,g,o; both biases; reverse runs on the flipped sequence)
+# ----------------------------------------------------------------------------------------------
+def _lstm_dir(x, w_ih, w_hh, b_ih, b_hh, reverse):
+    T = x.shape[0]
+    H = w_hh.shape[1]
+    gx = x @ w_ih.t() + b_ih + b_hh
+    h = torch.zeros(H)
+    c = torch.zeros(H)
+    out = torch.empty(T, H)
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        g = gx[t] + w_hh @ h
+        i, f, gg, o = g[:H], g[H:2 * H], g[2 * H:3 * H], g[3 * H:]
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        out[t] = h
+    return out
+
+
+def bilstm(W, p, x):
+    """x [T, I] -> [T, 2H]."""
+    f = _lstm_dir(x, W[p + ".weight_ih_l0"], W[p + ".weight_hh_l0"], W[p + ".bias_ih_l0"], W[p + ".bias_hh_l0"], False)
+    r = _lstm_dir(x, W[p + ".weight_ih_l0_reverse"], W[p + ".weight_hh_l0_reverse"],
+                  W[p + ".bias_ih_l0_reverse"], W[p + ".bias_hh_l0_reverse"], True)
+    return torch.cat([f, r], dim=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# Duration predictor, alignment expansion, articulatory predictors, decoder
+# ----------------------------------------------------------------------------------------------
+def duration_predictor(W, p, tokens, ema_ext):
+    """DurationPredictor.forward, models.py:540-566 -> fp32 [N]."""
+    ds = tower2d(W, p + ".dur_block", ema_ext[None], ["channelpreserve"] * 2 + ["half"], 5, 2)   # :545
+    ds = F.linear(ds, W[p + ".dur_linear.weight"], W[p + ".dur_linear.bias"])
+    d = rel_encoder(W, p + ".text_encoder", tokens, 2)
+    for i in range(3):
+        d = adain_resblk1d(W, f"{p}.duration.{i}", d, ds)
+    x = bilstm(W, p + ".LSTM", d.t())
+    return F.linear(x, W[p + ".duration_proj.linear_layer.weight"], W[p + ".duration_proj.linear_layer.bias"])[:, 0]
+
+
+def round_durations(duration):
+    """models.py:361: round half to even, clamp(min=1) -> int64 [N]."""
+    return torch.round(duration).clamp(min=1).to(torch.int64)
+
+
+def expand(x, dur):
+    """models.py:362-368: x [C,N] @ one-hot alignment == repeat each column dur[i] times."""
+    return x.repeat_interleave(dur, dim=1)
+
+
+def arts_predictor(W, p, a_en, style):
+    """ArtsPredictor.forward, models.py:596-621.  a_en [C,M], style [512] -> F0 [1,2M], N [1,2M], EMA [10,2M]."""
+    sl = {"EMA": style[256:384], "F0": style[384:448], "N": style[448:512]}
+    a = adain_resblk1d(W, p + ".shared", a_en, style)
+    outs = {}
+    for br in ("F0", "N", "EMA"):
+        x = adain_resblk1d(W, f"{p}.{br}.0", a, style, upsample=True)
+        x = adain_resblk1d(W, f"{p}.{br}.1", x, sl[br])
+        x = adain_resblk1d(W, f"{p}.{br}.2", x, sl[br])
+        x = bilstm(W, f"{p}.{br}_LSTM", x.t()).t()
+        outs[br] = conv1d(x, W[f"{p}.{br}_proj.weight"], W[f"{p}.{br}_proj.bias"])
+    return outs["F0"], outs["N"], outs["EMA"]
+
+
+def decoder(W, p, asr, style, f0, n, ema):
+    """Decoder.forward, models.py:497-517.  asr [C,M] -> mel [80,2M]."""
+    mel_style = style[:256]
+    asr = asr.repeat_interleave(2, dim=-1)                                         # :500
+    f0 = conv1d(f0, W[p + ".F0_conv.weight"], W[p + ".F0_conv.bias"])
+    n = conv1d(n, W[p + ".N_conv.weight"], W[p + ".N_conv.bias"])
+    ema = conv1d(ema, W[p + ".EMA_conv.weight"], W[p + ".EMA_conv.bias"])
+    x = torch.cat([asr, f0, n, ema], 0)
+    x = adain_resblk1d(W, p + ".encode", x, style)
+    asr_res = conv1d(asr, W[p + ".asr_res.0.weight"], W[p + ".asr_res.0.bias"])
+    for i in range(3):
+        x = torch.cat([x, asr_res, f0, n, ema], 0)
+        x = adain_resblk1d(W, f"{p}.decode.{i}", x, style)
+    for i in range(3, 6):
+        x = adain_resblk1d(W, f"{p}.decode.{i}", x, mel_style)
+    return conv1d(x, W[p + ".to_out.0.weight"], W[p + ".to_out.0.bias"])
+
+
+def forward_test(W, tokens, mel, f0_raw, ema_raw, dist, forced_dur=None):
+    """ArtsSpeech.forward(step="test"), models.py:356-371, for ONE utterance.
+
+    tokens int64 [N]; mel [80,T]; f0_raw [1,T], ema_raw [10,T] = outputs of the frozen extractors
+    (supplied by the caller).  Returns a dict of every module-boundary tensor."""
+    with torch.no_grad():
+        t_en = rel_encoder(W, "text_encoder", tokens, 4)
+        a_en = rel_encoder(W, "arts_encoder", tokens, 4)
+        f0_ext, n_ext, ema_ext, style = style_encoder(W, "style_encoder", mel, f0_raw, ema_raw, dist)
+        duration = duration_predictor(W, "durationPredictor", tokens, ema_ext)
+        pred_dur = round_durations(duration) if forced_dur is None else torch.as_tensor(forced_dur, dtype=torch.int64)
+        t_ex, a_ex = expand(t_en, pred_dur), expand(a_en, pred_dur)
+        f0, n, ema = arts_predictor(W, "artsPredictor", a_ex, style)
+        mel_out = decoder(W, "decoder", t_ex, style, f0, n, ema)
+    return dict(t_en=t_en, a_en=a_en, f0_ext=f0_ext, n_ext=n_ext, ema_ext=ema_ext, style=style,
+                duration=duration, pred_dur=pred_dur, F0=f0, N=n, EMA=ema, mel=mel_out)
