@@ -1,0 +1,182 @@
+// K5 -- windowed relative-position self-attention (Glow-TTS style), replacing
+// MultiHeadAttention.attention + the pad/reshape "skew" helpers (RelTransformerEnc.py:138-233).
+//
+//   scores[i][j] = q_i.k_j / sqrt(dk) + [|j-i| <= w] q_i.Ek[j-i+w] / sqrt(dk)
+//   p = softmax_j(scores)                    (keys of the SAME utterance only)
+//   out_i = sum_j p_ij v_j + sum_{|j-i|<=w} p_ij Ev[j-i+w]
+//
+// The reference zero-pads the (2w+1)-row tables to 2N-1 rows and multiplies densely (O(N^2 d) of
+// zeros) and materialises [B,h,N,N] scores; here the relative terms are the +-w band they equal
+//  and the softmax is computed online over 64-key tiles staged in LDS, so
+// nothing of size N^2 ever exists.  q/k/v come from one fused [3C][N] projection GEMM.
+//
+// Workgroup = (utterance, head, 16-query tile), 4 waves x 4 queries.  QK^T: lane = key (K tile rows
+// padded to 65 floats -> conflict-free), softmax statistics by wave shuffles; PV: lane = channel.
+// This round's version runs on the vector ALU in exact fp32; the MFMA version is future work
+// (DESIGN.md "next").
+#include "common.h"
+#include "artspeech_hip.h"
+
+#define QT 16
+#define KT 64
+#define KPAD 65
+#define MAXDK 128
+#define MAXREL 9
+
+static __device__ __forceinline__ float wmax(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+static __device__ __forceinline__ float wsum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+relpos_attention_kernel(const float* __restrict__ qkv, int ld, int C, int heads, int window,
+                        const float* __restrict__ emb_k, const float* __restrict__ emb_v,
+                        const int* __restrict__ col_off, float* __restrict__ out, int ldo)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int dk = C / heads;
+    const int nrel = 2 * window + 1;
+    float* Ks = sm;                              // [dk][KPAD]
+    float* Vs = Ks + dk * KPAD;                  // [dk][KPAD]
+    float* Qs = Vs + dk * KPAD;                  // [QT][dk]
+    float* Ps = Qs + QT * dk;                    // [4 waves][KT][4]
+    float* Rk = Ps + 4 * KT * 4;                 // [QT][MAXREL]
+    float* Ek = Rk + QT * MAXREL;                // [nrel][dk]
+    float* Ev = Ek + MAXREL * dk;                // [nrel][dk]
+
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int o0 = col_off[b], N = col_off[b + 1] - o0;
+    const int q0 = blockIdx.x * QT;
+    if (q0 >= N) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float scale = sqrtf((float)dk);
+
+    const float* Qg = qkv + (size_t)(h * dk) * ld + o0;
+    const float* Kg = qkv + (size_t)(C + h * dk) * ld + o0;
+    const float* Vg = qkv + (size_t)(2 * C + h * dk) * ld + o0;
+
+    for (int i = tid; i < QT * dk; i += 256) {
+        const int q = i % QT, d = i / QT;
+        const int qi = q0 + q;
+        Qs[q * dk + d] = qi < N ? Qg[(size_t)d * ld + qi] : 0.f;
+    }
+    for (int i = tid; i < nrel * dk; i += 256) { Ek[i] = emb_k[i]; Ev[i] = emb_v[i]; }
+    __syncthreads();
+    for (int i = tid; i < QT * nrel; i += 256) {
+        const int q = i / nrel, r = i - q * nrel;
+        float s = 0.f;
+        for (int d = 0; d < dk; ++d) s += Qs[q * dk + d] * Ek[r * dk + d];
+        Rk[q * MAXREL + r] = s / scale;
+    }
+
+    float m[4], l[4], acc[4][2];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) { m[qq] = -INFINITY; l[qq] = 0.f; acc[qq][0] = 0.f; acc[qq][1] = 0.f; }
+    float* Pw = Ps + wave * KT * 4;
+    const int d0 = lane, d1 = lane + 64;
+
+    for (int k0 = 0; k0 < N; k0 += KT) {
+        __syncthreads();                                    // previous tile fully consumed (and Rk visible)
+        for (int i = tid; i < dk * KT; i += 256) {
+            const int jj = i % KT, d = i / KT;
+            const int kj = k0 + jj;
+            const bool ok = kj < N;
+            Ks[d * KPAD + jj] = ok ? Kg[(size_t)d * ld + kj] : 0.f;
+            Vs[d * KPAD + jj] = ok ? Vg[(size_t)d * ld + kj] : 0.f;
+        }
+        __syncthreads();
+        // ---- scores: lane = key
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* qb = Qs + (wave * 4) * dk;
+        for (int d = 0; d < dk; ++d) {
+            const float kv = Ks[d * KPAD + lane];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) s[qq] += qb[qq * dk + d] * kv;
+        }
+        const int kj = k0 + lane;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int qi = q0 + wave * 4 + qq;
+            float sc = s[qq] / scale;
+            const int r = kj - qi + window;
+            if (r >= 0 && r < nrel) sc += Rk[(wave * 4 + qq) * MAXREL + r];
+            if (kj >= N) sc = -INFINITY;
+            const float mn = fmaxf(m[qq], wmax(sc));
+            const float p = (kj < N) ? expf(sc - mn) : 0.f;
+            const float corr = expf(m[qq] - mn);           // exp(-inf) = 0 on the first tile
+            l[qq] = l[qq] * corr + wsum(p);
+            acc[qq][0] *= corr;
+            acc[qq][1] *= corr;
+            m[qq] = mn;
+            Pw[lane * 4 + qq] = p;
+        }
+        __syncthreads();
+        // ---- PV: lane = channel (d0, d1)
+        const int jn = (N - k0) < KT ? (N - k0) : KT;
+        if (d0 < dk) {
+            const bool two = d1 < dk;
+            for (int jj = 0; jj < jn; ++jj) {
+                const float4 p4 = *reinterpret_cast<const float4*>(Pw + jj * 4);
+                const float v0 = Vs[d0 * KPAD + jj];
+                const float v1 = two ? Vs[d1 * KPAD + jj] : 0.f;
+                acc[0][0] += p4.x * v0; acc[1][0] += p4.y * v0; acc[2][0] += p4.z * v0; acc[3][0] += p4.w * v0;
+                acc[0][1] += p4.x * v1; acc[1][1] += p4.y * v1; acc[2][1] += p4.z * v1; acc[3][1] += p4.w * v1;
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int qi = q0 + wave * 4 + qq;
+                for (int r = 0; r < nrel; ++r) {
+                    const int jg = qi + r - window;
+                    if (jg < k0 || jg >= k0 + jn || jg < 0) continue;
+                    const float p = Pw[(jg - k0) * 4 + qq];
+                    acc[qq][0] += p * Ev[r * dk + d0];
+                    if (two) acc[qq][1] += p * Ev[r * dk + d1];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- normalise, transpose through LDS (Ks is free now), store rows of 16 consecutive frames
+    float* Os = Ks;                                         // [dk][QT]
+    if (d0 < dk) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            Os[d0 * QT + wave * 4 + qq] = acc[qq][0] / l[qq];
+            if (d1 < dk) Os[d1 * QT + wave * 4 + qq] = acc[qq][1] / l[qq];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < dk * QT; i += 256) {
+        const int q = i % QT, d = i / QT;
+        if (q0 + q < N) out[(size_t)(h * dk + d) * ldo + o0 + q0 + q] = Os[d * QT + q];
+    }
+}
+
+extern "C" int as_relpos_attention_f32(const float* qkv, int ld, int C, int heads, int window, const float* emb_rel_k,
+                                       const float* emb_rel_v, const int32_t* col_off, int B, int max_len, float* out,
+                                       int ldo, as_stream_t stream)
+{
+    if (!qkv || !emb_rel_k || !emb_rel_v || !col_off || !out || C <= 0 || heads <= 0 || C % heads) return AS_EINVAL;
+    const int dk = C / heads;
+    if (dk > MAXDK || 2 * window + 1 > MAXREL || window < 0 || B < 0) return AS_EINVAL;
+    if (B == 0 || max_len <= 0) return AS_OK;
+    const size_t smem = sizeof(float) * ((size_t)2 * dk * KPAD + QT * dk + 4 * KT * 4 + QT * MAXREL + 2 * MAXREL * dk);
+    static bool attr_set = false;                          // > 64 KiB of dynamic LDS needs an explicit opt-in
+    if (!attr_set) {
+        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(relpos_attention_kernel, dim3(as_cdiv(max_len, QT), heads, B), dim3(256), smem, (hipStream_t)stream,
+                       qkv, ld, C, heads, window, emb_rel_k, emb_rel_v, col_off, out, ldo);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}

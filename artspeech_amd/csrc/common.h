@@ -1,0 +1,24 @@
+// Shared helpers for the gfx950 kernels behind include/artspeech_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AS_OK 0
+#define AS_EINVAL (-1)
+
+// Launch-error check: returns the hipError_t (>0) from the calling extern "C" function.
+#define AS_CHECK_LAUNCH()                        \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+#define AS_CHECK(call)                           \
+    do {                                         \
+        hipError_t e__ = (call);                 \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+static inline int as_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#define AS_WAVE 64

@@ -1,0 +1,180 @@
+// K3/K4/K8/K10 -- every dense convolution / linear layer of the path as ONE implicit-GEMM kernel on
+// the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain, 157 TFLOP/s peak).
+//
+//   Y[m][j] = epilogue( sum_t sum_k  Wt[t][k][m] * X[k][ j + dh[t]*Wj + dw[t] ] )      m < M, j < N
+//
+// Activations use the "packed frames" layout: a tensor is [C][N] with all utterances of
+// the batch concatenated along the contiguous column axis and NO padding; column j carries a 64-bit
+// descriptor (h, w, H, W) of its position inside its own utterance, so a tap (dh, dw) is valid iff
+// 0 <= h+dh < H and 0 <= w+dw < W -- that is the conv's zero padding, and it is also what keeps
+// utterances from seeing each other.  1-D convs are the H = 1 case.  Replaces
+//   nn.Conv1d k in {1,3,5,9}  (RelTransformerEnc.py:110-118,257-258,306-314; models.py:176-181,480-495,592-594)
+//   nn.Conv2d 3x3 / 1x1       (models.py:71-77, 385-399, 530-535)
+//   nn.Linear on [*, C] rows  (the LSTM input projections, hoisted out of the recurrence)
+// Weights are pre-transposed at load time to [tap][Cin][Cout] so both operands stage as coalesced
+// rows.  Tile: (64*TM) x (64*TN) x 16 per 256-thread workgroup, 2x2 waves, TM x TN MFMA tiles of
+// 32x32 per wave, register prefetch of the next k-tile + double-buffered LDS (one barrier per k-tile).
+#include "common.h"
+#include "conv_gemm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 16
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256)
+conv_gemm_kernel(const ConvGemmArgs a)
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int AROWS = BK * BM / 256;      // elements per thread per k-tile (A)
+    constexpr int BROWS = BK * BN / 256;
+    __shared__ float As[2][BK][BM];
+    __shared__ float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tile = blockIdx.x;
+    const int m0 = (tile % tiles_m) * BM;
+    const int n0 = (tile / tiles_m) * BN;
+
+    // ---- staging geometry: thread -> one column (A: output channel, B: frame column), BK/stride rows
+    const int a_c = tid % BM, a_r0 = tid / BM;            // rows a_r0 + i*(256/BM)
+    const int b_c = tid % BN, b_r0 = tid / BN;
+    constexpr int A_RSTEP = 256 / BM, B_RSTEP = 256 / BN;
+    const bool a_ok = (m0 + a_c) < a.M;
+    const int j = n0 + b_c;
+    unsigned tapmask = 0;
+    int Wj = 0;
+    if (j < a.N) {
+        if (a.meta) {
+            const unsigned long long md = a.meta[j];
+            const int h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff);
+            const int H = (int)((md >> 32) & 0xffff);
+            Wj = (int)(md >> 48);
+            for (int t = 0; t < a.T; ++t)
+                if ((unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)Wj) tapmask |= 1u << t;
+        } else {
+            tapmask = 0xffffffffu;
+        }
+    }
+
+    const int kt_per_tap = (a.K + BK - 1) / BK;
+    const int nkt = a.T * kt_per_tap;
+
+    float ra[AROWS], rb[BROWS];
+    auto gload = [&](int kt) {
+        const int t = kt / kt_per_tap;
+        const int k0 = (kt - t * kt_per_tap) * BK;
+        const float* wp = a.W + ((size_t)t * a.K + k0) * a.M + m0 + a_c;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int r = a_r0 + i * A_RSTEP;
+            ra[i] = (a_ok && (k0 + r) < a.K) ? wp[(size_t)r * a.M] : 0.f;
+        }
+        const bool ok = (tapmask >> t) & 1u;
+        const long src = (long)j + (long)a.dh[t] * Wj + a.dw[t];
+        const float* xp = a.X + (size_t)k0 * a.ldx + src;
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            const int r = b_r0 + i * B_RSTEP;
+            float v = (ok && (k0 + r) < a.K) ? xp[(size_t)r * a.ldx] : 0.f;
+            if (a.in_act == 2) v = v > 0.f ? v : 0.2f * v;     // LeakyReLU fused on the operand (models.py:89,142)
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) As[buf][a_r0 + i * A_RSTEP][a_c] = ra[i];
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) Bs[buf][b_r0 + i * B_RSTEP][b_c] = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    const int l31 = lane & 31, lk = lane >> 5;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = As[buf][kk + lk][wm * 32 * TM + i * 32 + l31];
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) bf[jn] = Bs[buf][kk + lk][wn * 32 * TN + jn * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jn], acc[i][jn], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int col = n0 + wn * 32 * TN + jn * 32 + l31;
+            if (col >= a.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (row >= a.M) continue;
+                float v = acc[i][jn][e];
+                if (a.bias) v += a.bias[row];
+                if (a.res) v += a.res[(size_t)row * a.ldr + col];
+                if (a.div_sqrt2) v = v / 1.41421356237309504880f;
+                if (a.act == 1) v = v > 0.f ? v : 0.f;
+                else if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
+                if (a.transpose_out) a.Y[(size_t)col * a.ldy + row] = v;   // time-major output for the LSTM
+                else a.Y[(size_t)row * a.ldy + col] = v;
+            }
+        }
+    }
+}
+
+static int gemm_tile_choice(int M, int N)
+{
+    const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 22, 21, 12, 11
+    if (env && atoi(env) > 0) return atoi(env);
+    const long t22 = (long)as_cdiv(M, 128) * as_cdiv(N, 128);
+    if (t22 >= 384) return 22;                           // >= 1.5 waves of 128x128 tiles over 256 CUs
+    const long t21 = (long)as_cdiv(M, 128) * as_cdiv(N, 64);
+    if (t21 >= 384 && M > 64) return 21;
+    return 11;
+}
+
+extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!args_host) return AS_EINVAL;
+    const ConvGemmArgs& a = *args_host;
+    if (!a.W || !a.X || !a.Y || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS) return AS_EINVAL;
+    if (a.ldx < a.N || a.ldy < (a.transpose_out ? a.M : a.N) || (a.res && (a.ldr < a.N || a.transpose_out))) return AS_EINVAL;
+    if (a.N == 0) return AS_OK;
+    const int choice = gemm_tile_choice(a.M, a.N);
+    switch (choice) {
+    case 22: hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 128)), dim3(256), 0, stream, a); break;
+    case 21: hipLaunchKernelGGL((conv_gemm_kernel<2, 1>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 64)), dim3(256), 0, stream, a); break;
+    case 12: hipLaunchKernelGGL((conv_gemm_kernel<1, 2>), dim3(as_cdiv(a.M, 64) * as_cdiv(a.N, 128)), dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL((conv_gemm_kernel<1, 1>), dim3(as_cdiv(a.M, 64) * as_cdiv(a.N, 64)), dim3(256), 0, stream, a); break;
+    }
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}

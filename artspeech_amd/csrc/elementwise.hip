@@ -1,0 +1,496 @@
+// K2, K6, K7, K11 and the style-tower helpers: the bandwidth-bound kernels of the path.
+// All operate on the packed-frames layout ([C][N] fp32, utterances concatenated along columns;
+// col_off int32 [B+1] gives each utterance's column range).
+#include "common.h"
+#include "artspeech_hip.h"
+
+static __device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+static __device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 0.2f * v; }
+
+// ---------------------------------------------------------------------------------------------------
+// column descriptors
+// ---------------------------------------------------------------------------------------------------
+__global__ void make_meta_kernel(const int* __restrict__ widths, const int* __restrict__ col_off, int B, int H,
+                                 unsigned long long* __restrict__ meta)
+{
+    const int b = blockIdx.y;
+    const int W = widths[b];
+    const int base = col_off[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+        const unsigned long long h = i / W, w = i - (i / W) * W;
+        meta[base + i] = h | (w << 16) | ((unsigned long long)H << 32) | ((unsigned long long)W << 48);
+    }
+}
+
+extern "C" int as_make_meta(const int32_t* widths, const int32_t* col_off, int B, int H, int n_cols_max,
+                            uint64_t* meta, as_stream_t stream)
+{
+    if (!widths || !col_off || !meta || B < 0 || H <= 0 || H > 65535) return AS_EINVAL;
+    if (B == 0) return AS_OK;
+    const int gx = n_cols_max > 0 ? as_cdiv(as_cdiv(n_cols_max, B > 0 ? B : 1), 256) : 1;
+    hipLaunchKernelGGL(make_meta_kernel, dim3(gx < 1 ? 1 : (gx > 64 ? 64 : gx), B), dim3(256), 0, (hipStream_t)stream,
+                       widths, col_off, B, H, reinterpret_cast<unsigned long long*>(meta));
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Embedding * sqrt(C), transposed to [C][N]   (RelTransformerEnc.py:373-374)
+// ---------------------------------------------------------------------------------------------------
+__global__ void embed_kernel(const int* __restrict__ tok, const float* __restrict__ emb, int C, int N, int V,
+                             float scale, float* __restrict__ y, int ldy)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (j >= N) return;
+    int t = tok[j];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    y[(size_t)c * ldy + j] = emb[(size_t)t * C + c] * scale;
+}
+
+extern "C" int as_embed_f32(const int32_t* tokens, const float* emb, int C, int N, int V, float scale, float* y,
+                            int ldy, as_stream_t stream)
+{
+    if (!tokens || !emb || !y || C <= 0 || N < 0 || V <= 0 || ldy < N) return AS_EINVAL;
+    if (N == 0) return AS_OK;
+    hipLaunchKernelGGL(embed_kernel, dim3(as_cdiv(N, 64), C), dim3(64), 0, (hipStream_t)stream, tokens, emb, C, N, V,
+                       scale, y, ldy);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Channel LayerNorm over dim 0 of [C][N]  (RelTransformerEnc.py:281-290), optional ReLU (prenet :323)
+// block = 64 columns x 4 channel slices
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+channel_ln_kernel(const float* __restrict__ x, int ldx, int C, int N, const float* __restrict__ gamma,
+                  const float* __restrict__ beta, float eps, int relu, float* __restrict__ y, int ldy)
+{
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const bool ok = j < N;
+    float s = 0.f;
+    if (ok) for (int c = part; c < C; c += 4) s += x[(size_t)c * ldx + j];
+    red[part][lane] = s;
+    __syncthreads();
+    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    __syncthreads();
+    float v = 0.f;
+    if (ok) for (int c = part; c < C; c += 4) { const float d = x[(size_t)c * ldx + j] - mean; v += d * d; }
+    red[part][lane] = v;
+    __syncthreads();
+    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (ok) for (int c = part; c < C; c += 4) {
+        float o = (x[(size_t)c * ldx + j] - mean) * rs;
+        o = o * gamma[c] + beta[c];
+        if (relu) o = o > 0.f ? o : 0.f;
+        y[(size_t)c * ldy + j] = o;
+    }
+}
+
+extern "C" int as_channel_layernorm_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta,
+                                        float eps, int relu, float* y, int ldy, as_stream_t stream)
+{
+    if (!x || !y || !gamma || !beta || C <= 0 || N < 0 || ldx < N || ldy < N) return AS_EINVAL;
+    if (N == 0) return AS_OK;
+    hipLaunchKernelGGL(channel_ln_kernel, dim3(as_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, C, N, gamma,
+                       beta, eps, relu, y, ldy);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// AdaIN + LeakyReLU (+ fused depthwise ConvTranspose1d x2 upsample)   models.py:189-197, 230-240, 172
+// one wave per (channel, utterance): per-(b,c) statistics over the utterance's own frames only.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+adain_kernel(const float* __restrict__ x, int ldx, int C, const float* __restrict__ gb, int ldgb,
+             const int* __restrict__ col_off, int B, float* __restrict__ y, int ldy, int act,
+             const float* __restrict__ pool_w, const float* __restrict__ pool_b, float* __restrict__ xup, int ldup)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);     // (c, b) pair, b fastest
+    if (row >= C * B) return;
+    const int c = row / B, b = row - c * B;
+    const int o0 = col_off[b], L = col_off[b + 1] - o0;
+    if (L <= 0) return;
+    const float* xr = x + (size_t)c * ldx + o0;
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) s += xr[i];
+    const float mean = wave_sum(s) / (float)L;
+    float v = 0.f;
+    for (int i = lane; i < L; i += 64) { const float d = xr[i] - mean; v += d * d; }
+    const float var = wave_sum(v) / (float)L;
+    const float rs = 1.0f / sqrtf(var + 1e-5f);
+    const float g = 1.0f + gb[(size_t)b * ldgb + c];
+    const float be = gb[(size_t)b * ldgb + C + c];
+    if (!pool_w) {
+        float* yr = y + (size_t)c * ldy + o0;
+        for (int i = lane; i < L; i += 64) {
+            float o = g * ((xr[i] - mean) * rs) + be;
+            if (act) o = lrelu02(o);
+            yr[i] = o;
+        }
+    } else {
+        // depthwise ConvTranspose1d(k3,s2,p1,op1): out[2i] = a[i] w1 + b ; out[2i+1] = a[i] w2 + a[i+1] w0 + b
+        const float w0 = pool_w[c * 3 + 0], w1 = pool_w[c * 3 + 1], w2 = pool_w[c * 3 + 2], pb = pool_b[c];
+        float* yr = y + (size_t)c * ldy + 2 * o0;
+        float* ur = xup ? xup + (size_t)c * ldup + 2 * o0 : nullptr;
+        for (int i = lane; i < L; i += 64) {
+            const float xi = xr[i];
+            float a0 = g * ((xi - mean) * rs) + be;
+            if (act) a0 = lrelu02(a0);
+            float a1 = 0.f;
+            if (i + 1 < L) {
+                a1 = g * ((xr[i + 1] - mean) * rs) + be;
+                if (act) a1 = lrelu02(a1);
+            }
+            yr[2 * i] = a0 * w1 + pb;
+            yr[2 * i + 1] = (a0 * w2 + a1 * w0) + pb;
+            if (ur) { ur[2 * i] = xi; ur[2 * i + 1] = xi; }
+        }
+    }
+}
+
+extern "C" int as_adain_f32(const float* x, int ldx, int C, const float* gamma_beta, int ldgb, const int32_t* col_off,
+                            int B, float* y, int ldy, int lrelu, const float* pool_w, const float* pool_b,
+                            float* x_up, int ld_up, as_stream_t stream)
+{
+    if (!x || !y || !gamma_beta || !col_off || C <= 0 || B < 0 || ldgb < 2 * C) return AS_EINVAL;
+    if ((pool_w == nullptr) != (pool_b == nullptr)) return AS_EINVAL;
+    if (B == 0) return AS_OK;
+    hipLaunchKernelGGL(adain_kernel, dim3(as_cdiv((long)C * B, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, C,
+                       gamma_beta, ldgb, col_off, B, y, ldy, lrelu, pool_w, pool_b, x_up, ld_up);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small dense layer on per-utterance vectors: y[b][m] = bias[m] + sum_k W[m][k] x[b][k]
+// (AdaIN fc models.py:237, style linears models.py:412-415,538, duration_proj models.py:565)
+// one wave per output element, lanes over k.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+linear_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
+                   int B, int M, int K, float* __restrict__ y, int ldy)
+{
+    const int lane = threadIdx.x & 63;
+    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= (long)B * M) return;
+    const int b = (int)(o / M), m = (int)(o - (long)b * M);
+    const float* wr = w + (size_t)m * K;
+    const float* xr = x + (size_t)b * ldx;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += wr[k] * xr[k];
+    s = wave_sum(s);
+    if (lane == 0) y[(size_t)b * ldy + m] = s + (bias ? bias[m] : 0.f);
+}
+
+extern "C" int as_linear_rows_f32(const float* x, int ldx, const float* w, const float* bias, int B, int M, int K,
+                                  float* y, int ldy, as_stream_t stream)
+{
+    if (!x || !w || !y || B < 0 || M <= 0 || K <= 0 || ldx < K || ldy < M) return AS_EINVAL;
+    if (B == 0) return AS_OK;
+    hipLaunchKernelGGL(linear_rows_kernel, dim3(as_cdiv((long)B * M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
+                       bias, B, M, K, y, ldy);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2: durations -> integer alignment -> gather          models.py:361-368
+// ---------------------------------------------------------------------------------------------------
+// round-half-even, clamp(min=1) (torch.round + clamp, models.py:361); frame offsets per utterance;
+// tok_of_frame[f] = packed token column that frame f repeats.  Single workgroup (B and N are small).
+__global__ void __launch_bounds__(1024)
+durations_kernel(const float* __restrict__ dur_f, const int* __restrict__ forced, const int* __restrict__ tok_off,
+                 int B, int* __restrict__ dur_i, int* __restrict__ frame_off, int* __restrict__ tok_of_frame,
+                 int max_frames)
+{
+    __shared__ int sums[1024];
+    const int ntok = tok_off[B];
+    for (int i = threadIdx.x; i < ntok; i += blockDim.x) {
+        int d;
+        if (forced) d = forced[i];
+        else {
+            const float r = rintf(dur_f[i]);               // ties to even, like torch.round
+            d = (int)(r < 1.f ? 1.f : r);
+        }
+        dur_i[i] = d;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        int s = 0;
+        for (int i = tok_off[b]; i < tok_off[b + 1]; ++i) s += dur_i[i];
+        sums[b] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < B; ++b) { frame_off[b] = acc; acc += sums[b]; }
+        frame_off[B] = acc;
+    }
+    __syncthreads();
+    if (!tok_of_frame) return;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        int f = frame_off[b];
+        for (int i = tok_off[b]; i < tok_off[b + 1]; ++i)
+            for (int r = 0; r < dur_i[i]; ++r, ++f)
+                if (f < max_frames) tok_of_frame[f] = i;
+    }
+}
+
+extern "C" int as_durations_f32(const float* dur_f32, const int32_t* forced_dur, const int32_t* tok_off, int B,
+                                int32_t* dur_i32, int32_t* frame_off, int32_t* tok_of_frame, int max_frames,
+                                as_stream_t stream)
+{
+    if ((!dur_f32 && !forced_dur) || !tok_off || !dur_i32 || !frame_off || B < 0 || B > 1024) return AS_EINVAL;
+    hipLaunchKernelGGL(durations_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dur_f32, forced_dur, tok_off, B,
+                       dur_i32, frame_off, tok_of_frame, max_frames);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// y[c][f*rep + r] = x[c][tok_of_frame[f]]     (T_en @ aln, and the decoder's nearest x2: models.py:367-368, :500)
+__global__ void expand_kernel(const float* __restrict__ x, int ldx, int C, const int* __restrict__ tok_of_frame,
+                              int n_frames, int rep, float* __restrict__ y, int ldy)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (j >= n_frames * rep) return;
+    y[(size_t)c * ldy + j] = x[(size_t)c * ldx + tok_of_frame[j / rep]];
+}
+
+extern "C" int as_expand_f32(const float* x, int ldx, int C, const int32_t* tok_of_frame, int n_frames, int repeat,
+                             float* y, int ldy, as_stream_t stream)
+{
+    if (!x || !y || !tok_of_frame || C <= 0 || n_frames < 0 || repeat < 1 || ldy < n_frames * repeat) return AS_EINVAL;
+    if (n_frames == 0) return AS_OK;
+    hipLaunchKernelGGL(expand_kernel, dim3(as_cdiv((long)n_frames * repeat, 256), C), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, C, tok_of_frame, n_frames, repeat, y, ldy);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K11: reference-feature glue   models.py:431,447-449,655-660
+// n[j] = (log || exp(4 mel - 4) ||_2 - e_mean) / e_std ; f0 = (f0 - p_mean)/p_std ; ema[c] = (ema[c]-m[c])/s[c]
+// feat rows: 0 = n, 1 = f0, 2..11 = ema  ([12][N])
+// ---------------------------------------------------------------------------------------------------
+__global__ void ref_features_kernel(const float* __restrict__ mel, int ldm, int n_mels, const float* __restrict__ f0_raw,
+                                    const float* __restrict__ ema_raw, int lde, int N, const float* __restrict__ stats,
+                                    float* __restrict__ feat, int ldf)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    float ss = 0.f;
+    for (int m = 0; m < n_mels; ++m) {
+        const float e = expf(mel[(size_t)m * ldm + j] * 4.0f + -4.0f);
+        ss += e * e;
+    }
+    const float n = logf(sqrtf(ss));
+    // stats: [0]=energy_mean [1]=energy_std [2]=pitch_mean [3]=pitch_std [4..13]=EMA_mean [14..23]=EMA_std
+    feat[j] = (n - stats[0]) / stats[1];
+    feat[(size_t)ldf + j] = (f0_raw[j] - stats[2]) / stats[3];
+    for (int c = 0; c < 10; ++c)
+        feat[(size_t)(2 + c) * ldf + j] = (ema_raw[(size_t)c * lde + j] - stats[4 + c]) / stats[14 + c];
+}
+
+extern "C" int as_ref_features_f32(const float* mel, int ldm, int n_mels, const float* f0_raw, const float* ema_raw,
+                                   int lde, int N, const float* stats24, float* feat, int ldf, as_stream_t stream)
+{
+    if (!mel || !f0_raw || !ema_raw || !stats24 || !feat || N < 0 || n_mels <= 0 || ldm < N || lde < N || ldf < N) return AS_EINVAL;
+    if (N == 0) return AS_OK;
+    hipLaunchKernelGGL(ref_features_kernel, dim3(as_cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, mel, ldm, n_mels,
+                       f0_raw, ema_raw, lde, N, stats24, feat, ldf);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// copy a [C][*] tensor's per-utterance column windows into another packed layout:
+// dst[c][dst_off[b] + i] = src[c][src_off[b] + start + i], i < dst_len(b)  (the T-1 crop, models.py:459-471)
+__global__ void crop_kernel(const float* __restrict__ src, int lds, const int* __restrict__ src_off, int start,
+                            float* __restrict__ dst, int ldd, const int* __restrict__ dst_off, int C)
+{
+    const int b = blockIdx.y, c = blockIdx.z;
+    const int L = dst_off[b + 1] - dst_off[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x)
+        dst[(size_t)c * ldd + dst_off[b] + i] = src[(size_t)c * lds + src_off[b] + start + i];
+}
+
+extern "C" int as_crop_f32(const float* src, int lds, const int32_t* src_off, int start, float* dst, int ldd,
+                           const int32_t* dst_off, int B, int C, int max_len, as_stream_t stream)
+{
+    if (!src || !dst || !src_off || !dst_off || B < 0 || C <= 0) return AS_EINVAL;
+    if (B == 0 || max_len <= 0) return AS_OK;
+    hipLaunchKernelGGL(crop_kernel, dim3(as_cdiv(max_len, 256), B, C), dim3(256), 0, (hipStream_t)stream, src, lds,
+                       src_off, start, dst, ldd, dst_off, C);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Style-tower helpers (K10): learned / average 2x down-sampling, im2col for the valid 5x5 convs,
+// LeakyReLU + global average pool.  Images are [C][sum_b H*W_b] with per-utterance widths.
+// ---------------------------------------------------------------------------------------------------
+// LearnedDownSample (models.py:27-31): depthwise conv, 'half' = 3x3 s2 p1, 'channelpreserve' = 1x3 s(1,2) p(0,1);
+// ResBlk1d.pool (models.py:116) is the H = 1 case of 'channelpreserve'.  Optional LeakyReLU on the result
+// (the activation that follows it at models.py:94 / :148).
+__global__ void dwconv_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off,
+                                   const int* __restrict__ in_w, int Hin, float* __restrict__ y, int ldy,
+                                   const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout,
+                                   const float* __restrict__ w, const float* __restrict__ bias, int kh, int sh, int ph,
+                                   int act)
+{
+    const int b = blockIdx.y, c = blockIdx.z;
+    const int Wi = in_w[b], Wo = out_w[b];
+    const float* xr = x + (size_t)c * ldx + in_off[b];
+    float* yr = y + (size_t)c * ldy + out_off[b];
+    const float* wc = w + (size_t)c * kh * 3;
+    const float bb = bias[c];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
+        const int ho = i / Wo, wo = i - ho * Wo;
+        float s = 0.f;
+        for (int a = 0; a < kh; ++a) {
+            const int hi = ho * sh - ph + a;
+            if (hi < 0 || hi >= Hin) continue;
+            for (int d = 0; d < 3; ++d) {
+                const int wi = wo * 2 - 1 + d;
+                if (wi < 0 || wi >= Wi) continue;
+                s += xr[(size_t)hi * Wi + wi] * wc[a * 3 + d];
+            }
+        }
+        s += bb;
+        if (act) s = lrelu02(s);
+        yr[i] = s;
+    }
+}
+
+extern "C" int as_dwconv_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin,
+                                  float* y, int ldy, const int32_t* out_off, const int32_t* out_w, int Hout,
+                                  const float* w, const float* bias, int kh, int B, int C, int max_out, int lrelu,
+                                  as_stream_t stream)
+{
+    if (!x || !y || !in_off || !in_w || !out_off || !out_w || !w || !bias || (kh != 1 && kh != 3) || B < 0 || C <= 0) return AS_EINVAL;
+    if (B == 0 || max_out <= 0) return AS_OK;
+    const int sh = kh == 3 ? 2 : 1, ph = kh == 3 ? 1 : 0;
+    int gx = as_cdiv(max_out, 256);
+    gx = gx > 32 ? 32 : gx;
+    hipLaunchKernelGGL(dwconv_down_kernel, dim3(gx, B, C), dim3(256), 0, (hipStream_t)stream, x, ldx, in_off, in_w, Hin,
+                       y, ldy, out_off, out_w, Hout, w, bias, kh, sh, ph, lrelu);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// DownSample (models.py:43-57) / ResBlk1d.downsample (:127-130): replicate the last column when W is odd,
+// then average pool (ph x 2); optionally  y = (pool(x) + res) / sqrt(2)  (the block's output, models.py:99-100).
+__global__ void avgpool_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off,
+                                    const int* __restrict__ in_w, int Hin, float* __restrict__ y, int ldy,
+                                    const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout, int ph,
+                                    const float* __restrict__ res, int ldr)
+{
+    const int b = blockIdx.y, c = blockIdx.z;
+    const int Wi = in_w[b], Wo = out_w[b];
+    const float* xr = x + (size_t)c * ldx + in_off[b];
+    float* yr = y + (size_t)c * ldy + out_off[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
+        const int ho = i / Wo, wo = i - ho * Wo;
+        float s = 0.f;
+        for (int a = 0; a < ph; ++a) {
+            const int hi = ho * ph + a;
+            const int w0 = 2 * wo, w1 = (2 * wo + 1 < Wi) ? 2 * wo + 1 : Wi - 1;
+            s += xr[(size_t)hi * Wi + w0];
+            s += xr[(size_t)hi * Wi + w1];
+        }
+        s = s / (float)(2 * ph);
+        if (res) s = (s + res[(size_t)c * ldr + out_off[b] + i]) / 1.41421356237309504880f;
+        yr[i] = s;
+    }
+}
+
+extern "C" int as_avgpool_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin,
+                                   float* y, int ldy, const int32_t* out_off, const int32_t* out_w, int Hout,
+                                   int pool_h, const float* res, int ldr, int B, int C, int max_out, as_stream_t stream)
+{
+    if (!x || !y || !in_off || !in_w || !out_off || !out_w || (pool_h != 1 && pool_h != 2) || B < 0 || C <= 0) return AS_EINVAL;
+    if (B == 0 || max_out <= 0) return AS_OK;
+    int gx = as_cdiv(max_out, 256);
+    gx = gx > 32 ? 32 : gx;
+    hipLaunchKernelGGL(avgpool_down_kernel, dim3(gx, B, C), dim3(256), 0, (hipStream_t)stream, x, ldx, in_off, in_w, Hin,
+                       y, ldy, out_off, out_w, Hout, pool_h, res, ldr);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// im2col for the valid KxK convs that close the 2-D towers (models.py:391,399,535), with the LeakyReLU that
+// precedes them (models.py:390,398,534) applied on the fly.  col[(c*K*K + a*K + d)][out_off[b] + ho*Wo + wo]
+__global__ void im2col_valid_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off,
+                                    const int* __restrict__ in_w, int Hin, float* __restrict__ col, int ldc,
+                                    const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout, int K,
+                                    int stride, int act)
+{
+    const int b = blockIdx.y, ck = blockIdx.z;              // ck = c*K*K + a*K + d
+    const int c = ck / (K * K), a = (ck / K) % K, d = ck % K;
+    const int Wi = in_w[b], Wo = out_w[b];
+    const float* xr = x + (size_t)c * ldx + in_off[b];
+    float* cr = col + (size_t)ck * ldc + out_off[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
+        const int ho = i / Wo, wo = i - ho * Wo;
+        float v = xr[(size_t)(ho * stride + a) * Wi + wo * stride + d];
+        if (act) v = lrelu02(v);
+        cr[i] = v;
+    }
+}
+
+extern "C" int as_im2col_valid_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin,
+                                   float* col, int ldc, const int32_t* out_off, const int32_t* out_w, int Hout, int K,
+                                   int stride, int lrelu, int B, int C, int max_out, as_stream_t stream)
+{
+    if (!x || !col || !in_off || !in_w || !out_off || !out_w || K <= 0 || stride <= 0 || B < 0 || C <= 0) return AS_EINVAL;
+    if (B == 0 || max_out <= 0) return AS_OK;
+    if ((long)C * K * K > 65535) return AS_EINVAL;
+    hipLaunchKernelGGL(im2col_valid_kernel, dim3(as_cdiv(max_out, 64), B, C * K * K), dim3(64), 0, (hipStream_t)stream, x,
+                       ldx, in_off, in_w, Hin, col, ldc, out_off, out_w, Hout, K, stride, lrelu);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// y[b][c] = mean_j act(x[c][off[b] + j])     (LeakyReLU + AdaptiveAvgPool, models.py:392-393,400-401,405-406)
+__global__ void __launch_bounds__(256)
+mean_pool_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ col_off, int B, int C, int act,
+                 float* __restrict__ y, int ldy)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= C * B) return;
+    const int c = row / B, b = row - c * B;
+    const int o0 = col_off[b], L = col_off[b + 1] - o0;
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) {
+        float v = x[(size_t)c * ldx + o0 + i];
+        if (act) v = lrelu02(v);
+        s += v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) y[(size_t)b * ldy + c] = s / (float)L;
+}
+
+extern "C" int as_mean_pool_f32(const float* x, int ldx, const int32_t* col_off, int B, int C, int lrelu, float* y,
+                                int ldy, as_stream_t stream)
+{
+    if (!x || !y || !col_off || B < 0 || C <= 0 || ldy < C) return AS_EINVAL;
+    if (B == 0) return AS_OK;
+    hipLaunchKernelGGL(mean_pool_kernel, dim3(as_cdiv((long)C * B, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, col_off,
+                       B, C, lrelu, y, ldy);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}

@@ -1,0 +1,548 @@
+"""Host side of the acoustic-model inference path: the reference's models.py call surface
+(build_model / load_checkpoint / ArtsSpeech.forward(step="test") and the sub-module forwards,
+SURVEY.md 8(b) row B1) on top of the HIP kernels in csrc/.
+
+Inside, every activation is a packed-frames tensor [C][N] (DESIGN.md "Data layout"): all utterances
+of the batch concatenated along the contiguous axis, no padding.  Batched calls therefore give, per
+utterance, exactly what the reference computes one utterance at a time (the reference's own
+step="test" is batch-1 only, models.py:361-362) -- instance-norm statistics, conv zero padding and
+the reverse LSTM pass all see the utterance's own frames only.
+
+Out of scope here: the two frozen feature extractors (JDCNet, EMA_Predictor).
+Their OUTPUTS are inputs of this path: pass ``features=(f0_raw, ema_raw)`` or attach torch modules as
+``style_encoder.pitch_extractor`` / ``style_encoder.ema_extractor``.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, Layout, taps_1d, taps_2d
+from .spec import N_HEADS, WINDOW
+from .weights import DEFAULT_STATS, fold_state_dict, load_distribution
+
+
+class Munch(dict):
+    """attribute-access dict (what the reference takes from the `munch` package)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _need_gpu(device):
+    if not torch.cuda.is_available():
+        raise ops._lib.HipLibraryError("the HIP path needs a GPU: torch.cuda.is_available() is False (no CPU fallback)")
+    return torch.device(device if device is not None else "cuda")
+
+
+# ------------------------------------------------------------------------------------------------
+# Weight store: folded fp32 weights on the device in the layouts the kernels want
+# ------------------------------------------------------------------------------------------------
+class Weights:
+    def __init__(self, folded, device):
+        self.raw = folded                   # name -> CPU fp32 tensor (folded: plain `.weight` keys)
+        self.device = device
+        self._cache = {}
+
+    def has(self, name):
+        return name in self.raw
+
+    def vec(self, name):
+        """a tensor as-is (bias, gamma, table ...), on the device."""
+        if name not in self._cache:
+            self._cache[name] = self.raw[name].to(self.device).contiguous()
+        return self._cache[name]
+
+    def conv(self, name):
+        """conv weight [Cout,Cin,k] or [Cout,Cin,kh,kw] -> [taps][Cin][Cout]."""
+        key = "T:" + name
+        if key not in self._cache:
+            w = self.raw[name + ".weight"]
+            cout, cin = w.shape[0], w.shape[1]
+            self._cache[key] = w.reshape(cout, cin, -1).permute(2, 1, 0).contiguous().to(self.device)
+        return self._cache[key]
+
+    def bias(self, name):
+        return self.vec(name + ".bias") if self.has(name + ".bias") else None
+
+    def qkv(self, p):
+        key = "QKV:" + p
+        if key not in self._cache:
+            w = torch.cat([self.raw[f"{p}.conv_{n}.weight"] for n in "qkv"], 0)      # [3C, C, 1]
+            b = torch.cat([self.raw[f"{p}.conv_{n}.bias"] for n in "qkv"], 0)
+            self._cache[key] = (w.permute(2, 1, 0).contiguous().to(self.device), b.to(self.device))
+        return self._cache[key]
+
+    def lstm(self, p):
+        key = "LSTM:" + p
+        if key not in self._cache:
+            r = self.raw
+            w_ih = torch.cat([r[p + ".weight_ih_l0"], r[p + ".weight_ih_l0_reverse"]], 0)          # [8H, I]
+            b = torch.cat([r[p + ".bias_ih_l0"] + r[p + ".bias_hh_l0"],
+                           r[p + ".bias_ih_l0_reverse"] + r[p + ".bias_hh_l0_reverse"]], 0)
+            whh_t = torch.stack([r[p + ".weight_hh_l0"].t().contiguous(), r[p + ".weight_hh_l0_reverse"].t().contiguous()], 0)
+            H = r[p + ".weight_hh_l0"].shape[1]
+            self._cache[key] = (w_ih.t().contiguous()[None].to(self.device), b.to(self.device), whh_t.to(self.device), H)
+        return self._cache[key]
+
+    def cached(self, key, fn):
+        if key not in self._cache:
+            self._cache[key] = fn()
+        return self._cache[key]
+
+    def dw(self, name):
+        """depthwise weight [C,1,...] -> [C][kh*3]."""
+        key = "DW:" + name
+        if key not in self._cache:
+            w = self.raw[name + ".weight"]
+            self._cache[key] = w.reshape(w.shape[0], -1).contiguous().to(self.device)
+        return self._cache[key]
+
+
+# ------------------------------------------------------------------------------------------------
+# building blocks on packed frames
+# ------------------------------------------------------------------------------------------------
+def conv1d(W, name, X, lay, k, Y=None, **kw):
+    Wt = W.conv(name)
+    if Y is None:
+        Y = lay.new(Wt.shape[2])
+    return ops.conv_gemm(Wt, X, lay, Y, taps_1d(k), bias=W.bias(name), **kw)
+
+
+def adain_gb(W, p, style):
+    """gamma/beta of one AdaIN1d: fc(style) -> [B][2C]   (models.py:237)."""
+    return ops.linear_rows(style, W.vec(p + ".fc.weight"), W.vec(p + ".fc.bias"))
+
+
+def adain_resblk1d(W, p, X, lay, style, out=None, upsample=False):
+    """AdainResBlk1d.forward (models.py:189-202).  X [din][N] -> [dout][N or 2N].  Returns (Y, layout)."""
+    din = X.shape[0]
+    gb1 = adain_gb(W, p + ".norm1", style)
+    gb2 = adain_gb(W, p + ".norm2", style)
+    if upsample:
+        lay2 = lay.scaled(2)
+        h = lay2.new(din)
+        sc = lay2.new(din)
+        ops.adain(X, gb1, lay, h, True, W.dw(p + ".pool"), W.vec(p + ".pool.bias"), sc)
+    else:
+        lay2 = lay
+        h = ops.adain(X, gb1, lay, lay.new(din), True)
+        sc = X
+    h = conv1d(W, p + ".conv1", h, lay2, 3)
+    dout = h.shape[0]
+    h2 = ops.adain(h, gb2, lay2, lay2.new(dout), True)
+    if out is None:
+        out = lay2.new(dout)
+    if W.has(p + ".conv1x1.weight"):
+        sc = conv1d(W, p + ".conv1x1", sc, lay2, 1, Y=out)
+    conv1d(W, p + ".conv2", h2, lay2, 3, Y=out, res=sc, div_sqrt2=True)
+    return out, lay2
+
+
+def bilstm(W, p, X, lay):
+    """nn.LSTM(bidirectional) on packed [I][N] -> [2H][N]: hoisted input GEMM + recurrence kernel."""
+    wih_t, b, whh_t, H = W.lstm(p)
+    gx = torch.empty((max(lay.N, 1), 8 * H), dtype=torch.float32, device=X.device)
+    ops.conv_gemm(wih_t, X, lay, gx, [(0, 0)], bias=b, transpose_out=True)
+    out = lay.new(2 * H)
+    return ops.bilstm(gx, whh_t, lay, H, out)
+
+
+def rel_encoder(W, p, tokens_i32, lay, n_layers):
+    """RelTransformerEncoder.forward (RelTransformerEnc.py:371-380) on packed tokens -> [C][N]."""
+    emb = W.vec(p + ".emb.weight")
+    C = emb.shape[1]
+    x = ops.embed(tokens_i32, emb, math.sqrt(C), lay.new(C))
+    h = x
+    for i in range(3):                                                    # ConvReluNorm :318-325
+        h = conv1d(W, f"{p}.pre.conv_layers.{i}", h, lay, 5)
+        h = ops.channel_layernorm(h, lay.N, W.vec(f"{p}.pre.norm_layers.{i}.gamma"),
+                                  W.vec(f"{p}.pre.norm_layers.{i}.beta"), lay.new(C), relu=True)
+    x = conv1d(W, p + ".pre.proj", h, lay, 1, res=x)
+    e = p + ".encoder"
+    for i in range(n_layers):                                             # Encoder.forward :66-90
+        y = ops.channel_layernorm(x, lay.N, W.vec(f"{e}.norm_layers_1.{i}.gamma"), W.vec(f"{e}.norm_layers_1.{i}.beta"),
+                                  lay.new(C))
+        a = f"{e}.attn_layers.{i}"
+        wqkv, bqkv = W.qkv(a)
+        qkv = ops.conv_gemm(wqkv, y, lay, lay.new(3 * C), [(0, 0)], bias=bqkv)
+        att = ops.relpos_attention(qkv, C, N_HEADS, WINDOW, W.vec(a + ".emb_rel_k"), W.vec(a + ".emb_rel_v"), lay,
+                                   lay.new(C))
+        x = conv1d(W, a + ".conv_o", att, lay, 1, res=x)
+        y = ops.channel_layernorm(x, lay.N, W.vec(f"{e}.norm_layers_2.{i}.gamma"), W.vec(f"{e}.norm_layers_2.{i}.beta"),
+                                  lay.new(C))
+        f = f"{e}.ffn_layers.{i}"
+        y = conv1d(W, f + ".conv_1", y, lay, 9, act=ACT_RELU)
+        x = conv1d(W, f + ".conv_2", y, lay, 1, res=x)
+    return ops.channel_layernorm(x, lay.N, W.vec(e + ".last_ln.gamma"), W.vec(e + ".last_ln.beta"), lay.new(C))
+
+
+def resblk_down(W, p, X, lay, kind, one_d=False):
+    """ResBlk (models.py:79-100) / ResBlk1d(downsample=True) (models.py:127-156).  Returns (Y, layout)."""
+    h_too = kind == "half"
+    lay2 = lay.halved(h_too)
+    cin = X.shape[0]
+    taps = taps_1d(3) if one_d else taps_2d(3, 3)
+    sc = X
+    if W.has(p + ".conv1x1.weight"):
+        sc = ops.conv_gemm(W.conv(p + ".conv1x1"), X, lay, lay.new(W.conv(p + ".conv1x1").shape[2]), [(0, 0)])
+    r = ops.conv_gemm(W.conv(p + ".conv1"), X, lay, lay.new(cin), taps, bias=W.bias(p + ".conv1"), in_act=ACT_LRELU)
+    dname = p + (".pool" if one_d else ".downsample_res.conv")
+    r2 = ops.dwconv_down(r, lay, lay2.new(cin), lay2, W.dw(dname), W.vec(dname + ".bias"), 3 if h_too else 1, True)
+    wt2 = W.conv(p + ".conv2")
+    r3 = ops.conv_gemm(wt2, r2, lay2, lay2.new(wt2.shape[2]), taps, bias=W.bias(p + ".conv2"))
+    out = ops.avgpool_down(sc, lay, lay2.new(wt2.shape[2]), lay2, 2 if h_too else 1, res=r3)
+    return out, lay2
+
+
+def tower2d(W, p, X, lay, kinds, last_idx, last_stride, linear):
+    """Mel_block / EMA_block / dur_block + their Linear (models.py:385-401,412-413,530-538) -> [B][S]."""
+    wt = W.conv(p + ".0")
+    x = ops.conv_gemm(wt, X, lay, lay.new(wt.shape[2]), taps_2d(3, 3), bias=W.bias(p + ".0"))
+    for i, kind in enumerate(kinds):
+        x, lay = resblk_down(W, f"{p}.{i + 1}", x, lay, kind)
+    K = 5
+    lout = lay.valid_conv(K, last_stride)
+    if min(lout.widths_host) < 1 or lout.H < 1:
+        raise ValueError(f"{p}: reference utterance too short for the {K}x{K} valid conv (SURVEY.md A9: T_ref >= 66)")
+    C = x.shape[0]
+    col = ops.im2col_valid(x, lay, lout.new(C * K * K), lout, K, last_stride, True)
+    wl = W.conv(f"{p}.{last_idx}")                       # [25][C][Cout] -> K-major [1][C*25][Cout]
+    wl2 = W.cached("IM2COL:" + p, lambda: wl.permute(1, 0, 2).reshape(1, C * K * K, wl.shape[2]).contiguous())
+    y = ops.conv_gemm(wl2, col, lout, lout.new(wl.shape[2]), [(0, 0)], bias=W.bias(f"{p}.{last_idx}"), act=ACT_LRELU)
+    pooled = ops.mean_pool(y, lout, False)
+    return ops.linear_rows(pooled, W.vec(linear + ".weight"), W.vec(linear + ".bias"))
+
+
+def tower1d(W, p, X, lay, linear):
+    """F0_block / energy_block + Linear (models.py:402-411,414-415) -> [B][S]."""
+    wt = W.conv(p + ".0")
+    x = ops.conv_gemm(wt, X, lay, lay.new(wt.shape[2]), taps_1d(3), bias=W.bias(p + ".0"))
+    for i in (1, 2, 3, 4):
+        x, lay = resblk_down(W, f"{p}.{i}", x, lay, "channelpreserve", one_d=True)
+    pooled = ops.mean_pool(x, lay, True)
+    return ops.linear_rows(pooled, W.vec(linear + ".weight"), W.vec(linear + ".bias"))
+
+
+# ------------------------------------------------------------------------------------------------
+# packing helpers (API boundary only)
+# ------------------------------------------------------------------------------------------------
+def pack(x, lens):
+    """[B, C, Lmax] padded -> packed [C][sum lens]."""
+    return torch.cat([x[b, :, : int(l)] for b, l in enumerate(lens)], dim=1).contiguous().float()
+
+
+def unpack(X, lay, scale_cols=1):
+    """packed [C][N] -> [B, C, Lmax] zero padded."""
+    C = X.shape[0]
+    out = torch.zeros((lay.B, C, lay.max_cols), dtype=X.dtype, device=X.device)
+    for b in range(lay.B):
+        o, n = lay.off_host[b], lay.off_host[b + 1] - lay.off_host[b]
+        out[b, :, :n] = X[:, o:o + n]
+    return out
+
+
+class _Module:
+    training = False
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+
+class RelTransformerEncoder(_Module):
+    """Utils/RelTransformerEnc.py:328-380.  forward(x int64 [B,N], x_lengths [B]) -> fp32 [B,N,C]."""
+
+    def __init__(self, W, prefix, n_layers):
+        self.W, self.p, self.n_layers = W, prefix, n_layers
+
+    def forward_packed(self, tokens_i32, lay):
+        return rel_encoder(self.W, self.p, tokens_i32, lay, self.n_layers)
+
+    def forward(self, x, x_lengths):
+        dev = self.W.device
+        lens = [int(v) for v in x_lengths]
+        lay = Layout(lens, dev)
+        tok = torch.cat([x[b, :l] for b, l in enumerate(lens)]).to(device=dev, dtype=torch.int32)
+        return unpack(self.forward_packed(tok, lay), lay).transpose(1, 2)
+
+
+class StyleEncoder(_Module):
+    """models.py:373-472.  forward(mel [B,80,T], mel_input_length, step, distribution, epoch) ->
+    (f0_ext [B,1,T], n_ext [B,1,T], ema_ext [B,10,T], Style [B,512]).  The frozen extractors are pluggable
+    torch modules; ``features=(f0_raw, ema_raw)`` bypasses them."""
+
+    def __init__(self, W, prefix="style_encoder"):
+        self.W, self.p = W, prefix
+        self.pitch_extractor = None
+        self.ema_extractor = None
+
+    def style_extractor_packed(self, feat, lay_full):
+        """feat [92][N]: rows 0 n, 1 f0, 2..11 ema, 12..91 mel, packed over FULL reference lengths."""
+        W, p = self.W, self.p
+        dev = W.device
+        lens = [w - 1 for w in lay_full.widths_host]                 # models.py:459 (start = randint(0,1) = 0)
+        l1 = Layout(lens, dev)
+        c = ops.crop(feat, lay_full, 0, l1.new(92), l1)
+        # 2-D images: [1][sum H*L] with H rows of L contiguous frames per utterance
+        lm, le = Layout(lens, dev, H=80), Layout(lens, dev, H=10)
+        mel_img = self._image(c[12:92], l1, lm)
+        ema_img = self._image(c[2:12], l1, le)
+        ms = tower2d(W, p + ".Mel_block", mel_img, lm, ["half"] * 4, 6, 1, p + ".Mellinear")
+        es = tower2d(W, p + ".EMA_block", ema_img, le, ["channelpreserve"] * 2 + ["half"], 5, 2, p + ".EMAlinear")
+        fs = tower1d(W, p + ".F0_block", c[1:2], l1, p + ".F0linear")
+        ns = tower1d(W, p + ".energy_block", c[0:1], l1, p + ".Energylinear")
+        return torch.cat([ms, es, fs, ns], dim=1).contiguous()
+
+    @staticmethod
+    def _image(rows, l1, limg):
+        """[H][sum L] (channel-per-row) -> [1][sum H*L] (per-utterance H x L images)."""
+        parts = [rows[:, l1.off_host[b]:l1.off_host[b + 1]].reshape(1, -1) for b in range(l1.B)]
+        return torch.cat(parts, dim=1).contiguous()
+
+    def features_packed(self, mel_p, f0_raw_p, ema_raw_p, lay, stats24):
+        return ops.ref_features(mel_p, f0_raw_p, ema_raw_p, lay.N, stats24, lay.new(12))
+
+    def forward_packed(self, mel_p, f0_raw_p, ema_raw_p, lay, stats24):
+        feat12 = self.features_packed(mel_p, f0_raw_p, ema_raw_p, lay, stats24)
+        feat = torch.cat([feat12, mel_p[:, : feat12.shape[1]]], dim=0).contiguous()
+        style = self.style_extractor_packed(feat, lay)
+        return feat12, style
+
+    def _extract(self, mel, features):
+        if features is not None:
+            return features
+        if self.pitch_extractor is None or self.ema_extractor is None:
+            raise RuntimeError("StyleEncoder: attach pitch_extractor / ema_extractor torch modules (the reference's "
+                               "JDCNet / EMA_Predictor) or pass features=(f0_raw, ema_raw); they are outside this path")
+        with torch.no_grad():
+            n_raw = torch.log(torch.exp(mel.unsqueeze(1) * 4 - 4).norm(dim=2))
+            f0 = self.pitch_extractor(mel.unsqueeze(1))
+            ema = self.ema_extractor(f0, n_raw, mel)
+        return f0, ema
+
+    def forward(self, mel, mel_input_length, step="second", distribution=None, epoch=20, features=None):
+        dev = self.W.device
+        lens = [int(v) for v in mel_input_length]
+        lay = Layout(lens, dev)
+        f0_raw, ema_raw = self._extract(mel, features)
+        stats24 = stats_vector(distribution, dev)
+        feat12, style = self.forward_packed(pack(mel.to(dev), lens), pack(f0_raw.to(dev), lens),
+                                            pack(ema_raw.to(dev), lens), lay, stats24)
+        return unpack(feat12[1:2], lay), unpack(feat12[0:1], lay), unpack(feat12[2:12], lay), style
+
+
+class DurationPredictor(_Module):
+    """models.py:519-571.  forward(texts [B,N], style=ema_ext [B,10,T], text_lengths, mel_input_length) -> [B,N]."""
+
+    def __init__(self, W, prefix="durationPredictor"):
+        self.W, self.p = W, prefix
+
+    def forward_packed(self, tokens_i32, tok_lay, ema_p, ref_lay):
+        W, p = self.W, self.p
+        limg = Layout(ref_lay.widths_host, W.device, H=10)
+        img = StyleEncoder._image(ema_p, ref_lay, limg)
+        ds = tower2d(W, p + ".dur_block", img, limg, ["channelpreserve"] * 2 + ["half"], 5, 2, p + ".dur_linear")
+        d = rel_encoder(W, p + ".text_encoder", tokens_i32, tok_lay, 2)
+        for i in range(3):
+            d, _ = adain_resblk1d(W, f"{p}.duration.{i}", d, tok_lay, ds)
+        x = bilstm(W, p + ".LSTM", d, tok_lay)
+        wt = W.cached("DP:" + p, lambda: W.raw[p + ".duration_proj.linear_layer.weight"].t().contiguous()[None].to(W.device))
+        return ops.conv_gemm(wt, x, tok_lay, tok_lay.new(1), [(0, 0)], bias=W.vec(p + ".duration_proj.linear_layer.bias"))
+
+    def forward(self, texts, style, text_lengths, mel_input_length):
+        dev = self.W.device
+        tl = [int(v) for v in text_lengths]
+        ml = [int(v) for v in mel_input_length]
+        tok_lay, ref_lay = Layout(tl, dev), Layout(ml, dev)
+        tok = torch.cat([texts[b, :l] for b, l in enumerate(tl)]).to(device=dev, dtype=torch.int32)
+        d = self.forward_packed(tok, tok_lay, pack(style.to(dev), ml), ref_lay)
+        return unpack(d, tok_lay)[:, 0, :]
+
+
+class ArtsPredictor(_Module):
+    """models.py:573-621.  forward(A_ens [B,512,M], style [B,512]) -> F0 [B,1,2M], N [B,1,2M], EMA [B,10,2M]."""
+
+    def __init__(self, W, prefix="artsPredictor"):
+        self.W, self.p = W, prefix
+
+    def forward_packed(self, a_en, lay, style):
+        W, p = self.W, self.p
+        sl = {"EMA": style[:, 256:384].contiguous(), "F0": style[:, 384:448].contiguous(),
+              "N": style[:, 448:512].contiguous()}
+        a, _ = adain_resblk1d(W, p + ".shared", a_en, lay, style)
+        outs = {}
+        lay2 = None
+        for br in ("F0", "N", "EMA"):
+            x, lay2 = adain_resblk1d(W, f"{p}.{br}.0", a, lay, style, upsample=True)
+            x, _ = adain_resblk1d(W, f"{p}.{br}.1", x, lay2, sl[br])
+            x, _ = adain_resblk1d(W, f"{p}.{br}.2", x, lay2, sl[br])
+            x = bilstm(W, f"{p}.{br}_LSTM", x, lay2)
+            outs[br] = conv1d(W, f"{p}.{br}_proj", x, lay2, 1)
+        return outs["F0"], outs["N"], outs["EMA"], lay2
+
+    def forward(self, A_ens, style, lengths=None):
+        dev = self.W.device
+        lens = [A_ens.shape[-1]] * A_ens.shape[0] if lengths is None else [int(v) for v in lengths]
+        lay = Layout(lens, dev)
+        f0, n, ema, lay2 = self.forward_packed(pack(A_ens.to(dev), lens), lay, style.to(dev).contiguous().float())
+        return unpack(f0, lay2), unpack(n, lay2), unpack(ema, lay2)
+
+
+class Decoder(_Module):
+    """models.py:474-517.  forward(asr [B,512,M], Style [B,512], F0 [B,1,2M], N [B,1,2M], EMA [B,10,2M]) -> [B,80,2M]."""
+
+    def __init__(self, W, prefix="decoder"):
+        self.W, self.p = W, prefix
+
+    def forward_packed(self, asr_up, lay2, style, f0, n, ema, out=None):
+        """asr_up: [C][2M-frames] (already nearest-x2, models.py:500)."""
+        W, p = self.W, self.p
+        C = asr_up.shape[0]
+        mel_style = style[:, :256].contiguous()
+        x0 = lay2.new(C + 128)
+        x0[:C].copy_(asr_up)
+        conv1d(W, p + ".F0_conv", f0, lay2, 1, Y=x0[C:C + 32])
+        conv1d(W, p + ".N_conv", n, lay2, 1, Y=x0[C + 32:C + 64])
+        conv1d(W, p + ".EMA_conv", ema, lay2, 1, Y=x0[C + 64:C + 128])
+        bott = 2 * C
+        cat_a, cat_b = lay2.new(bott + 64 + 128), lay2.new(bott + 64 + 128)
+        adain_resblk1d(W, p + ".encode", x0, lay2, style, out=cat_a[:bott])
+        conv1d(W, p + ".asr_res.0", asr_up, lay2, 1, Y=cat_a[bott:bott + 64])
+        cat_a[bott + 64:].copy_(x0[C:])
+        cat_b[bott:].copy_(cat_a[bott:])
+        adain_resblk1d(W, p + ".decode.0", cat_a, lay2, style, out=cat_b[:bott])
+        adain_resblk1d(W, p + ".decode.1", cat_b, lay2, style, out=cat_a[:bott])
+        x, _ = adain_resblk1d(W, p + ".decode.2", cat_a, lay2, style)
+        for i in (3, 4, 5):
+            x, _ = adain_resblk1d(W, f"{p}.decode.{i}", x, lay2, mel_style)
+        return conv1d(W, p + ".to_out.0", x, lay2, 1, Y=out)
+
+    def forward(self, asr, Style, F0, N, EMA, lengths=None):
+        dev = self.W.device
+        lens = [asr.shape[-1]] * asr.shape[0] if lengths is None else [int(v) for v in lengths]
+        lay2 = Layout([2 * l for l in lens], dev)
+        asr_up = pack(asr.to(dev).repeat_interleave(2, dim=-1), lay2.widths_host)
+        mel = self.forward_packed(asr_up, lay2, Style.to(dev).contiguous().float(), pack(F0.to(dev), lay2.widths_host),
+                                  pack(N.to(dev), lay2.widths_host), pack(EMA.to(dev), lay2.widths_host))
+        return unpack(mel, lay2)
+
+
+def stats_vector(distribution, device):
+    """distribution dict (utils.py:86-92 / test.py:75-79) -> the 24 floats as_ref_features_f32 takes."""
+    d = distribution if distribution else load_distribution(DEFAULT_STATS)
+    vals = [d["energy_mean"].reshape(1), d["energy_std"].reshape(1), d["pitch_mean"].reshape(1), d["pitch_std"].reshape(1),
+            d["EMA_mean"].reshape(10), d["EMA_std"].reshape(10)]
+    return torch.cat([v.detach().float().cpu() for v in vals]).to(device)
+
+
+class ArtsSpeech(_Module):
+    """models.py:275-371, inference branch only: forward(batch, s2s_attn, s2s_attn_mono, step="test")."""
+
+    def __init__(self, args, stage="second", distribution=None, device=None, state_dict=None):
+        if stage == "first":
+            raise NotImplementedError("only the inference path (stage='second' modules, step='test') is built")
+        self.args = args
+        self.device = _need_gpu(device)
+        self.distribution = distribution if distribution else load_distribution(DEFAULT_STATS)
+        self.W = None
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    def load_state_dict(self, sd, strict=False):
+        self.W = W = Weights(fold_state_dict(sd), self.device)
+        self.text_encoder = RelTransformerEncoder(W, "text_encoder", 4)
+        self.arts_encoder = RelTransformerEncoder(W, "arts_encoder", 4)
+        ext = getattr(self, "style_encoder", None)
+        self.style_encoder = StyleEncoder(W)
+        if ext is not None:
+            self.style_encoder.pitch_extractor, self.style_encoder.ema_extractor = ext.pitch_extractor, ext.ema_extractor
+        self.durationPredictor = DurationPredictor(W)
+        self.artsPredictor = ArtsPredictor(W)
+        self.decoder = Decoder(W)
+        return self
+
+    def forward(self, batch, s2s_attn=None, s2s_attn_mono=None, step="test", mode="train", epoch=0, features=None,
+                forced_durations=None, return_aux=False):
+        if step != "test":
+            raise NotImplementedError("training branches (step='first'/'second') are out of scope (SURVEY.md section 2)")
+        if self.W is None:
+            raise RuntimeError("no weights loaded: call load_checkpoint / load_state_dict first")
+        texts, input_lengths, mels, mel_input_length = batch[0], batch[1], batch[2], batch[3]   # 7- or 4-tuple (B1)
+        dev = self.device
+        tl = [int(v) for v in input_lengths]
+        ml = [int(v) for v in mel_input_length]
+        B = len(tl)
+        tok_lay, ref_lay = Layout(tl, dev), Layout(ml, dev)
+        tok = torch.cat([texts[b, :l] for b, l in enumerate(tl)]).to(device=dev, dtype=torch.int32)
+        f0_raw, ema_raw = self.style_encoder._extract(mels, features)
+        mel_p, f0_p, ema_p = pack(mels.to(dev), ml), pack(f0_raw.to(dev), ml), pack(ema_raw.to(dev), ml)
+        forced = None
+        if forced_durations is not None:
+            forced = torch.cat([torch.as_tensor(forced_durations[b])[: tl[b]].reshape(-1) for b in range(B)]).to(
+                device=dev, dtype=torch.int32)
+        out = self.forward_packed(tok, tok_lay, mel_p, f0_p, ema_p, ref_lay, forced=forced,
+                                  frames_hint=None if forced is None else [int(torch.as_tensor(forced_durations[b])[: tl[b]].sum()) for b in range(B)])
+        mel = unpack(out["mel"], out["lay2"])
+        if return_aux:
+            return mel, out
+        return mel
+
+    def forward_packed(self, tok, tok_lay, mel_p, f0_p, ema_p, ref_lay, forced=None, frames_hint=None):
+        """The whole hot path on packed tensors (what bench.py times).  One host sync (reading the integer
+        frame counts) unless `frames_hint` gives them (forced durations)."""
+        dev = self.device
+        stats24 = stats_vector(self.distribution, dev)
+        t_en = self.text_encoder.forward_packed(tok, tok_lay)
+        a_en = self.arts_encoder.forward_packed(tok, tok_lay)
+        feat12, style = self.style_encoder.forward_packed(mel_p, f0_p, ema_p, ref_lay, stats24)
+        duration = self.durationPredictor.forward_packed(tok, tok_lay, feat12[2:12], ref_lay)
+        if frames_hint is None:
+            dur_i, frame_off, _ = ops.durations(duration.reshape(-1), forced, tok_lay, 0)
+            off = frame_off.cpu().tolist()                                   # the one device->host sync
+            frames = [off[b + 1] - off[b] for b in range(tok_lay.B)]
+        else:
+            frames = list(frames_hint)
+        lay1 = Layout(frames, dev)
+        dur_i, frame_off, tof = ops.durations(duration.reshape(-1), forced, tok_lay, lay1.N)
+        C = t_en.shape[0]
+        a_ex = ops.expand(a_en, tof, lay1.N, 1, lay1.new(C))
+        f0, n, ema, lay2 = self.artsPredictor.forward_packed(a_ex, lay1, style)
+        t_up = ops.expand(t_en, tof, lay1.N, 2, lay2.new(C))
+        mel = self.decoder.forward_packed(t_up, lay2, style, f0, n, ema)
+        return dict(mel=mel, lay2=lay2, lay1=lay1, t_en=t_en, a_en=a_en, feat12=feat12, style=style,
+                    duration=duration, dur_i=dur_i, F0=f0, N=n, EMA=ema)
+
+
+def build_model(args, text_aligner=None, stage="second", distribution=None, device=None):
+    """models.py:680-683.  Returns Munch(ArtsSpeech, discriminator, text_aligner); the discriminator is a
+    training-only component and is None here."""
+    if not isinstance(args, dict):
+        args = Munch(vars(args))
+    return Munch(ArtsSpeech=ArtsSpeech(Munch(args), stage, distribution=distribution, device=device),
+                 discriminator=None, text_aligner=text_aligner)
+
+
+def load_checkpoint(model, optimizer, path, load_only_params=True):
+    """models.py:685-701: torch.load(path)['net'][key] per top-level key, non-strict, eval mode."""
+    state = path if isinstance(path, dict) else torch.load(path, map_location="cpu")
+    params = state["net"]
+    for key in model:
+        if key in params and model[key] is not None and hasattr(model[key], "load_state_dict"):
+            model[key].load_state_dict(params[key], False)
+    if not load_only_params:
+        epoch, iters = state["epoch"], state["iters"]
+    else:
+        epoch, iters = 0, 0
+    return model, optimizer, epoch, iters

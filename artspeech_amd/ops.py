@@ -1,0 +1,202 @@
+"""Thin torch-tensor wrappers over the C ABI (include/artspeech_hip.h).  PyTorch is used only for
+device memory and the current HIP stream; every computation below is a HIP kernel of this repo.
+No fallbacks: a missing library or a failing call raises."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+AS_MAX_TAPS = _lib.AS_MAX_TAPS
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+
+ConvGemmArgs = _lib.ConvGemmArgs
+
+
+def _ld(t):
+    """row stride (in elements) of a 2-D row-major tensor / row-slice view."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise _lib.HipLibraryError("expected a 2-D tensor with contiguous rows")
+    return t.stride(0)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.HipLibraryError("expected a tensor in GPU memory (the HIP path has no CPU fallback)")
+    return t.data_ptr()
+
+
+class Layout:
+    """Packed-frames geometry: B utterances, utterance b is an H x widths[b] image (H = 1: a sequence)."""
+
+    def __init__(self, widths, device, H=1):
+        self.widths_host = [int(w) for w in widths]
+        self.B = len(self.widths_host)
+        self.H = int(H)
+        off = [0]
+        for w in self.widths_host:
+            off.append(off[-1] + self.H * w)
+        self.off_host = off
+        self.N = off[-1]
+        self.max_w = max(self.widths_host) if self.widths_host else 0
+        self.max_cols = self.H * self.max_w
+        self.device = device
+        self.widths = torch.tensor(self.widths_host, dtype=torch.int32, device=device)
+        self.col_off = torch.tensor(off, dtype=torch.int32, device=device)
+        self._meta = None
+
+    @property
+    def meta(self):
+        if self._meta is None:
+            m = torch.empty(max(self.N, 1), dtype=torch.int64, device=self.device)
+            check(_lib.lib().as_make_meta(_p(self.widths), _p(self.col_off), self.B, self.H, self.N, _p(m), stream()),
+                  "as_make_meta")
+            self._meta = m
+        return self._meta
+
+    def new(self, C):
+        return torch.empty((C, max(self.N, 1)), dtype=torch.float32, device=self.device)
+
+    def scaled(self, k):
+        return Layout([w * k for w in self.widths_host], self.device, self.H)
+
+    def halved(self, h_too):
+        """geometry after a 2x down-sampling (W -> ceil(W/2); H -> H/2 when h_too)."""
+        H = self.H // 2 if h_too else self.H
+        return Layout([(w + 1) // 2 for w in self.widths_host], self.device, H)
+
+    def valid_conv(self, K, stride):
+        H = (self.H - K) // stride + 1
+        return Layout([(w - K) // stride + 1 for w in self.widths_host], self.device, H)
+
+
+def taps_1d(k):
+    return [(0, t - k // 2) for t in range(k)]
+
+
+def taps_2d(kh, kw):
+    return [(a - kh // 2, d - kw // 2) for a in range(kh) for d in range(kw)]
+
+
+def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
+              use_meta=True):
+    """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt [T][K][M]; X [K][*]; Y [M][*] (or [N][*] transposed)."""
+    T, K, M = Wt.shape
+    a = ConvGemmArgs()
+    a.W, a.X, a.Y, a.bias, a.res = _p(Wt), _p(X), _p(Y), _p(bias), _p(res)
+    a.meta = _p(lay.meta) if (use_meta and not (T == 1 and taps[0] == (0, 0))) else None
+    a.M, a.N, a.K, a.T = M, lay.N, K, T
+    a.ldx, a.ldy = _ld(X), _ld(Y)
+    a.ldr = _ld(res) if res is not None else 0
+    a.act, a.div_sqrt2, a.in_act, a.transpose_out = act, int(div_sqrt2), in_act, int(transpose_out)
+    assert len(taps) == T and X.shape[0] >= K
+    for i, (dh, dw) in enumerate(taps):
+        a.dh[i], a.dw[i] = dh, dw
+    check(_lib.lib().as_conv_gemm_f32(ctypes.byref(a), stream()), "as_conv_gemm_f32")
+    return Y
+
+
+def embed(tokens_i32, emb, scale, Y):
+    V, C = emb.shape
+    check(_lib.lib().as_embed_f32(_p(tokens_i32), _p(emb), C, tokens_i32.numel(), V, scale, _p(Y), _ld(Y), stream()),
+          "as_embed_f32")
+    return Y
+
+
+def channel_layernorm(X, N, gamma, beta, Y, relu=False, eps=1e-4):
+    check(_lib.lib().as_channel_layernorm_f32(_p(X), _ld(X), X.shape[0], N, _p(gamma), _p(beta), eps, int(relu), _p(Y),
+                                              _ld(Y), stream()), "as_channel_layernorm_f32")
+    return Y
+
+
+def adain(X, gb, lay, Y, lrelu=True, pool_w=None, pool_b=None, x_up=None):
+    C = X.shape[0]
+    check(_lib.lib().as_adain_f32(_p(X), _ld(X), C, _p(gb), _ld(gb), _p(lay.col_off), lay.B, _p(Y), _ld(Y), int(lrelu),
+                                  _p(pool_w), _p(pool_b), _p(x_up), _ld(x_up) if x_up is not None else 0, stream()),
+          "as_adain_f32")
+    return Y
+
+
+def linear_rows(x, w, bias, y=None):
+    B, K = x.shape
+    M = w.shape[0]
+    if y is None:
+        y = torch.empty((B, M), dtype=torch.float32, device=x.device)
+    check(_lib.lib().as_linear_rows_f32(_p(x), _ld(x), _p(w), _p(bias), B, M, K, _p(y), _ld(y), stream()),
+          "as_linear_rows_f32")
+    return y
+
+
+def durations(dur_f32, forced, tok_lay, max_frames):
+    dev = tok_lay.device
+    dur_i = torch.empty(max(tok_lay.N, 1), dtype=torch.int32, device=dev)
+    frame_off = torch.empty(tok_lay.B + 1, dtype=torch.int32, device=dev)
+    tof = torch.empty(max(max_frames, 1), dtype=torch.int32, device=dev) if max_frames > 0 else None
+    check(_lib.lib().as_durations_f32(_p(dur_f32), _p(forced), _p(tok_lay.col_off), tok_lay.B, _p(dur_i), _p(frame_off),
+                                      _p(tof), max_frames, stream()), "as_durations_f32")
+    return dur_i, frame_off, tof
+
+
+def expand(X, tok_of_frame, n_frames, repeat, Y):
+    check(_lib.lib().as_expand_f32(_p(X), _ld(X), X.shape[0], _p(tok_of_frame), n_frames, repeat, _p(Y), _ld(Y), stream()),
+          "as_expand_f32")
+    return Y
+
+
+def ref_features(mel, f0_raw, ema_raw, N, stats24, feat):
+    check(_lib.lib().as_ref_features_f32(_p(mel), _ld(mel), mel.shape[0], _p(f0_raw), _p(ema_raw), _ld(ema_raw), N,
+                                         _p(stats24), _p(feat), _ld(feat), stream()), "as_ref_features_f32")
+    return feat
+
+
+def crop(src, src_lay, start, dst, dst_lay):
+    check(_lib.lib().as_crop_f32(_p(src), _ld(src), _p(src_lay.col_off), start, _p(dst), _ld(dst), _p(dst_lay.col_off),
+                                 dst_lay.B, src.shape[0], dst_lay.max_cols, stream()), "as_crop_f32")
+    return dst
+
+
+def dwconv_down(X, lin, Y, lout, w, bias, kh, lrelu):
+    check(_lib.lib().as_dwconv_down_f32(_p(X), _ld(X), _p(lin.col_off), _p(lin.widths), lin.H, _p(Y), _ld(Y),
+                                        _p(lout.col_off), _p(lout.widths), lout.H, _p(w), _p(bias), kh, lin.B,
+                                        X.shape[0], lout.max_cols, int(lrelu), stream()), "as_dwconv_down_f32")
+    return Y
+
+
+def avgpool_down(X, lin, Y, lout, pool_h, res=None):
+    check(_lib.lib().as_avgpool_down_f32(_p(X), _ld(X), _p(lin.col_off), _p(lin.widths), lin.H, _p(Y), _ld(Y),
+                                         _p(lout.col_off), _p(lout.widths), lout.H, pool_h, _p(res),
+                                         _ld(res) if res is not None else 0, lin.B, X.shape[0], lout.max_cols, stream()),
+          "as_avgpool_down_f32")
+    return Y
+
+
+def im2col_valid(X, lin, col, lout, K, stride, lrelu):
+    check(_lib.lib().as_im2col_valid_f32(_p(X), _ld(X), _p(lin.col_off), _p(lin.widths), lin.H, _p(col), _ld(col),
+                                         _p(lout.col_off), _p(lout.widths), lout.H, K, stride, int(lrelu), lin.B,
+                                         X.shape[0], lout.max_cols, stream()), "as_im2col_valid_f32")
+    return col
+
+
+def mean_pool(X, lay, lrelu, y=None):
+    C = X.shape[0]
+    if y is None:
+        y = torch.empty((lay.B, C), dtype=torch.float32, device=X.device)
+    check(_lib.lib().as_mean_pool_f32(_p(X), _ld(X), _p(lay.col_off), lay.B, C, int(lrelu), _p(y), _ld(y), stream()),
+          "as_mean_pool_f32")
+    return y
+
+
+def relpos_attention(qkv, C, heads, window, ek, ev, lay, out):
+    check(_lib.lib().as_relpos_attention_f32(_p(qkv), _ld(qkv), C, heads, window, _p(ek), _p(ev), _p(lay.col_off), lay.B,
+                                             lay.max_w, _p(out), _ld(out), stream()), "as_relpos_attention_f32")
+    return out
+
+
+def bilstm(gx_tm, whh_t, lay, H, out):
+    check(_lib.lib().as_bilstm_f32(_p(gx_tm), _ld(gx_tm), _p(whh_t), _p(lay.col_off), lay.B, H, _p(out), _ld(out),
+                                   stream()), "as_bilstm_f32")
+    return out

@@ -1,0 +1,154 @@
+/*
+ * libartspeech_hip.so -- C ABI of the MI355X-native ArtSpeech acoustic-model inference path.
+ *
+ * The reference (Zhongxu-Wang/ArtSpeech) is pure Python/PyTorch and has no FFI; its "operator API"
+ * for this path is the Python call surface listed in SURVEY.md section 8(b).  Each entry point below
+ * names the reference interface it replaces (file:line in the reference tree).  INTEGRATION.md
+ * shows the ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions (all entry points)
+ *   - extern "C", plain pointers and sizes; every pointer is a DEVICE pointer owned by the caller
+ *     unless the parameter name ends in _host.
+ *   - returns 0 on success, <0 for an invalid argument (AS_EINVAL = -1), >0 = a hipError_t.
+ *   - never allocates, never synchronises, never throws: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*), scratch comes from a caller-provided workspace whose size
+ *     the matching *_workspace_bytes() query returns.  Safe to capture in a hipGraph.
+ *   - thread-safe for concurrent calls that use distinct streams and workspaces.
+ */
+#ifndef ARTSPEECH_HIP_H
+#define ARTSPEECH_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* as_stream_t; /* hipStream_t */
+
+/* library/ABI version; bumped on any signature change */
+int as_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Monotonic alignment search (K1).
+ * Replaces: maximum_path1  S_monotonic_align.py:5-47    (tie_mode = 1, "move")
+ *           maximum_path2  S_monotonic_align.py:50-95   (tie_mode = 0, "stay")
+ *           Triton maximum_path  S_monotonic_align_Triton.py:7-71 (tie_mode = 0)
+ *           Cython wrapper  utils.py:11-24 (call surface; arithmetic source not in the tree)
+ * value [B][Tx][Ty] fp32 (already masked or not: only the [t_x[b]) x [t_y[b]) corner is read; it is
+ * never written).  t_x, t_y int32 [B] = valid text / mel lengths (what the reference recovers from
+ * the mask at S_monotonic_align.py:15-16).
+ * Outputs (each may be NULL): path fp32 [B][Tx][Ty] dense 0/1 (zero-filled here);
+ * dur int32 [B][Tx] = path.sum(-1) (train_second.py:185); rows int32 [B][Ty] = text row of every mel
+ * column, -1 past t_y[b].
+ * ------------------------------------------------------------------------------------------- */
+size_t as_mas_workspace_bytes(int B, int Tx, int Ty);
+int as_mas_f32(const float* value, const int32_t* t_x, const int32_t* t_y, int B, int Tx, int Ty,
+               int tie_mode, float* path, int32_t* dur, int32_t* rows,
+               void* workspace, size_t workspace_bytes, as_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Packed-frames layout (DESIGN.md "Data layout").  An activation is fp32 [C][N] (row stride ld >= N)
+ * with every utterance of the batch concatenated along the contiguous column axis, no padding.
+ * Column j carries a descriptor  h | w<<16 | H<<32 | W<<48  (uint16 fields): its (row, column)
+ * inside its own utterance's H x W image (H = 1, w = frame index for 1-D sequences).
+ * as_make_meta builds the descriptors from per-utterance widths (int32 [B], device) for a common
+ * height H; col_off int32 [B+1] are the utterances' first columns (exclusive prefix sums of H*W_b).
+ * ------------------------------------------------------------------------------------------- */
+int as_make_meta(const int32_t* widths, const int32_t* col_off, int B, int H, int n_cols_max,
+                 uint64_t* meta, as_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense convolution / linear layer as implicit GEMM on the fp32 matrix cores (K3, K4, K8, K10).
+ *   Y[m][j] = epi( sum_t sum_k Wt[t][k][m] * X[k][j + dh[t]*W_j + dw[t]] ),   tap valid iff inside
+ *   the column's own H x W image (zero padding otherwise).
+ * Replaces nn.Conv1d (RelTransformerEnc.py:110-118,257-258,306-314; models.py:176-181,480-495,592-594),
+ * nn.Conv2d 3x3/1x1 stride 1 (models.py:71-77,385-399,530-535) and nn.Linear over rows.
+ * epi: +bias[m], +res[m][j], /sqrt(2) (models.py:201, :100, :156), then act (0 none, 1 ReLU,
+ * 2 LeakyReLU(0.2)).  Wt is the folded weight transposed to [tap][Cin][Cout].
+ * ------------------------------------------------------------------------------------------- */
+#define AS_MAX_TAPS 25
+typedef struct ConvGemmArgs {
+    const float* W;        /* [T][K][M] */
+    const float* X;        /* [K][ldx] */
+    float* Y;              /* [M][ldy] */
+    const float* bias;     /* [M] or NULL */
+    const float* res;      /* [M][ldr] or NULL (may alias Y) */
+    const uint64_t* meta;  /* [N] column descriptors, or NULL = every tap valid */
+    int32_t M, N, K, T;
+    int32_t ldx, ldy, ldr;
+    int32_t act;           /* epilogue activation: 0 none, 1 ReLU, 2 LeakyReLU(0.2) */
+    int32_t div_sqrt2;     /* epilogue: divide by sqrt(2) after bias and residual */
+    int32_t in_act;        /* 2 = LeakyReLU(0.2) applied to X while staging (models.py:89,142) */
+    int32_t transpose_out; /* 1 = write Y[j][m] (time-major, row stride ldy >= M) */
+    int8_t dh[AS_MAX_TAPS + 7];
+    int8_t dw[AS_MAX_TAPS + 7];
+} ConvGemmArgs;
+int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bandwidth-bound kernels on packed frames.  col_off int32 [B+1] = first column of each utterance.
+ * ------------------------------------------------------------------------------------------- */
+/* emb(x)*sqrt(C), transposed to [C][N]      RelTransformerEnc.py:373-374 */
+int as_embed_f32(const int32_t* tokens, const float* emb, int C, int N, int V, float scale, float* y, int ldy,
+                 as_stream_t stream);
+/* channel LayerNorm (eps 1e-4) (+ReLU)       RelTransformerEnc.py:272-290, :322-323 */
+int as_channel_layernorm_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta, float eps,
+                             int relu, float* y, int ldy, as_stream_t stream);
+/* AdaIN1d + LeakyReLU, per-utterance instance-norm statistics (biased var, eps 1e-5); gamma_beta [B][ldgb]
+ * = fc(style) (gamma first).  With pool_w/pool_b [C][3]/[C] the depthwise ConvTranspose1d(k3,s2,p1,op1)
+ * is fused: y gets 2x the frames (utterance b starts at 2*col_off[b]) and x_up (optional) the nearest-x2
+ * copy of x.                                  models.py:189-197, 230-240, 172, 184, 261-270 */
+int as_adain_f32(const float* x, int ldx, int C, const float* gamma_beta, int ldgb, const int32_t* col_off, int B,
+                 float* y, int ldy, int lrelu, const float* pool_w, const float* pool_b, float* x_up, int ld_up,
+                 as_stream_t stream);
+/* y[b][m] = bias[m] + W[m][:] . x[b][:]       nn.Linear on per-utterance vectors (models.py:237,412-415,538) */
+int as_linear_rows_f32(const float* x, int ldx, const float* w, const float* bias, int B, int M, int K, float* y,
+                       int ldy, as_stream_t stream);
+/* round-half-even + clamp(min=1) (or forced integer durations), per-utterance frame offsets [B+1] and the
+ * frame -> token map; then the gather that replaces `T_en @ pred_aln_trg`.    models.py:361-368, :500 */
+int as_durations_f32(const float* dur_f32, const int32_t* forced_dur, const int32_t* tok_off, int B, int32_t* dur_i32,
+                     int32_t* frame_off, int32_t* tok_of_frame, int max_frames, as_stream_t stream);
+int as_expand_f32(const float* x, int ldx, int C, const int32_t* tok_of_frame, int n_frames, int repeat, float* y,
+                  int ldy, as_stream_t stream);
+/* log_norm + stats.json normalisation; feat rows 0 = energy, 1 = f0, 2..11 = EMA.   models.py:431,447-449,655-660
+ * stats24 = {energy_mean, energy_std, pitch_mean, pitch_std, EMA_mean[10], EMA_std[10]} */
+int as_ref_features_f32(const float* mel, int ldm, int n_mels, const float* f0_raw, const float* ema_raw, int lde,
+                        int N, const float* stats24, float* feat, int ldf, as_stream_t stream);
+/* per-utterance column window copy (the T-1 crop, models.py:459-471) */
+int as_crop_f32(const float* src, int lds, const int32_t* src_off, int start, float* dst, int ldd,
+                const int32_t* dst_off, int B, int C, int max_len, as_stream_t stream);
+/* style-tower helpers: LearnedDownSample / ResBlk1d.pool (models.py:27-31,116), DownSample (+ residual merge,
+ * models.py:43-57,99-100,127-130), im2col for the valid KxK convs (models.py:391,399,535), LeakyReLU+avg-pool */
+int as_dwconv_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy,
+                       const int32_t* out_off, const int32_t* out_w, int Hout, const float* w, const float* bias,
+                       int kh, int B, int C, int max_out, int lrelu, as_stream_t stream);
+int as_avgpool_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy,
+                        const int32_t* out_off, const int32_t* out_w, int Hout, int pool_h, const float* res, int ldr,
+                        int B, int C, int max_out, as_stream_t stream);
+int as_im2col_valid_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* col,
+                        int ldc, const int32_t* out_off, const int32_t* out_w, int Hout, int K, int stride, int lrelu,
+                        int B, int C, int max_out, as_stream_t stream);
+int as_mean_pool_f32(const float* x, int ldx, const int32_t* col_off, int B, int C, int lrelu, float* y, int ldy,
+                     as_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Windowed relative-position attention (K5) on a fused [3C][N] q/k/v projection.
+ * Replaces MultiHeadAttention.attention and its skew helpers, RelTransformerEnc.py:138-233.
+ * emb_rel_k / emb_rel_v: [2*window+1][C/heads] (heads share them, :113-117).
+ * ------------------------------------------------------------------------------------------- */
+int as_relpos_attention_f32(const float* qkv, int ld, int C, int heads, int window, const float* emb_rel_k,
+                            const float* emb_rel_v, const int32_t* col_off, int B, int max_len, float* out, int ldo,
+                            as_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BiLSTM recurrence (K9).  gx_tm [N][ldg >= 8H] time-major gate pre-activations W_ih x + b_ih + b_hh
+ * (forward gates 0..4H-1, reverse 4H..8H-1), whh_t [2][H][4H] = W_hh transposed; out [2H][N].
+ * Replaces nn.LSTM at models.py:526,555-561 and :589-591,606-618.
+ * ------------------------------------------------------------------------------------------- */
+int as_bilstm_f32(const float* gx_tm, int ldg, const float* whh_t, const int32_t* col_off, int B, int H, float* out,
+                  int ldo, as_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTSPEECH_HIP_H */

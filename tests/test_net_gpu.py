@@ -1,0 +1,135 @@
+"""GPU: the HIP acoustic path through the C ABI against (a) outputs of the reference itself
+(tests/golden/net_*.npz) and (b) the CPU oracle.  Integer durations must be identical; mel frames within
+1e-4 abs (the north-star bound; observed values are printed)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from artspeech_amd import models, synth
+from artspeech_amd.weights import DEFAULT_STATS, fold_state_dict, load_distribution
+
+pytestmark = pytest.mark.gpu
+MEL_TOL = 1e-4
+AUX_TOL = 5e-5
+
+
+def raw_features(t_ref, seed):
+    mel, f0, ema = synth.synth_ref_features(t_ref, seed)
+    f0_raw = (f0 * np.float32(DEFAULT_STATS["pitch"][3]) + np.float32(DEFAULT_STATS["pitch"][2])).astype(np.float32)
+    ema_raw = (ema * np.asarray(DEFAULT_STATS["EMA"][3], np.float32)[:, None]
+               + np.asarray(DEFAULT_STATS["EMA"][2], np.float32)[:, None]).astype(np.float32)
+    return mel, f0_raw, ema_raw
+
+
+_MODELS = {}
+
+
+def get_model(hd, di, seed, device):
+    key = (hd, di, seed)
+    if key not in _MODELS:
+        sd = synth.synth_state_dict(hd, di, seed=seed)
+        m = models.build_model(models.Munch(hidden_dim=hd, dim_in=di, style_dim=256, n_mels=80, n_token=178, n_layer=3,
+                                            max_conv_dim=hd, dropout=0.2), None, stage="second",
+                               distribution=load_distribution(DEFAULT_STATS), device=device)
+        models.load_checkpoint(m, None, {"net": {"ArtsSpeech": sd}})
+        _MODELS[key] = m.ArtsSpeech
+    return _MODELS[key]
+
+
+def run_one(net, g):
+    tokens = torch.from_numpy(g["tokens"])[None]
+    mel, f0_raw, ema_raw = raw_features(int(g["t_ref"]), int(g["seed"]))
+    batch = [tokens, torch.tensor([tokens.shape[1]]), torch.from_numpy(mel)[None], torch.tensor([mel.shape[1]]), None, None, None]
+    out, aux = net(batch, None, None, step="test", features=(torch.from_numpy(f0_raw)[None], torch.from_numpy(ema_raw)[None]),
+                   return_aux=True)
+    return out, aux
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_forward_matches_reference(cuda, golden_dir, tag):
+    files = sorted(glob.glob(os.path.join(golden_dir, f"net_{tag}_*.npz")))
+    assert files
+    for f in files:
+        g = np.load(f)
+        net = get_model(int(g["hidden_dim"]), int(g["dim_in"]), int(g["weight_seed"]), cuda)
+        out, aux = run_one(net, g)
+        dur = aux["dur_i"][: len(g["tokens"])].cpu().numpy()
+        assert np.array_equal(dur, g["ref/pred_dur"].astype(np.int32)), (f, "durations")
+        rep = {}
+        for k, ref_k in (("style", "style"), ("duration", "duration"), ("F0", "F0"), ("N", "N"), ("EMA", "EMA")):
+            got = aux[k].cpu().numpy().reshape(g["ref/" + ref_k].shape)
+            rep[k] = float(np.abs(got - g["ref/" + ref_k]).max())
+            assert rep[k] <= AUX_TOL, (f, k, rep[k])
+        assert out.shape == (1, 80, 2 * int(g["ref/pred_dur"].sum()))
+        d = float(np.abs(out[0].cpu().numpy() - g["ref/mel"]).max())
+        print(os.path.basename(f), "mel max-abs", d, rep)
+        assert d <= MEL_TOL, (f, d)
+
+
+def test_batched_equals_single(cuda, golden_dir):
+    """A ragged batch gives, per utterance, the reference's B=1 result."""
+    files = sorted(glob.glob(os.path.join(golden_dir, "net_tiny_*.npz")))
+    gs = [np.load(f) for f in files]
+    net = get_model(64, 8, int(gs[0]["weight_seed"]), cuda)
+    B = len(gs)
+    nmax = max(len(g["tokens"]) for g in gs)
+    tmax = max(int(g["t_ref"]) for g in gs)
+    texts = torch.zeros(B, nmax, dtype=torch.long)
+    mels = torch.zeros(B, 80, tmax)
+    f0s = torch.zeros(B, 1, tmax)
+    emas = torch.zeros(B, 10, tmax)
+    for b, g in enumerate(gs):
+        n, t = len(g["tokens"]), int(g["t_ref"])
+        mel, f0_raw, ema_raw = raw_features(t, int(g["seed"]))
+        texts[b, :n] = torch.from_numpy(g["tokens"])
+        mels[b, :, :t] = torch.from_numpy(mel)
+        f0s[b, :, :t] = torch.from_numpy(f0_raw)
+        emas[b, :, :t] = torch.from_numpy(ema_raw)
+    tl = torch.tensor([len(g["tokens"]) for g in gs])
+    ml = torch.tensor([int(g["t_ref"]) for g in gs])
+    out = net([texts, tl, mels, ml], None, None, step="test", features=(f0s, emas))
+    for b, g in enumerate(gs):
+        M2 = 2 * int(g["ref/pred_dur"].sum())
+        d = float(np.abs(out[b, :, :M2].cpu().numpy() - g["ref/mel"]).max())
+        assert d <= MEL_TOL, (b, d)
+        assert float(out[b, :, M2:].abs().max()) == 0.0 if out.shape[2] > M2 else True
+
+
+def test_forced_durations(cuda, golden_dir):
+    g = np.load(sorted(glob.glob(os.path.join(golden_dir, "net_tiny_*.npz")))[0])
+    net = get_model(64, 8, int(g["weight_seed"]), cuda)
+    tokens = torch.from_numpy(g["tokens"])[None]
+    mel, f0_raw, ema_raw = raw_features(int(g["t_ref"]), int(g["seed"]))
+    batch = [tokens, torch.tensor([tokens.shape[1]]), torch.from_numpy(mel)[None], torch.tensor([mel.shape[1]])]
+    forced = [g["ref/pred_dur"].astype(np.int64)]
+    out = net(batch, None, None, step="test", features=(torch.from_numpy(f0_raw)[None], torch.from_numpy(ema_raw)[None]),
+              forced_durations=forced)
+    assert float(np.abs(out[0].cpu().numpy() - g["ref/mel"]).max()) <= MEL_TOL
+
+
+def test_submodule_surfaces(cuda, golden_dir):
+    """The reference's sub-module call surface on padded [B,C,L] tensors."""
+    from oracle import acoustic
+    g = np.load(os.path.join(golden_dir, "net_tiny_N12_T70_s1.npz"))
+    net = get_model(64, 8, int(g["weight_seed"]), cuda)
+    W = fold_state_dict(synth.synth_state_dict(64, 8, seed=int(g["weight_seed"])))
+    tokens = torch.from_numpy(g["tokens"])
+    enc = net.text_encoder(tokens[None], torch.tensor([len(tokens)]))
+    assert enc.shape == (1, len(tokens), 64)
+    assert float(np.abs(enc[0].t().cpu().numpy() - g["ref/t_en"]).max()) <= AUX_TOL
+    style = torch.from_numpy(g["ref/style"])[None]
+    M = int(g["ref/pred_dur"].sum())
+    a_ex = acoustic.expand(torch.from_numpy(g["ref/a_en"]), torch.from_numpy(g["ref/pred_dur"]))
+    f0, n, ema = net.artsPredictor(a_ex[None], style)
+    assert f0.shape == (1, 1, 2 * M) and ema.shape == (1, 10, 2 * M)
+    assert float(np.abs(f0[0].cpu().numpy() - g["ref/F0"]).max()) <= AUX_TOL
+    t_ex = acoustic.expand(torch.from_numpy(g["ref/t_en"]), torch.from_numpy(g["ref/pred_dur"]))
+    mel = net.decoder(t_ex[None], style, torch.from_numpy(g["ref/F0"])[None], torch.from_numpy(g["ref/N"])[None],
+                      torch.from_numpy(g["ref/EMA"])[None])
+    assert float(np.abs(mel[0].cpu().numpy() - g["ref/mel"]).max()) <= MEL_TOL
+    dur = net.durationPredictor(tokens[None], torch.from_numpy(g["ref/ema_ext"])[None], torch.tensor([len(tokens)]),
+                                torch.tensor([int(g["t_ref"])]))
+    assert float(np.abs(dur[0].cpu().numpy() - g["ref/duration"]).max()) <= AUX_TOL

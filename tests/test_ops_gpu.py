@@ -1,0 +1,198 @@
+"""GPU: individual kernels through the C ABI against plain fp32 torch (CPU) references of the same op."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from artspeech_amd import ops
+from artspeech_amd.ops import Layout, taps_1d, taps_2d
+
+pytestmark = pytest.mark.gpu
+
+
+def packed(x_list):
+    return torch.cat(x_list, dim=1).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,k,lens", [(64, 128, 3, [50, 13, 1, 200]), (10, 64, 1, [7, 9]), (1, 32, 1, [33]),
+                                             (96, 80, 5, [40, 41]), (130, 257, 9, [17, 300, 64]), (512, 1024, 3, [128] * 8)])
+@pytest.mark.parametrize("tile", ["", "11", "21", "22", "12"])
+def test_conv1d_gemm(cuda, monkeypatch, cin, cout, k, lens, tile):
+    if tile:
+        monkeypatch.setenv("AS_GEMM_TILE", tile)
+    else:
+        monkeypatch.delenv("AS_GEMM_TILE", raising=False)
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    xs = [torch.randn(cin, L, generator=g) for L in lens]
+    res = [torch.randn(cout, L, generator=g) for L in lens]
+    want = packed([(F.conv1d(x[None], w, b, padding=k // 2)[0] + r) / np.sqrt(2) for x, r in zip(xs, res)])
+    lay = Layout(lens, cuda)
+    wt = w.permute(2, 1, 0).contiguous().to(cuda)
+    y = ops.conv_gemm(wt, packed(xs).to(cuda), lay, lay.new(cout), taps_1d(k), bias=b.to(cuda), res=packed(res).to(cuda),
+                      div_sqrt2=True)
+    err = float((y.cpu() - want).abs().max())
+    assert err <= 2e-5, err
+
+
+def test_conv2d_gemm_and_transpose_out(cuda):
+    g = torch.Generator().manual_seed(3)
+    cin, cout, H = 16, 48, 10
+    widths = [23, 8, 40]
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 12
+    b = torch.randn(cout, generator=g)
+    xs = [torch.randn(cin, H, W, generator=g) for W in widths]
+    want = packed([F.conv2d(F.leaky_relu(x, 0.2)[None], w, b, padding=1)[0].reshape(cout, -1) for x in xs])
+    lay = Layout(widths, cuda, H=H)
+    wt = w.reshape(cout, cin, 9).permute(2, 1, 0).contiguous().to(cuda)
+    X = packed([x.reshape(cin, -1) for x in xs]).to(cuda)
+    y = ops.conv_gemm(wt, X, lay, lay.new(cout), taps_2d(3, 3), bias=b.to(cuda), in_act=ops.ACT_LRELU)
+    assert float((y.cpu() - want).abs().max()) <= 2e-5
+    yt = torch.empty(lay.N, cout, device=cuda)
+    ops.conv_gemm(wt, X, lay, yt, taps_2d(3, 3), bias=b.to(cuda), in_act=ops.ACT_LRELU, transpose_out=True)
+    assert torch.equal(yt.t().contiguous(), y)
+
+
+def test_mfma_layout_asymmetric(cuda):
+    """A = I with an asymmetric B: catches a transposed C fragment (guide section 3)."""
+    n = 64
+    w = torch.eye(n)[:, :, None]                                  # [cout, cin, 1]
+    x = torch.arange(n * 96, dtype=torch.float32).reshape(n, 96)
+    lay = Layout([96], cuda)
+    y = ops.conv_gemm(w.permute(2, 1, 0).contiguous().to(cuda), x.to(cuda), lay, lay.new(n), [(0, 0)])
+    assert torch.equal(y.cpu(), x)
+
+
+def test_adain_and_upsample(cuda):
+    g = torch.Generator().manual_seed(5)
+    C, lens = 48, [17, 64, 130, 1]
+    xs = [torch.randn(C, L, generator=g) * 2 + 1 for L in lens]
+    gb = torch.randn(len(lens), 2 * C, generator=g)
+    lay = Layout(lens, cuda)
+    y = ops.adain(packed(xs).to(cuda), gb.to(cuda), lay, lay.new(C), True)
+    want = []
+    for b, x in enumerate(xs):
+        n = F.instance_norm(x[None], eps=1e-5)[0] if x.shape[1] > 1 else torch.zeros_like(x)
+        want.append(F.leaky_relu((1 + gb[b, :C, None]) * n + gb[b, C:, None], 0.2))
+    assert float((y.cpu() - packed(want)).abs().max()) <= 2e-5
+    pw, pb = torch.randn(C, 1, 3, generator=g), torch.randn(C, generator=g)
+    lay2 = lay.scaled(2)
+    yu, xu = lay2.new(C), lay2.new(C)
+    ops.adain(packed(xs).to(cuda), gb.to(cuda), lay, yu, True, pw.reshape(C, 3).contiguous().to(cuda), pb.to(cuda), xu)
+    wantu = [F.conv_transpose1d(a[None], pw, pb, stride=2, padding=1, output_padding=1, groups=C)[0] for a in want]
+    assert float((yu.cpu() - packed(wantu)).abs().max()) <= 2e-5
+    assert torch.equal(xu.cpu(), packed([x.repeat_interleave(2, dim=1) for x in xs]))
+
+
+def test_channel_layernorm_embed(cuda):
+    g = torch.Generator().manual_seed(6)
+    C, N = 96, 150
+    x = torch.randn(C, N, generator=g)
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    y = ops.channel_layernorm(x.to(cuda), N, ga.to(cuda), be.to(cuda), torch.empty(C, N, device=cuda), relu=True)
+    mean = x.mean(0, keepdim=True)
+    var = ((x - mean) ** 2).mean(0, keepdim=True)
+    want = torch.relu((x - mean) * torch.rsqrt(var + 1e-4) * ga[:, None] + be[:, None])
+    assert float((y.cpu() - want).abs().max()) <= 2e-5
+    emb = torch.randn(178, C, generator=g)
+    tok = torch.randint(0, 178, (N,), generator=g)
+    e = ops.embed(tok.to(cuda, torch.int32), emb.to(cuda), float(np.sqrt(C)), torch.empty(C, N, device=cuda))
+    assert float((e.cpu() - (emb[tok] * np.sqrt(C)).t()).abs().max()) <= 1e-6
+
+
+def test_durations_expand(cuda):
+    d = torch.tensor([0.2, 0.5, 1.5, 2.5, 3.49, 2.51, 7.0, 0.99, 1.0, 4.5])
+    lay = Layout([4, 6], cuda)
+    dur_i, off, _ = ops.durations(d.to(cuda), None, lay, 0)
+    want = torch.round(d).clamp(min=1).int()
+    assert torch.equal(dur_i.cpu(), want)                        # [1,1,2,2,3,3,7,1,1,4]: half-to-even
+    tot = off.cpu().tolist()
+    assert tot == [0, int(want[:4].sum()), int(want.sum())]
+    dur_i, off, tof = ops.durations(d.to(cuda), None, lay, tot[-1])
+    x = torch.arange(30, dtype=torch.float32).reshape(3, 10)
+    y = ops.expand(x.to(cuda), tof, tot[-1], 2, torch.empty(3, 2 * tot[-1], device=cuda))
+    assert torch.equal(y.cpu(), x.repeat_interleave(want.long(), dim=1).repeat_interleave(2, dim=1))
+
+
+@pytest.mark.parametrize("lens,C", [([40, 33, 7], 64), ([150], 512), ([1, 2, 70, 64, 65], 64)])
+def test_relpos_attention(cuda, lens, C):
+    from oracle import acoustic
+    g = torch.Generator().manual_seed(sum(lens) + C)
+    W = {"a.emb_rel_k": torch.randn(1, 9, C // 4, generator=g) * 0.1, "a.emb_rel_v": torch.randn(1, 9, C // 4, generator=g) * 0.1}
+    for n in "qkvo":
+        W[f"a.conv_{n}.weight"] = torch.randn(C, C, 1, generator=g) / np.sqrt(C)
+        W[f"a.conv_{n}.bias"] = torch.randn(C, generator=g) * 0.1
+    xs = [torch.randn(C, L, generator=g) for L in lens]
+    eye = torch.eye(C)[:, :, None]
+    Wid = dict(W)
+    Wid["a.conv_o.weight"], Wid["a.conv_o.bias"] = eye, torch.zeros(C)
+    want = packed([acoustic.relpos_attention(Wid, "a", x) for x in xs])
+    qkv = packed([torch.cat([acoustic.conv1d(x, W[f"a.conv_{n}.weight"], W[f"a.conv_{n}.bias"]) for n in "qkv"], 0) for x in xs])
+    lay = Layout(lens, cuda)
+    out = ops.relpos_attention(qkv.to(cuda), C, 4, 4, W["a.emb_rel_k"][0].contiguous().to(cuda),
+                               W["a.emb_rel_v"][0].contiguous().to(cuda), lay, lay.new(C))
+    assert float((out.cpu() - want).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("H,I,lens", [(16, 16, [5, 1, 9]), (128, 128, [40, 200, 3, 77, 50, 60, 70, 80, 11]), (256, 512, [40, 12])])
+def test_bilstm(cuda, H, I, lens):
+    from artspeech_amd import models
+    g = torch.Generator().manual_seed(H + I)
+    lstm = torch.nn.LSTM(I, H, 1, batch_first=True, bidirectional=True)
+    xs = [torch.randn(I, L, generator=g) for L in lens]
+    with torch.no_grad():
+        want = packed([lstm(x.t()[None])[0][0].t() for x in xs])
+    raw = {"l." + k: v.detach() for k, v in lstm.state_dict().items()}
+    W = models.Weights(raw, cuda)
+    lay = Layout(lens, cuda)
+    out = models.bilstm(W, "l", packed(xs).to(cuda), lay)
+    assert float((out.cpu() - want).abs().max()) <= 2e-5
+
+
+def test_ref_features_crop_pool(cuda):
+    g = torch.Generator().manual_seed(9)
+    lens = [70, 66]
+    N = sum(lens)
+    mel, f0, ema = torch.randn(80, N, generator=g) * 0.5, torch.randn(1, N, generator=g) * 70 + 130, torch.randn(10, N, generator=g)
+    stats = torch.cat([torch.tensor([4.6, 3.1, 137.0, 78.0]), torch.linspace(-0.1, 0.1, 10), torch.linspace(0.8, 0.9, 10)])
+    lay = Layout(lens, cuda)
+    feat = ops.ref_features(mel.to(cuda), f0.to(cuda), ema.to(cuda), N, stats.to(cuda), lay.new(12)).cpu()
+    n = torch.log(torch.exp(mel * 4 - 4).norm(dim=0))
+    assert float((feat[0] - (n - 4.6) / 3.1).abs().max()) <= 1e-5
+    assert float((feat[1] - (f0[0] - 137.0) / 78.0).abs().max()) <= 1e-5
+    assert float((feat[2:] - (ema - stats[4:14, None]) / stats[14:, None]).abs().max()) <= 1e-5
+    l1 = Layout([l - 1 for l in lens], cuda)
+    c = ops.crop(feat.to(cuda), lay, 0, l1.new(12), l1).cpu()
+    assert torch.equal(c, torch.cat([feat[:, :69], feat[:, 70:70 + 65]], 1))
+    p = ops.mean_pool(feat.to(cuda), lay, True).cpu()
+    want = torch.stack([F.leaky_relu(feat[:, :70], 0.2).mean(1), F.leaky_relu(feat[:, 70:], 0.2).mean(1)])
+    assert float((p - want).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("kind", ["half", "channelpreserve"])
+def test_down_sampling(cuda, kind):
+    g = torch.Generator().manual_seed(10)
+    C, H, widths = 12, 10, [25, 8, 13]
+    xs = [torch.randn(C, H, W, generator=g) for W in widths]
+    kh = 3 if kind == "half" else 1
+    w, b = torch.randn(C, 1, kh, 3, generator=g), torch.randn(C, generator=g)
+    lay = Layout(widths, cuda, H=H)
+    lay2 = lay.halved(kind == "half")
+    X = packed([x.reshape(C, -1) for x in xs]).to(cuda)
+    y = ops.dwconv_down(X, lay, lay2.new(C), lay2, w.reshape(C, -1).contiguous().to(cuda), b.to(cuda), kh, True).cpu()
+    stride, pad = ((2, 2), 1) if kind == "half" else ((1, 2), (0, 1))
+    want = packed([F.leaky_relu(F.conv2d(x[None], w, b, stride=stride, padding=pad, groups=C)[0], 0.2).reshape(C, -1) for x in xs])
+    assert float((y - want).abs().max()) <= 1e-5
+    res = torch.randn(C, lay2.N, generator=g)
+    z = ops.avgpool_down(X, lay, lay2.new(C), lay2, 2 if kind == "half" else 1, res=res.to(cuda)).cpu()
+    pooled = []
+    for x in xs:
+        if x.shape[-1] % 2:
+            x = torch.cat([x, x[..., -1:]], -1)
+        pooled.append(F.avg_pool2d(x[None], (2, 2) if kind == "half" else (1, 2))[0].reshape(C, -1))
+    assert float((z - (packed(pooled) + res) / np.sqrt(2)).abs().max()) <= 1e-5
+    lo = lay.valid_conv(5, 2)
+    col = ops.im2col_valid(X, lay, lo.new(C * 25), lo, 5, 2, False).cpu()
+    want = packed([F.unfold(x[None], 5, stride=2)[0] for x in xs])
+    assert torch.equal(col, want)
