@@ -18,6 +18,8 @@ c_f = ctypes.c_float
 
 _SIGNATURES = {
     "as_abi_version": (c_i, []),
+    "as_prof_enable": (c_i, [c_i]),
+    "as_prof_collect": (c_i, [c_p, c_p, c_p, c_p, c_i]),
     "as_mas_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "as_mas_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
 }

@@ -16,6 +16,7 @@
 // (DESIGN.md "next").
 #include "common.h"
 #include "artspeech_hip.h"
+#define AS_FILE_CLS AS_CLS_ATTN
 
 #define QT 16
 #define KT 64
@@ -175,6 +176,7 @@ extern "C" int as_relpos_attention_f32(const float* qkv, int ld, int C, int head
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(relpos_attention_kernel, dim3(as_cdiv(max_len, QT), heads, B), dim3(256), smem, (hipStream_t)stream,
                        qkv, ld, C, heads, window, emb_rel_k, emb_rel_v, col_off, out, ldo);
     AS_CHECK_LAUNCH();

@@ -22,3 +22,12 @@
 static inline int as_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 #define AS_WAVE 64
+
+// kernel classes for the optional event profiler (prof.hip)
+enum { AS_CLS_GEMM = 0, AS_CLS_ADAIN = 1, AS_CLS_LN = 2, AS_CLS_ATTN = 3, AS_CLS_LSTM = 4, AS_CLS_MAS = 5, AS_CLS_OTHER = 6, AS_N_CLS = 7 };
+struct AsProfScope {
+    int idx;
+    hipStream_t stream;
+    AsProfScope(int cls, double flops, double bytes, hipStream_t s);
+    ~AsProfScope();
+};

@@ -169,6 +169,9 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if (a.ldx < a.N || a.ldy < (a.transpose_out ? a.M : a.N) || (a.res && (a.ldr < a.N || a.transpose_out))) return AS_EINVAL;
     if (a.N == 0) return AS_OK;
     const int choice = gemm_tile_choice(a.M, a.N);
+    // algorithmic work of this launch: 2*M*N*K*T flop; bytes = weights + input + output once
+    AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.K * a.T,
+                       4.0 * ((double)a.T * a.K * a.M + (double)a.K * a.N + (double)a.M * a.N), stream);
     switch (choice) {
     case 22: hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 128)), dim3(256), 0, stream, a); break;
     case 21: hipLaunchKernelGGL((conv_gemm_kernel<2, 1>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 64)), dim3(256), 0, stream, a); break;

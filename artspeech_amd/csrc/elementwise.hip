@@ -3,6 +3,7 @@
 // col_off int32 [B+1] gives each utterance's column range).
 #include "common.h"
 #include "artspeech_hip.h"
+#define AS_FILE_CLS AS_CLS_OTHER
 
 static __device__ __forceinline__ float wave_sum(float v)
 {
@@ -34,6 +35,7 @@ extern "C" int as_make_meta(const int32_t* widths, const int32_t* col_off, int B
     if (!widths || !col_off || !meta || B < 0 || H <= 0 || H > 65535) return AS_EINVAL;
     if (B == 0) return AS_OK;
     const int gx = n_cols_max > 0 ? as_cdiv(as_cdiv(n_cols_max, B > 0 ? B : 1), 256) : 1;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(make_meta_kernel, dim3(gx < 1 ? 1 : (gx > 64 ? 64 : gx), B), dim3(256), 0, (hipStream_t)stream,
                        widths, col_off, B, H, reinterpret_cast<unsigned long long*>(meta));
     AS_CHECK_LAUNCH();
@@ -59,6 +61,7 @@ extern "C" int as_embed_f32(const int32_t* tokens, const float* emb, int C, int 
 {
     if (!tokens || !emb || !y || C <= 0 || N < 0 || V <= 0 || ldy < N) return AS_EINVAL;
     if (N == 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(embed_kernel, dim3(as_cdiv(N, 64), C), dim3(64), 0, (hipStream_t)stream, tokens, emb, C, N, V,
                        scale, y, ldy);
     AS_CHECK_LAUNCH();
@@ -102,6 +105,7 @@ extern "C" int as_channel_layernorm_f32(const float* x, int ldx, int C, int N, c
 {
     if (!x || !y || !gamma || !beta || C <= 0 || N < 0 || ldx < N || ldy < N) return AS_EINVAL;
     if (N == 0) return AS_OK;
+    AsProfScope prof__(AS_CLS_LN, 8.0 * C * N, 8.0 * C * N, (hipStream_t)stream);
     hipLaunchKernelGGL(channel_ln_kernel, dim3(as_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, C, N, gamma,
                        beta, eps, relu, y, ldy);
     AS_CHECK_LAUNCH();
@@ -168,6 +172,7 @@ extern "C" int as_adain_f32(const float* x, int ldx, int C, const float* gamma_b
     if (!x || !y || !gamma_beta || !col_off || C <= 0 || B < 0 || ldgb < 2 * C) return AS_EINVAL;
     if ((pool_w == nullptr) != (pool_b == nullptr)) return AS_EINVAL;
     if (B == 0) return AS_OK;
+    AsProfScope prof__(AS_CLS_ADAIN, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(adain_kernel, dim3(as_cdiv((long)C * B, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, C,
                        gamma_beta, ldgb, col_off, B, y, ldy, lrelu, pool_w, pool_b, x_up, ld_up);
     AS_CHECK_LAUNCH();
@@ -200,6 +205,7 @@ extern "C" int as_linear_rows_f32(const float* x, int ldx, const float* w, const
 {
     if (!x || !w || !y || B < 0 || M <= 0 || K <= 0 || ldx < K || ldy < M) return AS_EINVAL;
     if (B == 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(linear_rows_kernel, dim3(as_cdiv((long)B * M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
                        bias, B, M, K, y, ldy);
     AS_CHECK_LAUNCH();
@@ -254,6 +260,7 @@ extern "C" int as_durations_f32(const float* dur_f32, const int32_t* forced_dur,
                                 as_stream_t stream)
 {
     if ((!dur_f32 && !forced_dur) || !tok_off || !dur_i32 || !frame_off || B < 0 || B > 1024) return AS_EINVAL;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(durations_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dur_f32, forced_dur, tok_off, B,
                        dur_i32, frame_off, tok_of_frame, max_frames);
     AS_CHECK_LAUNCH();
@@ -275,6 +282,7 @@ extern "C" int as_expand_f32(const float* x, int ldx, int C, const int32_t* tok_
 {
     if (!x || !y || !tok_of_frame || C <= 0 || n_frames < 0 || repeat < 1 || ldy < n_frames * repeat) return AS_EINVAL;
     if (n_frames == 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(expand_kernel, dim3(as_cdiv((long)n_frames * repeat, 256), C), dim3(256), 0, (hipStream_t)stream,
                        x, ldx, C, tok_of_frame, n_frames, repeat, y, ldy);
     AS_CHECK_LAUNCH();
@@ -310,6 +318,7 @@ extern "C" int as_ref_features_f32(const float* mel, int ldm, int n_mels, const 
 {
     if (!mel || !f0_raw || !ema_raw || !stats24 || !feat || N < 0 || n_mels <= 0 || ldm < N || lde < N || ldf < N) return AS_EINVAL;
     if (N == 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(ref_features_kernel, dim3(as_cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, mel, ldm, n_mels,
                        f0_raw, ema_raw, lde, N, stats24, feat, ldf);
     AS_CHECK_LAUNCH();
@@ -332,6 +341,7 @@ extern "C" int as_crop_f32(const float* src, int lds, const int32_t* src_off, in
 {
     if (!src || !dst || !src_off || !dst_off || B < 0 || C <= 0) return AS_EINVAL;
     if (B == 0 || max_len <= 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(crop_kernel, dim3(as_cdiv(max_len, 256), B, C), dim3(256), 0, (hipStream_t)stream, src, lds,
                        src_off, start, dst, ldd, dst_off, C);
     AS_CHECK_LAUNCH();
@@ -385,6 +395,7 @@ extern "C" int as_dwconv_down_f32(const float* x, int ldx, const int32_t* in_off
     const int sh = kh == 3 ? 2 : 1, ph = kh == 3 ? 1 : 0;
     int gx = as_cdiv(max_out, 256);
     gx = gx > 32 ? 32 : gx;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(dwconv_down_kernel, dim3(gx, B, C), dim3(256), 0, (hipStream_t)stream, x, ldx, in_off, in_w, Hin,
                        y, ldy, out_off, out_w, Hout, w, bias, kh, sh, ph, lrelu);
     AS_CHECK_LAUNCH();
@@ -425,6 +436,7 @@ extern "C" int as_avgpool_down_f32(const float* x, int ldx, const int32_t* in_of
     if (B == 0 || max_out <= 0) return AS_OK;
     int gx = as_cdiv(max_out, 256);
     gx = gx > 32 ? 32 : gx;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(avgpool_down_kernel, dim3(gx, B, C), dim3(256), 0, (hipStream_t)stream, x, ldx, in_off, in_w, Hin,
                        y, ldy, out_off, out_w, Hout, pool_h, res, ldr);
     AS_CHECK_LAUNCH();
@@ -458,6 +470,7 @@ extern "C" int as_im2col_valid_f32(const float* x, int ldx, const int32_t* in_of
     if (!x || !col || !in_off || !in_w || !out_off || !out_w || K <= 0 || stride <= 0 || B < 0 || C <= 0) return AS_EINVAL;
     if (B == 0 || max_out <= 0) return AS_OK;
     if ((long)C * K * K > 65535) return AS_EINVAL;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(im2col_valid_kernel, dim3(as_cdiv(max_out, 64), B, C * K * K), dim3(64), 0, (hipStream_t)stream, x,
                        ldx, in_off, in_w, Hin, col, ldc, out_off, out_w, Hout, K, stride, lrelu);
     AS_CHECK_LAUNCH();
@@ -489,6 +502,7 @@ extern "C" int as_mean_pool_f32(const float* x, int ldx, const int32_t* col_off,
 {
     if (!x || !y || !col_off || B < 0 || C <= 0 || ldy < C) return AS_EINVAL;
     if (B == 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(mean_pool_kernel, dim3(as_cdiv((long)C * B, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, col_off,
                        B, C, lrelu, y, ldy);
     AS_CHECK_LAUNCH();

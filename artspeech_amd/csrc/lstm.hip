@@ -11,6 +11,7 @@
 // Latency-bound by construction; reported in us/step.
 #include "common.h"
 #include "artspeech_hip.h"
+#define AS_FILE_CLS AS_CLS_LSTM
 
 #define NB 8
 
@@ -91,6 +92,7 @@ extern "C" int as_bilstm_f32(const float* gx_tm, int ldg, const float* whh_t, co
     if (!gx_tm || !whh_t || !col_off || !out || B < 0 || H <= 0 || (4 * H) % 64 || 4 * H > 1024 || ldg < 8 * H) return AS_EINVAL;
     if (B == 0) return AS_OK;
     const size_t smem = sizeof(float) * ((size_t)2 * H * NB + (size_t)4 * H * NB);
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(bilstm_kernel, dim3(as_cdiv(B, NB), 2), dim3(4 * H), smem, (hipStream_t)stream, gx_tm, ldg, whh_t,
                        col_off, B, H, out, ldo);
     AS_CHECK_LAUNCH();

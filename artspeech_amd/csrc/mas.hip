@@ -223,6 +223,7 @@ extern "C" int as_mas_f32(const float* value, const int* t_x, const int* t_y, in
     const size_t smem = (size_t)ch * W * R * 8 + 2 * 16 * sizeof(float) + (size_t)ch * sizeof(int);
     const bool vec4 = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0);
     unsigned long long* w64 = static_cast<unsigned long long*>(ws);
+    AsProfScope prof__(AS_CLS_MAS, 2.0 * B * Tx * (double)Ty, 4.0 * B * Tx * (double)Ty * (path ? 2 : 1), stream);
     switch (R) {
     case 1: mas_launch<1>(vec4, B, W, smem, stream, value, t_x, t_y, Tx, Ty, tie_mode, path, dur, rows, w64, ch); break;
     case 2: mas_launch<2>(vec4, B, W, smem, stream, value, t_x, t_y, Tx, Ty, tie_mode, path, dur, rows, w64, ch); break;

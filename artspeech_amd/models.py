@@ -17,7 +17,7 @@ import math
 import torch
 
 from . import ops
-from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, Layout, taps_1d, taps_2d
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, Layout, layout, taps_1d, taps_2d
 from .spec import N_HEADS, WINDOW
 from .weights import DEFAULT_STATS, fold_state_dict, load_distribution
 
@@ -273,7 +273,7 @@ class RelTransformerEncoder(_Module):
     def forward(self, x, x_lengths):
         dev = self.W.device
         lens = [int(v) for v in x_lengths]
-        lay = Layout(lens, dev)
+        lay = layout(lens, dev)
         tok = torch.cat([x[b, :l] for b, l in enumerate(lens)]).to(device=dev, dtype=torch.int32)
         return unpack(self.forward_packed(tok, lay), lay).transpose(1, 2)
 
@@ -293,10 +293,10 @@ class StyleEncoder(_Module):
         W, p = self.W, self.p
         dev = W.device
         lens = [w - 1 for w in lay_full.widths_host]                 # models.py:459 (start = randint(0,1) = 0)
-        l1 = Layout(lens, dev)
+        l1 = layout(lens, dev)
         c = ops.crop(feat, lay_full, 0, l1.new(92), l1)
         # 2-D images: [1][sum H*L] with H rows of L contiguous frames per utterance
-        lm, le = Layout(lens, dev, H=80), Layout(lens, dev, H=10)
+        lm, le = layout(lens, dev, H=80), layout(lens, dev, H=10)
         mel_img = self._image(c[12:92], l1, lm)
         ema_img = self._image(c[2:12], l1, le)
         ms = tower2d(W, p + ".Mel_block", mel_img, lm, ["half"] * 4, 6, 1, p + ".Mellinear")
@@ -335,7 +335,7 @@ class StyleEncoder(_Module):
     def forward(self, mel, mel_input_length, step="second", distribution=None, epoch=20, features=None):
         dev = self.W.device
         lens = [int(v) for v in mel_input_length]
-        lay = Layout(lens, dev)
+        lay = layout(lens, dev)
         f0_raw, ema_raw = self._extract(mel, features)
         stats24 = stats_vector(distribution, dev)
         feat12, style = self.forward_packed(pack(mel.to(dev), lens), pack(f0_raw.to(dev), lens),
@@ -351,7 +351,7 @@ class DurationPredictor(_Module):
 
     def forward_packed(self, tokens_i32, tok_lay, ema_p, ref_lay):
         W, p = self.W, self.p
-        limg = Layout(ref_lay.widths_host, W.device, H=10)
+        limg = layout(ref_lay.widths_host, W.device, H=10)
         img = StyleEncoder._image(ema_p, ref_lay, limg)
         ds = tower2d(W, p + ".dur_block", img, limg, ["channelpreserve"] * 2 + ["half"], 5, 2, p + ".dur_linear")
         d = rel_encoder(W, p + ".text_encoder", tokens_i32, tok_lay, 2)
@@ -365,7 +365,7 @@ class DurationPredictor(_Module):
         dev = self.W.device
         tl = [int(v) for v in text_lengths]
         ml = [int(v) for v in mel_input_length]
-        tok_lay, ref_lay = Layout(tl, dev), Layout(ml, dev)
+        tok_lay, ref_lay = layout(tl, dev), layout(ml, dev)
         tok = torch.cat([texts[b, :l] for b, l in enumerate(tl)]).to(device=dev, dtype=torch.int32)
         d = self.forward_packed(tok, tok_lay, pack(style.to(dev), ml), ref_lay)
         return unpack(d, tok_lay)[:, 0, :]
@@ -395,7 +395,7 @@ class ArtsPredictor(_Module):
     def forward(self, A_ens, style, lengths=None):
         dev = self.W.device
         lens = [A_ens.shape[-1]] * A_ens.shape[0] if lengths is None else [int(v) for v in lengths]
-        lay = Layout(lens, dev)
+        lay = layout(lens, dev)
         f0, n, ema, lay2 = self.forward_packed(pack(A_ens.to(dev), lens), lay, style.to(dev).contiguous().float())
         return unpack(f0, lay2), unpack(n, lay2), unpack(ema, lay2)
 
@@ -432,7 +432,7 @@ class Decoder(_Module):
     def forward(self, asr, Style, F0, N, EMA, lengths=None):
         dev = self.W.device
         lens = [asr.shape[-1]] * asr.shape[0] if lengths is None else [int(v) for v in lengths]
-        lay2 = Layout([2 * l for l in lens], dev)
+        lay2 = layout([2 * l for l in lens], dev)
         asr_up = pack(asr.to(dev).repeat_interleave(2, dim=-1), lay2.widths_host)
         mel = self.forward_packed(asr_up, lay2, Style.to(dev).contiguous().float(), pack(F0.to(dev), lay2.widths_host),
                                   pack(N.to(dev), lay2.widths_host), pack(EMA.to(dev), lay2.widths_host))
@@ -484,7 +484,7 @@ class ArtsSpeech(_Module):
         tl = [int(v) for v in input_lengths]
         ml = [int(v) for v in mel_input_length]
         B = len(tl)
-        tok_lay, ref_lay = Layout(tl, dev), Layout(ml, dev)
+        tok_lay, ref_lay = layout(tl, dev), layout(ml, dev)
         tok = torch.cat([texts[b, :l] for b, l in enumerate(tl)]).to(device=dev, dtype=torch.int32)
         f0_raw, ema_raw = self.style_encoder._extract(mels, features)
         mel_p, f0_p, ema_p = pack(mels.to(dev), ml), pack(f0_raw.to(dev), ml), pack(ema_raw.to(dev), ml)
@@ -503,7 +503,9 @@ class ArtsSpeech(_Module):
         """The whole hot path on packed tensors (what bench.py times).  One host sync (reading the integer
         frame counts) unless `frames_hint` gives them (forced durations)."""
         dev = self.device
-        stats24 = stats_vector(self.distribution, dev)
+        if getattr(self, "_stats24", None) is None:
+            self._stats24 = stats_vector(self.distribution, dev)
+        stats24 = self._stats24
         t_en = self.text_encoder.forward_packed(tok, tok_lay)
         a_en = self.arts_encoder.forward_packed(tok, tok_lay)
         feat12, style = self.style_encoder.forward_packed(mel_p, f0_p, ema_p, ref_lay, stats24)
@@ -514,7 +516,7 @@ class ArtsSpeech(_Module):
             frames = [off[b + 1] - off[b] for b in range(tok_lay.B)]
         else:
             frames = list(frames_hint)
-        lay1 = Layout(frames, dev)
+        lay1 = layout(frames, dev)
         dur_i, frame_off, tof = ops.durations(duration.reshape(-1), forced, tok_lay, lay1.N)
         C = t_en.shape[0]
         a_ex = ops.expand(a_en, tof, lay1.N, 1, lay1.new(C))

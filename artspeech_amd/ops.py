@@ -62,16 +62,31 @@ class Layout:
         return torch.empty((C, max(self.N, 1)), dtype=torch.float32, device=self.device)
 
     def scaled(self, k):
-        return Layout([w * k for w in self.widths_host], self.device, self.H)
+        return layout([w * k for w in self.widths_host], self.device, self.H)
 
     def halved(self, h_too):
         """geometry after a 2x down-sampling (W -> ceil(W/2); H -> H/2 when h_too)."""
         H = self.H // 2 if h_too else self.H
-        return Layout([(w + 1) // 2 for w in self.widths_host], self.device, H)
+        return layout([(w + 1) // 2 for w in self.widths_host], self.device, H)
 
     def valid_conv(self, K, stride):
         H = (self.H - K) // stride + 1
-        return Layout([(w - K) // stride + 1 for w in self.widths_host], self.device, H)
+        return layout([(w - K) // stride + 1 for w in self.widths_host], self.device, H)
+
+
+_LAYOUTS = {}
+
+
+def layout(widths, device, H=1):
+    """Cached Layout: geometry objects own small device arrays (offsets, descriptors); steady-state
+    batches of the same shape must not re-upload them every call."""
+    key = (tuple(int(w) for w in widths), int(H), str(device))
+    lay = _LAYOUTS.get(key)
+    if lay is None:
+        if len(_LAYOUTS) > 4096:
+            _LAYOUTS.clear()
+        lay = _LAYOUTS[key] = Layout(widths, device, H)
+    return lay
 
 
 def taps_1d(k):

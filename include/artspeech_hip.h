@@ -28,6 +28,13 @@ typedef void* as_stream_t; /* hipStream_t */
 /* library/ABI version; bumped on any signature change */
 int as_abi_version(void);
 
+/* Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg; no
+ * reference counterpart).  Classes: 0 conv-GEMM, 1 AdaIN, 2 LayerNorm, 3 attention, 4 LSTM, 5 MAS, 6 other.
+ * as_prof_collect blocks until the recorded events have completed and returns, per class, the summed
+ * kernel time (ms), algorithmic flop, algorithmic bytes and launch count since as_prof_enable(1). */
+int as_prof_enable(int on);
+int as_prof_collect(double* ms, double* flops, double* bytes, int32_t* launches, int n_classes);
+
 /* ---------------------------------------------------------------------------------------------
  * Monotonic alignment search (K1).
  * Replaces: maximum_path1  S_monotonic_align.py:5-47    (tie_mode = 1, "move")

@@ -48,13 +48,13 @@ def relpos_attention(W, p, x, n_heads=4, window=4):
     scores = torch.matmul(q, k.transpose(1, 2)) / scale    # :145
     rel = torch.matmul(q, ek.t()) / scale                  # [h, N, 2w+1]   (:149-151)
     for r in range(-window, window + 1):
-        i = torch.arange(max(0, -r), min(N, N - r))
+        i = torch.arange(max(0, -r), max(max(0, -r), min(N, N - r)))
         if len(i):
             scores[:, i, i + r] = scores[:, i, i + r] + rel[:, i, r + window]
     pr = F.softmax(scores, dim=-1)                         # :161
     out = torch.matmul(pr, v)                              # :163
     for r in range(-window, window + 1):                   # :165-167
-        i = torch.arange(max(0, -r), min(N, N - r))
+        i = torch.arange(max(0, -r), max(max(0, -r), min(N, N - r)))
         if len(i):
             out[:, i, :] = out[:, i, :] + pr[:, i, i + r][..., None] * ev[r + window]
     out = out.transpose(1, 2).contiguous().view(C, N)      # :168
