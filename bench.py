@@ -70,7 +70,7 @@ def cpu_baseline(host, sd, n_utt):
     """The oracle (CPU restatement of the reference, oracle/acoustic.py) on this box's host cores."""
     from artspeech_amd.weights import DEFAULT_STATS, fold_state_dict, load_distribution
     from oracle import acoustic
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)              # small per-utterance ops: more threads only add sync cost
     torch.set_num_threads(cores)
     W = fold_state_dict(sd)
     dist = load_distribution(DEFAULT_STATS)
@@ -78,8 +78,13 @@ def cpu_baseline(host, sd, n_utt):
              torch.from_numpy(host["ema"][b].astype(np.float32))) for b in range(n_utt)]
     acoustic.forward_test(W, *args[0], dist, forced_dur=host["forced"])          # warm-up
     t0 = time.perf_counter()
-    outs = [acoustic.forward_test(W, *a, dist, forced_dur=host["forced"]) for a in args]
+    outs = []
+    for a in args:                                     # bounded: stop after ~20 s of CPU work
+        outs.append(acoustic.forward_test(W, *a, dist, forced_dur=host["forced"]))
+        if time.perf_counter() - t0 > 20.0:
+            break
     dt = time.perf_counter() - t0
+    n_utt = len(outs)
     return dict(value=n_utt * FRAMES_PER_UTT / dt, unit="mel frames/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n_utt} utterances of the same C3 workload, one at a time (the reference is batch-1), "
                        f"{dt:.1f} s of CPU work, torch {torch.__version__} fp32"), outs
