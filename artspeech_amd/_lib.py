@@ -53,8 +53,16 @@ _SIGNATURES.update({
     "as_im2col_valid_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "as_mean_pool_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "as_relpos_attention_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
-    "as_bilstm_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
+    "as_bilstm_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p]),
 })
+
+
+AS_MAX_LSTM_JOBS = 4
+
+
+class BiLstmJob(ctypes.Structure):
+    _fields_ = [("gx_tm", ctypes.c_void_p), ("whh_t", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("ldg", ctypes.c_int32), ("ldo", ctypes.c_int32)]
 
 
 class HipLibraryError(RuntimeError):

@@ -28,6 +28,6 @@ enum { AS_CLS_GEMM = 0, AS_CLS_ADAIN = 1, AS_CLS_LN = 2, AS_CLS_ATTN = 3, AS_CLS
 struct AsProfScope {
     int idx;
     hipStream_t stream;
-    AsProfScope(int cls, double flops, double bytes, hipStream_t s);
+    AsProfScope(int cls, double flops, double bytes, hipStream_t s, const char* tag = nullptr);
     ~AsProfScope();
 };

@@ -153,10 +153,15 @@ static int gemm_tile_choice(int M, int N)
 {
     const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 22, 21, 12, 11
     if (env && atoi(env) > 0) return atoi(env);
-    const long t22 = (long)as_cdiv(M, 128) * as_cdiv(N, 128);
-    if (t22 >= 384) return 22;                           // >= 1.5 waves of 128x128 tiles over 256 CUs
-    const long t21 = (long)as_cdiv(M, 128) * as_cdiv(N, 64);
-    if (t21 >= 384 && M > 64) return 21;
+    // rows: a 128-row tile only when it is not half empty; columns: the widest tile that still gives
+    // >= 1.5 workgroups per CU (256 CUs)
+    const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);
+    if (tall) {
+        if ((long)as_cdiv(M, 128) * as_cdiv(N, 128) >= 384) return 22;
+        if ((long)as_cdiv(M, 128) * as_cdiv(N, 64) >= 384) return 21;
+    } else {
+        if ((long)as_cdiv(M, 64) * as_cdiv(N, 128) >= 384) return 12;
+    }
     return 11;
 }
 
@@ -170,8 +175,10 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if (a.N == 0) return AS_OK;
     const int choice = gemm_tile_choice(a.M, a.N);
     // algorithmic work of this launch: 2*M*N*K*T flop; bytes = weights + input + output once
+    char tag[64];
+    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d", a.M, a.N, a.K, a.T, choice);
     AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.K * a.T,
-                       4.0 * ((double)a.T * a.K * a.M + (double)a.K * a.N + (double)a.M * a.N), stream);
+                       4.0 * ((double)a.T * a.K * a.M + (double)a.K * a.N + (double)a.M * a.N), stream, tag);
     switch (choice) {
     case 22: hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 128)), dim3(256), 0, stream, a); break;
     case 21: hipLaunchKernelGGL((conv_gemm_kernel<2, 1>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 64)), dim3(256), 0, stream, a); break;

@@ -70,31 +70,65 @@ extern "C" int as_embed_f32(const int32_t* tokens, const float* emb, int C, int 
 
 // ---------------------------------------------------------------------------------------------------
 // Channel LayerNorm over dim 0 of [C][N]  (RelTransformerEnc.py:281-290), optional ReLU (prenet :323)
-// block = 64 columns x 4 channel slices
+// block = 32 columns x 32 channel slices (1024 threads); a thread's <= 16 values stay in registers across the
+// mean / variance / normalise passes (one HBM read, one write), two-pass statistics like the reference.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+#define LN_COLS 32
+#define LN_PARTS 32
+#define LN_MAXV 16
+__global__ void __launch_bounds__(1024)
 channel_ln_kernel(const float* __restrict__ x, int ldx, int C, int N, const float* __restrict__ gamma,
                   const float* __restrict__ beta, float eps, int relu, float* __restrict__ y, int ldy)
 {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
+    __shared__ float red[LN_PARTS][LN_COLS + 1];
+    const int col = threadIdx.x % LN_COLS, part = threadIdx.x / LN_COLS;
+    const int j = blockIdx.x * LN_COLS + col;
     const bool ok = j < N;
+    float v[LN_MAXV];
     float s = 0.f;
-    if (ok) for (int c = part; c < C; c += 4) s += x[(size_t)c * ldx + j];
-    red[part][lane] = s;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = part + i * LN_PARTS;
+        v[i] = (ok && c < C) ? x[(size_t)c * ldx + j] : 0.f;
+        s += v[i];
+    }
+    for (int c = part + LN_MAXV * LN_PARTS; c < C; c += LN_PARTS) s += ok ? x[(size_t)c * ldx + j] : 0.f;
+    red[part][col] = s;
     __syncthreads();
-    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_PARTS; ++q) tot += red[q][col];
+    const float mean = tot / (float)C;
     __syncthreads();
-    float v = 0.f;
-    if (ok) for (int c = part; c < C; c += 4) { const float d = x[(size_t)c * ldx + j] - mean; v += d * d; }
-    red[part][lane] = v;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = part + i * LN_PARTS;
+        const float d = v[i] - mean;
+        if (c < C) q2 += d * d;
+    }
+    for (int c = part + LN_MAXV * LN_PARTS; c < C; c += LN_PARTS) {
+        const float d = (ok ? x[(size_t)c * ldx + j] : 0.f) - mean;
+        q2 += d * d;
+    }
+    red[part][col] = q2;
     __syncthreads();
-    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
-    const float rs = 1.0f / sqrtf(var + eps);
-    if (ok) for (int c = part; c < C; c += 4) {
-        float o = (x[(size_t)c * ldx + j] - mean) * rs;
-        o = o * gamma[c] + beta[c];
+    tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_PARTS; ++q) tot += red[q][col];
+    const float rs = 1.0f / sqrtf(tot / (float)C + eps);
+    if (!ok) return;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = part + i * LN_PARTS;
+        if (c < C) {
+            float o = (v[i] - mean) * rs * gamma[c] + beta[c];
+            if (relu) o = o > 0.f ? o : 0.f;
+            y[(size_t)c * ldy + j] = o;
+        }
+    }
+    for (int c = part + LN_MAXV * LN_PARTS; c < C; c += LN_PARTS) {
+        float o = (x[(size_t)c * ldx + j] - mean) * rs * gamma[c] + beta[c];
         if (relu) o = o > 0.f ? o : 0.f;
         y[(size_t)c * ldy + j] = o;
     }
@@ -106,7 +140,7 @@ extern "C" int as_channel_layernorm_f32(const float* x, int ldx, int C, int N, c
     if (!x || !y || !gamma || !beta || C <= 0 || N < 0 || ldx < N || ldy < N) return AS_EINVAL;
     if (N == 0) return AS_OK;
     AsProfScope prof__(AS_CLS_LN, 8.0 * C * N, 8.0 * C * N, (hipStream_t)stream);
-    hipLaunchKernelGGL(channel_ln_kernel, dim3(as_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, C, N, gamma,
+    hipLaunchKernelGGL(channel_ln_kernel, dim3(as_cdiv(N, LN_COLS)), dim3(1024), 0, (hipStream_t)stream, x, ldx, C, N, gamma,
                        beta, eps, relu, y, ldy);
     AS_CHECK_LAUNCH();
     return AS_OK;

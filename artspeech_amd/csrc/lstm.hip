@@ -6,26 +6,35 @@
 // MFMA GEMM (conv_gemm.hip, written time-major [N][8H] so a step reads contiguous gate rows); this kernel
 // is the sequential part only.  Every utterance is its own recurrence (length-aware: the reverse pass
 // starts at the utterance's own last frame, never in padding -- the reference's unpacked BiLSTMs get this
-// wrong for padded batches), so a workgroup takes (direction, 8 utterances):
-// thread = gate row, W_hh^T streams from L2 each step as coalesced rows, h lives in LDS, c in registers.
-// Latency-bound by construction; reported in us/step.
+// wrong for padded batches), so a workgroup takes (job, direction, NB utterances) and
+// several independent LSTMs ("jobs": the F0 / energy / TV branches) share one launch so that their
+// latency-bound recurrences overlap on different CUs.
+// thread = gate row.  H <= 128: the thread's row of W_hh stays in REGISTERS for the whole sequence
+// (persistent weights, 128 VGPRs); larger H streams W_hh^T rows from L2 with 8 loads in flight.
+// h lives in LDS (read as one broadcast vector per k), c in registers, next step's input gates are
+// prefetched during the current step.  Latency-bound by construction; reported in us/step.
 #include "common.h"
 #include "artspeech_hip.h"
 #define AS_FILE_CLS AS_CLS_LSTM
 
-#define NB 8
+#define NB 4
 
 static __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ void __launch_bounds__(1024)
-bilstm_kernel(const float* __restrict__ gx, int ldg, const float* __restrict__ whh_t, const int* __restrict__ col_off,
-              int B, int H, float* __restrict__ out, int ldo)
+struct LstmJobs { BiLstmJob j[AS_MAX_LSTM_JOBS]; };
+
+// HREG = H when the weights are register resident (H in {16,32,64,128}), 0 for the streaming variant.
+template <int HREG>
+__global__ void __launch_bounds__(HREG ? 4 * HREG : 1024)
+bilstm_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B, int Hrt)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int H = HREG ? HREG : Hrt;
     float* hs = sm;                         // [2][H][NB]
     float* gs = sm + 2 * H * NB;            // [4H][NB]
     __shared__ int s_off[NB], s_len[NB];
 
+    const BiLstmJob job = jobs.j[blockIdx.z];
     const int dir = blockIdx.y;
     const int u0 = blockIdx.x * NB;
     const int r = threadIdx.x;              // gate row 0..4H-1
@@ -41,60 +50,93 @@ bilstm_kernel(const float* __restrict__ gx, int ldg, const float* __restrict__ w
 #pragma unroll
     for (int u = 0; u < NB; ++u) Lmax = s_len[u] > Lmax ? s_len[u] : Lmax;
 
-    const float* w = whh_t + (size_t)dir * H * G + r;
-    const int unit = r % H, q = r / H;      // cell-update role: (unit, utterances q and q+4)
-    float c0 = 0.f, c1 = 0.f;
+    const float* w = job.whh_t + (size_t)dir * H * G + r;
+    float wreg[HREG ? HREG : 1];
+    if (HREG) {
+#pragma unroll
+        for (int k = 0; k < HREG; ++k) wreg[k] = w[(size_t)k * G];
+    }
+    const int unit = r % H, q = r / H;      // cell-update role: (unit, utterance q)
+    float c = 0.f;
+
+    auto load_gx = [&](int t, float (&g)[NB]) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int L = s_len[u];
+            const int pos = dir ? L - 1 - t : t;
+            g[u] = (t < L) ? job.gx_tm[(size_t)(s_off[u] + pos) * job.ldg + dir * G + r] : 0.f;
+        }
+    };
+    float gnext[NB];
+    load_gx(0, gnext);
 
     for (int t = 0; t < Lmax; ++t) {
         const float* hc = hs + (t & 1) * H * NB;
         float* hn = hs + ((t + 1) & 1) * H * NB;
         float acc[NB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int L = s_len[u];
-            const int pos = dir ? L - 1 - t : t;
-            acc[u] = (t < L) ? gx[(size_t)(s_off[u] + pos) * ldg + dir * G + r] : 0.f;
-        }
-        for (int k = 0; k < H; ++k) {
-            const float wk = w[(size_t)k * G];
-            const float4 h0 = *reinterpret_cast<const float4*>(hc + k * NB);
-            const float4 h1 = *reinterpret_cast<const float4*>(hc + k * NB + 4);
-            acc[0] += wk * h0.x; acc[1] += wk * h0.y; acc[2] += wk * h0.z; acc[3] += wk * h0.w;
-            acc[4] += wk * h1.x; acc[5] += wk * h1.y; acc[6] += wk * h1.z; acc[7] += wk * h1.w;
-        }
+        for (int u = 0; u < NB; ++u) acc[u] = gnext[u];
+        if (t + 1 < Lmax) load_gx(t + 1, gnext);
+        if (HREG) {
 #pragma unroll
-        for (int u = 0; u < NB; ++u) gs[r * NB + u] = acc[u];
+            for (int k = 0; k < HREG; ++k) {
+                const float4 h4 = *reinterpret_cast<const float4*>(hc + k * NB);
+                acc[0] += wreg[k] * h4.x; acc[1] += wreg[k] * h4.y; acc[2] += wreg[k] * h4.z; acc[3] += wreg[k] * h4.w;
+            }
+        } else {
+            for (int k0 = 0; k0 < H; k0 += 8) {
+                float wk[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wk[i] = w[(size_t)(k0 + i) * G];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 h4 = *reinterpret_cast<const float4*>(hc + (k0 + i) * NB);
+                    acc[0] += wk[i] * h4.x; acc[1] += wk[i] * h4.y; acc[2] += wk[i] * h4.z; acc[3] += wk[i] * h4.w;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(gs + r * NB) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int u = q + 4 * s;
+        {
+            const int u = q;                 // 4H threads = H units x NB(=4) utterances
             const int L = s_len[u];
             if (t < L) {
                 const float ig = sigmoidf_(gs[(unit)*NB + u]);
                 const float fg = sigmoidf_(gs[(H + unit) * NB + u]);
                 const float gg = tanhf(gs[(2 * H + unit) * NB + u]);
                 const float og = sigmoidf_(gs[(3 * H + unit) * NB + u]);
-                float& c = s ? c1 : c0;
                 c = fg * c + ig * gg;
                 const float hv = og * tanhf(c);
                 hn[unit * NB + u] = hv;
                 const int pos = dir ? L - 1 - t : t;
-                out[(size_t)(dir * H + unit) * ldo + s_off[u] + pos] = hv;
+                job.out[(size_t)(dir * H + unit) * job.ldo + s_off[u] + pos] = hv;
             }
         }
         __syncthreads();
     }
 }
 
-extern "C" int as_bilstm_f32(const float* gx_tm, int ldg, const float* whh_t, const int32_t* col_off, int B, int H,
-                             float* out, int ldo, as_stream_t stream)
+extern "C" int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32_t* col_off, int B, int H,
+                             as_stream_t stream)
 {
-    if (!gx_tm || !whh_t || !col_off || !out || B < 0 || H <= 0 || (4 * H) % 64 || 4 * H > 1024 || ldg < 8 * H) return AS_EINVAL;
+    if (!jobs_host || n_jobs <= 0 || n_jobs > AS_MAX_LSTM_JOBS || !col_off || B < 0 || H <= 0 || (4 * H) % 64 ||
+        4 * H > 1024 || H % 8)
+        return AS_EINVAL;
+    LstmJobs jobs;
+    for (int i = 0; i < AS_MAX_LSTM_JOBS; ++i) jobs.j[i] = jobs_host[i < n_jobs ? i : 0];
+    for (int i = 0; i < n_jobs; ++i)
+        if (!jobs.j[i].gx_tm || !jobs.j[i].whh_t || !jobs.j[i].out || jobs.j[i].ldg < 8 * H) return AS_EINVAL;
     if (B == 0) return AS_OK;
     const size_t smem = sizeof(float) * ((size_t)2 * H * NB + (size_t)4 * H * NB);
+    const dim3 grid(as_cdiv(B, NB), 2, n_jobs), block(4 * H);
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(bilstm_kernel, dim3(as_cdiv(B, NB), 2), dim3(4 * H), smem, (hipStream_t)stream, gx_tm, ldg, whh_t,
-                       col_off, B, H, out, ldo);
+    switch (H) {
+    case 16: hipLaunchKernelGGL(bilstm_kernel<16>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
+    case 32: hipLaunchKernelGGL(bilstm_kernel<32>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
+    case 64: hipLaunchKernelGGL(bilstm_kernel<64>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
+    case 128: hipLaunchKernelGGL(bilstm_kernel<128>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
+    default: hipLaunchKernelGGL(bilstm_kernel<0>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
+    }
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

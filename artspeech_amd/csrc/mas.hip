@@ -7,14 +7,15 @@
 // DP column lives in registers, the row above a lane's first row comes from the neighbouring lane
 // (wave shuffle) or, across waves, through a 2-slot LDS mailbox.  Each thread streams ITS rows along
 // the contiguous mel axis 16 bytes at a time (one dwordx4 per row per 4 columns, next chunk
-// prefetched while the current one is consumed), so every fetched 64-B line is fully used -- the
+// prefetched while the current one is consumed), so every fetched line is fully used -- the
 // Triton kernel instead reads a stride-Ty column per step.
 //
-// The DP does exactly one fp32 add per cell, v = value + (a > c ? a : c), with -1e32 sentinels,
-// i.e. the reference's arithmetic; decisions are bit-exact with it.  Instead of storing the
-// cumulative lattice (the reference's in-place 4 B/cell) we keep 1 bit per cell: the compare that
-// feeds the max IS the wave-wide ballot (v_cmp writes the 64-lane mask), stored as R 64-bit words
-// per wave per column.  The backtrack stages those words through LDS in column chunks and one lane
+// The DP does exactly one fp32 add per cell, v = value + max(a, c), with -1e32 sentinels, i.e. the
+// reference's arithmetic; decisions are bit-exact with it (NaN inputs excepted).  Instead of storing
+// the cumulative lattice (the reference's in-place 4 B/cell) we keep 1 bit per cell ("came from the
+// row above"): each lane shifts its R decision bits per column into a register and stores one 64-bit
+// word per 4 columns (coalesced, 512 B per wave).  Per cell that is 4-5 vector instructions: compare,
+// select, add, shift-in.  The backtrack stages those words through LDS in column chunks and one lane
 // walks them; the dense 0/1 path, the per-column row index and the integer durations are emitted.
 //
 // Algorithmic bytes: 4*Tx*Ty read per utterance + 4*Tx*Ty path written (memset) +
@@ -23,23 +24,24 @@
 #include "artspeech_hip.h"
 
 #define MAS_NEG (-1e32f)
+typedef unsigned long long u64;
 
-template <int R, bool VEC4, int MAXT>
+template <int R, bool VEC4, bool TIE_MOVE, int MAXT>
 __global__ void __launch_bounds__(MAXT)
 mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const int* __restrict__ t_y,
-           int Tx, int Ty, int tie_move, float* __restrict__ path, int* __restrict__ dur,
-           int* __restrict__ rows, unsigned long long* __restrict__ ws, int chunk_cols)
+           int Tx, int Ty, float* __restrict__ path, int* __restrict__ dur, int* __restrict__ rows,
+           u64* __restrict__ ws, int stage_chunks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int W = blockDim.x >> 6;
-    const int nw = W * R;                                  // decision words per column
-    unsigned long long* stage = reinterpret_cast<unsigned long long*>(smem_raw);
-    float* bnd = reinterpret_cast<float*>(stage + (size_t)chunk_cols * nw);   // [2][W]
-    int* rowbuf = reinterpret_cast<int*>(bnd + 2 * 16);                      // [chunk_cols]
+    const int NT = blockDim.x;
+    const int W = NT >> 6;
+    u64* stage = reinterpret_cast<u64*>(smem_raw);                       // [stage_chunks][NT]
+    float* bnd = reinterpret_cast<float*>(stage + (size_t)stage_chunks * NT);   // [2][16]
+    int* rowbuf = reinterpret_cast<int*>(bnd + 2 * 16);                  // [4*stage_chunks]
 
     int x_len = t_x[b], y_len = t_y[b];
     x_len = x_len > Tx ? Tx : x_len;
@@ -47,7 +49,8 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
     if (x_len <= 0 || y_len <= 0) return;                  // uniform per block
 
     const float* vb = value + (size_t)b * Tx * Ty;
-    unsigned long long* wsb = ws + (size_t)b * Ty * nw;
+    const int nchunk_max = (Ty + 3) >> 2;
+    u64* wsb = ws + (size_t)b * nchunk_max * NT;
     const int r0 = tid * R;
 
     float prev[R];
@@ -78,6 +81,7 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
     load_chunk(0, cur);
     for (int c = 0; c < nchunk; ++c) {
         if (c + 1 < nchunk) load_chunk(c + 1, nxt);
+        unsigned bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int y = 4 * c + j;
@@ -88,29 +92,29 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
             } else {
                 float up = __shfl_up(prev[R - 1], 1);
                 if (lane == 0) up = (wave == 0) ? MAS_NEG : bnd[((y - 1) & 1) * 16 + wave - 1];
-                unsigned long long mine = 0ull;
                 float nv[R];
+                unsigned bj = 0u;
 #pragma unroll
-                for (int r = R - 1; r >= 0; --r) {
+                for (int r = 0; r < R; ++r) {
                     const float a = prev[r];
                     const float cc = (r > 0) ? prev[r - 1] : up;
-                    const bool gt = a > cc;
-                    const float m = gt ? a : cc;
-                    const bool move = tie_move ? !gt : (cc > a);
-                    const unsigned long long bal = __ballot(move);
-                    if (lane == r) mine = bal;
+                    // v1: direction = where(a > c, 0, -1);  v2/Triton: move iff c > a.  max = where(a > c, a, c).
+                    const bool move = TIE_MOVE ? !(a > cc) : (cc > a);
+                    const float m = move ? cc : a;
+                    bj = (bj << 1) | (move ? 1u : 0u);         // row r ends at bit R-1-r
                     const float val = (j == 0) ? cur[r].x : (j == 1) ? cur[r].y : (j == 2) ? cur[r].z : cur[r].w;
                     nv[r] = __fadd_rn(val, m);
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) prev[r] = nv[r];
-                if (lane < R) wsb[(size_t)y * nw + wave * R + lane] = mine;
+                bits[j] = bj;
             }
             if (W > 1) {
                 if (lane == 63) bnd[(y & 1) * 16 + wave] = prev[R - 1];
                 __syncthreads();
             }
         }
+        wsb[(size_t)c * NT + tid] = (u64)(bits[0] | (bits[1] << 16)) | ((u64)(bits[2] | (bits[3] << 16)) << 32);
 #pragma unroll
         for (int r = 0; r < R; ++r) cur[r] = nxt[r];
     }
@@ -123,28 +127,30 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
         if (path) path[((size_t)b * Tx + idx) * Ty + (y_len - 1)] = 1.f;
         if (rows) rows[(size_t)b * Ty + (y_len - 1)] = idx;
     }
-    for (int y_hi = y_len - 1; y_hi >= 1; y_hi -= chunk_cols) {
-        const int y_lo = (y_hi - chunk_cols + 1) > 1 ? (y_hi - chunk_cols + 1) : 1;
-        const int ncol = y_hi - y_lo + 1;
-        for (int i = tid; i < ncol * nw; i += blockDim.x) stage[i] = wsb[(size_t)y_lo * nw + i];
+    for (int c_hi = (y_len - 1) >> 2; c_hi >= 0; c_hi -= stage_chunks) {
+        const int c_lo = (c_hi - stage_chunks + 1) > 0 ? (c_hi - stage_chunks + 1) : 0;
+        const int nwords = (c_hi - c_lo + 1) * NT;
+        for (int i = tid; i < nwords; i += NT) stage[i] = wsb[(size_t)c_lo * NT + i];
         __syncthreads();
+        const int y_top = (4 * c_hi + 3) < (y_len - 1) ? (4 * c_hi + 3) : (y_len - 1);
+        const int y_bot = (4 * c_lo) > 1 ? (4 * c_lo) : 1;
         if (tid == 0) {
-            for (int y = y_hi; y >= y_lo; --y) {
+            for (int y = y_top; y >= y_bot; --y) {
                 const int t = idx / R, r = idx - t * R;
-                const unsigned long long w = stage[(size_t)(y - y_lo) * nw + (t >> 6) * R + r];
-                const int move = (int)((w >> (t & 63)) & 1ull);
+                const u64 w = stage[((y >> 2) - c_lo) * NT + t];
+                const int move = (int)((w >> (16 * (y & 3) + (R - 1 - r))) & 1ull);
                 if (move && idx > 0) {
                     if (dur) dur[(size_t)b * Tx + idx] = run;
                     idx -= 1;
                     run = 0;
                 }
                 run += 1;
-                rowbuf[y - y_lo] = idx;                    // row of column y-1
+                rowbuf[y - y_bot] = idx;                   // row of column y-1
             }
         }
         __syncthreads();
-        for (int i = tid; i < ncol; i += blockDim.x) {
-            const int col = y_lo + i - 1;
+        for (int i = tid; i <= y_top - y_bot; i += NT) {
+            const int col = y_bot + i - 1;
             const int rr = rowbuf[i];
             if (path) path[((size_t)b * Tx + rr) * Ty + col] = 1.f;
             if (rows) rows[(size_t)b * Ty + col] = rr;
@@ -172,36 +178,42 @@ static int mas_geometry(int Tx, int* R, int* W)
     return AS_OK;
 }
 
-static int mas_chunk_cols(int nw)
-{
-    int ch = 4096 / nw;                                    // <= 32 KiB of staged decision words
-    return ch > 64 ? 64 : (ch < 1 ? 1 : ch);
-}
-
 extern "C" size_t as_mas_workspace_bytes(int B, int Tx, int Ty)
 {
     int R, W;
     if (B <= 0 || Tx <= 0 || Ty <= 0 || mas_geometry(Tx, &R, &W) != AS_OK) return 0;
-    return (size_t)B * Ty * W * R * sizeof(unsigned long long);
+    return (size_t)B * ((Ty + 3) / 4) * 64 * W * sizeof(u64);
 }
 
-template <int R>
+template <int R, bool TIE>
 static void mas_launch(bool vec4, int B, int W, size_t smem, hipStream_t s, const float* value, const int* t_x,
-                       const int* t_y, int Tx, int Ty, int tie, float* path, int* dur, int* rows,
-                       unsigned long long* ws, int ch)
+                       const int* t_y, int Tx, int Ty, float* path, int* dur, int* rows, u64* ws, int sc)
 {
     // W == 1 (the common case, Tx <= 64*R): 64-thread workgroups may use the whole register file, which
     // the R = 16 prefetch needs; multi-wave geometries are capped at 8 waves (256 VGPRs each).
     if (W == 1) {
         if (vec4)
-            hipLaunchKernelGGL((mas_kernel<R, true, 64>), dim3(B), dim3(64), smem, s, value, t_x, t_y, Tx, Ty, tie, path, dur, rows, ws, ch);
+            hipLaunchKernelGGL((mas_kernel<R, true, TIE, 64>), dim3(B), dim3(64), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
         else
-            hipLaunchKernelGGL((mas_kernel<R, false, 64>), dim3(B), dim3(64), smem, s, value, t_x, t_y, Tx, Ty, tie, path, dur, rows, ws, ch);
+            hipLaunchKernelGGL((mas_kernel<R, false, TIE, 64>), dim3(B), dim3(64), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
     } else {
         if (vec4)
-            hipLaunchKernelGGL((mas_kernel<R, true, 512>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, tie, path, dur, rows, ws, ch);
+            hipLaunchKernelGGL((mas_kernel<R, true, TIE, 512>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
         else
-            hipLaunchKernelGGL((mas_kernel<R, false, 512>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, tie, path, dur, rows, ws, ch);
+            hipLaunchKernelGGL((mas_kernel<R, false, TIE, 512>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
+    }
+}
+
+template <bool TIE>
+static void mas_dispatch(int R, bool vec4, int B, int W, size_t smem, hipStream_t s, const float* value, const int* t_x,
+                         const int* t_y, int Tx, int Ty, float* path, int* dur, int* rows, u64* ws, int sc)
+{
+    switch (R) {
+    case 1: mas_launch<1, TIE>(vec4, B, W, smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc); break;
+    case 2: mas_launch<2, TIE>(vec4, B, W, smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc); break;
+    case 4: mas_launch<4, TIE>(vec4, B, W, smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc); break;
+    case 8: mas_launch<8, TIE>(vec4, B, W, smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc); break;
+    default: mas_launch<16, TIE>(vec4, B, W, smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc); break;
     }
 }
 
@@ -214,23 +226,20 @@ extern "C" int as_mas_f32(const float* value, const int* t_x, const int* t_y, in
     if (B == 0) return AS_OK;
     int R, W;
     if (mas_geometry(Tx, &R, &W) != AS_OK) return AS_EINVAL;
-    const size_t need = (size_t)B * Ty * W * R * sizeof(unsigned long long);
+    const size_t need = (size_t)B * ((Ty + 3) / 4) * 64 * W * sizeof(u64);
     if (!ws || ws_bytes < need) return AS_EINVAL;
     if (path) AS_CHECK(hipMemsetAsync(path, 0, (size_t)B * Tx * Ty * sizeof(float), stream));
     if (dur) AS_CHECK(hipMemsetAsync(dur, 0, (size_t)B * Tx * sizeof(int), stream));
     if (rows) AS_CHECK(hipMemsetAsync(rows, 0xFF, (size_t)B * Ty * sizeof(int), stream));
-    const int ch = mas_chunk_cols(W * R);
-    const size_t smem = (size_t)ch * W * R * 8 + 2 * 16 * sizeof(float) + (size_t)ch * sizeof(int);
+    const int NT = 64 * W;
+    int sc = 4096 / NT;                                    // <= 32 KiB of staged decision words
+    sc = sc > 16 ? 16 : sc;
+    const size_t smem = (size_t)sc * NT * 8 + 2 * 16 * sizeof(float) + (size_t)4 * sc * sizeof(int);
     const bool vec4 = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0);
-    unsigned long long* w64 = static_cast<unsigned long long*>(ws);
+    u64* w64 = static_cast<u64*>(ws);
     AsProfScope prof__(AS_CLS_MAS, 2.0 * B * Tx * (double)Ty, 4.0 * B * Tx * (double)Ty * (path ? 2 : 1), stream);
-    switch (R) {
-    case 1: mas_launch<1>(vec4, B, W, smem, stream, value, t_x, t_y, Tx, Ty, tie_mode, path, dur, rows, w64, ch); break;
-    case 2: mas_launch<2>(vec4, B, W, smem, stream, value, t_x, t_y, Tx, Ty, tie_mode, path, dur, rows, w64, ch); break;
-    case 4: mas_launch<4>(vec4, B, W, smem, stream, value, t_x, t_y, Tx, Ty, tie_mode, path, dur, rows, w64, ch); break;
-    case 8: mas_launch<8>(vec4, B, W, smem, stream, value, t_x, t_y, Tx, Ty, tie_mode, path, dur, rows, w64, ch); break;
-    default: mas_launch<16>(vec4, B, W, smem, stream, value, t_x, t_y, Tx, Ty, tie_mode, path, dur, rows, w64, ch); break;
-    }
+    if (tie_mode) mas_dispatch<true>(R, vec4, B, W, smem, stream, value, t_x, t_y, Tx, Ty, path, dur, rows, w64, sc);
+    else mas_dispatch<false>(R, vec4, B, W, smem, stream, value, t_x, t_y, Tx, Ty, path, dur, rows, w64, sc);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

@@ -1,21 +1,28 @@
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 // Off by default; when on, every launcher brackets its kernel with an event pair.  as_prof_collect
 // synchronises the recorded events (it is the only entry point of the library that blocks).
+// If the environment variable AS_PROF_CSV names a file, as_prof_collect also appends one line per launch
+// (class, tag, ms, algorithmic flop, algorithmic bytes) to it -- per-shape tuning data.
 #include "common.h"
 #include "artspeech_hip.h"
-#include <vector>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
+#include <vector>
 
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; char tag[64]; };
 static bool g_on = false;
 static std::vector<ProfRec> g_recs;
 static std::mutex g_mu;
 
-AsProfScope::AsProfScope(int cls, double flops, double bytes, hipStream_t s) : idx(-1), stream(s)
+AsProfScope::AsProfScope(int cls, double flops, double bytes, hipStream_t s, const char* tag) : idx(-1), stream(s)
 {
     if (!g_on) return;
     ProfRec r;
     r.cls = cls; r.flops = flops; r.bytes = bytes;
+    r.tag[0] = 0;
+    if (tag) { strncpy(r.tag, tag, sizeof(r.tag) - 1); r.tag[sizeof(r.tag) - 1] = 0; }
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     hipEventRecord(r.a, s);
     std::lock_guard<std::mutex> g(g_mu);
@@ -44,12 +51,16 @@ extern "C" int as_prof_collect(double* ms, double* flops, double* bytes, int32_t
     if (!ms || !flops || !bytes || !launches || n_classes <= 0) return AS_EINVAL;
     std::lock_guard<std::mutex> g(g_mu);
     for (int i = 0; i < n_classes; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    const char* csv = getenv("AS_PROF_CSV");
+    FILE* f = csv ? fopen(csv, "a") : nullptr;
     for (auto& r : g_recs) {
         AS_CHECK(hipEventSynchronize(r.b));
         float t = 0.f;
         AS_CHECK(hipEventElapsedTime(&t, r.a, r.b));
         const int c = r.cls < n_classes ? r.cls : n_classes - 1;
         ms[c] += t; flops[c] += r.flops; bytes[c] += r.bytes; launches[c] += 1;
+        if (f) fprintf(f, "%d,%s,%.6f,%.0f,%.0f\n", r.cls, r.tag, t, r.flops, r.bytes);
     }
+    if (f) fclose(f);
     return AS_OK;
 }

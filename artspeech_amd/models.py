@@ -147,11 +147,19 @@ def adain_resblk1d(W, p, X, lay, style, out=None, upsample=False):
 
 def bilstm(W, p, X, lay):
     """nn.LSTM(bidirectional) on packed [I][N] -> [2H][N]: hoisted input GEMM + recurrence kernel."""
-    wih_t, b, whh_t, H = W.lstm(p)
-    gx = torch.empty((max(lay.N, 1), 8 * H), dtype=torch.float32, device=X.device)
-    ops.conv_gemm(wih_t, X, lay, gx, [(0, 0)], bias=b, transpose_out=True)
-    out = lay.new(2 * H)
-    return ops.bilstm(gx, whh_t, lay, H, out)
+    return bilstm_many(W, [(p, X)], lay)[0]
+
+
+def bilstm_many(W, items, lay):
+    """Several independent BiLSTMs of the same size over the same layout (ArtsPredictor's three branches,
+    models.py:606-618): one hoisted input GEMM each, ONE recurrence launch for all of them."""
+    jobs, H = [], None
+    for p, X in items:
+        wih_t, b, whh_t, H = W.lstm(p)
+        gx = torch.empty((max(lay.N, 1), 8 * H), dtype=torch.float32, device=X.device)
+        ops.conv_gemm(wih_t, X, lay, gx, [(0, 0)], bias=b, transpose_out=True)
+        jobs.append((gx, whh_t, lay.new(2 * H)))
+    return ops.bilstm(jobs, lay, H)
 
 
 def rel_encoder(W, p, tokens_i32, lay, n_layers):
@@ -382,14 +390,16 @@ class ArtsPredictor(_Module):
         sl = {"EMA": style[:, 256:384].contiguous(), "F0": style[:, 384:448].contiguous(),
               "N": style[:, 448:512].contiguous()}
         a, _ = adain_resblk1d(W, p + ".shared", a_en, lay, style)
-        outs = {}
+        outs, feats = {}, []
         lay2 = None
         for br in ("F0", "N", "EMA"):
             x, lay2 = adain_resblk1d(W, f"{p}.{br}.0", a, lay, style, upsample=True)
             x, _ = adain_resblk1d(W, f"{p}.{br}.1", x, lay2, sl[br])
             x, _ = adain_resblk1d(W, f"{p}.{br}.2", x, lay2, sl[br])
-            x = bilstm(W, f"{p}.{br}_LSTM", x, lay2)
-            outs[br] = conv1d(W, f"{p}.{br}_proj", x, lay2, 1)
+            feats.append((f"{p}.{br}_LSTM", x))
+        hs = bilstm_many(W, feats, lay2)                  # the three recurrences share one launch
+        for br, h in zip(("F0", "N", "EMA"), hs):
+            outs[br] = conv1d(W, f"{p}.{br}_proj", h, lay2, 1)
         return outs["F0"], outs["N"], outs["EMA"], lay2
 
     def forward(self, A_ens, style, lengths=None):

@@ -211,7 +211,11 @@ def relpos_attention(qkv, C, heads, window, ek, ev, lay, out):
     return out
 
 
-def bilstm(gx_tm, whh_t, lay, H, out):
-    check(_lib.lib().as_bilstm_f32(_p(gx_tm), _ld(gx_tm), _p(whh_t), _p(lay.col_off), lay.B, H, _p(out), _ld(out),
-                                   stream()), "as_bilstm_f32")
-    return out
+def bilstm(jobs, lay, H):
+    """jobs: list of (gx_tm [N][8H], whh_t [2][H][4H], out [2H][N]) -- independent LSTMs sharing one launch."""
+    arr = (_lib.BiLstmJob * len(jobs))()
+    for i, (gx_tm, whh_t, out) in enumerate(jobs):
+        arr[i].gx_tm, arr[i].whh_t, arr[i].out = _p(gx_tm), _p(whh_t), _p(out)
+        arr[i].ldg, arr[i].ldo = _ld(gx_tm), _ld(out)
+    check(_lib.lib().as_bilstm_f32(arr, len(jobs), _p(lay.col_off), lay.B, H, stream()), "as_bilstm_f32")
+    return [j[2] for j in jobs]

@@ -151,9 +151,17 @@ int as_relpos_attention_f32(const float* qkv, int ld, int C, int heads, int wind
  * BiLSTM recurrence (K9).  gx_tm [N][ldg >= 8H] time-major gate pre-activations W_ih x + b_ih + b_hh
  * (forward gates 0..4H-1, reverse 4H..8H-1), whh_t [2][H][4H] = W_hh transposed; out [2H][N].
  * Replaces nn.LSTM at models.py:526,555-561 and :589-591,606-618.
+ * Up to AS_MAX_LSTM_JOBS independent LSTMs of the same H over the same layout (the F0 / energy / TV
+ * branches, models.py:606-618) go in one launch so their sequential recurrences overlap.
  * ------------------------------------------------------------------------------------------- */
-int as_bilstm_f32(const float* gx_tm, int ldg, const float* whh_t, const int32_t* col_off, int B, int H, float* out,
-                  int ldo, as_stream_t stream);
+#define AS_MAX_LSTM_JOBS 4
+typedef struct BiLstmJob {
+    const float* gx_tm;    /* [N][ldg] */
+    const float* whh_t;    /* [2][H][4H] */
+    float* out;            /* [2H][ldo] */
+    int32_t ldg, ldo;
+} BiLstmJob;
+int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32_t* col_off, int B, int H, as_stream_t stream);
 
 #ifdef __cplusplus
 }
