@@ -37,4 +37,4 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     L = _lib.lib()
     assert L.as_mas_f32(None, None, None, 1, 4, 4, 0, None, None, None, None, 0, None) == -1
     assert L.as_conv_gemm_f32(None, None) == -1
-    assert L.as_bilstm_f32(None, 0, None, None, 1, 128, None, 0, None) == -1
+    assert L.as_bilstm_f32(None, 1, None, 1, 128, None) == -1
