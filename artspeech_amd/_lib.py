@@ -31,10 +31,11 @@ class ConvGemmArgs(ctypes.Structure):
     _fields_ = [("W", ctypes.c_void_p), ("X", ctypes.c_void_p), ("Y", ctypes.c_void_p), ("bias", ctypes.c_void_p),
                 ("res", ctypes.c_void_p), ("meta", ctypes.c_void_p),
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("T", ctypes.c_int32),
+                ("Kp", ctypes.c_int32),
                 ("ldx", ctypes.c_int32), ("ldy", ctypes.c_int32), ("ldr", ctypes.c_int32),
                 ("act", ctypes.c_int32), ("div_sqrt2", ctypes.c_int32), ("in_act", ctypes.c_int32),
                 ("transpose_out", ctypes.c_int32),
-                ("dh", ctypes.c_int8 * (AS_MAX_TAPS + 7)), ("dw", ctypes.c_int8 * (AS_MAX_TAPS + 7))]
+                ("dh", ctypes.c_int32 * AS_MAX_TAPS), ("dw", ctypes.c_int32 * AS_MAX_TAPS)]
 
 
 _SIGNATURES.update({

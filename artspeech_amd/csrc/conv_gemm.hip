@@ -11,15 +11,29 @@
 //   nn.Conv1d k in {1,3,5,9}  (RelTransformerEnc.py:110-118,257-258,306-314; models.py:176-181,480-495,592-594)
 //   nn.Conv2d 3x3 / 1x1       (models.py:71-77, 385-399, 530-535)
 //   nn.Linear on [*, C] rows  (the LSTM input projections, hoisted out of the recurrence)
-// Weights are pre-transposed at load time to [tap][Cin][Cout] so both operands stage as coalesced
-// rows.  Tile: (64*TM) x (64*TN) x 16 per 256-thread workgroup, 2x2 waves, TM x TN MFMA tiles of
-// 32x32 per wave, register prefetch of the next k-tile + double-buffered LDS (one barrier per k-tile).
+// Weights are pre-transposed at load time to [tap][Kp][Cout] (Kp = Cin rounded up to 16, zero rows) so both
+// operands stage as coalesced rows.  Tile: (64*TM) x (64*TN) x 16 per 256-thread workgroup, 2x2 waves,
+// TM x TN MFMA tiles of 32x32 per wave.
+//
+// Staging uses raw BUFFER loads: the hardware range check returns 0 for any offset >= num_records, so
+// "tap outside the utterance", "row >= Cin", "column >= Cout" all become one select of an out-of-range
+// offset -- no divergent branches and no explicit zero fill in the loop.  The next k-tile's 16 loads per
+// thread are issued before the current tile's MFMAs and written to the other LDS buffer after them (one
+// barrier per k-tile); a k-tile's fragments are all read from LDS up front so the 8*TM*TN MFMAs issue
+// back to back behind counted lgkmcnt waits.
 #include "common.h"
 #include "conv_gemm.h"
+#include <cstdio>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK 16
+#define OOB 0xFFFFFFFFu
+
+static __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
 
 template <int TM, int TN>
 __global__ void __launch_bounds__(256)
@@ -28,6 +42,7 @@ conv_gemm_kernel(const ConvGemmArgs a)
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AROWS = BK * BM / 256;      // elements per thread per k-tile (A)
     constexpr int BROWS = BK * BN / 256;
+    constexpr int A_RSTEP = 256 / BM, B_RSTEP = 256 / BN;
     __shared__ float As[2][BK][BM];
     __shared__ float Bs[2][BK][BN];
 
@@ -41,11 +56,16 @@ conv_gemm_kernel(const ConvGemmArgs a)
     const int m0 = (tile % tiles_m) * BM;
     const int n0 = (tile / tiles_m) * BN;
 
+    const __amdgpu_buffer_rsrc_t rsW =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, (int)((unsigned)a.T * a.Kp * a.M * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((unsigned)a.K * a.ldx * 4u), 0x00020000);
+
     // ---- staging geometry: thread -> one column (A: output channel, B: frame column), BK/stride rows
-    const int a_c = tid % BM, a_r0 = tid / BM;            // rows a_r0 + i*(256/BM)
+    const int a_c = tid % BM, a_r0 = tid / BM;
     const int b_c = tid % BN, b_r0 = tid / BN;
-    constexpr int A_RSTEP = 256 / BM, B_RSTEP = 256 / BN;
     const bool a_ok = (m0 + a_c) < a.M;
+    const unsigned a_base = (unsigned)((a_r0 * a.M + m0 + a_c) * 4);
     const int j = n0 + b_c;
     unsigned tapmask = 0;
     int Wj = 0;
@@ -62,35 +82,37 @@ conv_gemm_kernel(const ConvGemmArgs a)
         }
     }
 
-    const int kt_per_tap = (a.K + BK - 1) / BK;
+    const int kt_per_tap = a.Kp / BK;
     const int nkt = a.T * kt_per_tap;
 
     float ra[AROWS], rb[BROWS];
     auto gload = [&](int kt) {
-        const int t = kt / kt_per_tap;
+        const int t = kt / kt_per_tap;                     // wave-uniform
         const int k0 = (kt - t * kt_per_tap) * BK;
-        const float* wp = a.W + ((size_t)t * a.K + k0) * a.M + m0 + a_c;
+        const unsigned a_tile = (unsigned)((t * a.Kp + k0) * a.M) * 4u;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
-            const int r = a_r0 + i * A_RSTEP;
-            ra[i] = (a_ok && (k0 + r) < a.K) ? wp[(size_t)r * a.M] : 0.f;
+            const unsigned off = a_base + a_tile + (unsigned)(i * A_RSTEP * a.M) * 4u;
+            ra[i] = buf_load(rsW, a_ok ? off : OOB);
         }
         const bool ok = (tapmask >> t) & 1u;
-        const long src = (long)j + (long)a.dh[t] * Wj + a.dw[t];
-        const float* xp = a.X + (size_t)k0 * a.ldx + src;
+        const int src = j + a.dh[t] * Wj + a.dw[t];
+        const unsigned b_base = (unsigned)((b_r0 + k0) * a.ldx + src) * 4u;
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
-            const int r = b_r0 + i * B_RSTEP;
-            float v = (ok && (k0 + r) < a.K) ? xp[(size_t)r * a.ldx] : 0.f;
-            if (a.in_act == 2) v = v > 0.f ? v : 0.2f * v;     // LeakyReLU fused on the operand (models.py:89,142)
-            rb[i] = v;
+            const unsigned off = b_base + (unsigned)(i * B_RSTEP * a.ldx) * 4u;
+            rb[i] = buf_load(rsX, ok ? off : OOB);         // rows >= K fall outside num_records -> 0
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) As[buf][a_r0 + i * A_RSTEP][a_c] = ra[i];
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) Bs[buf][b_r0 + i * B_RSTEP][b_c] = rb[i];
+        for (int i = 0; i < BROWS; ++i) {
+            float v = rb[i];
+            if (a.in_act == 2) v = v > 0.f ? v : 0.2f * v;  // LeakyReLU fused on the operand (models.py:89,142)
+            Bs[buf][b_r0 + i * B_RSTEP][b_c] = v;
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -108,19 +130,21 @@ conv_gemm_kernel(const ConvGemmArgs a)
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) gload(kt + 1);
+        float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[TM], bf[TN];
+        for (int s = 0; s < BK / 2; ++s) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[buf][kk + lk][wm * 32 * TM + i * 32 + l31];
+            for (int i = 0; i < TM; ++i) af[s][i] = As[buf][2 * s + lk][wm * 32 * TM + i * 32 + l31];
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn) bf[jn] = Bs[buf][kk + lk][wn * 32 * TN + jn * 32 + l31];
+            for (int jn = 0; jn < TN; ++jn) bf[s][jn] = Bs[buf][2 * s + lk][wn * 32 * TN + jn * 32 + l31];
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jn], acc[i][jn], 0, 0, 0);
-        }
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i], bf[s][jn], acc[i][jn], 0, 0, 0);
         if (kt + 1 < nkt) lstore(buf ^ 1);
         __syncthreads();
     }
@@ -171,12 +195,15 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if (!args_host) return AS_EINVAL;
     const ConvGemmArgs& a = *args_host;
     if (!a.W || !a.X || !a.Y || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS) return AS_EINVAL;
+    if (a.Kp < a.K || a.Kp % BK) return AS_EINVAL;
     if (a.ldx < a.N || a.ldy < (a.transpose_out ? a.M : a.N) || (a.res && (a.ldr < a.N || a.transpose_out))) return AS_EINVAL;
+    // 32-bit byte offsets inside the buffer descriptors
+    if ((double)a.T * a.Kp * a.M * 4.0 >= 4294967296.0 || (double)a.K * a.ldx * 4.0 >= 4294967296.0) return AS_EINVAL;
     if (a.N == 0) return AS_OK;
     const int choice = gemm_tile_choice(a.M, a.N);
-    // algorithmic work of this launch: 2*M*N*K*T flop; bytes = weights + input + output once
     char tag[64];
     snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d", a.M, a.N, a.K, a.T, choice);
+    // algorithmic work of this launch: 2*M*N*K*T flop; bytes = weights + input + output once
     AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.K * a.T,
                        4.0 * ((double)a.T * a.K * a.M + (double)a.K * a.N + (double)a.M * a.N), stream, tag);
     switch (choice) {

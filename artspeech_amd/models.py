@@ -63,9 +63,7 @@ class Weights:
         """conv weight [Cout,Cin,k] or [Cout,Cin,kh,kw] -> [taps][Cin][Cout]."""
         key = "T:" + name
         if key not in self._cache:
-            w = self.raw[name + ".weight"]
-            cout, cin = w.shape[0], w.shape[1]
-            self._cache[key] = w.reshape(cout, cin, -1).permute(2, 1, 0).contiguous().to(self.device)
+            self._cache[key] = ops.prep_weight(self.raw[name + ".weight"]).to(self.device)
         return self._cache[key]
 
     def bias(self, name):
@@ -76,7 +74,7 @@ class Weights:
         if key not in self._cache:
             w = torch.cat([self.raw[f"{p}.conv_{n}.weight"] for n in "qkv"], 0)      # [3C, C, 1]
             b = torch.cat([self.raw[f"{p}.conv_{n}.bias"] for n in "qkv"], 0)
-            self._cache[key] = (w.permute(2, 1, 0).contiguous().to(self.device), b.to(self.device))
+            self._cache[key] = (ops.prep_weight(w).to(self.device), b.to(self.device))
         return self._cache[key]
 
     def lstm(self, p):
@@ -221,9 +219,9 @@ def tower2d(W, p, X, lay, kinds, last_idx, last_stride, linear):
         raise ValueError(f"{p}: reference utterance too short for the {K}x{K} valid conv (SURVEY.md A9: T_ref >= 66)")
     C = x.shape[0]
     col = ops.im2col_valid(x, lay, lout.new(C * K * K), lout, K, last_stride, True)
-    wl = W.conv(f"{p}.{last_idx}")                       # [25][C][Cout] -> K-major [1][C*25][Cout]
-    wl2 = W.cached("IM2COL:" + p, lambda: wl.permute(1, 0, 2).reshape(1, C * K * K, wl.shape[2]).contiguous())
-    y = ops.conv_gemm(wl2, col, lout, lout.new(wl.shape[2]), [(0, 0)], bias=W.bias(f"{p}.{last_idx}"), act=ACT_LRELU)
+    wraw = W.raw[f"{p}.{last_idx}.weight"]               # [Cout][C][5][5] -> one tap with K = C*25 (im2col row order)
+    wl2 = W.cached("IM2COL:" + p, lambda: ops.prep_weight(wraw.reshape(wraw.shape[0], C * K * K, 1)).to(W.device))
+    y = ops.conv_gemm(wl2, col, lout, lout.new(wraw.shape[0]), [(0, 0)], bias=W.bias(f"{p}.{last_idx}"), act=ACT_LRELU)
     pooled = ops.mean_pool(y, lout, False)
     return ops.linear_rows(pooled, W.vec(linear + ".weight"), W.vec(linear + ".bias"))
 

@@ -89,6 +89,17 @@ def layout(widths, device, H=1):
     return lay
 
 
+def prep_weight(w):
+    """conv / linear weight [Cout, Cin, *kernel] -> the GEMM's [taps][Kp][Cout] image: transposed so that output
+    channels are contiguous, input channels zero-padded to a multiple of 16 (one k-tile)."""
+    cout, cin = w.shape[0], w.shape[1]
+    wt = w.reshape(cout, cin, -1).permute(2, 1, 0)
+    kp = (cin + 15) // 16 * 16
+    if kp != cin:
+        wt = torch.cat([wt, wt.new_zeros(wt.shape[0], kp - cin, cout)], dim=1)
+    return wt.contiguous()
+
+
 def taps_1d(k):
     return [(0, t - k // 2) for t in range(k)]
 
@@ -99,16 +110,21 @@ def taps_2d(kh, kw):
 
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
               use_meta=True):
-    """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt [T][K][M]; X [K][*]; Y [M][*] (or [N][*] transposed)."""
-    T, K, M = Wt.shape
+    """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt [T][Kp][M] (prep_weight: K zero-padded to a multiple
+    of 16); X [K][*]; Y [M][*] (or [N][*] transposed)."""
+    T, Kp, M = Wt.shape
+    K = X.shape[0]
+    if Kp % 16 or not (Kp - 16 < K <= Kp):
+        raise ValueError(f"conv_gemm: weight rows {Kp} do not match input channels {K} (use ops.prep_weight)")
     a = ConvGemmArgs()
+    a.Kp = Kp
     a.W, a.X, a.Y, a.bias, a.res = _p(Wt), _p(X), _p(Y), _p(bias), _p(res)
     a.meta = _p(lay.meta) if (use_meta and not (T == 1 and taps[0] == (0, 0))) else None
     a.M, a.N, a.K, a.T = M, lay.N, K, T
     a.ldx, a.ldy = _ld(X), _ld(Y)
     a.ldr = _ld(res) if res is not None else 0
     a.act, a.div_sqrt2, a.in_act, a.transpose_out = act, int(div_sqrt2), in_act, int(transpose_out)
-    assert len(taps) == T and X.shape[0] >= K
+    assert len(taps) == T
     for i, (dh, dw) in enumerate(taps):
         a.dh[i], a.dw[i] = dh, dw
     check(_lib.lib().as_conv_gemm_f32(ctypes.byref(a), stream()), "as_conv_gemm_f32")

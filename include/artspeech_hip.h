@@ -75,20 +75,21 @@ int as_make_meta(const int32_t* widths, const int32_t* col_off, int B, int H, in
  * ------------------------------------------------------------------------------------------- */
 #define AS_MAX_TAPS 25
 typedef struct ConvGemmArgs {
-    const float* W;        /* [T][K][M] */
+    const float* W;        /* [T][Kp][M] */
     const float* X;        /* [K][ldx] */
     float* Y;              /* [M][ldy] */
     const float* bias;     /* [M] or NULL */
     const float* res;      /* [M][ldr] or NULL (may alias Y) */
     const uint64_t* meta;  /* [N] column descriptors, or NULL = every tap valid */
     int32_t M, N, K, T;
+    int32_t Kp;            /* rows per tap in W: K rounded up to a multiple of 16, the extra rows zero */
     int32_t ldx, ldy, ldr;
     int32_t act;           /* epilogue activation: 0 none, 1 ReLU, 2 LeakyReLU(0.2) */
     int32_t div_sqrt2;     /* epilogue: divide by sqrt(2) after bias and residual */
     int32_t in_act;        /* 2 = LeakyReLU(0.2) applied to X while staging (models.py:89,142) */
     int32_t transpose_out; /* 1 = write Y[j][m] (time-major, row stride ldy >= M) */
-    int8_t dh[AS_MAX_TAPS + 7];
-    int8_t dw[AS_MAX_TAPS + 7];
+    int32_t dh[AS_MAX_TAPS];   /* tap row offsets (scalar-loadable) */
+    int32_t dw[AS_MAX_TAPS];   /* tap column offsets */
 } ConvGemmArgs;
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
 

@@ -29,7 +29,7 @@ def test_conv1d_gemm(cuda, monkeypatch, cin, cout, k, lens, tile):
     res = [torch.randn(cout, L, generator=g) for L in lens]
     want = packed([(F.conv1d(x[None], w, b, padding=k // 2)[0] + r) / np.sqrt(2) for x, r in zip(xs, res)])
     lay = Layout(lens, cuda)
-    wt = w.permute(2, 1, 0).contiguous().to(cuda)
+    wt = ops.prep_weight(w).to(cuda)
     y = ops.conv_gemm(wt, packed(xs).to(cuda), lay, lay.new(cout), taps_1d(k), bias=b.to(cuda), res=packed(res).to(cuda),
                       div_sqrt2=True)
     err = float((y.cpu() - want).abs().max())
@@ -45,7 +45,7 @@ def test_conv2d_gemm_and_transpose_out(cuda):
     xs = [torch.randn(cin, H, W, generator=g) for W in widths]
     want = packed([F.conv2d(F.leaky_relu(x, 0.2)[None], w, b, padding=1)[0].reshape(cout, -1) for x in xs])
     lay = Layout(widths, cuda, H=H)
-    wt = w.reshape(cout, cin, 9).permute(2, 1, 0).contiguous().to(cuda)
+    wt = ops.prep_weight(w).to(cuda)
     X = packed([x.reshape(cin, -1) for x in xs]).to(cuda)
     y = ops.conv_gemm(wt, X, lay, lay.new(cout), taps_2d(3, 3), bias=b.to(cuda), in_act=ops.ACT_LRELU)
     assert float((y.cpu() - want).abs().max()) <= 2e-5
@@ -60,7 +60,7 @@ def test_mfma_layout_asymmetric(cuda):
     w = torch.eye(n)[:, :, None]                                  # [cout, cin, 1]
     x = torch.arange(n * 96, dtype=torch.float32).reshape(n, 96)
     lay = Layout([96], cuda)
-    y = ops.conv_gemm(w.permute(2, 1, 0).contiguous().to(cuda), x.to(cuda), lay, lay.new(n), [(0, 0)])
+    y = ops.conv_gemm(ops.prep_weight(w).to(cuda), x.to(cuda), lay, lay.new(n), [(0, 0)])
     assert torch.equal(y.cpu(), x)
 
 
