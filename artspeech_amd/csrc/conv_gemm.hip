@@ -83,7 +83,11 @@ conv_gemm_kernel(const ConvGemmArgs a)
     }
 
     const int kt_per_tap = a.Kp / BK;
-    const int nkt = a.T * kt_per_tap;
+    const int nkt_all = a.T * kt_per_tap;
+    // split-K: blockIdx.y owns a contiguous slice of the (tap, k-tile) sequence and writes a raw partial slab
+    const int S = gridDim.y;
+    const int kt_lo = (int)((long)nkt_all * blockIdx.y / S);
+    const int nkt = (int)((long)nkt_all * (blockIdx.y + 1) / S);
 
     float ra[AROWS], rb[BROWS];
     auto gload = [&](int kt) {
@@ -124,32 +128,56 @@ conv_gemm_kernel(const ConvGemmArgs a)
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
     const int l31 = lane & 31, lk = lane >> 5;
-    gload(0);
-    lstore(0);
+    gload(kt_lo);
+    lstore(kt_lo & 1);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt_lo; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) gload(kt + 1);
-        float af[BK / 2][TM], bf[BK / 2][TN];
+        // fragments of k-step s+1 are requested BEFORE the MFMAs of step s issue (sched_barrier pins the order;
+        // hipcc otherwise sinks each ds_read next to its use and exposes the LDS latency once per step)
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = As[buf][lk][wm * 32 * TM + i * 32 + l31];
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bf[0][jn] = Bs[buf][lk][wn * 32 * TN + jn * 32 + l31];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
+            if (s + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[s][i] = As[buf][2 * s + lk][wm * 32 * TM + i * 32 + l31];
+                for (int i = 0; i < TM; ++i) af[(s + 1) & 1][i] = As[buf][2 * (s + 1) + lk][wm * 32 * TM + i * 32 + l31];
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn) bf[s][jn] = Bs[buf][2 * s + lk][wn * 32 * TN + jn * 32 + l31];
-        }
-#pragma unroll
-        for (int s = 0; s < BK / 2; ++s)
+                for (int jn = 0; jn < TN; ++jn) bf[(s + 1) & 1][jn] = Bs[buf][2 * (s + 1) + lk][wn * 32 * TN + jn * 32 + l31];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i], bf[s][jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i], bf[s & 1][jn], acc[i][jn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (kt + 1 < nkt) lstore(buf ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue: C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+    if (S > 1) {                                           // raw partial sums; splitk_reduce_kernel finishes
+        float* slab = a.ws + (size_t)blockIdx.y * a.M * a.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                const int col = n0 + wn * 32 * TN + jn * 32 + l31;
+                if (col >= a.N) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                    if (row < a.M) slab[(size_t)row * a.N + col] = acc[i][jn][e];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -171,6 +199,56 @@ conv_gemm_kernel(const ConvGemmArgs a)
             }
         }
     }
+}
+
+// y = epi(sum_s slab[s]) in a fixed order (deterministic, unlike float atomics)
+__global__ void splitk_reduce_kernel(const ConvGemmArgs a, int S)
+{
+    const long total = (long)a.M * a.N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += a.ws[(size_t)s * total + i];
+        if (a.bias) v += a.bias[row];
+        if (a.res) v += a.res[(size_t)row * a.ldr + col];
+        if (a.div_sqrt2) v = v / 1.41421356237309504880f;
+        if (a.act == 1) v = v > 0.f ? v : 0.f;
+        else if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
+        if (a.transpose_out) a.Y[(size_t)col * a.ldy + row] = v;
+        else a.Y[(size_t)row * a.ldy + col] = v;
+    }
+}
+
+static void tile_dims(int choice, int* bm, int* bn)
+{
+    *bm = (choice == 22 || choice == 21) ? 128 : 64;
+    *bn = (choice == 22 || choice == 12) ? 128 : 64;
+}
+
+// number of K slices: only for grids that cannot fill 256 CUs, and only while a slice keeps >= 8 k-tiles
+static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
+{
+    const char* env = getenv("AS_GEMM_KSPLIT");          // tuning/experiments only
+    int bm, bn;
+    tile_dims(choice, &bm, &bn);
+    const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
+    const int nkt = T * (Kp / BK);
+    int s = 1;
+    if (env && atoi(env) > 0) s = atoi(env);
+    else if (tiles < 384) s = as_cdiv(768, tiles);
+    if (s > nkt / 8) s = nkt / 8;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+static int gemm_tile_choice(int M, int N);
+
+extern "C" size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host)
+{
+    if (!args_host || args_host->M <= 0 || args_host->N <= 0 || args_host->Kp <= 0 || args_host->T <= 0) return 0;
+    const ConvGemmArgs& a = *args_host;
+    const int s = gemm_ksplit(a.M, a.N, a.Kp, a.T, gemm_tile_choice(a.M, a.N));
+    return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
 }
 
 static int gemm_tile_choice(int M, int N)
@@ -201,17 +279,26 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if ((double)a.T * a.Kp * a.M * 4.0 >= 4294967296.0 || (double)a.K * a.ldx * 4.0 >= 4294967296.0) return AS_EINVAL;
     if (a.N == 0) return AS_OK;
     const int choice = gemm_tile_choice(a.M, a.N);
+    int S = gemm_ksplit(a.M, a.N, a.Kp, a.T, choice);
+    if (S > 1 && (!a.ws || a.ws_bytes < (size_t)S * a.M * a.N * sizeof(float))) S = 1;   // no workspace: no split
     char tag[64];
-    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d", a.M, a.N, a.K, a.T, choice);
+    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d S%d", a.M, a.N, a.K, a.T, choice, S);
     // algorithmic work of this launch: 2*M*N*K*T flop; bytes = weights + input + output once
     AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.K * a.T,
                        4.0 * ((double)a.T * a.K * a.M + (double)a.K * a.N + (double)a.M * a.N), stream, tag);
     switch (choice) {
-    case 22: hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 128)), dim3(256), 0, stream, a); break;
-    case 21: hipLaunchKernelGGL((conv_gemm_kernel<2, 1>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 64)), dim3(256), 0, stream, a); break;
-    case 12: hipLaunchKernelGGL((conv_gemm_kernel<1, 2>), dim3(as_cdiv(a.M, 64) * as_cdiv(a.N, 128)), dim3(256), 0, stream, a); break;
-    default: hipLaunchKernelGGL((conv_gemm_kernel<1, 1>), dim3(as_cdiv(a.M, 64) * as_cdiv(a.N, 64)), dim3(256), 0, stream, a); break;
+    case 22: hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 128), S), dim3(256), 0, stream, a); break;
+    case 21: hipLaunchKernelGGL((conv_gemm_kernel<2, 1>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 64), S), dim3(256), 0, stream, a); break;
+    case 12: hipLaunchKernelGGL((conv_gemm_kernel<1, 2>), dim3(as_cdiv(a.M, 64) * as_cdiv(a.N, 128), S), dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL((conv_gemm_kernel<1, 1>), dim3(as_cdiv(a.M, 64) * as_cdiv(a.N, 64), S), dim3(256), 0, stream, a); break;
     }
     AS_CHECK_LAUNCH();
+    if (S > 1) {
+        const long total = (long)a.M * a.N;
+        int blocks = as_cdiv(total, 256 * 4);
+        blocks = blocks > 2048 ? 2048 : blocks;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a, S);
+        AS_CHECK_LAUNCH();
+    }
     return AS_OK;
 }

@@ -127,7 +127,12 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     assert len(taps) == T
     for i, (dh, dw) in enumerate(taps):
         a.dh[i], a.dw[i] = dh, dw
-    check(_lib.lib().as_conv_gemm_f32(ctypes.byref(a), stream()), "as_conv_gemm_f32")
+    L = _lib.lib()
+    nbytes = L.as_conv_gemm_workspace_bytes(ctypes.byref(a))
+    if nbytes:                                       # small grid: split-K partial slabs (caller-owned scratch)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=Y.device)
+        a.ws, a.ws_bytes = ws.data_ptr(), nbytes
+    check(L.as_conv_gemm_f32(ctypes.byref(a), stream()), "as_conv_gemm_f32")
     return Y
 
 

@@ -81,6 +81,8 @@ typedef struct ConvGemmArgs {
     const float* bias;     /* [M] or NULL */
     const float* res;      /* [M][ldr] or NULL (may alias Y) */
     const uint64_t* meta;  /* [N] column descriptors, or NULL = every tap valid */
+    float* ws;             /* split-K partial slabs (as_conv_gemm_workspace_bytes), or NULL = never split */
+    size_t ws_bytes;
     int32_t M, N, K, T;
     int32_t Kp;            /* rows per tap in W: K rounded up to a multiple of 16, the extra rows zero */
     int32_t ldx, ldy, ldr;
@@ -92,6 +94,9 @@ typedef struct ConvGemmArgs {
     int32_t dw[AS_MAX_TAPS];   /* tap column offsets */
 } ConvGemmArgs;
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
+/* Bytes of split-K workspace this shape wants (0 = none).  Shapes whose tile grid cannot fill the 256 CUs
+ * are split along (tap, Cin) into slices; a second kernel sums the slabs in a fixed order (deterministic). */
+size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host);
 
 /* ---------------------------------------------------------------------------------------------
  * Bandwidth-bound kernels on packed frames.  col_off int32 [B+1] = first column of each utterance.

@@ -196,3 +196,20 @@ def test_down_sampling(cuda, kind):
     col = ops.im2col_valid(X, lay, lo.new(C * 25), lo, 5, 2, False).cpu()
     want = packed([F.unfold(x[None], 5, stride=2)[0] for x in xs])
     assert torch.equal(col, want)
+
+
+@pytest.mark.parametrize("ksplit", ["2", "5", "16"])
+def test_conv_gemm_split_k(cuda, monkeypatch, ksplit):
+    """split-K slabs + fixed-order reduce give the same result as the unsplit kernel (to rounding)."""
+    monkeypatch.setenv("AS_GEMM_KSPLIT", ksplit)
+    g = torch.Generator().manual_seed(int(ksplit))
+    cin, cout, k, lens = 200, 96, 5, [33, 70]
+    w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    xs = [torch.randn(cin, L, generator=g) for L in lens]
+    res = [torch.randn(cout, L, generator=g) for L in lens]
+    want = packed([F.leaky_relu((F.conv1d(x[None], w, b, padding=k // 2)[0] + r) / np.sqrt(2), 0.2) for x, r in zip(xs, res)])
+    lay = Layout(lens, cuda)
+    y = ops.conv_gemm(ops.prep_weight(w).to(cuda), packed(xs).to(cuda), lay, lay.new(cout), taps_1d(k), bias=b.to(cuda),
+                      res=packed(res).to(cuda), div_sqrt2=True, act=ops.ACT_LRELU)
+    assert float((y.cpu() - want).abs().max()) <= 2e-5
