@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libartspeech_hip.so")
+LIB_PATH = os.environ.get("AS_LIB_PATH") or os.path.join(_HERE, "lib", "libartspeech_hip.so")   # override: kernel experiments
 _lib = None
 
 c_p = ctypes.c_void_p

@@ -132,8 +132,14 @@ conv_gemm_kernel(const ConvGemmArgs a)
     lstore(kt_lo & 1);
     __syncthreads();
     for (int kt = kt_lo; kt < nkt; ++kt) {
+#ifdef AS_EXP_NO_STAGE                      // experiment: MFMA + LDS reads only (results are garbage)
+        const int buf = 0;
+#else
         const int buf = kt & 1;
+#endif
+#if !defined(AS_EXP_NO_GLOAD) && !defined(AS_EXP_NO_STAGE)
         if (kt + 1 < nkt) gload(kt + 1);
+#endif
         // fragments of k-step s+1 are requested BEFORE the MFMAs of step s issue (sched_barrier pins the order;
         // hipcc otherwise sinks each ds_read next to its use and exposes the LDS latency once per step)
         float af[2][TM], bf[2][TN];
@@ -157,8 +163,10 @@ conv_gemm_kernel(const ConvGemmArgs a)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i], bf[s & 1][jn], acc[i][jn], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef AS_EXP_NO_STAGE
         if (kt + 1 < nkt) lstore(buf ^ 1);
         __syncthreads();
+#endif
     }
 
     // ---- epilogue: C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
