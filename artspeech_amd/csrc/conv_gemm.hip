@@ -52,7 +52,11 @@ conv_gemm_kernel(const ConvGemmArgs a)
     const int wm = wave & 1, wn = wave >> 1;
 
     const int tiles_m = (a.M + BM - 1) / BM;
-    const int tile = blockIdx.x;
+    // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+    // contiguous run of logical tiles -- the output-channel tiles of one column range then share that XCD's L2
+    // copy of the activation columns instead of fetching them 8 times.  Bijective for any grid size.
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, q8 = nb >> 3, r8 = nb & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     const int m0 = (tile % tiles_m) * BM;
     const int n0 = (tile / tiles_m) * BN;
 

@@ -133,3 +133,36 @@ def test_submodule_surfaces(cuda, golden_dir):
     dur = net.durationPredictor(tokens[None], torch.from_numpy(g["ref/ema_ext"])[None], torch.tensor([len(tokens)]),
                                 torch.tensor([int(g["t_ref"])]))
     assert float(np.abs(dur[0].cpu().numpy() - g["ref/duration"]).max()) <= AUX_TOL
+
+
+def test_long_form_c5(cuda):
+    """BASELINE config 5: 1024 phonemes -> 2048 mel frames, batch 8 (attention over 16 key tiles, 2048-step
+    LSTMs, K1-sized lattices).  Forced all-ones durations as SURVEY.md section 8 prescribes; two of the eight
+    utterances are checked against the oracle (CPU time), the rest through batch-independence."""
+    from oracle import acoustic
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    hd, di, seed = 512, 64, 3407
+    net = get_model(hd, di, seed, cuda)
+    W = fold_state_dict(synth.synth_state_dict(hd, di, seed=seed))
+    dist = load_distribution(DEFAULT_STATS)
+    B, N, T = 8, 1024, 200
+    toks = [synth.synth_tokens(N, 100 + b) for b in range(B)]
+    feats = [raw_features(T, 100 + b) for b in range(B)]
+    texts = torch.from_numpy(np.stack(toks))
+    mels = torch.from_numpy(np.stack([f[0] for f in feats]))
+    f0s = torch.from_numpy(np.stack([f[1] for f in feats]))
+    emas = torch.from_numpy(np.stack([f[2] for f in feats]))
+    forced = [np.ones(N, np.int64)] * B
+    out = net([texts, torch.full((B,), N), mels, torch.full((B,), T)], None, None, step="test", features=(f0s, emas),
+              forced_durations=forced)
+    assert out.shape == (B, 80, 2 * N)
+    for b in (0, 5):
+        ref = acoustic.forward_test(W, torch.from_numpy(toks[b]), torch.from_numpy(feats[b][0]), torch.from_numpy(feats[b][1]),
+                                    torch.from_numpy(feats[b][2]), dist, forced_dur=forced[b])
+        d = float((out[b].cpu() - ref["mel"]).abs().max())
+        print("C5 utterance", b, "mel max-abs", d)
+        assert d <= MEL_TOL, (b, d)
+    # batch independence: utterance 3 alone == utterance 3 inside the batch
+    solo = net([texts[3:4], torch.tensor([N]), mels[3:4], torch.tensor([T])], None, None, step="test",
+               features=(f0s[3:4], emas[3:4]), forced_durations=forced[3:4])
+    assert float((solo[0] - out[3]).abs().max()) <= 1e-5
