@@ -13,167 +13,79 @@
 //   nn.Linear on [*, C] rows  (the LSTM input projections, hoisted out of the recurrence)
 // Weights are pre-transposed at load time to [tap][Kp][Cout] (Kp = Cin rounded up to 16, zero rows) so both
 // operands stage as coalesced rows.  Tile: (64*TM) x (64*TN) x 16 per 256-thread workgroup, 2x2 waves,
-// TM x TN MFMA tiles of 32x32 per wave.
+// TM x TN MFMA tiles of 32x32 per wave; double-buffered LDS, one barrier per k-tile; the fragments of k-step
+// s+1 are requested before the MFMAs of step s issue.
 //
 // Staging uses raw BUFFER loads: the hardware range check returns 0 for any offset >= num_records, so
-// "tap outside the utterance", "row >= Cin", "column >= Cout" all become one select of an out-of-range
-// offset -- no divergent branches and no explicit zero fill in the loop.  The next k-tile's 16 loads per
-// thread are issued before the current tile's MFMAs and written to the other LDS buffer after them (one
-// barrier per k-tile); a k-tile's fragments are all read from LDS up front so the 8*TM*TN MFMAs issue
-// back to back behind counted lgkmcnt waits.
+// "tap outside the utterance", "row >= Cin", "column >= Cout" become a select of an out-of-range offset --
+// no divergent branches, no zero fill in the loop.  Two instantiations of the staging:
+//   QUAD   (args.quad_ok): a thread stages 16-byte quads -- 4 output channels / 4 consecutive frame columns of
+//          one k row -- with ONE buffer_load_dwordx4 whose offset is a per-thread VGPR (fixed per tap) plus a
+//          wave-uniform SGPR, and one ds_write_b128.  Needs M % 4 == 0, 16 readable bytes in front of X and no
+//          quad straddling images of different width (the caller knows its layout; ops.py decides).
+//   SCALAR (always correct): one dword per load, validity per column.
 #include "common.h"
 #include "conv_gemm.h"
 #include <cstdio>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define BK 16
 #define OOB 0xFFFFFFFFu
 
-static __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off)
+static __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+static __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-template <int TM, int TN>
-__global__ void __launch_bounds__(256)
-conv_gemm_kernel(const ConvGemmArgs a)
+// XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
+// run of logical tiles -- the output-channel tiles of one column range then share that XCD's L2 copy of the
+// activation columns.  Bijective for any grid size.
+static __device__ __forceinline__ int logical_tile()
 {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int AROWS = BK * BM / 256;      // elements per thread per k-tile (A)
-    constexpr int BROWS = BK * BN / 256;
-    constexpr int A_RSTEP = 256 / BM, B_RSTEP = 256 / BN;
-    __shared__ float As[2][BK][BM];
-    __shared__ float Bs[2][BK][BN];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-
-    const int tiles_m = (a.M + BM - 1) / BM;
-    // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
-    // contiguous run of logical tiles -- the output-channel tiles of one column range then share that XCD's L2
-    // copy of the activation columns instead of fetching them 8 times.  Bijective for any grid size.
     const int nb = gridDim.x, xcd = blockIdx.x & 7, q8 = nb >> 3, r8 = nb & 7;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int m0 = (tile % tiles_m) * BM;
-    const int n0 = (tile / tiles_m) * BN;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+}
 
-    const __amdgpu_buffer_rsrc_t rsW =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, (int)((unsigned)a.T * a.Kp * a.M * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsX =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((unsigned)a.K * a.ldx * 4u), 0x00020000);
-
-    // ---- staging geometry: thread -> one column (A: output channel, B: frame column), BK/stride rows
-    const int a_c = tid % BM, a_r0 = tid / BM;
-    const int b_c = tid % BN, b_r0 = tid / BN;
-    const bool a_ok = (m0 + a_c) < a.M;
-    const unsigned a_base = (unsigned)((a_r0 * a.M + m0 + a_c) * 4);
-    const int j = n0 + b_c;
-    unsigned tapmask = 0;
-    int Wj = 0;
-    if (j < a.N) {
-        if (a.meta) {
-            const unsigned long long md = a.meta[j];
-            const int h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff);
-            const int H = (int)((md >> 32) & 0xffff);
-            Wj = (int)(md >> 48);
-            for (int t = 0; t < a.T; ++t)
-                if ((unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)Wj) tapmask |= 1u << t;
-        } else {
-            tapmask = 0xffffffffu;
+// one k-tile of MFMAs from LDS buffer `buf`
+template <int TM, int TN, int BM, int BN>
+static __device__ __forceinline__ void mma_tile(const float (*As)[BK][BM], const float (*Bs)[BK][BN], int buf, int wm,
+                                                int wn, int l31, int lk, f32x16 (&acc)[TM][TN])
+{
+    float af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = As[buf][lk][wm * 32 * TM + i * 32 + l31];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) bf[0][jn] = Bs[buf][lk][wn * 32 * TN + jn * 32 + l31];
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+        if (s + 1 < BK / 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[(s + 1) & 1][i] = As[buf][2 * (s + 1) + lk][wm * 32 * TM + i * 32 + l31];
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) bf[(s + 1) & 1][jn] = Bs[buf][2 * (s + 1) + lk][wn * 32 * TN + jn * 32 + l31];
         }
+        // sched_barrier pins "request next fragments, then MFMA": hipcc otherwise sinks each ds_read next to its use
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i], bf[s & 1][jn], acc[i][jn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
+}
 
-    const int kt_per_tap = a.Kp / BK;
-    const int nkt_all = a.T * kt_per_tap;
-    // split-K: blockIdx.y owns a contiguous slice of the (tap, k-tile) sequence and writes a raw partial slab
-    const int S = gridDim.y;
-    const int kt_lo = (int)((long)nkt_all * blockIdx.y / S);
-    const int nkt = (int)((long)nkt_all * (blockIdx.y + 1) / S);
-
-    float ra[AROWS], rb[BROWS];
-    auto gload = [&](int kt) {
-        const int t = kt / kt_per_tap;                     // wave-uniform
-        const int k0 = (kt - t * kt_per_tap) * BK;
-        const unsigned a_tile = (unsigned)((t * a.Kp + k0) * a.M) * 4u;
-#pragma unroll
-        for (int i = 0; i < AROWS; ++i) {
-            const unsigned off = a_base + a_tile + (unsigned)(i * A_RSTEP * a.M) * 4u;
-            ra[i] = buf_load(rsW, a_ok ? off : OOB);
-        }
-        const bool ok = (tapmask >> t) & 1u;
-        const int src = j + a.dh[t] * Wj + a.dw[t];
-        const unsigned b_base = (unsigned)((b_r0 + k0) * a.ldx + src) * 4u;
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i) {
-            const unsigned off = b_base + (unsigned)(i * B_RSTEP * a.ldx) * 4u;
-            rb[i] = buf_load(rsX, ok ? off : OOB);         // rows >= K fall outside num_records -> 0
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AROWS; ++i) As[buf][a_r0 + i * A_RSTEP][a_c] = ra[i];
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i) {
-            float v = rb[i];
-            if (a.in_act == 2) v = v > 0.f ? v : 0.2f * v;  // LeakyReLU fused on the operand (models.py:89,142)
-            Bs[buf][b_r0 + i * B_RSTEP][b_c] = v;
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
-
-    const int l31 = lane & 31, lk = lane >> 5;
-    gload(kt_lo);
-    lstore(kt_lo & 1);
-    __syncthreads();
-    for (int kt = kt_lo; kt < nkt; ++kt) {
-#ifdef AS_EXP_NO_STAGE                      // experiment: MFMA + LDS reads only (results are garbage)
-        const int buf = 0;
-#else
-        const int buf = kt & 1;
-#endif
-#if !defined(AS_EXP_NO_GLOAD) && !defined(AS_EXP_NO_STAGE)
-        if (kt + 1 < nkt) gload(kt + 1);
-#endif
-        // fragments of k-step s+1 are requested BEFORE the MFMAs of step s issue (sched_barrier pins the order;
-        // hipcc otherwise sinks each ds_read next to its use and exposes the LDS latency once per step)
-        float af[2][TM], bf[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = As[buf][lk][wm * 32 * TM + i * 32 + l31];
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) bf[0][jn] = Bs[buf][lk][wn * 32 * TN + jn * 32 + l31];
-#pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            if (s + 1 < BK / 2) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[(s + 1) & 1][i] = As[buf][2 * (s + 1) + lk][wm * 32 * TM + i * 32 + l31];
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn) bf[(s + 1) & 1][jn] = Bs[buf][2 * (s + 1) + lk][wn * 32 * TN + jn * 32 + l31];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i], bf[s & 1][jn], acc[i][jn], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#ifndef AS_EXP_NO_STAGE
-        if (kt + 1 < nkt) lstore(buf ^ 1);
-        __syncthreads();
-#endif
-    }
-
-    // ---- epilogue: C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+// C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+template <int TM, int TN>
+static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
+                                                int wn, int l31, int lk, int S)
+{
     if (S > 1) {                                           // raw partial sums; splitk_reduce_kernel finishes
         float* slab = a.ws + (size_t)blockIdx.y * a.M * a.N;
 #pragma unroll
@@ -213,6 +125,260 @@ conv_gemm_kernel(const ConvGemmArgs a)
     }
 }
 
+// ======================================================================================================
+// QUAD staging
+// ======================================================================================================
+template <int TM, int TN>
+__global__ void __launch_bounds__(256)
+conv_gemm_quad_kernel(const ConvGemmArgs a)
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int AQ = BK * BM / 4 / 256;     // quads per thread per k-tile
+    constexpr int BQ = BK * BN / 4 / 256;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1, l31 = lane & 31, lk = lane >> 5;
+    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tile = logical_tile();
+    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+
+    const __amdgpu_buffer_rsrc_t rsW =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, (int)((unsigned)a.T * a.Kp * a.M * 4u), 0x00020000);
+    // X descriptor starts 16 bytes in front of X (quad_ok promises they are readable): a quad whose first column
+    // is masked may start at column -1..-4 of row 0 without its offset wrapping
+    const __amdgpu_buffer_rsrc_t rsX =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X) - 4, 0, (int)((unsigned)a.K * a.ldx * 4u + 16u), 0x00020000);
+
+    // thread -> quads q = tid + i*256: row = q / (B?/4), first column = (q % (B?/4)) * 4
+    unsigned a_voff[AQ];
+#pragma unroll
+    for (int i = 0; i < AQ; ++i) {
+        const int q = tid + i * 256, row = q / (BM / 4), col = (q % (BM / 4)) * 4;
+        a_voff[i] = (m0 + col) < a.M ? (unsigned)((row * a.M + m0 + col) * 4) : OOB;
+    }
+    unsigned b_mask[BQ][4];                                // per column: bit t = tap t reads inside the utterance
+    int b_W[BQ];
+#pragma unroll
+    for (int i = 0; i < BQ; ++i) {
+        const int q = tid + i * 256, col = (q % (BN / 4)) * 4;
+        b_W[i] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = n0 + col + c;
+            unsigned m = 0;
+            if (j < a.N) {
+                if (a.meta) {
+                    const unsigned long long md = a.meta[j];
+                    const int h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff);
+                    const int H = (int)((md >> 32) & 0xffff), Wj = (int)(md >> 48);
+                    for (int t = 0; t < a.T; ++t)
+                        if ((unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)Wj) m |= 1u << t;
+                    if (c == 0) b_W[i] = Wj;
+                } else {
+                    m = 0xffffffffu;
+                }
+            }
+            b_mask[i][c] = m;
+        }
+    }
+
+    const int kt_per_tap = a.Kp / BK;
+    const int nkt_all = a.T * kt_per_tap;
+    const int S = gridDim.y;                               // split-K: blockIdx.y owns a slice of the (tap, k-tile) sequence
+    const int kt_lo = (int)((long)nkt_all * blockIdx.y / S);
+    const int nkt = (int)((long)nkt_all * (blockIdx.y + 1) / S);
+    const bool k_ragged = (a.K % BK) != 0;
+
+    // next tile to load: (tap, k0) advance without a division; per tap: quad offsets + validity bits
+    int ld_t = kt_lo / kt_per_tap, ld_k0 = (kt_lo - ld_t * kt_per_tap) * BK;
+    unsigned b_voff[BQ], b_ok[BQ];
+    auto tap_setup = [&]() {
+        const int dh = a.dh[ld_t], dw = a.dw[ld_t];
+#pragma unroll
+        for (int i = 0; i < BQ; ++i) {
+            const int q = tid + i * 256, row = q / (BN / 4), col = (q % (BN / 4)) * 4;
+            unsigned ok = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ok |= ((b_mask[i][c] >> ld_t) & 1u) << c;
+            b_ok[i] = ok;
+            b_voff[i] = ok ? (unsigned)((row * a.ldx + n0 + col + dh * b_W[i] + dw) * 4 + 16) : OOB;
+        }
+    };
+    tap_setup();
+
+    f32x4 ra[AQ], rb[BQ];
+    unsigned rok[BQ];
+    auto gload = [&]() {
+        const int a_soff = (ld_t * a.Kp + ld_k0) * a.M * 4;
+        const int b_soff = ld_k0 * a.ldx * 4;
+#pragma unroll
+        for (int i = 0; i < AQ; ++i) ra[i] = buf_load4(rsW, a_voff[i], a_soff);
+        const bool ragged_tile = k_ragged && ld_k0 + BK > a.K;   // last k-tile of a tap with Cin % 16 != 0
+#pragma unroll
+        for (int i = 0; i < BQ; ++i) {
+            const int row = (tid + i * 256) / (BN / 4);
+            const bool row_ok = !ragged_tile || (ld_k0 + row) < a.K;
+            rb[i] = buf_load4(rsX, row_ok ? b_voff[i] : OOB, b_soff);
+            rok[i] = b_ok[i];
+        }
+        ld_k0 += BK;
+        if (ld_k0 >= a.Kp) { ld_k0 = 0; ld_t += 1; if (ld_t < a.T) tap_setup(); }
+    };
+    const bool in_lrelu = a.in_act == 2;
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AQ; ++i) {
+            const int q = tid + i * 256;
+            *reinterpret_cast<f32x4*>(&As[buf][q / (BM / 4)][(q % (BM / 4)) * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BQ; ++i) {
+            const int q = tid + i * 256;
+            f32x4 v = rb[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float x = ((rok[i] >> c) & 1u) ? v[c] : 0.f;
+                if (in_lrelu) x = x > 0.f ? x : 0.2f * x;  // LeakyReLU fused on the operand (models.py:89,142)
+                v[c] = x;
+            }
+            *reinterpret_cast<f32x4*>(&Bs[buf][q / (BN / 4)][(q % (BN / 4)) * 4]) = v;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    gload();
+    lstore(kt_lo & 1);
+    __syncthreads();
+    for (int kt = kt_lo; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) gload();
+        mma_tile<TM, TN, BM, BN>(As, Bs, buf, wm, wn, l31, lk, acc);
+        if (kt + 1 < nkt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    epilogue<TM, TN>(a, acc, m0, n0, wm, wn, l31, lk, S);
+}
+
+// ======================================================================================================
+// SCALAR staging (general)
+// ======================================================================================================
+template <int TM, int TN>
+__global__ void __launch_bounds__(256)
+conv_gemm_kernel(const ConvGemmArgs a)
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int AROWS = BK * BM / 256;      // elements per thread per k-tile (A)
+    constexpr int BROWS = BK * BN / 256;
+    constexpr int A_RSTEP = 256 / BM, B_RSTEP = 256 / BN;
+    __shared__ float As[2][BK][BM];
+    __shared__ float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1, l31 = lane & 31, lk = lane >> 5;
+    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tile = logical_tile();
+    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+
+    const __amdgpu_buffer_rsrc_t rsW =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, (int)((unsigned)a.T * a.Kp * a.M * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((unsigned)a.K * a.ldx * 4u), 0x00020000);
+
+    // thread -> one column (A: output channel, B: frame column), BK/stride rows
+    const int a_c = tid % BM, a_r0 = tid / BM;
+    const int b_c = tid % BN, b_r0 = tid / BN;
+    const unsigned a_voff = (m0 + a_c) < a.M ? (unsigned)((a_r0 * a.M + m0 + a_c) * 4) : OOB;
+    const int j = n0 + b_c;
+    unsigned tapmask = 0;
+    int Wj = 0;
+    if (j < a.N) {
+        if (a.meta) {
+            const unsigned long long md = a.meta[j];
+            const int h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff);
+            const int H = (int)((md >> 32) & 0xffff);
+            Wj = (int)(md >> 48);
+            for (int t = 0; t < a.T; ++t)
+                if ((unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)Wj) tapmask |= 1u << t;
+        } else {
+            tapmask = 0xffffffffu;
+        }
+    }
+
+    const int kt_per_tap = a.Kp / BK;
+    const int nkt_all = a.T * kt_per_tap;
+    const int S = gridDim.y;
+    const int kt_lo = (int)((long)nkt_all * blockIdx.y / S);
+    const int nkt = (int)((long)nkt_all * (blockIdx.y + 1) / S);
+    const bool k_ragged = (a.K % BK) != 0;
+    const int a_step = A_RSTEP * a.M * 4, b_step = B_RSTEP * a.ldx * 4;
+
+    int ld_t = kt_lo / kt_per_tap, ld_k0 = (kt_lo - ld_t * kt_per_tap) * BK;
+    unsigned b_voff = OOB;
+    auto tap_setup = [&]() {
+        const bool ok = (tapmask >> ld_t) & 1u;
+        const int src = j + a.dh[ld_t] * Wj + a.dw[ld_t];
+        b_voff = (ok && (b_r0 * a.ldx + src) >= 0) ? (unsigned)(b_r0 * a.ldx + src) * 4u : OOB;
+    };
+    tap_setup();
+    float ra[AROWS], rb[BROWS];
+    auto gload = [&]() {
+        const int a_soff = (ld_t * a.Kp + ld_k0) * a.M * 4;
+        const int b_soff = ld_k0 * a.ldx * 4;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) ra[i] = buf_load1(rsW, a_voff, a_soff + i * a_step);
+        if (k_ragged && ld_k0 + BK > a.K) {                 // last k-tile of a tap with Cin % 16 != 0
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i)
+                rb[i] = buf_load1(rsX, (ld_k0 + b_r0 + i * B_RSTEP) < a.K ? b_voff : OOB, b_soff + i * b_step);
+        } else {
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) rb[i] = buf_load1(rsX, b_voff, b_soff + i * b_step);
+        }
+        ld_k0 += BK;
+        if (ld_k0 >= a.Kp) { ld_k0 = 0; ld_t += 1; if (ld_t < a.T) tap_setup(); }
+    };
+    const bool in_lrelu = a.in_act == 2;
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) As[buf][a_r0 + i * A_RSTEP][a_c] = ra[i];
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            float v = rb[i];
+            if (in_lrelu) v = v > 0.f ? v : 0.2f * v;
+            Bs[buf][b_r0 + i * B_RSTEP][b_c] = v;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    gload();
+    lstore(kt_lo & 1);
+    __syncthreads();
+    for (int kt = kt_lo; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) gload();
+        mma_tile<TM, TN, BM, BN>(As, Bs, buf, wm, wn, l31, lk, acc);
+        if (kt + 1 < nkt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    epilogue<TM, TN>(a, acc, m0, n0, wm, wn, l31, lk, S);
+}
+
 // y = epi(sum_s slab[s]) in a fixed order (deterministic, unlike float atomics)
 __global__ void splitk_reduce_kernel(const ConvGemmArgs a, int S)
 {
@@ -237,32 +403,6 @@ static void tile_dims(int choice, int* bm, int* bn)
     *bn = (choice == 22 || choice == 12) ? 128 : 64;
 }
 
-// number of K slices: only for grids that cannot fill 256 CUs, and only while a slice keeps >= 8 k-tiles
-static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
-{
-    const char* env = getenv("AS_GEMM_KSPLIT");          // tuning/experiments only
-    int bm, bn;
-    tile_dims(choice, &bm, &bn);
-    const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
-    const int nkt = T * (Kp / BK);
-    int s = 1;
-    if (env && atoi(env) > 0) s = atoi(env);
-    else if (tiles < 384) s = as_cdiv(768, tiles);
-    if (s > nkt / 8) s = nkt / 8;
-    if (s > 16) s = 16;
-    return s < 1 ? 1 : s;
-}
-
-static int gemm_tile_choice(int M, int N);
-
-extern "C" size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host)
-{
-    if (!args_host || args_host->M <= 0 || args_host->N <= 0 || args_host->Kp <= 0 || args_host->T <= 0) return 0;
-    const ConvGemmArgs& a = *args_host;
-    const int s = gemm_ksplit(a.M, a.N, a.Kp, a.T, gemm_tile_choice(a.M, a.N));
-    return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
-}
-
 static int gemm_tile_choice(int M, int N)
 {
     const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 22, 21, 12, 11
@@ -279,6 +419,37 @@ static int gemm_tile_choice(int M, int N)
     return 11;
 }
 
+// number of K slices: only for grids that cannot fill 256 CUs, and only while a slice keeps >= 8 k-tiles
+static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
+{
+    const char* env = getenv("AS_GEMM_KSPLIT");          // tuning/experiments only
+    int bm, bn;
+    tile_dims(choice, &bm, &bn);
+    const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
+    const int nkt = T * (Kp / BK);
+    int s = 1;
+    if (env && atoi(env) > 0) s = atoi(env);
+    else if (tiles < 384) s = as_cdiv(768, tiles);
+    if (s > nkt / 8) s = nkt / 8;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host)
+{
+    if (!args_host || args_host->M <= 0 || args_host->N <= 0 || args_host->Kp <= 0 || args_host->T <= 0) return 0;
+    const ConvGemmArgs& a = *args_host;
+    const int s = gemm_ksplit(a.M, a.N, a.Kp, a.T, gemm_tile_choice(a.M, a.N));
+    return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
+}
+
+template <int TM, int TN>
+static void launch(bool quad, dim3 grid, hipStream_t stream, const ConvGemmArgs& a)
+{
+    if (quad) hipLaunchKernelGGL((conv_gemm_quad_kernel<TM, TN>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<TM, TN>), grid, dim3(256), 0, stream, a);
+}
+
 extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -288,21 +459,26 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if (a.Kp < a.K || a.Kp % BK) return AS_EINVAL;
     if (a.ldx < a.N || a.ldy < (a.transpose_out ? a.M : a.N) || (a.res && (a.ldr < a.N || a.transpose_out))) return AS_EINVAL;
     // 32-bit byte offsets inside the buffer descriptors
-    if ((double)a.T * a.Kp * a.M * 4.0 >= 4294967296.0 || (double)a.K * a.ldx * 4.0 >= 4294967296.0) return AS_EINVAL;
+    if ((double)a.T * a.Kp * a.M * 4.0 >= 4294967296.0 || (double)a.K * a.ldx * 4.0 + 16.0 >= 4294967296.0) return AS_EINVAL;
     if (a.N == 0) return AS_OK;
     const int choice = gemm_tile_choice(a.M, a.N);
     int S = gemm_ksplit(a.M, a.N, a.Kp, a.T, choice);
     if (S > 1 && (!a.ws || a.ws_bytes < (size_t)S * a.M * a.N * sizeof(float))) S = 1;   // no workspace: no split
+    const char* envq = getenv("AS_GEMM_QUAD");           // tuning/experiments only: 0 forces the scalar staging
+    const bool quad = a.quad_ok && (a.M & 3) == 0 && !(envq && atoi(envq) == 0);
     char tag[64];
-    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d S%d", a.M, a.N, a.K, a.T, choice, S);
+    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d S%d %s", a.M, a.N, a.K, a.T, choice, S, quad ? "q" : "s");
     // algorithmic work of this launch: 2*M*N*K*T flop; bytes = weights + input + output once
     AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.K * a.T,
                        4.0 * ((double)a.T * a.K * a.M + (double)a.K * a.N + (double)a.M * a.N), stream, tag);
+    int bm, bn;
+    tile_dims(choice, &bm, &bn);
+    const dim3 grid(as_cdiv(a.M, bm) * as_cdiv(a.N, bn), S);
     switch (choice) {
-    case 22: hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 128), S), dim3(256), 0, stream, a); break;
-    case 21: hipLaunchKernelGGL((conv_gemm_kernel<2, 1>), dim3(as_cdiv(a.M, 128) * as_cdiv(a.N, 64), S), dim3(256), 0, stream, a); break;
-    case 12: hipLaunchKernelGGL((conv_gemm_kernel<1, 2>), dim3(as_cdiv(a.M, 64) * as_cdiv(a.N, 128), S), dim3(256), 0, stream, a); break;
-    default: hipLaunchKernelGGL((conv_gemm_kernel<1, 1>), dim3(as_cdiv(a.M, 64) * as_cdiv(a.N, 64), S), dim3(256), 0, stream, a); break;
+    case 22: launch<2, 2>(quad, grid, stream, a); break;
+    case 21: launch<2, 1>(quad, grid, stream, a); break;
+    case 12: launch<1, 2>(quad, grid, stream, a); break;
+    default: launch<1, 1>(quad, grid, stream, a); break;
     }
     AS_CHECK_LAUNCH();
     if (S > 1) {

@@ -59,7 +59,16 @@ class Layout:
         return self._meta
 
     def new(self, C):
-        return torch.empty((C, max(self.N, 1)), dtype=torch.float32, device=self.device)
+        """[C][N] activation with 4 floats of slack in front of it: the GEMM's 16-byte staging may start a quad
+        up to 3 columns before the tensor (those columns are masked, but the bytes must be readable)."""
+        n = max(self.N, 1)
+        return torch.empty(C * n + 4, dtype=torch.float32, device=self.device)[4:].view(C, n)
+
+    def quads_regular(self):
+        """no aligned group of 4 columns straddles two images of different width (2-D layouts only matter)"""
+        if self.H == 1 or len(set(self.widths_host)) <= 1:
+            return True
+        return all((self.H * w) % 4 == 0 for w in self.widths_host)
 
     def scaled(self, k):
         return layout([w * k for w in self.widths_host], self.device, self.H)
@@ -127,6 +136,8 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     assert len(taps) == T
     for i, (dh, dw) in enumerate(taps):
         a.dh[i], a.dw[i] = dh, dw
+    front_ok = X.storage_offset() >= 4 or all(dh >= 0 and dw >= 0 for dh, dw in taps)
+    a.quad_ok = int(front_ok and (lay.quads_regular() or all(dh == 0 for dh, _ in taps)))
     L = _lib.lib()
     nbytes = L.as_conv_gemm_workspace_bytes(ctypes.byref(a))
     if nbytes:                                       # small grid: split-K partial slabs (caller-owned scratch)

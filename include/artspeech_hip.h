@@ -90,6 +90,10 @@ typedef struct ConvGemmArgs {
     int32_t div_sqrt2;     /* epilogue: divide by sqrt(2) after bias and residual */
     int32_t in_act;        /* 2 = LeakyReLU(0.2) applied to X while staging (models.py:89,142) */
     int32_t transpose_out; /* 1 = write Y[j][m] (time-major, row stride ldy >= M) */
+    int32_t quad_ok;       /* caller's promise enabling the 16-byte staging: (a) the 16 bytes in front of X are
+                              readable (or no tap has a negative offset), (b) no group of 4 consecutive columns
+                              starting at a multiple of 4 straddles two images of different width while a tap has
+                              dh != 0.  0 = always-correct scalar staging.  (M % 4 == 0 is checked here.) */
     int32_t dh[AS_MAX_TAPS];   /* tap row offsets (scalar-loadable) */
     int32_t dw[AS_MAX_TAPS];   /* tap column offsets */
 } ConvGemmArgs;

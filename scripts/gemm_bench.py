@@ -14,7 +14,7 @@ print("lib:", _lib.LIB_PATH)
 for (M, N, K, T, L) in SHAPES:
     lay = ops.layout([L] * (N // L), dev)
     wt = ops.prep_weight(torch.randn(M, K, T)).to(dev)
-    X = torch.randn(K, lay.N, device=dev)
+    X = lay.new(K); X.copy_(torch.randn(K, lay.N, device=dev))
     Y = lay.new(M)
     b = torch.randn(M, device=dev)
     taps = ops.taps_1d(T)

@@ -165,4 +165,5 @@ def test_long_form_c5(cuda):
     # batch independence: utterance 3 alone == utterance 3 inside the batch
     solo = net([texts[3:4], torch.tensor([N]), mels[3:4], torch.tensor([T])], None, None, step="test",
                features=(f0s[3:4], emas[3:4]), forced_durations=forced[3:4])
-    assert float((solo[0] - out[3]).abs().max()) <= 1e-5
+    # (not bitwise: the GEMM's tile / split-K choice depends on the batch's total column count)
+    assert float((solo[0] - out[3]).abs().max()) <= 5e-5

@@ -17,7 +17,10 @@ def packed(x_list):
 @pytest.mark.parametrize("cin,cout,k,lens", [(64, 128, 3, [50, 13, 1, 200]), (10, 64, 1, [7, 9]), (1, 32, 1, [33]),
                                              (96, 80, 5, [40, 41]), (130, 257, 9, [17, 300, 64]), (512, 1024, 3, [128] * 8)])
 @pytest.mark.parametrize("tile", ["", "11", "21", "22", "12"])
-def test_conv1d_gemm(cuda, monkeypatch, cin, cout, k, lens, tile):
+@pytest.mark.parametrize("quad", ["", "0"])
+def test_conv1d_gemm(cuda, monkeypatch, cin, cout, k, lens, tile, quad):
+    if quad:
+        monkeypatch.setenv("AS_GEMM_QUAD", quad)          # force the scalar staging
     if tile:
         monkeypatch.setenv("AS_GEMM_TILE", tile)
     else:
@@ -30,23 +33,28 @@ def test_conv1d_gemm(cuda, monkeypatch, cin, cout, k, lens, tile):
     want = packed([(F.conv1d(x[None], w, b, padding=k // 2)[0] + r) / np.sqrt(2) for x, r in zip(xs, res)])
     lay = Layout(lens, cuda)
     wt = ops.prep_weight(w).to(cuda)
-    y = ops.conv_gemm(wt, packed(xs).to(cuda), lay, lay.new(cout), taps_1d(k), bias=b.to(cuda), res=packed(res).to(cuda),
-                      div_sqrt2=True)
+    X = lay.new(cin)
+    X.copy_(packed(xs))                                   # lay.new: 16 bytes of slack in front -> 16-byte staging allowed
+    y = ops.conv_gemm(wt, X, lay, lay.new(cout), taps_1d(k), bias=b.to(cuda), res=packed(res).to(cuda), div_sqrt2=True)
     err = float((y.cpu() - want).abs().max())
     assert err <= 2e-5, err
+    y2 = ops.conv_gemm(wt, packed(xs).to(cuda), lay, lay.new(cout), taps_1d(k), bias=b.to(cuda), res=packed(res).to(cuda),
+                       div_sqrt2=True)                    # no slack in front of X: scalar staging
+    assert float((y2.cpu() - want).abs().max()) <= 2e-5
 
 
-def test_conv2d_gemm_and_transpose_out(cuda):
+@pytest.mark.parametrize("widths", [[23, 8, 40], [23, 23, 23], [12, 8, 40]])
+def test_conv2d_gemm_and_transpose_out(cuda, widths):
     g = torch.Generator().manual_seed(3)
     cin, cout, H = 16, 48, 10
-    widths = [23, 8, 40]
     w = torch.randn(cout, cin, 3, 3, generator=g) / 12
     b = torch.randn(cout, generator=g)
     xs = [torch.randn(cin, H, W, generator=g) for W in widths]
     want = packed([F.conv2d(F.leaky_relu(x, 0.2)[None], w, b, padding=1)[0].reshape(cout, -1) for x in xs])
     lay = Layout(widths, cuda, H=H)
     wt = ops.prep_weight(w).to(cuda)
-    X = packed([x.reshape(cin, -1) for x in xs]).to(cuda)
+    X = lay.new(cin)
+    X.copy_(packed([x.reshape(cin, -1) for x in xs]))
     y = ops.conv_gemm(wt, X, lay, lay.new(cout), taps_2d(3, 3), bias=b.to(cuda), in_act=ops.ACT_LRELU)
     assert float((y.cpu() - want).abs().max()) <= 2e-5
     yt = torch.empty(lay.N, cout, device=cuda)
