@@ -389,12 +389,15 @@ class ArtsPredictor(_Module):
               "N": style[:, 448:512].contiguous()}
         a, _ = adain_resblk1d(W, p + ".shared", a_en, lay, style)
         outs, feats = {}, []
-        lay2 = None
-        for br in ("F0", "N", "EMA"):
-            x, lay2 = adain_resblk1d(W, f"{p}.{br}.0", a, lay, style, upsample=True)
-            x, _ = adain_resblk1d(W, f"{p}.{br}.1", x, lay2, sl[br])
-            x, _ = adain_resblk1d(W, f"{p}.{br}.2", x, lay2, sl[br])
-            feats.append((f"{p}.{br}_LSTM", x))
+        lay2 = lay.scaled(2)
+        with Fork(side_streams(W.device, 3), uses=(a, style) + tuple(sl.values())) as side:   # F0 / N / EMA branches
+            for i, br in enumerate(("F0", "N", "EMA")):
+                with side(i):
+                    x, _ = adain_resblk1d(W, f"{p}.{br}.0", a, lay, style, upsample=True)
+                    x, _ = adain_resblk1d(W, f"{p}.{br}.1", x, lay2, sl[br])
+                    x, _ = adain_resblk1d(W, f"{p}.{br}.2", x, lay2, sl[br])
+                    feats.append((f"{p}.{br}_LSTM", x))
+            side.produced(*[x for _, x in feats])
         hs = bilstm_many(W, feats, lay2)                  # the three recurrences share one launch
         for br, h in zip(("F0", "N", "EMA"), hs):
             outs[br] = conv1d(W, f"{p}.{br}_proj", h, lay2, 1)
@@ -445,6 +448,46 @@ class Decoder(_Module):
         mel = self.forward_packed(asr_up, lay2, Style.to(dev).contiguous().float(), pack(F0.to(dev), lay2.widths_host),
                                   pack(N.to(dev), lay2.widths_host), pack(EMA.to(dev), lay2.widths_host))
         return unpack(mel, lay2)
+
+
+_STREAMS = {}
+
+
+def side_streams(device, n):
+    key = str(device)
+    pool = _STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+class Fork:
+    """Fork/join of independent branches over side HIP streams.  Every side stream first waits for the calling
+    stream; on exit the calling stream waits for all of them.  Tensors that cross streams are registered with the
+    caching allocator (`record_stream`) so their memory is not recycled while another stream still uses it."""
+
+    def __init__(self, streams, uses=()):
+        self.streams, self.uses = streams, uses
+        self.main = torch.cuda.current_stream()
+
+    def __enter__(self):
+        for s in self.streams:
+            s.wait_stream(self.main)
+            for t in self.uses:
+                t.record_stream(s)
+        return self
+
+    def __call__(self, i):
+        return torch.cuda.stream(self.streams[i])
+
+    def produced(self, *tensors):
+        for t in tensors:
+            t.record_stream(self.main)
+
+    def __exit__(self, *exc):
+        for s in self.streams:
+            self.main.wait_stream(s)
+        return False
 
 
 def stats_vector(distribution, device):
@@ -514,10 +557,21 @@ class ArtsSpeech(_Module):
         if getattr(self, "_stats24", None) is None:
             self._stats24 = stats_vector(self.distribution, dev)
         stats24 = self._stats24
-        t_en = self.text_encoder.forward_packed(tok, tok_lay)
-        a_en = self.arts_encoder.forward_packed(tok, tok_lay)
-        feat12, style = self.style_encoder.forward_packed(mel_p, f0_p, ema_p, ref_lay, stats24)
-        duration = self.durationPredictor.forward_packed(tok, tok_lay, feat12[2:12], ref_lay)
+        # The two phoneme encoders, the style towers and the duration predictor are mutually independent
+        # (models.py:357-360) and individually too small to fill 256 CUs: run them as four concurrent branches
+        # on side HIP streams (a fork/join that hipGraph capture records as parallel nodes).
+        feat12 = self.style_encoder.features_packed(mel_p, f0_p, ema_p, ref_lay, stats24)
+        with Fork(side_streams(dev, 4), uses=(feat12,)) as side:
+            with side(0):
+                t_en = self.text_encoder.forward_packed(tok, tok_lay)
+            with side(1):
+                a_en = self.arts_encoder.forward_packed(tok, tok_lay)
+            with side(2):
+                feat = torch.cat([feat12, mel_p[:, : feat12.shape[1]]], dim=0).contiguous()
+                style = self.style_encoder.style_extractor_packed(feat, ref_lay)
+            with side(3):
+                duration = self.durationPredictor.forward_packed(tok, tok_lay, feat12[2:12], ref_lay)
+            side.produced(t_en, a_en, style, duration)
         if frames_hint is None:
             dur_i, frame_off, _ = ops.durations(duration.reshape(-1), forced, tok_lay, 0)
             off = frame_off.cpu().tolist()                                   # the one device->host sync
