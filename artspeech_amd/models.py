@@ -118,26 +118,55 @@ def adain_gb(W, p, style):
     return ops.linear_rows(style, W.vec(p + ".fc.weight"), W.vec(p + ".fc.bias"))
 
 
-def adain_resblk1d(W, p, X, lay, style, out=None, upsample=False):
-    """AdainResBlk1d.forward (models.py:189-202).  X [din][N] -> [dout][N or 2N].  Returns (Y, layout)."""
+def adain_fc_batch(W, prefixes, style):
+    """All AdaIN fc layers of several AdainResBlk1d blocks that take the SAME style vector, as one launch over
+    the row-concatenated weights.  Returns {block prefix: (gamma_beta_norm1, gamma_beta_norm2)} (row-strided views)."""
+    names = [f"{p}.{n}" for p in prefixes for n in ("norm1", "norm2")]
+    key = "ADAINFC:" + "|".join(names)
+    wcat, bcat, offs = W.cached(key, lambda: (
+        torch.cat([W.raw[n + ".fc.weight"] for n in names], 0).contiguous().to(W.device),
+        torch.cat([W.raw[n + ".fc.bias"] for n in names], 0).contiguous().to(W.device),
+        [W.raw[n + ".fc.weight"].shape[0] for n in names]))
+    gb = ops.linear_rows(style, wcat, bcat)
+    out, o = {}, 0
+    for i, p in enumerate(prefixes):
+        n1, n2 = offs[2 * i], offs[2 * i + 1]
+        out[p] = (gb[:, o:o + n1], gb[:, o + n1:o + n1 + n2])
+        o += n1 + n2
+    return out
+
+
+def adain_resblk1d(W, p, X, lay, style, out=None, upsample=False, gb=None):
+    """AdainResBlk1d.forward (models.py:189-202).  X [din][N] -> [dout][N or 2N].  Returns (Y, layout).
+    gb: this block's precomputed (norm1, norm2) gamma/beta from adain_fc_batch.  The learned 1x1 shortcut
+    (models.py:185-186) only depends on X, so it runs on a side stream next to norm1 -> conv1 -> norm2."""
     din = X.shape[0]
-    gb1 = adain_gb(W, p + ".norm1", style)
-    gb2 = adain_gb(W, p + ".norm2", style)
+    gb1, gb2 = gb if gb is not None else (adain_gb(W, p + ".norm1", style), adain_gb(W, p + ".norm2", style))
+    has_sc = W.has(p + ".conv1x1.weight")
+    dout = W.conv(p + ".conv1").shape[2]
+    lay2 = lay.scaled(2) if upsample else lay
+    if out is None:
+        out = lay2.new(dout)
+    fork = None
+    if has_sc and not upsample:
+        cur = torch.cuda.current_stream()
+        fork = Fork(side_streams(W.device, 1, f"shortcut{cur.stream_id}"), uses=(X, out))
+        fork.__enter__()
+        with fork(0):
+            conv1d(W, p + ".conv1x1", X, lay2, 1, Y=out)
     if upsample:
-        lay2 = lay.scaled(2)
         h = lay2.new(din)
         sc = lay2.new(din)
         ops.adain(X, gb1, lay, h, True, W.dw(p + ".pool"), W.vec(p + ".pool.bias"), sc)
     else:
-        lay2 = lay
         h = ops.adain(X, gb1, lay, lay.new(din), True)
         sc = X
     h = conv1d(W, p + ".conv1", h, lay2, 3)
-    dout = h.shape[0]
     h2 = ops.adain(h, gb2, lay2, lay2.new(dout), True)
-    if out is None:
-        out = lay2.new(dout)
-    if W.has(p + ".conv1x1.weight"):
+    if fork is not None:
+        fork.__exit__(None, None, None)
+        sc = out
+    elif has_sc:
         sc = conv1d(W, p + ".conv1x1", sc, lay2, 1, Y=out)
     conv1d(W, p + ".conv2", h2, lay2, 3, Y=out, res=sc, div_sqrt2=True)
     return out, lay2
@@ -361,8 +390,9 @@ class DurationPredictor(_Module):
         img = StyleEncoder._image(ema_p, ref_lay, limg)
         ds = tower2d(W, p + ".dur_block", img, limg, ["channelpreserve"] * 2 + ["half"], 5, 2, p + ".dur_linear")
         d = rel_encoder(W, p + ".text_encoder", tokens_i32, tok_lay, 2)
+        gbs = adain_fc_batch(W, [f"{p}.duration.{i}" for i in range(3)], ds)
         for i in range(3):
-            d, _ = adain_resblk1d(W, f"{p}.duration.{i}", d, tok_lay, ds)
+            d, _ = adain_resblk1d(W, f"{p}.duration.{i}", d, tok_lay, ds, gb=gbs[f"{p}.duration.{i}"])
         x = bilstm(W, p + ".LSTM", d, tok_lay)
         wt = W.cached("DP:" + p, lambda: W.raw[p + ".duration_proj.linear_layer.weight"].t().contiguous()[None].to(W.device))
         return ops.conv_gemm(wt, x, tok_lay, tok_lay.new(1), [(0, 0)], bias=W.vec(p + ".duration_proj.linear_layer.bias"))
@@ -387,15 +417,18 @@ class ArtsPredictor(_Module):
         W, p = self.W, self.p
         sl = {"EMA": style[:, 256:384].contiguous(), "F0": style[:, 384:448].contiguous(),
               "N": style[:, 448:512].contiguous()}
-        a, _ = adain_resblk1d(W, p + ".shared", a_en, lay, style)
+        gbs = adain_fc_batch(W, [p + ".shared"] + [f"{p}.{br}.0" for br in ("F0", "N", "EMA")], style)
+        for br in ("F0", "N", "EMA"):
+            gbs.update(adain_fc_batch(W, [f"{p}.{br}.1", f"{p}.{br}.2"], sl[br]))
+        a, _ = adain_resblk1d(W, p + ".shared", a_en, lay, style, gb=gbs[p + ".shared"])
         outs, feats = {}, []
         lay2 = lay.scaled(2)
-        with Fork(side_streams(W.device, 3), uses=(a, style) + tuple(sl.values())) as side:   # F0 / N / EMA branches
+        with Fork(side_streams(W.device, 3), uses=(a,) + tuple(t for v in gbs.values() for t in v)) as side:   # F0 / N / EMA branches
             for i, br in enumerate(("F0", "N", "EMA")):
                 with side(i):
-                    x, _ = adain_resblk1d(W, f"{p}.{br}.0", a, lay, style, upsample=True)
-                    x, _ = adain_resblk1d(W, f"{p}.{br}.1", x, lay2, sl[br])
-                    x, _ = adain_resblk1d(W, f"{p}.{br}.2", x, lay2, sl[br])
+                    x, _ = adain_resblk1d(W, f"{p}.{br}.0", a, lay, style, upsample=True, gb=gbs[f"{p}.{br}.0"])
+                    x, _ = adain_resblk1d(W, f"{p}.{br}.1", x, lay2, sl[br], gb=gbs[f"{p}.{br}.1"])
+                    x, _ = adain_resblk1d(W, f"{p}.{br}.2", x, lay2, sl[br], gb=gbs[f"{p}.{br}.2"])
                     feats.append((f"{p}.{br}_LSTM", x))
             side.produced(*[x for _, x in feats])
         hs = bilstm_many(W, feats, lay2)                  # the three recurrences share one launch
@@ -429,15 +462,17 @@ class Decoder(_Module):
         conv1d(W, p + ".EMA_conv", ema, lay2, 1, Y=x0[C + 64:C + 128])
         bott = 2 * C
         cat_a, cat_b = lay2.new(bott + 64 + 128), lay2.new(bott + 64 + 128)
-        adain_resblk1d(W, p + ".encode", x0, lay2, style, out=cat_a[:bott])
+        gbs = adain_fc_batch(W, [p + ".encode"] + [f"{p}.decode.{i}" for i in (0, 1, 2)], style)
+        gbs.update(adain_fc_batch(W, [f"{p}.decode.{i}" for i in (3, 4, 5)], mel_style))
+        adain_resblk1d(W, p + ".encode", x0, lay2, style, out=cat_a[:bott], gb=gbs[p + ".encode"])
         conv1d(W, p + ".asr_res.0", asr_up, lay2, 1, Y=cat_a[bott:bott + 64])
         cat_a[bott + 64:].copy_(x0[C:])
         cat_b[bott:].copy_(cat_a[bott:])
-        adain_resblk1d(W, p + ".decode.0", cat_a, lay2, style, out=cat_b[:bott])
-        adain_resblk1d(W, p + ".decode.1", cat_b, lay2, style, out=cat_a[:bott])
-        x, _ = adain_resblk1d(W, p + ".decode.2", cat_a, lay2, style)
+        adain_resblk1d(W, p + ".decode.0", cat_a, lay2, style, out=cat_b[:bott], gb=gbs[p + ".decode.0"])
+        adain_resblk1d(W, p + ".decode.1", cat_b, lay2, style, out=cat_a[:bott], gb=gbs[p + ".decode.1"])
+        x, _ = adain_resblk1d(W, p + ".decode.2", cat_a, lay2, style, gb=gbs[p + ".decode.2"])
         for i in (3, 4, 5):
-            x, _ = adain_resblk1d(W, f"{p}.decode.{i}", x, lay2, mel_style)
+            x, _ = adain_resblk1d(W, f"{p}.decode.{i}", x, lay2, mel_style, gb=gbs[f"{p}.decode.{i}"])
         return conv1d(W, p + ".to_out.0", x, lay2, 1, Y=out)
 
     def forward(self, asr, Style, F0, N, EMA, lengths=None):
@@ -453,8 +488,8 @@ class Decoder(_Module):
 _STREAMS = {}
 
 
-def side_streams(device, n):
-    key = str(device)
+def side_streams(device, n, tag=""):
+    key = str(device) + "/" + tag
     pool = _STREAMS.setdefault(key, [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
