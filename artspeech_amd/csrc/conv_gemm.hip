@@ -53,9 +53,11 @@ static __device__ __forceinline__ int logical_tile()
 }
 
 // one k-tile of MFMAs from LDS buffer `buf`
-template <int TM, int TN, int BM, int BN>
+// `mid` runs once after the first k-step's MFMAs have been issued: the staging work of the NEXT tiles (LDS store,
+// global loads) is issued in the shadow of those MFMAs instead of at the end of the k-tile.
+template <int TM, int TN, int BM, int BN, typename Mid>
 static __device__ __forceinline__ void mma_tile(const float (*As)[BK][BM], const float (*Bs)[BK][BN], int buf, int wm,
-                                                int wn, int l31, int lk, f32x16 (&acc)[TM][TN])
+                                                int wn, int l31, int lk, f32x16 (&acc)[TM][TN], Mid&& mid)
 {
     float af[2][TM], bf[2][TN];
 #pragma unroll
@@ -78,6 +80,10 @@ static __device__ __forceinline__ void mma_tile(const float (*As)[BK][BM], const
             for (int jn = 0; jn < TN; ++jn)
                 acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i], bf[s & 1][jn], acc[i][jn], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (s == 0) {
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -255,14 +261,19 @@ conv_gemm_quad_kernel(const ConvGemmArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
+    // tile kt_lo -> LDS, tile kt_lo+1 -> registers.  In iteration kt the registers (tile kt+1, loaded one whole
+    // iteration earlier) are written to the other LDS buffer and refilled with tile kt+2 right behind the first
+    // MFMAs, so the only thing left at the end of a k-tile is the barrier.
     gload();
     lstore(kt_lo & 1);
+    if (kt_lo + 1 < nkt) gload();
     __syncthreads();
     for (int kt = kt_lo; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) gload();
-        mma_tile<TM, TN, BM, BN>(As, Bs, buf, wm, wn, l31, lk, acc);
-        if (kt + 1 < nkt) lstore(buf ^ 1);
+        mma_tile<TM, TN, BM, BN>(As, Bs, buf, wm, wn, l31, lk, acc, [&]() {
+            if (kt + 1 < nkt) lstore(buf ^ 1);
+            if (kt + 2 < nkt) gload();
+        });
         __syncthreads();
     }
     epilogue<TM, TN>(a, acc, m0, n0, wm, wn, l31, lk, S);
@@ -366,14 +377,19 @@ conv_gemm_kernel(const ConvGemmArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
+    // tile kt_lo -> LDS, tile kt_lo+1 -> registers.  In iteration kt the registers (tile kt+1, loaded one whole
+    // iteration earlier) are written to the other LDS buffer and refilled with tile kt+2 right behind the first
+    // MFMAs, so the only thing left at the end of a k-tile is the barrier.
     gload();
     lstore(kt_lo & 1);
+    if (kt_lo + 1 < nkt) gload();
     __syncthreads();
     for (int kt = kt_lo; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) gload();
-        mma_tile<TM, TN, BM, BN>(As, Bs, buf, wm, wn, l31, lk, acc);
-        if (kt + 1 < nkt) lstore(buf ^ 1);
+        mma_tile<TM, TN, BM, BN>(As, Bs, buf, wm, wn, l31, lk, acc, [&]() {
+            if (kt + 1 < nkt) lstore(buf ^ 1);
+            if (kt + 2 < nkt) gload();
+        });
         __syncthreads();
     }
     epilogue<TM, TN>(a, acc, m0, n0, wm, wn, l31, lk, S);

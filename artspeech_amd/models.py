@@ -113,6 +113,11 @@ def conv1d(W, name, X, lay, k, Y=None, **kw):
     return ops.conv_gemm(Wt, X, lay, Y, taps_1d(k), bias=W.bias(name), **kw)
 
 
+import os as _os
+
+SHORTCUT_FORK = _os.environ.get("AS_SHORTCUT_FORK", "0") != "0"     # experiment (no gain measured): 1x1 shortcut on a side stream
+
+
 def adain_gb(W, p, style):
     """gamma/beta of one AdaIN1d: fc(style) -> [B][2C]   (models.py:237)."""
     return ops.linear_rows(style, W.vec(p + ".fc.weight"), W.vec(p + ".fc.bias"))
@@ -136,7 +141,7 @@ def adain_fc_batch(W, prefixes, style):
     return out
 
 
-def adain_resblk1d(W, p, X, lay, style, out=None, upsample=False, gb=None):
+def adain_resblk1d(W, p, X, lay, style, out=None, upsample=False, gb=None, fork_shortcut=False):
     """AdainResBlk1d.forward (models.py:189-202).  X [din][N] -> [dout][N or 2N].  Returns (Y, layout).
     gb: this block's precomputed (norm1, norm2) gamma/beta from adain_fc_batch.  The learned 1x1 shortcut
     (models.py:185-186) only depends on X, so it runs on a side stream next to norm1 -> conv1 -> norm2."""
@@ -148,7 +153,7 @@ def adain_resblk1d(W, p, X, lay, style, out=None, upsample=False, gb=None):
     if out is None:
         out = lay2.new(dout)
     fork = None
-    if has_sc and not upsample:
+    if has_sc and not upsample and fork_shortcut and SHORTCUT_FORK:
         cur = torch.cuda.current_stream()
         fork = Fork(side_streams(W.device, 1, f"shortcut{cur.stream_id}"), uses=(X, out))
         fork.__enter__()
@@ -464,13 +469,13 @@ class Decoder(_Module):
         cat_a, cat_b = lay2.new(bott + 64 + 128), lay2.new(bott + 64 + 128)
         gbs = adain_fc_batch(W, [p + ".encode"] + [f"{p}.decode.{i}" for i in (0, 1, 2)], style)
         gbs.update(adain_fc_batch(W, [f"{p}.decode.{i}" for i in (3, 4, 5)], mel_style))
-        adain_resblk1d(W, p + ".encode", x0, lay2, style, out=cat_a[:bott], gb=gbs[p + ".encode"])
+        adain_resblk1d(W, p + ".encode", x0, lay2, style, out=cat_a[:bott], gb=gbs[p + ".encode"], fork_shortcut=True)
         conv1d(W, p + ".asr_res.0", asr_up, lay2, 1, Y=cat_a[bott:bott + 64])
         cat_a[bott + 64:].copy_(x0[C:])
         cat_b[bott:].copy_(cat_a[bott:])
-        adain_resblk1d(W, p + ".decode.0", cat_a, lay2, style, out=cat_b[:bott], gb=gbs[p + ".decode.0"])
-        adain_resblk1d(W, p + ".decode.1", cat_b, lay2, style, out=cat_a[:bott], gb=gbs[p + ".decode.1"])
-        x, _ = adain_resblk1d(W, p + ".decode.2", cat_a, lay2, style, gb=gbs[p + ".decode.2"])
+        adain_resblk1d(W, p + ".decode.0", cat_a, lay2, style, out=cat_b[:bott], gb=gbs[p + ".decode.0"], fork_shortcut=True)
+        adain_resblk1d(W, p + ".decode.1", cat_b, lay2, style, out=cat_a[:bott], gb=gbs[p + ".decode.1"], fork_shortcut=True)
+        x, _ = adain_resblk1d(W, p + ".decode.2", cat_a, lay2, style, gb=gbs[p + ".decode.2"], fork_shortcut=True)
         for i in (3, 4, 5):
             x, _ = adain_resblk1d(W, f"{p}.decode.{i}", x, lay2, mel_style, gb=gbs[f"{p}.decode.{i}"])
         return conv1d(W, p + ".to_out.0", x, lay2, 1, Y=out)

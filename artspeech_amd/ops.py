@@ -9,6 +9,7 @@ from . import _lib
 from ._lib import check, ptr, stream
 
 AS_MAX_TAPS = _lib.AS_MAX_TAPS
+KTILE = 16                      # the GEMM k-tile (BK in csrc/conv_gemm.hip): weights are zero-padded to it
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 
 
@@ -103,7 +104,7 @@ def prep_weight(w):
     channels are contiguous, input channels zero-padded to a multiple of 16 (one k-tile)."""
     cout, cin = w.shape[0], w.shape[1]
     wt = w.reshape(cout, cin, -1).permute(2, 1, 0)
-    kp = (cin + 15) // 16 * 16
+    kp = (cin + KTILE - 1) // KTILE * KTILE
     if kp != cin:
         wt = torch.cat([wt, wt.new_zeros(wt.shape[0], kp - cin, cout)], dim=1)
     return wt.contiguous()
@@ -123,7 +124,7 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     of 16); X [K][*]; Y [M][*] (or [N][*] transposed)."""
     T, Kp, M = Wt.shape
     K = X.shape[0]
-    if Kp % 16 or not (Kp - 16 < K <= Kp):
+    if Kp % KTILE or not (Kp - KTILE < K <= Kp):
         raise ValueError(f"conv_gemm: weight rows {Kp} do not match input channels {K} (use ops.prep_weight)")
     a = ConvGemmArgs()
     a.Kp = Kp
