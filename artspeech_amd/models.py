@@ -601,17 +601,15 @@ class ArtsSpeech(_Module):
         # (models.py:357-360) and individually too small to fill 256 CUs: run them as four concurrent branches
         # on side HIP streams (a fork/join that hipGraph capture records as parallel nodes).
         feat12 = self.style_encoder.features_packed(mel_p, f0_p, ema_p, ref_lay, stats24)
-        with Fork(side_streams(dev, 4), uses=(feat12,)) as side:
+        with Fork(side_streams(dev, 3), uses=(feat12,)) as side:
             with side(0):
-                t_en = self.text_encoder.forward_packed(tok, tok_lay)
-            with side(1):
                 a_en = self.arts_encoder.forward_packed(tok, tok_lay)
-            with side(2):
+            with side(1):
                 feat = torch.cat([feat12, mel_p[:, : feat12.shape[1]]], dim=0).contiguous()
                 style = self.style_encoder.style_extractor_packed(feat, ref_lay)
-            with side(3):
+            with side(2):
                 duration = self.durationPredictor.forward_packed(tok, tok_lay, feat12[2:12], ref_lay)
-            side.produced(t_en, a_en, style, duration)
+            side.produced(a_en, style, duration)
         if frames_hint is None:
             dur_i, frame_off, _ = ops.durations(duration.reshape(-1), forced, tok_lay, 0)
             off = frame_off.cpu().tolist()                                   # the one device->host sync
@@ -620,9 +618,15 @@ class ArtsSpeech(_Module):
             frames = list(frames_hint)
         lay1 = layout(frames, dev)
         dur_i, frame_off, tof = ops.durations(duration.reshape(-1), forced, tok_lay, lay1.N)
-        C = t_en.shape[0]
-        a_ex = ops.expand(a_en, tof, lay1.N, 1, lay1.new(C))
-        f0, n, ema, lay2 = self.artsPredictor.forward_packed(a_ex, lay1, style)
+        # The text encoder feeds only the decoder: it is deferred to run beside the articulatory predictors, whose
+        # three branches and sequential LSTM recurrences leave most of the chip idle (critical path: scripts/phase_bench.py).
+        with Fork(side_streams(dev, 1, "text_encoder")) as side:
+            with side(0):
+                t_en = self.text_encoder.forward_packed(tok, tok_lay)
+            C = a_en.shape[0]
+            a_ex = ops.expand(a_en, tof, lay1.N, 1, lay1.new(C))
+            f0, n, ema, lay2 = self.artsPredictor.forward_packed(a_ex, lay1, style)
+            side.produced(t_en)
         t_up = ops.expand(t_en, tof, lay1.N, 2, lay2.new(C))
         mel = self.decoder.forward_packed(t_up, lay2, style, f0, n, ema)
         return dict(mel=mel, lay2=lay2, lay1=lay1, t_en=t_en, a_en=a_en, feat12=feat12, style=style,

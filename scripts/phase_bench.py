@@ -50,7 +50,9 @@ cases = {
     "phase C (decoder)": lambda: net.decoder.forward_packed(t_up, lay2, style, f0, n, ema),
     "whole step": lambda: net.forward_packed(g["tok"], g["tok_lay"], g["mel"], g["f0"], g["ema"], g["ref_lay"], forced=g["forced"], frames_hint=g["frames"]),
 }
+sel = os.environ.get('CASE')
 for name, fn in cases.items():
+    if sel is not None and str(list(cases).index(name)) != sel: continue
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     gr = torch.cuda.CUDAGraph()
