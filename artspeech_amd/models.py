@@ -229,15 +229,19 @@ def resblk_down(W, p, X, lay, kind, one_d=False):
     lay2 = lay.halved(h_too)
     cin = X.shape[0]
     taps = taps_1d(3) if one_d else taps_2d(3, 3)
-    sc = X
-    if W.has(p + ".conv1x1.weight"):
-        sc = ops.conv_gemm(W.conv(p + ".conv1x1"), X, lay, lay.new(W.conv(p + ".conv1x1").shape[2]), [(0, 0)])
     r = ops.conv_gemm(W.conv(p + ".conv1"), X, lay, lay.new(cin), taps, bias=W.bias(p + ".conv1"), in_act=ACT_LRELU)
     dname = p + (".pool" if one_d else ".downsample_res.conv")
     r2 = ops.dwconv_down(r, lay, lay2.new(cin), lay2, W.dw(dname), W.vec(dname + ".bias"), 3 if h_too else 1, True)
     wt2 = W.conv(p + ".conv2")
     r3 = ops.conv_gemm(wt2, r2, lay2, lay2.new(wt2.shape[2]), taps, bias=W.bias(p + ".conv2"))
-    out = ops.avgpool_down(sc, lay, lay2.new(wt2.shape[2]), lay2, 2 if h_too else 1, res=r3)
+    if W.has(p + ".conv1x1.weight"):
+        # shortcut = avgpool(conv1x1(x)) (models.py:79-84).  Both are linear and the 1x1 conv has no bias, so it is
+        # evaluated as conv1x1(avgpool(x)): a quarter of the columns, and the residual merge (x + r)/sqrt(2) becomes
+        # the GEMM's epilogue.  Same value up to fp32 summation order.
+        xs = ops.avgpool_down(X, lay, lay2.new(cin), lay2, 2 if h_too else 1)
+        out = ops.conv_gemm(W.conv(p + ".conv1x1"), xs, lay2, lay2.new(wt2.shape[2]), [(0, 0)], res=r3, div_sqrt2=True)
+    else:
+        out = ops.avgpool_down(X, lay, lay2.new(wt2.shape[2]), lay2, 2 if h_too else 1, res=r3)
     return out, lay2
 
 
