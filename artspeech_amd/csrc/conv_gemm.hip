@@ -419,23 +419,23 @@ static void tile_dims(int choice, int* bm, int* bn)
     *bn = (choice == 22 || choice == 12) ? 128 : 64;
 }
 
+// Tile and split-K choice, from sweeps on MI355X (scripts/gemm_bench.py): the kernel wants >= ~1000 workgroups
+// (4-5 per CU) so that tile quantisation over 256 CUs and the lock-step load/compute phases of co-resident
+// workgroups average out; shapes with fewer tiles get 128x64 tiles and 2-4 K slices (16 for tiny outputs).
 static int gemm_tile_choice(int M, int N)
 {
     const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 22, 21, 12, 11
     if (env && atoi(env) > 0) return atoi(env);
-    // rows: a 128-row tile only when it is not half empty; columns: the widest tile that still gives
-    // >= 1.5 workgroups per CU (256 CUs)
-    const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);
+    const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);   // a 128-row tile is not half empty
     if (tall) {
-        if ((long)as_cdiv(M, 128) * as_cdiv(N, 128) >= 384) return 22;
-        if ((long)as_cdiv(M, 128) * as_cdiv(N, 64) >= 384) return 21;
-    } else {
-        if ((long)as_cdiv(M, 64) * as_cdiv(N, 128) >= 384) return 12;
+        if ((long)as_cdiv(M, 128) * as_cdiv(N, 128) >= 1000) return 22;
+        if ((long)as_cdiv(M, 128) * as_cdiv(N, 64) >= 300) return 21;
+        return 11;
     }
+    if ((long)as_cdiv(M, 64) * as_cdiv(N, 128) >= 1000) return 12;
     return 11;
 }
 
-// number of K slices: only for grids that cannot fill 256 CUs, and only while a slice keeps >= 8 k-tiles
 static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
 {
     const char* env = getenv("AS_GEMM_KSPLIT");          // tuning/experiments only
@@ -445,9 +445,12 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
     const int nkt = T * (Kp / BK);
     int s = 1;
     if (env && atoi(env) > 0) s = atoi(env);
-    else if (tiles < 384) s = as_cdiv(768, tiles);
-    if (s > nkt / 8) s = nkt / 8;
-    if (s > 16) s = 16;
+    else if (tiles < 1000) {
+        s = as_cdiv(1200, tiles);
+        const int cap = (long)M * N >= 262144 ? 4 : 16;  // the reduce pass moves S*M*N*8 bytes
+        if (s > cap) s = cap;
+    }
+    if (s > nkt / 8) s = nkt / 8;                        // a slice keeps >= 8 k-tiles
     return s < 1 ? 1 : s;
 }
 
