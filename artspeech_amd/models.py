@@ -332,22 +332,31 @@ class StyleEncoder(_Module):
         self.pitch_extractor = None
         self.ema_extractor = None
 
-    def style_extractor_packed(self, feat, lay_full):
-        """feat [92][N]: rows 0 n, 1 f0, 2..11 ema, 12..91 mel, packed over FULL reference lengths."""
-        W, p = self.W, self.p
-        dev = W.device
-        lens = [w - 1 for w in lay_full.widths_host]                 # models.py:459 (start = randint(0,1) = 0)
+    def tower_inputs(self, feat, lay_full):
+        """feat [92][N] (rows 0 n, 1 f0, 2..11 ema, 12..91 mel; FULL reference lengths) -> the T-1 crop
+        (models.py:459-471, start = randint(0,1) = 0) and the mel / TV images [1][sum H*L] of the 2-D towers."""
+        dev = self.W.device
+        lens = [w - 1 for w in lay_full.widths_host]
         l1 = layout(lens, dev)
         c = ops.crop(feat, lay_full, 0, l1.new(92), l1)
-        # 2-D images: [1][sum H*L] with H rows of L contiguous frames per utterance
         lm, le = layout(lens, dev, H=80), layout(lens, dev, H=10)
-        mel_img = self._image(c[12:92], l1, lm)
-        ema_img = self._image(c[2:12], l1, le)
-        ms = tower2d(W, p + ".Mel_block", mel_img, lm, ["half"] * 4, 6, 1, p + ".Mellinear")
-        es = tower2d(W, p + ".EMA_block", ema_img, le, ["channelpreserve"] * 2 + ["half"], 5, 2, p + ".EMAlinear")
-        fs = tower1d(W, p + ".F0_block", c[1:2], l1, p + ".F0linear")
-        ns = tower1d(W, p + ".energy_block", c[0:1], l1, p + ".Energylinear")
-        return torch.cat([ms, es, fs, ns], dim=1).contiguous()
+        return dict(c=c, l1=l1, lm=lm, le=le, mel_img=self._image(c[12:92], l1, lm), ema_img=self._image(c[2:12], l1, le))
+
+    def tower(self, which, ti):
+        """one of the four towers + its Linear (models.py:385-415) -> [B][S]"""
+        W, p = self.W, self.p
+        if which == "mel":
+            return tower2d(W, p + ".Mel_block", ti["mel_img"], ti["lm"], ["half"] * 4, 6, 1, p + ".Mellinear")
+        if which == "ema":
+            return tower2d(W, p + ".EMA_block", ti["ema_img"], ti["le"], ["channelpreserve"] * 2 + ["half"], 5, 2, p + ".EMAlinear")
+        if which == "f0":
+            return tower1d(W, p + ".F0_block", ti["c"][1:2], ti["l1"], p + ".F0linear")
+        return tower1d(W, p + ".energy_block", ti["c"][0:1], ti["l1"], p + ".Energylinear")
+
+    def style_extractor_packed(self, feat, lay_full):
+        """StyleEncoder.style_extractor (models.py:417-424) on packed features -> Style [B][512]."""
+        ti = self.tower_inputs(feat, lay_full)
+        return torch.cat([self.tower(w, ti) for w in ("mel", "ema", "f0", "energy")], dim=1).contiguous()
 
     @staticmethod
     def _image(rows, l1, limg):
@@ -393,18 +402,28 @@ class DurationPredictor(_Module):
     def __init__(self, W, prefix="durationPredictor"):
         self.W, self.p = W, prefix
 
-    def forward_packed(self, tokens_i32, tok_lay, ema_p, ref_lay):
+    def style_tower(self, ema_p, ref_lay):
+        """dur_block + dur_linear on the FULL-length TV track (models.py:543-546) -> [B][64]"""
         W, p = self.W, self.p
         limg = layout(ref_lay.widths_host, W.device, H=10)
         img = StyleEncoder._image(ema_p, ref_lay, limg)
-        ds = tower2d(W, p + ".dur_block", img, limg, ["channelpreserve"] * 2 + ["half"], 5, 2, p + ".dur_linear")
-        d = rel_encoder(W, p + ".text_encoder", tokens_i32, tok_lay, 2)
+        return tower2d(W, p + ".dur_block", img, limg, ["channelpreserve"] * 2 + ["half"], 5, 2, p + ".dur_linear")
+
+    def encoder(self, tokens_i32, tok_lay):
+        return rel_encoder(self.W, self.p + ".text_encoder", tokens_i32, tok_lay, 2)
+
+    def tail(self, d, ds, tok_lay):
+        """3 x AdainResBlk1d -> BiLSTM -> duration_proj (models.py:549-566) -> [1][N_tok]"""
+        W, p = self.W, self.p
         gbs = adain_fc_batch(W, [f"{p}.duration.{i}" for i in range(3)], ds)
         for i in range(3):
             d, _ = adain_resblk1d(W, f"{p}.duration.{i}", d, tok_lay, ds, gb=gbs[f"{p}.duration.{i}"])
         x = bilstm(W, p + ".LSTM", d, tok_lay)
         wt = W.cached("DP:" + p, lambda: W.raw[p + ".duration_proj.linear_layer.weight"].t().contiguous()[None].to(W.device))
         return ops.conv_gemm(wt, x, tok_lay, tok_lay.new(1), [(0, 0)], bias=W.vec(p + ".duration_proj.linear_layer.bias"))
+
+    def forward_packed(self, tokens_i32, tok_lay, ema_p, ref_lay):
+        return self.tail(self.encoder(tokens_i32, tok_lay), self.style_tower(ema_p, ref_lay), tok_lay)
 
     def forward(self, texts, style, text_lengths, mel_input_length):
         dev = self.W.device
@@ -601,10 +620,12 @@ class ArtsSpeech(_Module):
         if getattr(self, "_stats24", None) is None:
             self._stats24 = stats_vector(self.distribution, dev)
         stats24 = self._stats24
-        # The two phoneme encoders, the style towers and the duration predictor are mutually independent
-        # (models.py:357-360) and individually too small to fill 256 CUs: run them as four concurrent branches
-        # on side HIP streams (a fork/join that hipGraph capture records as parallel nodes).
         feat12 = self.style_encoder.features_packed(mel_p, f0_p, ema_p, ref_lay, stats24)
+        # The articulatory encoder, the style towers and the duration predictor are mutually independent
+        # (models.py:358-360) and individually too small to fill 256 CUs: three concurrent branches on side HIP streams
+        # (a fork/join that hipGraph capture records as parallel nodes).  Measured on MI355X: finer splits (each tower,
+        # tower beside encoder) are slower -- three branches already saturate the chip -- and stream-to-stream edges
+        # between side streams crash hipGraph instantiation on ROCm 7.2, so every branch forks from / joins the caller.
         with Fork(side_streams(dev, 3), uses=(feat12,)) as side:
             with side(0):
                 a_en = self.arts_encoder.forward_packed(tok, tok_lay)
