@@ -20,15 +20,23 @@
 #define NB 2
 
 // exp via the hardware v_exp_f32 path (~1e-7 abs on the bounded gate outputs; the test bound is 2e-5)
-static __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+static __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 static __device__ __forceinline__ float tanhf_(float x)
 {
     const float e = __expf(-2.0f * fabsf(x));              // in (0, 1]: no overflow
-    const float t = (1.0f - e) / (1.0f + e);
+    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
     return x < 0.f ? -t : t;
 }
 
 struct LstmJobs { BiLstmJob j[AS_MAX_LSTM_JOBS]; };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait every step
+// for the step's global store of h to be acknowledged and for the prefetch of the next step's input gates -- the
+// recurrence needs neither (global data is never re-read by the workgroup).
+static __device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // HREG = H when the weights are register resident (H in {16,32,64,128}), 0 for the streaming variant.
 template <int HREG>
@@ -103,7 +111,7 @@ bilstm_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B, int H
             }
         }
         *reinterpret_cast<float2*>(gs + r * NB) = make_float2(acc[0], acc[1]);
-        __syncthreads();
+        lds_barrier();
         if (q < NB) {                        // the first H*NB threads update one (unit, utterance) cell each
             const int u = q;
             const int L = s_len[u];
@@ -119,7 +127,96 @@ bilstm_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B, int H
                 job.out[(size_t)(dir * H + unit) * job.ldo + s_off[u] + pos] = hv;
             }
         }
-        __syncthreads();
+        lds_barrier();
+    }
+}
+
+// H <= 128: thread = (hidden unit, K quarter).  A thread keeps the W_hh entries of ALL FOUR gates of its unit for its
+// quarter of the hidden vector in registers (4 * H/4 = H VGPRs), accumulates 8 independent chains (4 gates x 2
+// utterances) -- instruction-level parallelism instead of one 128-long dependent chain -- and the four quarters are
+// summed inside the lane quad with two DPP shuffles, so the gate pre-activations of a unit meet in registers:
+// no LDS round trip for them and ONE barrier per step (after the new h is published).
+template <int H>
+__global__ void __launch_bounds__(4 * H)
+bilstm_quad_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B)
+{
+    constexpr int KQ = H / 4, G = 4 * H;
+    __shared__ __attribute__((aligned(16))) float hs[2][H][NB];
+    __shared__ int s_off[NB], s_len[NB];
+    const BiLstmJob job = jobs.j[blockIdx.z];
+    const int dir = blockIdx.y, u0 = blockIdx.x * NB;
+    const int tid = threadIdx.x, unit = tid >> 2, kq = tid & 3;
+    if (tid < NB) {
+        const int u = u0 + tid;
+        s_off[tid] = u < B ? col_off[u] : 0;
+        s_len[tid] = u < B ? col_off[u + 1] - col_off[u] : 0;
+    }
+    for (int i = tid; i < 2 * H * NB; i += G) (&hs[0][0][0])[i] = 0.f;
+    __syncthreads();
+    const int L0 = s_len[0], L1 = s_len[1], o0 = s_off[0], o1 = s_off[1];
+    const int Lmax = L0 > L1 ? L0 : L1;
+
+    float w[4][KQ];
+    const float* wp = job.whh_t + (size_t)dir * H * G + unit;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) w[g][kk] = wp[(size_t)(kq * KQ + kk) * G + g * H];
+
+    // lane kq adds the input-projection term of gate kq (one coalesced-ish load per utterance per step)
+    const float* gxp = job.gx_tm + dir * G + kq * H + unit;
+    auto load_gx = [&](int t, float& g0, float& g1) {
+        g0 = (t < L0) ? gxp[(size_t)(o0 + (dir ? L0 - 1 - t : t)) * job.ldg] : 0.f;
+        g1 = (t < L1) ? gxp[(size_t)(o1 + (dir ? L1 - 1 - t : t)) * job.ldg] : 0.f;
+    };
+    // input-gate terms are prefetched PF steps ahead (a step is ~1 us, a miss beyond L2 is longer)
+    constexpr int PF = 4;
+    float gq0[PF], gq1[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) load_gx(j, gq0[j], gq1[j]);
+    float c = 0.f;
+    const int my_u = kq & 1, my_L = my_u ? L1 : L0, my_o = my_u ? o1 : o0;
+
+    for (int t0 = 0; t0 < Lmax; t0 += PF) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        const int t = t0 + j;
+        if (t >= Lmax) break;
+        const float(*hc)[NB] = hs[t & 1];
+        float(*hn)[NB] = hs[(t + 1) & 1];
+        float acc[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            acc[g][0] = (g == kq) ? gq0[j] : 0.f;
+            acc[g][1] = (g == kq) ? gq1[j] : 0.f;
+        }
+        load_gx(t + PF, gq0[j], gq1[j]);
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const float2 h2 = *reinterpret_cast<const float2*>(&hc[kq * KQ + kk][0]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[g][0] += w[g][kk] * h2.x;
+                acc[g][1] += w[g][kk] * h2.y;
+            }
+        }
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float a0 = acc[g][0], a1 = acc[g][1];
+            a0 += __shfl_xor(a0, 1); a1 += __shfl_xor(a1, 1);
+            a0 += __shfl_xor(a0, 2); a1 += __shfl_xor(a1, 2);
+            pre[g] = my_u ? a1 : a0;
+        }
+        if (kq < 2 && t < my_L) {                        // lanes 0 / 1 of the quad own utterances 0 / 1
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+            c = fg * c + ig * gg;
+            const float hv = og * tanhf_(c);
+            hn[unit][my_u] = hv;
+            job.out[(size_t)(dir * H + unit) * job.ldo + my_o + (dir ? my_L - 1 - t : t)] = hv;
+        }
+        lds_barrier();
+      }
     }
 }
 
@@ -138,10 +235,10 @@ extern "C" int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32
     const dim3 grid(as_cdiv(B, NB), 2, n_jobs), block(4 * H);
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     switch (H) {
-    case 16: hipLaunchKernelGGL(bilstm_kernel<16>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
-    case 32: hipLaunchKernelGGL(bilstm_kernel<32>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
-    case 64: hipLaunchKernelGGL(bilstm_kernel<64>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
-    case 128: hipLaunchKernelGGL(bilstm_kernel<128>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
+    case 16: hipLaunchKernelGGL(bilstm_quad_kernel<16>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B); break;
+    case 32: hipLaunchKernelGGL(bilstm_quad_kernel<32>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B); break;
+    case 64: hipLaunchKernelGGL(bilstm_quad_kernel<64>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B); break;
+    case 128: hipLaunchKernelGGL(bilstm_quad_kernel<128>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B); break;
     default: hipLaunchKernelGGL(bilstm_kernel<0>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
     }
     AS_CHECK_LAUNCH();

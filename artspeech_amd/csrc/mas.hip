@@ -23,6 +23,9 @@
 #include "common.h"
 #include "artspeech_hip.h"
 
+// the DP must do exactly one fp32 add per cell: no fused multiply-add anywhere in this file
+#pragma clang fp contract(off)
+
 #define MAS_NEG (-1e32f)
 typedef unsigned long long u64;
 
