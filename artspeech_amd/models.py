@@ -524,16 +524,21 @@ def side_streams(device, n, tag=""):
     return pool[:n]
 
 
+CONCURRENT = True        # False: every branch runs on the calling stream (bench.py's per-kernel timing pass)
+
+
 class Fork:
     """Fork/join of independent branches over side HIP streams.  Every side stream first waits for the calling
     stream; on exit the calling stream waits for all of them.  Tensors that cross streams are registered with the
     caching allocator (`record_stream`) so their memory is not recycled while another stream still uses it."""
 
     def __init__(self, streams, uses=()):
-        self.streams, self.uses = streams, uses
         self.main = torch.cuda.current_stream()
+        self.streams, self.uses = (streams if CONCURRENT else [self.main] * len(streams)), uses
 
     def __enter__(self):
+        if not CONCURRENT:
+            return self
         for s in self.streams:
             s.wait_stream(self.main)
             for t in self.uses:
@@ -544,12 +549,14 @@ class Fork:
         return torch.cuda.stream(self.streams[i])
 
     def produced(self, *tensors):
-        for t in tensors:
-            t.record_stream(self.main)
+        if CONCURRENT:
+            for t in tensors:
+                t.record_stream(self.main)
 
     def __exit__(self, *exc):
-        for s in self.streams:
-            self.main.wait_stream(s)
+        if CONCURRENT:
+            for s in self.streams:
+                self.main.wait_stream(s)
         return False
 
 

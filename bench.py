@@ -74,8 +74,8 @@ def cpu_baseline(host, sd, n_utt):
     torch.set_num_threads(cores)
     W = fold_state_dict(sd)
     dist = load_distribution(DEFAULT_STATS)
-    args = [(torch.from_numpy(host["tokens"][b]), torch.from_numpy(host["mel"][b]), torch.from_numpy(host["f0"][b].astype(np.float32)),
-             torch.from_numpy(host["ema"][b].astype(np.float32))) for b in range(n_utt)]
+    args = [(torch.from_numpy(host["tokens"][b % B]), torch.from_numpy(host["mel"][b % B]), torch.from_numpy(host["f0"][b % B].astype(np.float32)),
+             torch.from_numpy(host["ema"][b % B].astype(np.float32))) for b in range(n_utt)]
     acoustic.forward_test(W, *args[0], dist, forced_dur=host["forced"])          # warm-up
     t0 = time.perf_counter()
     outs = []
@@ -95,8 +95,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--cpu-utts", type=int, default=32, help="utterances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-utts", type=int, default=96, help="utterances in the CPU-baseline sample, capped at ~20 s (0 = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-concurrency", action="store_true", help="run the independent branches back to back (profiling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,6 +123,8 @@ def main():
     models.load_checkpoint(model, None, {"net": {"ArtsSpeech": sd}})
     net = model.ArtsSpeech
     host, g = make_inputs(dev)
+    if args.no_concurrency:
+        models.CONCURRENT = False
 
     def step():
         return net.forward_packed(g["tok"], g["tok_lay"], g["mel"], g["f0"], g["ema"], g["ref_lay"], forced=g["forced"],
@@ -172,8 +175,13 @@ def main():
         assert torch.equal(gout["mel"], mel_first), "graph replay changed the result"
 
     # ---- instrumented pass: per-kernel-class time with HIP events on the launch stream (eager launches)
+    # (branches that normally overlap on side streams run back to back here, so a kernel's event-bracketed duration is
+    #  its own and not that of whatever shared the chip with it)
     L = _lib.lib()
     prof_steps = 3
+    models.CONCURRENT = False
+    step()
+    torch.cuda.synchronize()
     L.as_prof_enable(1)
     for _ in range(prof_steps):
         step()
@@ -182,10 +190,20 @@ def main():
     cnt = (ctypes.c_int32 * n)()
     _lib.check(L.as_prof_collect(ms, fl, by, cnt, n), "as_prof_collect")
     L.as_prof_enable(0)
+    models.CONCURRENT = not args.no_concurrency
     kern = {CLASSES[i]: dict(ms_per_step=ms[i] / prof_steps, launches_per_step=cnt[i] // prof_steps,
                              gflop_per_step=fl[i] / prof_steps / 1e9) for i in range(n) if cnt[i]}
     gemm_ms = ms[0] / max(cnt[0], 1)
     gemm_tflops = (fl[0] / max(cnt[0], 1)) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+
+    # HBM traffic of the dominant kernel cannot be read live (PMC needs rocprofv3): it comes from the committed
+    # counter pass of this same command (profiles/latest_pmc_traffic.json, made by scripts/gpu_profile.sh)
+    traffic, traffic_src = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_traffic.json")))
+        traffic, traffic_src = pj["conv_gemm_hbm_bytes_per_launch"], pj["source"]
+    except Exception:
+        pass
 
     frames_per_step = B * FRAMES_PER_UTT
     ms_per_step = elapsed / args.steps * 1e3
@@ -203,7 +221,7 @@ def main():
         "x_realtime_per_gpu": (value / world) * FRAME_SEC,
         "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 MFMA implicit-GEMM conv)",
                      "achieved": gemm_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": gemm_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "frac": gemm_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_ms": gemm_ms, "launches_per_step": int(cnt[0] // prof_steps),
                      "algorithmic_gflop_per_step": fl[0] / prof_steps / 1e9},
         "kernel_classes": kern,
@@ -212,7 +230,7 @@ def main():
         cb, outs = cpu_baseline(host, sd, args.cpu_utts)
         line["cpu_baseline"] = cb
         err = max(float((mel_first[:, b * FRAMES_PER_UTT:(b + 1) * FRAMES_PER_UTT].cpu() - outs[b]["mel"]).abs().max())
-                  for b in range(len(outs)))
+                  for b in range(min(len(outs), B)))
         line["parity_mel_max_abs_vs_oracle"] = err
     if rank == 0:
         print(json.dumps(line), flush=True)
