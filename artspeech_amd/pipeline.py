@@ -1,0 +1,75 @@
+"""The acoustic-model part of the reference's inference script (test.py:58-119) on the HIP path.
+
+``test.py`` does: espeak phonemizer -> TextCleaner -> reference wav -> log-mel -> ArtsSpeech(step="test") -> HiFi-GAN.
+The phonemizer, the wav/mel front end and the vocoder are outside this path;
+this class covers test.py:75-88 (distribution, build_model, load_checkpoint) and test.py:96-113 (ids, tensor packing,
+the model call) so that a caller with phonemes and a reference mel gets the mel the reference would vocode.
+"""
+import json
+
+import torch
+
+from . import models
+from .text import TextCleaner
+from .weights import DEFAULT_STATS, load_distribution
+
+
+class ArtSpeech:
+    def __init__(self, config=None, checkpoint=None, device=None, stats_path=None):
+        """config: dict with the keys of Configs/config.yaml (model_params, stats_path, pretrained_model) or a path to
+        such a YAML; checkpoint: a path / dict in the reference's format ({'net': {'ArtsSpeech': state_dict}})."""
+        if isinstance(config, str):
+            import yaml
+            with open(config) as f:
+                config = yaml.safe_load(f)
+        config = config or {}
+        mp = dict(hidden_dim=512, n_token=178, style_dim=256, n_layer=3, dim_in=64, max_conv_dim=512, n_mels=80, dropout=0.2)
+        mp.update(config.get("model_params", {}))
+        stats_path = stats_path or config.get("stats_path")
+        if stats_path:                                                                  # test.py:75-79
+            with open(stats_path) as f:
+                stats = json.load(f)
+        else:
+            stats = DEFAULT_STATS
+        dev = models._need_gpu(device if device is not None else config.get("device", "cuda"))
+        self.model = models.build_model(models.Munch(mp), None, stage="second",
+                                        distribution=load_distribution(stats, dev), device=dev)   # test.py:81
+        ckpt = checkpoint if checkpoint is not None else config.get("pretrained_model")
+        if ckpt:
+            models.load_checkpoint(self.model, None, ckpt, load_only_params=True)       # test.py:85
+        self.textcleaner = TextCleaner()
+        self.device = dev
+
+    @torch.no_grad()
+    def synthesis_mel(self, phonemes, ref_mel, features=None, forced_durations=None):
+        """phonemes: the string the phonemizer returns (test.py:94-96) or a list of such strings; ref_mel: normalised
+        log-mel [80,T] (test.py:43-47) or a list; features: (f0_raw, ema_raw) per utterance when no extractor modules
+        are attached.  Returns mel [B,80,2*max M] (what test.py:115 hands to the vocoder)."""
+        if isinstance(phonemes, str):
+            phonemes, ref_mel = [phonemes], [ref_mel]
+            if features is not None:
+                features = [features]
+        ids = [torch.LongTensor(self.textcleaner(p)) for p in phonemes]               # test.py:96-97
+        B = len(ids)
+        nmax, tmax = max(len(i) for i in ids), max(m.shape[-1] for m in ref_mel)
+        text = torch.zeros(B, nmax, dtype=torch.long)
+        mels = torch.zeros(B, ref_mel[0].shape[0], tmax)
+        for b in range(B):
+            text[b, : len(ids[b])] = ids[b]
+            mels[b, :, : ref_mel[b].shape[-1]] = torch.as_tensor(ref_mel[b])
+        input_lengths = torch.LongTensor([len(i) for i in ids])                       # test.py:110
+        mel_input_length = torch.LongTensor([m.shape[-1] for m in ref_mel])           # test.py:111
+        feats = None
+        if features is not None:
+            f0 = torch.zeros(B, 1, tmax)
+            ema = torch.zeros(B, 10, tmax)
+            for b, (f, e) in enumerate(features):
+                f0[b, :, : f.shape[-1]] = torch.as_tensor(f).reshape(1, -1)
+                ema[b, :, : e.shape[-1]] = torch.as_tensor(e)
+            feats = (f0, ema)
+        return self.model.ArtsSpeech([text, input_lengths, mels, mel_input_length, None, None, None], None, None,
+                                     step="test", features=feats, forced_durations=forced_durations)   # test.py:113
+
+    def synthesis(self, text, ref_wav, save_path):
+        raise NotImplementedError("text -> phonemes (espeak), wav -> log-mel and mel -> wav (HiFi-GAN) are outside the "
+                                  "acoustic-model path (SURVEY.md section 2); use synthesis_mel(phonemes, ref_mel)")

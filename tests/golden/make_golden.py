@@ -220,8 +220,25 @@ def make_net():
             np.savez_compressed(os.path.join(HERE, f"net_{tag}_N{n_tok}_T{t_ref}_s{seed}.npz"), **out)
 
 
+def make_text():
+    """symbol table + token ids produced by the reference's own TextCleaner (meldataset.py:14-29; test.py:19-38 is a
+    copy that prints and drops unknown characters) on real IPA lines of the shipped validation lists."""
+    import meldataset as ref_md  # the reference
+    tc = ref_md.TextCleaner()
+    lines = []
+    for lst in ("Data/val_list_LJspeech.txt", "Data/val_list_libritts.txt"):
+        rows = open(os.path.join(_refshim.REF, lst), encoding="utf-8").read().splitlines()
+        lines += [r.split("|")[1] for r in rows[:6]]
+    gold = [{"text": t, "ids": tc(t)} for t in lines]
+    json.dump({"symbols": ref_md.symbols, "cases": gold}, open(os.path.join(HERE, "text_golden.json"), "w", encoding="utf-8"),
+              ensure_ascii=False)
+    print("text golden:", len(ref_md.symbols), "symbols,", len(gold), "lines")
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["params", "mas", "net"]
+    what = sys.argv[1:] or ["params", "mas", "net", "text"]
+    if "text" in what:
+        make_text()
     if "params" in what:
         make_param_inventory()
     if "mas" in what:

@@ -167,3 +167,26 @@ def test_long_form_c5(cuda):
                features=(f0s[3:4], emas[3:4]), forced_durations=forced[3:4])
     # (not bitwise: the GEMM's tile / split-K choice depends on the batch's total column count)
     assert float((solo[0] - out[3]).abs().max()) <= 5e-5
+
+
+def test_pipeline_surface(cuda, golden_dir):
+    """test.py's ArtSpeech class, acoustic part: phoneme string + reference mel -> mel, batched."""
+    import json
+    from artspeech_amd.pipeline import ArtSpeech
+    sd = synth.synth_state_dict(64, 8, seed=3407)
+    tts = ArtSpeech(config={"model_params": {"hidden_dim": 64, "dim_in": 8, "max_conv_dim": 64}},
+                    checkpoint={"net": {"ArtsSpeech": sd}}, device=cuda)
+    with open(os.path.join(golden_dir, "text_golden.json"), encoding="utf-8") as f:
+        g = json.load(f)
+    ph = [g["cases"][0]["text"][:40], g["cases"][1]["text"][:25]]
+    mels, feats = [], []
+    for i, t in enumerate((90, 70)):
+        mel, f0_raw, ema_raw = raw_features(t, 40 + i)
+        mels.append(mel)
+        feats.append((f0_raw, ema_raw))
+    out = tts.synthesis_mel(ph, mels, features=feats)
+    assert out.shape[0] == 2 and out.shape[1] == 80 and bool(torch.isfinite(out).all())
+    solo = tts.synthesis_mel(ph[1], mels[1], features=feats[1])
+    assert float((solo[0] - out[1, :, : solo.shape[2]]).abs().max()) <= 5e-5
+    with pytest.raises(NotImplementedError):
+        tts.synthesis("hello", "ref.wav", "out.wav")
