@@ -28,7 +28,7 @@ AS_MAX_TAPS = 25
 
 
 class ConvGemmArgs(ctypes.Structure):
-    _fields_ = [("W", ctypes.c_void_p), ("X", ctypes.c_void_p), ("Y", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+    _fields_ = [("W", ctypes.c_void_p), ("Wx", ctypes.c_void_p), ("X", ctypes.c_void_p), ("Y", ctypes.c_void_p), ("bias", ctypes.c_void_p),
                 ("res", ctypes.c_void_p), ("meta", ctypes.c_void_p),
                 ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_size_t),
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("T", ctypes.c_int32),

@@ -28,29 +28,7 @@
 #include "conv_gemm.h"
 #include <cstdio>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 #define BK 16
-#define OOB 0xFFFFFFFFu
-
-static __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
-{
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-static __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-
-// XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
-// run of logical tiles -- the output-channel tiles of one column range then share that XCD's L2 copy of the
-// activation columns.  Bijective for any grid size.
-static __device__ __forceinline__ int logical_tile()
-{
-    const int nb = gridDim.x, xcd = blockIdx.x & 7, q8 = nb >> 3, r8 = nb & 7;
-    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-}
 
 // one k-tile of MFMAs from LDS buffer `buf`
 // `mid` runs once after the first k-step's MFMAs have been issued: the staging work of the NEXT tiles (LDS store,
@@ -83,50 +61,6 @@ static __device__ __forceinline__ void mma_tile(const float (*As)[BK][BM], const
         if (s == 0) {
             mid();
             __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
-template <int TM, int TN>
-static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
-                                                int wn, int l31, int lk, int S)
-{
-    if (S > 1) {                                           // raw partial sums; splitk_reduce_kernel finishes
-        float* slab = a.ws + (size_t)blockIdx.y * a.M * a.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) {
-                const int col = n0 + wn * 32 * TN + jn * 32 + l31;
-                if (col >= a.N) continue;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                    if (row < a.M) slab[(size_t)row * a.N + col] = acc[i][jn][e];
-                }
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-            const int col = n0 + wn * 32 * TN + jn * 32 + l31;
-            if (col >= a.N) continue;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                if (row >= a.M) continue;
-                float v = acc[i][jn][e];
-                if (a.bias) v += a.bias[row];
-                if (a.res) v += a.res[(size_t)row * a.ldr + col];
-                if (a.div_sqrt2) v = v / 1.41421356237309504880f;
-                if (a.act == 1) v = v > 0.f ? v : 0.f;
-                else if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
-                if (a.transpose_out) a.Y[(size_t)col * a.ldy + row] = v;   // time-major output for the LSTM
-                else a.Y[(size_t)row * a.ldy + col] = v;
-            }
         }
     }
 }
@@ -419,14 +353,42 @@ static void tile_dims(int choice, int* bm, int* bn)
     *bn = (choice == 22 || choice == 12) ? 128 : 64;
 }
 
+// which arithmetic: bf16x6 when the caller supplied the split weights (AS_GEMM_IMPL=f32 forces the fp32 MFMAs when
+// the fp32 image is there too -- experiments only)
+static bool use_x6(const ConvGemmArgs& a)
+{
+    if (!a.Wx) return false;
+    const char* env = getenv("AS_GEMM_IMPL");
+    return !(env && env[0] == 'f' && a.W);
+}
+
 // Tile and split-K choice, from sweeps on MI355X (scripts/gemm_bench.py): the kernel wants >= ~1000 workgroups
 // (4-5 per CU) so that tile quantisation over 256 CUs and the lock-step load/compute phases of co-resident
 // workgroups average out; shapes with fewer tiles get 128x64 tiles and 2-4 K slices (16 for tiny outputs).
-static int gemm_tile_choice(int M, int N)
+static int gemm_tile_choice(int M, int N, bool x6)
 {
     const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 22, 21, 12, 11
     if (env && atoi(env) > 0) return atoi(env);
     const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);   // a 128-row tile is not half empty
+    if (x6) {
+        // cost model fitted to sweeps on MI355X (scripts/gemm_bench.py): a CU runs its L = ceil(tiles / 256) tiles
+        // together (they overlap each other's waits: x0.85 when L >= 2); relative speed per tile shape from the sweep
+        // (the 64x64 tile stages twice the bytes per flop and is never the best)
+        static const int choices[3] = {22, 21, 12};
+        static const double eff[3] = {1.0, 0.95, 0.85};
+        int best = 12;
+        double best_cost = 1e30;
+        for (int c = 0; c < 3; ++c) {
+            int bm, bn;
+            tile_dims(choices[c], &bm, &bn);
+            if (bm == 128 && !tall) continue;
+            const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
+            const long L = (tiles + 255) / 256;
+            const double cost = (double)L * bm * bn / eff[c] * (L >= 2 ? 0.85 : 1.0);
+            if (cost < best_cost) { best_cost = cost; best = choices[c]; }
+        }
+        return best;
+    }
     if (tall) {
         if ((long)as_cdiv(M, 128) * as_cdiv(N, 128) >= 1000) return 22;
         if ((long)as_cdiv(M, 128) * as_cdiv(N, 64) >= 300) return 21;
@@ -436,21 +398,29 @@ static int gemm_tile_choice(int M, int N)
     return 11;
 }
 
-static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
+static int gemm_ksplit(int M, int N, int Kp, int T, int choice, bool x6)
 {
     const char* env = getenv("AS_GEMM_KSPLIT");          // tuning/experiments only
     int bm, bn;
     tile_dims(choice, &bm, &bn);
     const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
-    const int nkt = T * (Kp / BK);
+    int nkt = T * (Kp / BK);
+    if (x6) nkt = T * as_cdiv(Kp / 16, 256 * 64 / (bm * bn));   // k-tile = 16 * WK, WK = 4 / (tile / 64x64)
     int s = 1;
     if (env && atoi(env) > 0) s = atoi(env);
-    else if (tiles < 1000) {
+    else if (x6) {
+        if (tiles < 256) {
+            s = as_cdiv(512, tiles);
+            const int cap = (long)M * N >= 262144 ? 4 : 16;
+            if (s > cap) s = cap;
+        }
+    } else if (tiles < 1000) {
         s = as_cdiv(1200, tiles);
         const int cap = (long)M * N >= 262144 ? 4 : 16;  // the reduce pass moves S*M*N*8 bytes
         if (s > cap) s = cap;
     }
-    if (s > nkt / 8) s = nkt / 8;                        // a slice keeps >= 8 k-tiles
+    const int min_kt = x6 ? 4 : 8;                       // k-tiles a slice keeps
+    if (s > nkt / min_kt) s = nkt / min_kt;
     return s < 1 ? 1 : s;
 }
 
@@ -458,7 +428,8 @@ extern "C" size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host)
 {
     if (!args_host || args_host->M <= 0 || args_host->N <= 0 || args_host->Kp <= 0 || args_host->T <= 0) return 0;
     const ConvGemmArgs& a = *args_host;
-    const int s = gemm_ksplit(a.M, a.N, a.Kp, a.T, gemm_tile_choice(a.M, a.N));
+    const bool x6 = use_x6(a);
+    const int s = gemm_ksplit(a.M, a.N, a.Kp, a.T, gemm_tile_choice(a.M, a.N, x6), x6);
     return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
 }
 
@@ -474,32 +445,38 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!args_host) return AS_EINVAL;
     const ConvGemmArgs& a = *args_host;
-    if (!a.W || !a.X || !a.Y || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS) return AS_EINVAL;
+    if ((!a.W && !a.Wx) || !a.X || !a.Y || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS) return AS_EINVAL;
     if (a.Kp < a.K || a.Kp % BK) return AS_EINVAL;
     if (a.ldx < a.N || a.ldy < (a.transpose_out ? a.M : a.N) || (a.res && (a.ldr < a.N || a.transpose_out))) return AS_EINVAL;
     // 32-bit byte offsets inside the buffer descriptors
-    if ((double)a.T * a.Kp * a.M * 4.0 >= 4294967296.0 || (double)a.K * a.ldx * 4.0 + 16.0 >= 4294967296.0) return AS_EINVAL;
+    if ((double)a.T * (a.Kp + 48) * a.M * 6.0 >= 4294967296.0 || (double)a.K * a.ldx * 4.0 + 16.0 >= 4294967296.0) return AS_EINVAL;
     if (a.N == 0) return AS_OK;
-    const int choice = gemm_tile_choice(a.M, a.N);
-    int S = gemm_ksplit(a.M, a.N, a.Kp, a.T, choice);
+    const bool x6 = use_x6(a);
+    const int choice = gemm_tile_choice(a.M, a.N, x6);
+    int S = gemm_ksplit(a.M, a.N, a.Kp, a.T, choice, x6);
     if (S > 1 && (!a.ws || a.ws_bytes < (size_t)S * a.M * a.N * sizeof(float))) S = 1;   // no workspace: no split
     const char* envq = getenv("AS_GEMM_QUAD");           // tuning/experiments only: 0 forces the scalar staging
     const bool quad = a.quad_ok && (a.M & 3) == 0 && !(envq && atoi(envq) == 0);
     char tag[64];
-    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d S%d %s", a.M, a.N, a.K, a.T, choice, S, quad ? "q" : "s");
+    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d S%d %s", a.M, a.N, a.K, a.T, choice, S, x6 ? "x6" : quad ? "q" : "s");
     // algorithmic work of this launch: 2*M*N*K*T flop; bytes = weights + input + output once
     AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.K * a.T,
                        4.0 * ((double)a.T * a.K * a.M + (double)a.K * a.N + (double)a.M * a.N), stream, tag);
-    int bm, bn;
-    tile_dims(choice, &bm, &bn);
-    const dim3 grid(as_cdiv(a.M, bm) * as_cdiv(a.N, bn), S);
-    switch (choice) {
-    case 22: launch<2, 2>(quad, grid, stream, a); break;
-    case 21: launch<2, 1>(quad, grid, stream, a); break;
-    case 12: launch<1, 2>(quad, grid, stream, a); break;
-    default: launch<1, 1>(quad, grid, stream, a); break;
+    if (x6) {
+        const int rc = as_conv_gemm_x6_launch(a, choice, S, stream);
+        if (rc != AS_OK) return rc;
+    } else {
+        int bm, bn;
+        tile_dims(choice, &bm, &bn);
+        const dim3 grid(as_cdiv(a.M, bm) * as_cdiv(a.N, bn), S);
+        switch (choice) {
+        case 22: launch<2, 2>(quad, grid, stream, a); break;
+        case 21: launch<2, 1>(quad, grid, stream, a); break;
+        case 12: launch<1, 2>(quad, grid, stream, a); break;
+        default: launch<1, 1>(quad, grid, stream, a); break;
+        }
+        AS_CHECK_LAUNCH();
     }
-    AS_CHECK_LAUNCH();
     if (S > 1) {
         const long total = (long)a.M * a.N;
         int blocks = as_cdiv(total, 256 * 4);

@@ -63,7 +63,7 @@ class Weights:
         """conv weight [Cout,Cin,k] or [Cout,Cin,kh,kw] -> [taps][Cin][Cout]."""
         key = "T:" + name
         if key not in self._cache:
-            self._cache[key] = ops.prep_weight(self.raw[name + ".weight"]).to(self.device)
+            self._cache[key] = ops.prep_weight(self.raw[name + ".weight"], self.device)
         return self._cache[key]
 
     def bias(self, name):
@@ -74,7 +74,7 @@ class Weights:
         if key not in self._cache:
             w = torch.cat([self.raw[f"{p}.conv_{n}.weight"] for n in "qkv"], 0)      # [3C, C, 1]
             b = torch.cat([self.raw[f"{p}.conv_{n}.bias"] for n in "qkv"], 0)
-            self._cache[key] = (ops.prep_weight(w).to(self.device), b.to(self.device))
+            self._cache[key] = (ops.prep_weight(w, self.device), b.to(self.device))
         return self._cache[key]
 
     def lstm(self, p):
@@ -86,7 +86,7 @@ class Weights:
                            r[p + ".bias_ih_l0_reverse"] + r[p + ".bias_hh_l0_reverse"]], 0)
             whh_t = torch.stack([r[p + ".weight_hh_l0"].t().contiguous(), r[p + ".weight_hh_l0_reverse"].t().contiguous()], 0)
             H = r[p + ".weight_hh_l0"].shape[1]
-            self._cache[key] = (w_ih.t().contiguous()[None].to(self.device), b.to(self.device), whh_t.to(self.device), H)
+            self._cache[key] = (ops.prep_weight(w_ih[:, :, None], self.device), b.to(self.device), whh_t.to(self.device), H)
         return self._cache[key]
 
     def cached(self, key, fn):
@@ -258,7 +258,7 @@ def tower2d(W, p, X, lay, kinds, last_idx, last_stride, linear):
     C = x.shape[0]
     col = ops.im2col_valid(x, lay, lout.new(C * K * K), lout, K, last_stride, True)
     wraw = W.raw[f"{p}.{last_idx}.weight"]               # [Cout][C][5][5] -> one tap with K = C*25 (im2col row order)
-    wl2 = W.cached("IM2COL:" + p, lambda: ops.prep_weight(wraw.reshape(wraw.shape[0], C * K * K, 1)).to(W.device))
+    wl2 = W.cached("IM2COL:" + p, lambda: ops.prep_weight(wraw.reshape(wraw.shape[0], C * K * K, 1), W.device))
     y = ops.conv_gemm(wl2, col, lout, lout.new(wraw.shape[0]), [(0, 0)], bias=W.bias(f"{p}.{last_idx}"), act=ACT_LRELU)
     pooled = ops.mean_pool(y, lout, False)
     return ops.linear_rows(pooled, W.vec(linear + ".weight"), W.vec(linear + ".bias"))

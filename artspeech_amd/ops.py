@@ -2,6 +2,7 @@
 device memory and the current HIP stream; every computation below is a HIP kernel of this repo.
 No fallbacks: a missing library or a failing call raises."""
 import ctypes
+import os
 
 import torch
 
@@ -99,15 +100,43 @@ def layout(widths, device, H=1):
     return lay
 
 
-def prep_weight(w):
+# arithmetic of the conv GEMM: "x6" = bf16 matrix cores, three-way split operands, fp32-accurate (default);
+# "f32" = fp32 MFMAs (exact fp32 products).  Both run on the GPU through the same entry point.
+GEMM_IMPL = os.environ.get("AS_GEMM_IMPL", "x6")
+
+
+def split_bf16x3(wt):
+    """fp32 GEMM image [T][Kp][M] -> the bf16x6 kernel's image [T][KBx][6][M][8] (int16 bit patterns), KBx = Kp/16
+    rounded up to a multiple of 4 (zero blocks): w = h + m + l with h, m, l bf16 (round-to-nearest-even at each
+    step, exact sum); slot p*2 + kh holds part p of k = 16*kb + 8*kh + 0..7 (csrc/conv_gemm_x6.hip)."""
+    T, Kp, M = wt.shape
+    kx = (Kp + 63) // 64 * 64
+    if kx != Kp:
+        wt = torch.cat([wt, wt.new_zeros(T, kx - Kp, M)], dim=1)
+    h = wt.to(torch.bfloat16)
+    r = wt - h.float()
+    m = r.to(torch.bfloat16)
+    l = (r - m.float()).to(torch.bfloat16)
+    parts = torch.stack([h, m, l], dim=0)                                   # [3][T][kx][M]
+    img = parts.reshape(3, T, kx // 16, 2, 8, M).permute(1, 2, 0, 3, 5, 4)   # [T][kb][p][kh][M][8]
+    return img.contiguous().view(torch.int16).reshape(T, kx // 16, 6, M, 8)
+
+
+def prep_weight(w, device=None):
     """conv / linear weight [Cout, Cin, *kernel] -> the GEMM's [taps][Kp][Cout] image: transposed so that output
-    channels are contiguous, input channels zero-padded to a multiple of 16 (one k-tile)."""
+    channels are contiguous, input channels zero-padded to a multiple of 16 (one k-tile).  The returned tensor
+    carries `.x6`, the same weights split for the bf16x6 arithmetic (split_bf16x3)."""
     cout, cin = w.shape[0], w.shape[1]
     wt = w.reshape(cout, cin, -1).permute(2, 1, 0)
     kp = (cin + KTILE - 1) // KTILE * KTILE
     if kp != cin:
         wt = torch.cat([wt, wt.new_zeros(wt.shape[0], kp - cin, cout)], dim=1)
-    return wt.contiguous()
+    wt = wt.contiguous()
+    x6 = split_bf16x3(wt)
+    if device is not None:
+        wt, x6 = wt.to(device), x6.to(device)
+    wt.x6 = x6                                       # a plain attribute: tensor ops on `wt` drop it
+    return wt
 
 
 def taps_1d(k):
@@ -129,6 +158,8 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     a = ConvGemmArgs()
     a.Kp = Kp
     a.W, a.X, a.Y, a.bias, a.res = _p(Wt), _p(X), _p(Y), _p(bias), _p(res)
+    x6 = getattr(Wt, "x6", None) if GEMM_IMPL == "x6" else None
+    a.Wx = _p(x6)
     a.meta = _p(lay.meta) if (use_meta and not (T == 1 and taps[0] == (0, 0))) else None
     a.M, a.N, a.K, a.T = M, lay.N, K, T
     a.ldx, a.ldy = _ld(X), _ld(Y)

@@ -75,7 +75,10 @@ int as_make_meta(const int32_t* widths, const int32_t* col_off, int B, int H, in
  * ------------------------------------------------------------------------------------------- */
 #define AS_MAX_TAPS 25
 typedef struct ConvGemmArgs {
-    const float* W;        /* [T][Kp][M] */
+    const float* W;        /* [T][Kp][M] fp32 (the fp32-MFMA path), or NULL when Wx is given */
+    const uint16_t* Wx;    /* [T][KBx][6][M][8] bf16, KBx = Kp/16 rounded up to a multiple of 4 (zero blocks): the same
+                              weights split w = h + m + l (three bf16, exact) for the bf16x6 path -- slot p*2 + kh holds
+                              part p (h, m, l) of k = 16*kb + 8*kh + 0..7; NULL = fp32 path */
     const float* X;        /* [K][ldx] */
     float* Y;              /* [M][ldy] */
     const float* bias;     /* [M] or NULL */

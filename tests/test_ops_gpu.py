@@ -14,11 +14,20 @@ def packed(x_list):
     return torch.cat(x_list, dim=1).contiguous()
 
 
+@pytest.fixture(params=["x6", "f32"])
+def impl(request, monkeypatch):
+    """both arithmetic paths of the conv GEMM: bf16x6 (default) and fp32 MFMA"""
+    monkeypatch.setattr(ops, "GEMM_IMPL", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("cin,cout,k,lens", [(64, 128, 3, [50, 13, 1, 200]), (10, 64, 1, [7, 9]), (1, 32, 1, [33]),
                                              (96, 80, 5, [40, 41]), (130, 257, 9, [17, 300, 64]), (512, 1024, 3, [128] * 8)])
 @pytest.mark.parametrize("tile", ["", "11", "21", "22", "12"])
 @pytest.mark.parametrize("quad", ["", "0"])
-def test_conv1d_gemm(cuda, monkeypatch, cin, cout, k, lens, tile, quad):
+def test_conv1d_gemm(cuda, monkeypatch, impl, cin, cout, k, lens, tile, quad):
+    if impl == "x6" and quad:
+        pytest.skip("one staging in the bf16x6 kernel")
     if quad:
         monkeypatch.setenv("AS_GEMM_QUAD", quad)          # force the scalar staging
     if tile:
@@ -32,7 +41,7 @@ def test_conv1d_gemm(cuda, monkeypatch, cin, cout, k, lens, tile, quad):
     res = [torch.randn(cout, L, generator=g) for L in lens]
     want = packed([(F.conv1d(x[None], w, b, padding=k // 2)[0] + r) / np.sqrt(2) for x, r in zip(xs, res)])
     lay = Layout(lens, cuda)
-    wt = ops.prep_weight(w).to(cuda)
+    wt = ops.prep_weight(w, cuda)
     X = lay.new(cin)
     X.copy_(packed(xs))                                   # lay.new: 16 bytes of slack in front -> 16-byte staging allowed
     y = ops.conv_gemm(wt, X, lay, lay.new(cout), taps_1d(k), bias=b.to(cuda), res=packed(res).to(cuda), div_sqrt2=True)
@@ -44,7 +53,7 @@ def test_conv1d_gemm(cuda, monkeypatch, cin, cout, k, lens, tile, quad):
 
 
 @pytest.mark.parametrize("widths", [[23, 8, 40], [23, 23, 23], [12, 8, 40]])
-def test_conv2d_gemm_and_transpose_out(cuda, widths):
+def test_conv2d_gemm_and_transpose_out(cuda, impl, widths):
     g = torch.Generator().manual_seed(3)
     cin, cout, H = 16, 48, 10
     w = torch.randn(cout, cin, 3, 3, generator=g) / 12
@@ -52,7 +61,7 @@ def test_conv2d_gemm_and_transpose_out(cuda, widths):
     xs = [torch.randn(cin, H, W, generator=g) for W in widths]
     want = packed([F.conv2d(F.leaky_relu(x, 0.2)[None], w, b, padding=1)[0].reshape(cout, -1) for x in xs])
     lay = Layout(widths, cuda, H=H)
-    wt = ops.prep_weight(w).to(cuda)
+    wt = ops.prep_weight(w, cuda)
     X = lay.new(cin)
     X.copy_(packed([x.reshape(cin, -1) for x in xs]))
     y = ops.conv_gemm(wt, X, lay, lay.new(cout), taps_2d(3, 3), bias=b.to(cuda), in_act=ops.ACT_LRELU)
@@ -62,13 +71,13 @@ def test_conv2d_gemm_and_transpose_out(cuda, widths):
     assert torch.equal(yt.t().contiguous(), y)
 
 
-def test_mfma_layout_asymmetric(cuda):
+def test_mfma_layout_asymmetric(cuda, impl):
     """A = I with an asymmetric B: catches a transposed C fragment (guide section 3)."""
     n = 64
     w = torch.eye(n)[:, :, None]                                  # [cout, cin, 1]
     x = torch.arange(n * 96, dtype=torch.float32).reshape(n, 96)
     lay = Layout([96], cuda)
-    y = ops.conv_gemm(ops.prep_weight(w).to(cuda), x.to(cuda), lay, lay.new(n), [(0, 0)])
+    y = ops.conv_gemm(ops.prep_weight(w, cuda), x.to(cuda), lay, lay.new(n), [(0, 0)])
     assert torch.equal(y.cpu(), x)
 
 
@@ -207,7 +216,7 @@ def test_down_sampling(cuda, kind):
 
 
 @pytest.mark.parametrize("ksplit", ["2", "5", "16"])
-def test_conv_gemm_split_k(cuda, monkeypatch, ksplit):
+def test_conv_gemm_split_k(cuda, monkeypatch, impl, ksplit):
     """split-K slabs + fixed-order reduce give the same result as the unsplit kernel (to rounding)."""
     monkeypatch.setenv("AS_GEMM_KSPLIT", ksplit)
     g = torch.Generator().manual_seed(int(ksplit))
@@ -218,6 +227,6 @@ def test_conv_gemm_split_k(cuda, monkeypatch, ksplit):
     res = [torch.randn(cout, L, generator=g) for L in lens]
     want = packed([F.leaky_relu((F.conv1d(x[None], w, b, padding=k // 2)[0] + r) / np.sqrt(2), 0.2) for x, r in zip(xs, res)])
     lay = Layout(lens, cuda)
-    y = ops.conv_gemm(ops.prep_weight(w).to(cuda), packed(xs).to(cuda), lay, lay.new(cout), taps_1d(k), bias=b.to(cuda),
+    y = ops.conv_gemm(ops.prep_weight(w, cuda), packed(xs).to(cuda), lay, lay.new(cout), taps_1d(k), bias=b.to(cuda),
                       res=packed(res).to(cuda), div_sqrt2=True, act=ops.ACT_LRELU)
     assert float((y.cpu() - want).abs().max()) <= 2e-5
