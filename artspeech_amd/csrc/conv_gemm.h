@@ -4,6 +4,7 @@
 #include "common.h"
 
 #define OOB 0xFFFFFFFFu
+#define OOBH 0x80000000u   /* epilogue: out of range for every descriptor (< 2 GiB, host-checked) even after adding an in-range offset */
 
 // host: launch the bf16x6 kernel for tile `choice` (22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64) on a grid of
 // (tiles, S); returns AS_OK or a hipError_t.  (conv_gemm_x6.hip)
@@ -12,6 +13,7 @@ int as_conv_gemm_x6_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t
 #ifdef __HIPCC__
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
 {
@@ -34,80 +36,125 @@ static __device__ __forceinline__ int logical_tile()
 // Accumulator tiles -> Y.  A 32x32 MFMA accumulator holds C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31];
 // a wave owns TM x TN of them at rows m0 + wm*32*TM, columns n0 + wn*32*TN.  S > 1: raw partial sums into this
 // slice's slab (splitk_reduce_kernel applies the epilogue).
-template <int TM, int TN>
-static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
-                                                int wn, int l31, int lk, int S)
+// Branch-free: every access is a raw BUFFER access whose per-lane offset carries the whole (row, column) position, so
+// rows >= M fall past the descriptor's end (loads return 0, stores are dropped by the range check) and columns >= N
+// get an out-of-range offset -- no exec-mask branches, no 64-bit address arithmetic per element (the branchy
+// version of this function took 20-40k cycles per 128x128 tile, a third of a small GEMM).
+static __device__ __forceinline__ float div_sqrt2f(float x)
 {
-    if (S > 1) {
-        float* slab = a.ws + (size_t)blockIdx.y * a.M * a.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) {
-                const int col = n0 + wn * 32 * TN + jn * 32 + l31;
-                if (col >= a.N) continue;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                    if (row < a.M) slab[(size_t)row * a.N + col] = acc[i][jn][e];
-                }
-            }
-        return;
-    }
-    // Loads first, stores after: Y may alias res, so the compiler keeps program order, and a load issued after a
-    // store waits out its whole latency alone (measured: 64 such round trips = 40k cycles per 128x128 tile).
-    float bv[TM][16];
+    // x / sqrt(2), correctly rounded without the division sequence: q = x*(1/c), one Newton correction in fma
+    const float c = 1.41421356237309504880f, rc = 0.70710678118654752440f;
+    const float q = x * rc;
+    return __builtin_fmaf(__builtin_fmaf(-q, c, x), rc, q);
+}
+
+template <int TM, int TN, bool DIV, int ACT, bool TR>
+static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int rbase, int cbase,
+                                                      int l31)
+{
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res), 0, a.res ? (int)((unsigned)a.M * a.ldr * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY =
+        __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, (int)((unsigned)(TR ? a.N : a.M) * a.ldy * 4u), 0x00020000);
+    float bv[TM][16];                                      // loads first: Y may alias res, so program order is kept
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-            bv[i][e] = (a.bias && row < a.M) ? a.bias[row] : 0.f;
-        }
+        for (int e = 0; e < 16; ++e) bv[i][e] = 0.f;
+    if (a.bias) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                bv[i][e] = buf_load1(rsB, (unsigned)(rbase + i * 32 + (e & 3) + 8 * (e >> 2)) * 4u, 0);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
-            const int col = n0 + wn * 32 * TN + jn * 32 + l31;
-            if (col >= a.N) continue;
-            const int row0 = m0 + wm * 32 * TM + i * 32 + 4 * lk;
-            float rv[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = row0 + (e & 3) + 8 * (e >> 2);
-                rv[e] = (a.res && row < a.M) ? a.res[(size_t)row * a.ldr + col] : 0.f;
-            }
+            const int col = cbase + jn * 32 + l31;
+            const int row0 = rbase + i * 32;
+            const unsigned r_off = col < a.N ? (unsigned)(row0 * a.ldr + col) * 4u : OOBH;
             float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = 0.f;
+            if (a.res) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = buf_load1(rsR, r_off + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.ldr * 4), 0);
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float x = acc[i][jn][e] + bv[i][e];
-                x += rv[e];
-                if (a.div_sqrt2) x = x / 1.41421356237309504880f;
-                if (a.act == 1) x = x > 0.f ? x : 0.f;
-                else if (a.act == 2) x = x > 0.f ? x : 0.2f * x;
+                x += v[e];
+                if (DIV) x = div_sqrt2f(x);
+                if (ACT == 1) x = x > 0.f ? x : 0.f;
+                if (ACT == 2) x = x > 0.f ? x : 0.2f * x;
                 v[e] = x;
             }
-            if (a.transpose_out) {                           // time-major output for the LSTM: 4 consecutive rows = 16 bytes
+            if (TR) {                                        // time-major output for the LSTM: Y[col][row], 4 rows = 16 bytes
+                const bool quad = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 && row0 + 28 <= a.M;
+                const unsigned off = col < a.N ? (unsigned)(col * a.ldy + row0) * 4u : OOBH;
+                if (quad) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = row0 + 8 * q;
-                    float* y = a.Y + (size_t)col * a.ldy + row;
-                    if (row + 3 < a.M && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0) {
-                        *reinterpret_cast<f32x4*>(y) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-                    } else {
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, t), rsY, off + 32u * q, 0, 0);
+                    }
+                } else {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (row + c < a.M) y[c] = v[4 * q + c];
+                    for (int e = 0; e < 16; ++e) {
+                        const int dr = (e & 3) + 8 * (e >> 2);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rsY,
+                                                              row0 + dr < a.M ? off + 4u * dr : OOBH, 0, 0);
                     }
                 }
             } else {
+                const unsigned off = col < a.N ? (unsigned)(row0 * a.ldy + col) * 4u : OOBH;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = row0 + (e & 3) + 8 * (e >> 2);
-                    if (row < a.M) a.Y[(size_t)row * a.ldy + col] = v[e];
-                }
+                for (int e = 0; e < 16; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rsY,
+                                                          off + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.ldy * 4), 0, 0);
             }
         }
     }
+}
+
+template <int TM, int TN>
+static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
+                                                int wn, int l31, int lk, int S)
+{
+    const int rbase = m0 + wm * 32 * TM + 4 * lk;          // this lane's first row; element e adds i*32 + (e&3) + 8*(e>>2)
+    const int cbase = n0 + wn * 32 * TN;
+    if (S > 1) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            a.ws + (size_t)blockIdx.y * a.M * a.N, 0, (int)((unsigned)a.M * a.N * 4u), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                const int col = cbase + jn * 32 + l31;
+                const unsigned v0 = col < a.N ? (unsigned)((rbase + i * 32) * a.N + col) * 4u : OOBH;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    // through a VGPR: storing element e of an accumulator tuple directly, hipcc 7.2 emits the
+                    // tuple's first register for every e
+                    float t = acc[i][jn][e];
+                    asm volatile("" : "+v"(t));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rs,
+                                                          v0 + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.N * 4), 0, 0);
+                }
+            }
+        return;
+    }
+    // one lean copy per (divide, activation, transposed) combination the path uses
+    if (a.transpose_out) epilogue_tiles<TM, TN, false, 0, true>(a, acc, rbase, cbase, l31);
+    else if (a.div_sqrt2 && a.act == 0) epilogue_tiles<TM, TN, true, 0, false>(a, acc, rbase, cbase, l31);
+    else if (a.div_sqrt2 && a.act == 2) epilogue_tiles<TM, TN, true, 2, false>(a, acc, rbase, cbase, l31);
+    else if (a.div_sqrt2) epilogue_tiles<TM, TN, true, 1, false>(a, acc, rbase, cbase, l31);
+    else if (a.act == 0) epilogue_tiles<TM, TN, false, 0, false>(a, acc, rbase, cbase, l31);
+    else if (a.act == 1) epilogue_tiles<TM, TN, false, 1, false>(a, acc, rbase, cbase, l31);
+    else epilogue_tiles<TM, TN, false, 2, false>(a, acc, rbase, cbase, l31);
 }
 #endif

@@ -450,6 +450,9 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if (a.ldx < a.N || a.ldy < (a.transpose_out ? a.M : a.N) || (a.res && (a.ldr < a.N || a.transpose_out))) return AS_EINVAL;
     // 32-bit byte offsets inside the buffer descriptors
     if ((double)a.T * (a.Kp + 48) * a.M * 6.0 >= 4294967296.0 || (double)a.K * a.ldx * 4.0 + 16.0 >= 4294967296.0) return AS_EINVAL;
+    // the epilogue's buffer descriptors (output, residual, split-K slab) stay below 2 GiB
+    if ((double)(a.transpose_out ? a.N : a.M) * a.ldy * 4.0 >= 2147483648.0 || (double)a.M * a.ldr * 4.0 >= 2147483648.0 ||
+        (double)a.M * a.N * 4.0 >= 2147483648.0) return AS_EINVAL;
     if (a.N == 0) return AS_OK;
     const bool x6 = use_x6(a);
     const int choice = gemm_tile_choice(a.M, a.N, x6);
