@@ -222,16 +222,46 @@ __global__ void __launch_bounds__(256)
 linear_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
                    int B, int M, int K, float* __restrict__ y, int ldy)
 {
+    // one wave per output feature m, all B rows: the weight row is read from HBM exactly once (the batched AdaIN
+    // projections are 64 MB of weights against 64 KB of styles) and stays in registers; x is cache resident
     const int lane = threadIdx.x & 63;
-    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (o >= (long)B * M) return;
-    const int b = (int)(o / M), m = (int)(o - (long)b * M);
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
     const float* wr = w + (size_t)m * K;
-    const float* xr = x + (size_t)b * ldx;
-    float s = 0.f;
-    for (int k = lane; k < K; k += 64) s += wr[k] * xr[k];
-    s = wave_sum(s);
-    if (lane == 0) y[(size_t)b * ldy + m] = s + (bias ? bias[m] : 0.f);
+    const float bm = bias ? bias[m] : 0.f;
+    constexpr int KR = 8;                                  // K <= 64 * 4 * KR values of the row per lane in registers
+    const bool vec = (K & 3) == 0 && (ldx & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    if (vec && K <= 256 * KR) {
+        const int nq = K >> 2;                             // float4 quads in a row
+        float4 wq[KR];
+#pragma unroll
+        for (int c = 0; c < KR; ++c) {
+            const int q = lane + 64 * c;
+            wq[c] = q < nq ? reinterpret_cast<const float4*>(wr)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int b = 0; b < B; ++b) {
+            const float4* xq = reinterpret_cast<const float4*>(x + (size_t)b * ldx);
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < KR; ++c) {
+                const int q = lane + 64 * c;
+                if (q < nq) {
+                    const float4 v = xq[q];
+                    s += wq[c].x * v.x + wq[c].y * v.y + wq[c].z * v.z + wq[c].w * v.w;
+                }
+            }
+            s = wave_sum(s);
+            if (lane == 0) y[(size_t)b * ldy + m] = s + bm;
+        }
+        return;
+    }
+    for (int b = 0; b < B; ++b) {
+        const float* xr = x + (size_t)b * ldx;
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += wr[k] * xr[k];
+        s = wave_sum(s);
+        if (lane == 0) y[(size_t)b * ldy + m] = s + bm;
+    }
 }
 
 extern "C" int as_linear_rows_f32(const float* x, int ldx, const float* w, const float* bias, int B, int M, int K,
@@ -240,7 +270,7 @@ extern "C" int as_linear_rows_f32(const float* x, int ldx, const float* w, const
     if (!x || !w || !y || B < 0 || M <= 0 || K <= 0 || ldx < K || ldy < M) return AS_EINVAL;
     if (B == 0) return AS_OK;
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(linear_rows_kernel, dim3(as_cdiv((long)B * M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
+    hipLaunchKernelGGL(linear_rows_kernel, dim3(as_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
                        bias, B, M, K, y, ldy);
     AS_CHECK_LAUNCH();
     return AS_OK;
@@ -378,6 +408,29 @@ extern "C" int as_crop_f32(const float* src, int lds, const int32_t* src_off, in
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(crop_kernel, dim3(as_cdiv(max_len, 256), B, C), dim3(256), 0, (hipStream_t)stream, src, lds,
                        src_off, start, dst, ldd, dst_off, C);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// H channel rows of per-utterance column windows -> per-utterance H x W images, packed [1][sum_b H*W_b]:
+// dst[img_off[b] + h*W_b + i] = src[h][src_off[b] + start + i]   (the mel / TV inputs of the 2-D towers, models.py:419-421)
+__global__ void rows_to_images_kernel(const float* __restrict__ src, int lds, const int* __restrict__ src_off, int start,
+                                      float* __restrict__ dst, const int* __restrict__ img_off, int H)
+{
+    const int b = blockIdx.y, h = blockIdx.z;
+    const int Wb = (img_off[b + 1] - img_off[b]) / H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Wb; i += gridDim.x * blockDim.x)
+        dst[(size_t)img_off[b] + (size_t)h * Wb + i] = src[(size_t)h * lds + src_off[b] + start + i];
+}
+
+extern "C" int as_rows_to_images_f32(const float* src, int lds, const int32_t* src_off, int start, int H, float* dst,
+                                     const int32_t* img_off, int B, int max_w, as_stream_t stream)
+{
+    if (!src || !dst || !src_off || !img_off || B < 0 || H <= 0) return AS_EINVAL;
+    if (B == 0 || max_w <= 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(rows_to_images_kernel, dim3(as_cdiv(max_w, 256), B, H), dim3(256), 0, (hipStream_t)stream, src, lds,
+                       src_off, start, dst, img_off, H);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

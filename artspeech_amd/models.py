@@ -340,7 +340,8 @@ class StyleEncoder(_Module):
         l1 = layout(lens, dev)
         c = ops.crop(feat, lay_full, 0, l1.new(92), l1)
         lm, le = layout(lens, dev, H=80), layout(lens, dev, H=10)
-        return dict(c=c, l1=l1, lm=lm, le=le, mel_img=self._image(c[12:92], l1, lm), ema_img=self._image(c[2:12], l1, le))
+        return dict(c=c, l1=l1, lm=lm, le=le, mel_img=ops.rows_to_images(c[12:92], l1, 0, 80, lm),
+                    ema_img=ops.rows_to_images(c[2:12], l1, 0, 10, le))
 
     def tower(self, which, ti):
         """one of the four towers + its Linear (models.py:385-415) -> [B][S]"""
@@ -357,12 +358,6 @@ class StyleEncoder(_Module):
         """StyleEncoder.style_extractor (models.py:417-424) on packed features -> Style [B][512]."""
         ti = self.tower_inputs(feat, lay_full)
         return torch.cat([self.tower(w, ti) for w in ("mel", "ema", "f0", "energy")], dim=1).contiguous()
-
-    @staticmethod
-    def _image(rows, l1, limg):
-        """[H][sum L] (channel-per-row) -> [1][sum H*L] (per-utterance H x L images)."""
-        parts = [rows[:, l1.off_host[b]:l1.off_host[b + 1]].reshape(1, -1) for b in range(l1.B)]
-        return torch.cat(parts, dim=1).contiguous()
 
     def features_packed(self, mel_p, f0_raw_p, ema_raw_p, lay, stats24):
         return ops.ref_features(mel_p, f0_raw_p, ema_raw_p, lay.N, stats24, lay.new(12))
@@ -406,7 +401,7 @@ class DurationPredictor(_Module):
         """dur_block + dur_linear on the FULL-length TV track (models.py:543-546) -> [B][64]"""
         W, p = self.W, self.p
         limg = layout(ref_lay.widths_host, W.device, H=10)
-        img = StyleEncoder._image(ema_p, ref_lay, limg)
+        img = ops.rows_to_images(ema_p, ref_lay, 0, ema_p.shape[0], limg)
         return tower2d(W, p + ".dur_block", img, limg, ["channelpreserve"] * 2 + ["half"], 5, 2, p + ".dur_linear")
 
     def encoder(self, tokens_i32, tok_lay):

@@ -238,6 +238,14 @@ def crop(src, src_lay, start, dst, dst_lay):
     return dst
 
 
+def rows_to_images(src, src_lay, start, H, img_lay):
+    """rows [H][sum L] (a row-slice view is fine) -> [1][sum H*L] images in `img_lay` (same utterance widths, H rows)."""
+    dst = img_lay.new(1)
+    check(_lib.lib().as_rows_to_images_f32(_p(src), _ld(src), _p(src_lay.col_off), start, H, _p(dst), _p(img_lay.col_off),
+                                           img_lay.B, src_lay.max_cols, stream()), "as_rows_to_images_f32")
+    return dst
+
+
 def dwconv_down(X, lin, Y, lout, w, bias, kh, lrelu):
     check(_lib.lib().as_dwconv_down_f32(_p(X), _ld(X), _p(lin.col_off), _p(lin.widths), lin.H, _p(Y), _ld(Y),
                                         _p(lout.col_off), _p(lout.widths), lout.H, _p(w), _p(bias), kh, lin.B,

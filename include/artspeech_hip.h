@@ -137,6 +137,10 @@ int as_ref_features_f32(const float* mel, int ldm, int n_mels, const float* f0_r
 /* per-utterance column window copy (the T-1 crop, models.py:459-471) */
 int as_crop_f32(const float* src, int lds, const int32_t* src_off, int start, float* dst, int ldd,
                 const int32_t* dst_off, int B, int C, int max_len, as_stream_t stream);
+/* H channel rows -> per-utterance H x W images packed [1][sum H*W_b] (img_off = the image layout's column offsets):
+ * dst[img_off[b] + h*W_b + i] = src[h][src_off[b] + start + i]       the 2-D towers' inputs, models.py:419-421 */
+int as_rows_to_images_f32(const float* src, int lds, const int32_t* src_off, int start, int H, float* dst,
+                          const int32_t* img_off, int B, int max_w, as_stream_t stream);
 /* style-tower helpers: LearnedDownSample / ResBlk1d.pool (models.py:27-31,116), DownSample (+ residual merge,
  * models.py:43-57,99-100,127-130), im2col for the valid KxK convs (models.py:391,399,535), LeakyReLU+avg-pool */
 int as_dwconv_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy,

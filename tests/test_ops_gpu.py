@@ -182,6 +182,9 @@ def test_ref_features_crop_pool(cuda):
     l1 = Layout([l - 1 for l in lens], cuda)
     c = ops.crop(feat.to(cuda), lay, 0, l1.new(12), l1).cpu()
     assert torch.equal(c, torch.cat([feat[:, :69], feat[:, 70:70 + 65]], 1))
+    limg = Layout([l - 1 for l in lens], cuda, H=10)
+    img = ops.rows_to_images(c.to(cuda)[2:12], l1, 0, 10, limg).cpu()          # row-slice view in, H x W images out
+    assert torch.equal(img, torch.cat([c[2:12, :69].reshape(1, -1), c[2:12, 69:].reshape(1, -1)], 1))
     p = ops.mean_pool(feat.to(cuda), lay, True).cpu()
     want = torch.stack([F.leaky_relu(feat[:, :70], 0.2).mean(1), F.leaky_relu(feat[:, 70:], 0.2).mean(1)])
     assert float((p - want).abs().max()) <= 1e-5
