@@ -23,7 +23,6 @@ static __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsi
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
-
 // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
 // run of logical tiles -- the output-channel tiles of one column range then share that XCD's L2 copy of the
 // activation columns.  Bijective for any grid size.
@@ -121,33 +120,32 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
     }
 }
 
-template <int TM, int TN>
-static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
-                                                int wn, int l31, int lk, int S)
+template <int TM, int TN, int AUX>
+static __device__ __forceinline__ void slab_store(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], __amdgpu_buffer_rsrc_t rs,
+                                                  int rbase, int cbase, int l31)
 {
-    const int rbase = m0 + wm * 32 * TM + 4 * lk;          // this lane's first row; element e adds i*32 + (e&3) + 8*(e>>2)
-    const int cbase = n0 + wn * 32 * TN;
-    if (S > 1) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            a.ws + (size_t)blockIdx.y * a.M * a.N, 0, (int)((unsigned)a.M * a.N * 4u), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn) {
-                const int col = cbase + jn * 32 + l31;
-                const unsigned v0 = col < a.N ? (unsigned)((rbase + i * 32) * a.N + col) * 4u : OOBH;
+        for (int jn = 0; jn < TN; ++jn) {
+            const int col = cbase + jn * 32 + l31;
+            const unsigned v0 = col < a.N ? (unsigned)((rbase + i * 32) * a.N + col) * 4u : OOBH;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    // through a VGPR: storing element e of an accumulator tuple directly, hipcc 7.2 emits the
-                    // tuple's first register for every e
-                    float t = acc[i][jn][e];
-                    asm volatile("" : "+v"(t));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rs,
-                                                          v0 + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.N * 4), 0, 0);
-                }
+            for (int e = 0; e < 16; ++e) {
+                // through a VGPR: storing element e of an accumulator tuple directly, hipcc 7.2 emits the tuple's
+                // first register for every e
+                float t = acc[i][jn][e];
+                asm volatile("" : "+v"(t));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rs,
+                                                      v0 + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.N * 4), 0, AUX);
             }
-        return;
-    }
+        }
+}
+
+template <int TM, int TN>
+static __device__ __forceinline__ void epilogue_dispatch(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int rbase, int cbase,
+                                                         int l31)
+{
     // one lean copy per (divide, activation, transposed) combination the path uses
     if (a.transpose_out) epilogue_tiles<TM, TN, false, 0, true>(a, acc, rbase, cbase, l31);
     else if (a.div_sqrt2 && a.act == 0) epilogue_tiles<TM, TN, true, 0, false>(a, acc, rbase, cbase, l31);
@@ -156,5 +154,28 @@ static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32
     else if (a.act == 0) epilogue_tiles<TM, TN, false, 0, false>(a, acc, rbase, cbase, l31);
     else if (a.act == 1) epilogue_tiles<TM, TN, false, 1, false>(a, acc, rbase, cbase, l31);
     else epilogue_tiles<TM, TN, false, 2, false>(a, acc, rbase, cbase, l31);
+}
+
+// S > 1 (split-K): this slice's raw partial sums go to its slab; splitk_reduce_kernel sums the slabs in a fixed order
+// and applies the epilogue.  (Combining inside this kernel -- per-tile arrival counters, the last slice reduces -- was
+// built and measured on MI355X: slower.  With agent-scope release/acquire fences the whole step went from 9.9 to
+// 12.5 ms (every fence writes back / invalidates an L2), with write-through slabs and sc1 loads to 11.5 ms (the last
+// arriver reads S slabs serially while the reduce kernel is wide and short), and keeping the accumulators live across
+// the hand-off cost 56 VGPRs = one wave per SIMD for every launch.)
+// `active` = this wave holds a result (false for the waves of a K group that already folded theirs into group 0).
+template <int TM, int TN>
+static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
+                                                int wn, int l31, int lk, int S, bool active = true)
+{
+    if (!active) return;
+    const int rbase = m0 + wm * 32 * TM + 4 * lk;          // this lane's first row; element e adds i*32 + (e&3) + 8*(e>>2)
+    const int cbase = n0 + wn * 32 * TN;
+    if (S == 1) {
+        epilogue_dispatch<TM, TN>(a, acc, rbase, cbase, l31);
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.ws + (size_t)blockIdx.y * a.M * a.N, 0,
+                                                                       (int)((unsigned)a.M * a.N * 4u), 0x00020000);
+    slab_store<TM, TN, 0>(a, acc, rs, rbase, cbase, l31);
 }
 #endif

@@ -457,7 +457,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
                     }
         }
         __syncthreads();
-        if (wk > 0) return;
+        if (wk == 0)
 #pragma unroll
         for (int s = 1; s < WK; ++s)
 #pragma unroll
@@ -471,7 +471,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
                         for (int c = 0; c < 4; ++c) acc[i][jn][4 * e4 + c] += v[c];
                     }
     }
-    epilogue<2, 2>(a, acc, m0, n0, wm, wn, l31, lk, S);
+    epilogue<2, 2>(a, acc, m0, n0, wm, wn, l31, lk, S, wk == 0);
 #ifdef X6_EXP_STAMPS
     X6_STAMP(t3)
     if (tid == 0) {                                  // thread 0 owns Y[m0 + 0..3][n0]: overwrite with the segment times

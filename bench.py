@@ -13,8 +13,9 @@ Inputs are resident in HBM before the timed region.  With N > 1 every rank runs 
 GPU (utterance batches shard embarrassingly; no data-path collective) => weak scaling; the only
 torch.distributed use is the barrier and the max-over-ranks of the elapsed time.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (the fp32-MFMA conv GEMM,
-timed with HIP events on its launch stream in an instrumented pass of the same step) and "cpu_baseline"
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (the implicit-GEMM conv on the
+matrix cores -- bf16x6 split-operand arithmetic, fp32-accurate, or fp32 MFMAs with AS_GEMM_IMPL=f32 -- timed with
+HIP events on its launch stream in an instrumented pass of the same step) and "cpu_baseline"
 (the oracle's CPU restatement timed on this box's host cores on a bounded sample of the same workload).
 """
 import argparse
@@ -34,7 +35,10 @@ B, N_TOK, M_HALF, T_REF = 32, 40, 100, 200          # config C3
 FRAMES_PER_UTT = 2 * M_HALF
 FRAME_SEC = 300.0 / 24000.0                          # hop 300 @ 24 kHz (test.py:40)
 WEIGHT_SEED, DATA_SEED = 3407, 1234
-PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 (64 cycles per SIMD)
+# bf16x6: every fp32 product is six bf16 MFMA products; dense bf16 peak 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz = 2516.6
+PEAK_BF16_MFMA_TFLOPS = 2516.6
+PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0         # fp32-equivalent ceiling of the split-operand GEMM: 419.4
 CLASSES = ["conv_gemm", "adain", "layernorm", "attention", "lstm", "mas", "other"]
 
 
@@ -205,6 +209,14 @@ def main():
     except Exception:
         pass
 
+    from artspeech_amd import ops as _ops
+    gemm_impl = _ops.GEMM_IMPL
+    if gemm_impl == "f32":
+        gemm_kernel, gemm_peak = "conv_gemm_quad_kernel / conv_gemm_kernel (fp32 MFMA implicit-GEMM conv)", PEAK_F32_MFMA_TFLOPS
+        gemm_peak_basis = "dense v_mfma_f32_32x32x2_f32"
+    else:
+        gemm_kernel, gemm_peak = "conv_gemm_x6_kernel (implicit-GEMM conv, bf16x6 split operands on the bf16 MFMAs)", PEAK_X6_TFLOPS
+        gemm_peak_basis = "dense bf16 MFMA 2516.6 TFLOP/s / 6 partial products per fp32 product (achieved = algorithmic fp32 flop)"
     frames_per_step = B * FRAMES_PER_UTT
     ms_per_step = elapsed / args.steps * 1e3
     value = world * frames_per_step * args.steps / elapsed
@@ -212,16 +224,17 @@ def main():
         "metric": "mel frames/sec (whole job; per-GPU = value / n_gpus), acoustic-model inference path, batch 32 x 200-frame utterances",
         "value": value, "unit": "mel frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if gemm_impl == "f32" else "f32 (bf16x6 split-operand MFMA, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": "C3: LibriTTS-like batch=32 per GPU, 40 tokens -> 200 mel frames per utterance, T_ref=200, "
                                "full predictor+decoder path, forced integer durations, synthetic weights seed 3407",
                    "global_batch": B * world, "frames_per_utt": FRAMES_PER_UTT, "parallelism": f"batch-shard x{world}, no collectives",
                    "launch": "eager" if graph is None else "hipGraph replay"},
         "rtf": (elapsed / args.steps) / (frames_per_step * FRAME_SEC),
         "x_realtime_per_gpu": (value / world) * FRAME_SEC,
-        "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 MFMA implicit-GEMM conv)",
-                     "achieved": gemm_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": gemm_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+        "roofline": {"bound": "mfma", "kernel": gemm_kernel, "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s",
+                     "frac": gemm_tflops / gemm_peak, "peak_basis": gemm_peak_basis,
+                     "frac_of_fp32_mfma_peak": gemm_tflops / PEAK_F32_MFMA_TFLOPS,
+                     "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_ms": gemm_ms, "launches_per_step": int(cnt[0] // prof_steps),
                      "algorithmic_gflop_per_step": fl[0] / prof_steps / 1e9},
         "kernel_classes": kern,
