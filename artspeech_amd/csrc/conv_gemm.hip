@@ -419,7 +419,10 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice, bool x6)
         const int cap = (long)M * N >= 262144 ? 4 : 16;  // the reduce pass moves S*M*N*8 bytes
         if (s > cap) s = cap;
     }
-    const int min_kt = x6 ? 4 : 8;                       // k-tiles a slice keeps
+    // k-tiles a slice keeps: a slice pays ~6 us of prologue + epilogue and the split a reduce launch (~8 us), against
+    // ~0.65 us per 32-deep k-tile; swept on the whole step (bench.py): a slice of >= 384 k (12 k-tiles of 32) is best
+    const int env_min = getenv("AS_GEMM_MINKT") ? atoi(getenv("AS_GEMM_MINKT")) : 0;   // tuning/experiments only
+    const int min_kt = env_min > 0 ? env_min : x6 ? 12 * 32 / (16 * 256 * 64 / (bm * bn)) : 8;
     if (s > nkt / min_kt) s = nkt / min_kt;
     return s < 1 ? 1 : s;
 }
