@@ -349,8 +349,10 @@ __global__ void splitk_reduce_kernel(const ConvGemmArgs a, int S)
 
 static void tile_dims(int choice, int* bm, int* bn)
 {
-    *bm = (choice == 22 || choice == 21) ? 128 : 64;
-    *bn = (choice == 22 || choice == 12) ? 128 : 64;
+    // 22 / 21 / 12 / 11: 128x128, 128x64, 64x128, 64x64 with 4 waves; 228 / 218 / 128 (bf16x6 only): the same tiles with
+    // 8 waves (two per SIMD), the extra four splitting K
+    *bm = (choice == 22 || choice == 21 || choice == 228 || choice == 218) ? 128 : 64;
+    *bn = (choice == 22 || choice == 12 || choice == 228 || choice == 128) ? 128 : 64;
 }
 
 // which arithmetic: bf16x6 when the caller supplied the split weights (AS_GEMM_IMPL=f32 forces the fp32 MFMAs when
@@ -405,7 +407,8 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice, bool x6)
     tile_dims(choice, &bm, &bn);
     const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
     int nkt = T * (Kp / BK);
-    if (x6) nkt = T * as_cdiv(Kp / 16, 256 * 64 / (bm * bn));   // k-tile = 16 * WK, WK = 4 / (tile / 64x64)
+    const int waves = choice > 100 ? 8 : 4;
+    if (x6) nkt = T * as_cdiv(Kp / 16, waves * 64 * 64 / (bm * bn));   // k-tile = 16 * WK, WK = waves / (tile / 64x64)
     int s = 1;
     if (env && atoi(env) > 0) s = atoi(env);
     else if (x6) {
@@ -422,7 +425,7 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice, bool x6)
     // k-tiles a slice keeps: a slice pays ~6 us of prologue + epilogue and the split a reduce launch (~8 us), against
     // ~0.65 us per 32-deep k-tile; swept on the whole step (bench.py): a slice of >= 384 k (12 k-tiles of 32) is best
     const int env_min = getenv("AS_GEMM_MINKT") ? atoi(getenv("AS_GEMM_MINKT")) : 0;   // tuning/experiments only
-    const int min_kt = env_min > 0 ? env_min : x6 ? 12 * 32 / (16 * 256 * 64 / (bm * bn)) : 8;
+    const int min_kt = env_min > 0 ? env_min : x6 ? 12 * 32 / (16 * waves * 64 * 64 / (bm * bn)) : 8;
     if (s > nkt / min_kt) s = nkt / min_kt;
     return s < 1 ? 1 : s;
 }

@@ -85,8 +85,9 @@ struct X6Cfg {
     static constexpr int STAGE = WK * (A_BLK + B_BLK);
     static constexpr int RED = (WK - 1) * WM * WN * 64 * 64 * 4;        // cross-wave K reduction scratch
     static constexpr int LDS = 2 * STAGE > RED ? 2 * STAGE : RED;
-    static constexpr int ACH = WK * 6 * BM / 256;                        // 16-byte weight chunks per thread per k-tile
-    static constexpr int UB = WK * 2 * BN / 256;                         // (column, 8 k) activation units per thread
+    static constexpr int NT = 64 * WM * WN * WK;                         // threads: one wave per (M, N, K) block, 4 or 8 waves
+    static constexpr int ACH = WK * 6 * BM / NT;                         // 16-byte weight chunks per thread per k-tile
+    static constexpr int UB = WK * 2 * BN / NT;                          // (column, 8 k) activation units per thread
 };
 
 #ifdef X6_EXP_NOMFMA
@@ -135,22 +136,23 @@ struct X6Plan {
     static constexpr int M_SP = M_FR + 12;                // 4*UB element pairs x 2 halves of the split    (5, 6)
     static constexpr int M_ST = M_SP + 8 * UB;            // 3*UB LDS stores                               (1 each)
     static constexpr int NM = M_ST + 3 * UB;
-    static constexpr int weight(int m)
+    // Slot (0..23 = behind which MFMA) of each piece.  The categories are interleaved rather than issued one after
+    // the other: a slot then mixes a VALU chain (split), a scalar chain (addresses, cursors) and a memory
+    // instruction, which one wave can issue back to back, where a slot holding a single dependent chain stalls on it
+    // (PMC: a third of the wave's cycles were such issue stalls).  Order constraints: TAPA < TAPB < loads < XADV;
+    // ASOFF < DMA < WADV; both halves of a pair in order and before the stores; everything before the barrier.
+    static constexpr int slot_of(int m)
     {
-        return m == M_TAPA ? 8 : m == M_TAPB ? 9 : m < M_XADV ? 3 : m == M_XADV ? 8 : m == M_ASOFF ? 3 : m < M_WADV ? 2
-             : m == M_WADV ? 8 : m < M_SP ? 1 : m < M_ST ? ((m - M_SP) % 2 ? 6 : 5) : 1;
-    }
-    static constexpr int total()
-    {
-        int t = 0;
-        for (int m = 0; m < NM; ++m) t += weight(m);
-        return t;
-    }
-    static constexpr int slot_of(int m)                   // 0..23, by the midpoint of the piece in cumulative weight
-    {
-        int c = 0;
-        for (int q = 0; q < m; ++q) c += weight(q);
-        return ((2 * c + weight(m)) * 12) / total();
+        if (m == M_TAPA) return 0;
+        if (m == M_TAPB) return 1;
+        if (m < M_XADV) return 2 + (m - M_LD) / UB;                      // loads: slots 2..9
+        if (m == M_XADV) return 10;
+        if (m == M_ASOFF) return 10;
+        if (m < M_WADV) return 11 + ((m - M_DMA) * 6) / ACH;             // LDS-DMA pieces: slots 11..16
+        if (m == M_WADV) return 17;
+        if (m < M_SP) return 6 + (m - M_FR);                             // fragment reads: slots 6..17
+        if (m < M_ST) return ((m - M_SP) * 22) / (8 * UB);               // split halves: spread over slots 0..21
+        return 22 + ((m - M_ST) * 2) / (3 * UB);                         // stores: slots 22, 23
     }
 };
 
@@ -170,12 +172,12 @@ struct X6Taps {
 // so a lone workgroup on a CU never starts a k-tile by waiting for LDS, and every global access has a whole k-tile
 // (~800 cycles of MFMA) to land.
 template <int WM, int WN, int WK, bool LRELU>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * WM * WN * WK)
 conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
 {
     using C = X6Cfg<WM, WN, WK>;
-    constexpr int BM = C::BM, BN = C::BN, ACH = C::ACH, UB = C::UB;
-    static_assert(WM * WN * WK == 4 && ACH * 256 == WK * 6 * BM && UB * 256 == WK * 2 * BN, "tile shape");
+    constexpr int BM = C::BM, BN = C::BN, ACH = C::ACH, UB = C::UB, NT = C::NT;
+    static_assert((NT == 256 || NT == 512) && ACH * NT == WK * 6 * BM && UB * NT == WK * 2 * BN, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     X6_STAMP(t0)
@@ -194,15 +196,15 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
     const __amdgpu_buffer_rsrc_t rsX =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, X6_EXP_X((int)((unsigned)a.K * a.ldx * 4u)), 0x00020000);
 
-    // weights: chunk c = tid + 256 i of the k-tile image [kblk][p*2+kh][row] goes to LDS offset 16 c (lane-linear, so
+    // weights: chunk c = tid + NT i of the k-tile image [kblk][p*2+kh][row] goes to LDS offset 16 c (lane-linear, so
     // one LDS-DMA wave-instruction moves 64 chunks); rows past M are out of range (nothing that is stored reads them)
     unsigned a_voff[ACH];
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
-        const int c = tid + 256 * i, kblk = c / (6 * BM), rem = c % (6 * BM), pk = rem / BM, row = rem % BM;
+        const int c = tid + NT * i, kblk = c / (6 * BM), rem = c % (6 * BM), pk = rem / BM, row = rem % BM;
         a_voff[i] = (m0 + row) < a.M ? (unsigned)(((kblk * 6 + pk) * a.M + m0 + row) * 16) : OOB;
     }
-    // activations: unit u = tid + 256 i -> column u % BN (the same for every i), k rows 8 g .. 8 g + 7, g = u / BN
+    // activations: unit u = tid + NT i -> column u % BN (the same for every i), k rows 8 g .. 8 g + 7, g = u / BN
     const int j = n0 + tid % BN;
     const int g0 = __builtin_amdgcn_readfirstlane(tid / BN);             // wave-uniform (BN >= 64)
     unsigned tapmask = 0;
@@ -243,8 +245,14 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
         // (device pass only: with this builtin in the body hipcc 7.2's HOST pass silently drops the kernel's launch stub)
 #if __HIP_DEVICE_COMPILE__
 #pragma unroll
-        for (int i = 0; i < ACH; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(st + i * 4096), 16, a_voff[i], a_soff, 0, 0);
+        for (int i = 0; i < ACH; ++i) {
+#ifdef X6_EXP_REGSTAGE
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, a_voff[i], a_soff, 0);
+            *reinterpret_cast<u32x4*>(smem + buf * C::STAGE + (tid + NT * i) * 16) = v;
+#else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(st + i * (NT * 16)), 16, a_voff[i], a_soff, 0, 0);
+#endif
+        }
 #endif
         advance(wa_t, wa_kb);
     };
@@ -262,7 +270,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
         for (int i = 0; i < UB; ++i)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const int soff = base + (i * (256 / BN) * 8 + r) * ldx4;
+                const int soff = base + (i * (NT / BN) * 8 + r) * ldx4;
                 r8[i][r] = buf_load1(rsX, b_voff, soff < last_row ? soff : last_row);
             }
         advance(xb_t, xb_kb);
@@ -299,7 +307,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
                 split_pair(r8[i][2 * e], r8[i][2 * e + 1], sh[i], sm[i], sl[i], e);
             }
             if (half == 1) {
-                const int g = g0 + i * (256 / BN), kblk = g >> 1, kh = g & 1;
+                const int g = g0 + i * (NT / BN), kblk = g >> 1, kh = g & 1;
                 unsigned char* b = st + (kblk * 6 + kh) * BN * 16;
                 *reinterpret_cast<u32x4*>(b) = sh[i];
                 *reinterpret_cast<u32x4*>(b + 2 * BN * 16) = sm[i];
@@ -345,6 +353,10 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
     lstore_b(rb[1], 1, 1);
     __syncthreads();
     read_frags(fr[0], 0);
+    // every wave must HOLD its fragments of tile 0 before any wave lets tile 2 into stage 0 (the first iteration's
+    // LDS-DMA and stores): in the loop the end-of-iteration barrier orders this, here nothing else does -- without it
+    // a wave delayed by another kernel sharing the CU read tile 2's weights as tile 0's (seen only under concurrency)
+    __syncthreads();
 
     // A wave issues one instruction per ~4 cycles and an MFMA occupies the matrix core for 32, so the ~150 staging
     // instructions of an iteration are dealt out five or six behind EACH of the 24 MFMAs (measured: issued as four
@@ -365,7 +377,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
             c_base = (xb_kb * 16 + g0 * 8) * ldx4;
         } else if constexpr (M < PL::M_XADV) {
             constexpr int q = M - PL::M_LD, i = q / 8, r = q % 8;
-            const int soff = c_base + (i * (256 / BN) * 8 + r) * ldx4;
+            const int soff = c_base + (i * (NT / BN) * 8 + r) * ldx4;
             rb[Q][i][r] = buf_load1(rsX, c_voff, soff < last_row ? soff : last_row);
         } else if constexpr (M == PL::M_XADV) {
             advance(xb_t, xb_kb);
@@ -374,8 +386,13 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
         } else if constexpr (M < PL::M_WADV) {
 #if __HIP_DEVICE_COMPILE__
             constexpr int i = M - PL::M_DMA;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(smem + P * C::STAGE + wave * 1024 + i * 4096), 16,
+#ifdef X6_EXP_REGSTAGE
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, a_voff[i], c_asoff, 0);
+            *reinterpret_cast<u32x4*>(smem + P * C::STAGE + (tid + NT * i) * 16) = v;
+#else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(smem + P * C::STAGE + wave * 1024 + i * (NT * 16)), 16,
                                                      a_voff[i], c_asoff, 0, 0);
+#endif
 #endif
         } else if constexpr (M == PL::M_WADV) {
             advance(wa_t, wa_kb);
@@ -405,7 +422,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
             }
         } else {
             constexpr int q = M - PL::M_ST, i = q / 3, p = q % 3;
-            const int g = g0 + i * (256 / BN), kblk = g >> 1, kh = g & 1;
+            const int g = g0 + i * (NT / BN), kblk = g >> 1, kh = g & 1;
             unsigned char* b = smem + P * C::STAGE + WK * C::A_BLK + (tid % BN) * 16 + (kblk * 6 + kh + 2 * p) * BN * 16;
             *reinterpret_cast<u32x4*>(b) = p == 0 ? sh[i] : p == 1 ? sm[i] : sl[i];
         }
@@ -500,7 +517,7 @@ static int launch_x6(const ConvGemmArgs& a, int S, hipStream_t stream)
         w[t >> 3] |= (unsigned long long)(((a.dh[t] + 8) << 4) | (a.dw[t] + 8)) << ((t & 7) * 8);
     }
     const dim3 grid(as_cdiv(a.M, C::BM) * as_cdiv(a.N, C::BN), S);
-    hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WK, LRELU>), grid, dim3(256), C::LDS, stream, a, tp);
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WK, LRELU>), grid, dim3(C::NT), C::LDS, stream, a, tp);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
@@ -510,6 +527,9 @@ int as_conv_gemm_x6_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t
     if (a.in_act != 0 && a.in_act != 2) return AS_EINVAL;
     const bool lr = a.in_act == 2;
     switch (choice) {
+    case 228: return lr ? launch_x6<2, 2, 2, true>(a, S, stream) : launch_x6<2, 2, 2, false>(a, S, stream);   // 8 waves
+    case 218: return lr ? launch_x6<2, 1, 4, true>(a, S, stream) : launch_x6<2, 1, 4, false>(a, S, stream);
+    case 128: return lr ? launch_x6<1, 2, 4, true>(a, S, stream) : launch_x6<1, 2, 4, false>(a, S, stream);
     case 22: return lr ? launch_x6<2, 2, 1, true>(a, S, stream) : launch_x6<2, 2, 1, false>(a, S, stream);
     case 21: return lr ? launch_x6<2, 1, 2, true>(a, S, stream) : launch_x6<2, 1, 2, false>(a, S, stream);
     case 12: return lr ? launch_x6<1, 2, 2, true>(a, S, stream) : launch_x6<1, 2, 2, false>(a, S, stream);

@@ -624,19 +624,25 @@ class ArtsSpeech(_Module):
         stats24 = self._stats24
         feat12 = self.style_encoder.features_packed(mel_p, f0_p, ema_p, ref_lay, stats24)
         # The articulatory encoder, the style towers and the duration predictor are mutually independent
-        # (models.py:358-360) and individually too small to fill 256 CUs: three concurrent branches on side HIP streams
-        # (a fork/join that hipGraph capture records as parallel nodes).  Measured on MI355X: finer splits (each tower,
-        # tower beside encoder) are slower -- three branches already saturate the chip -- and stream-to-stream edges
-        # between side streams crash hipGraph instantiation on ROCm 7.2, so every branch forks from / joins the caller.
-        with Fork(side_streams(dev, 3), uses=(feat12,)) as side:
+        # (models.py:358-360) and individually too small to fill 256 CUs: four concurrent branches on side HIP streams
+        # (a fork/join that hipGraph capture records as parallel nodes) -- the mel tower, the longest chain, on its own.
+        # Measured on MI355X (bench.py, C3): 3 branches (all towers in one) 9.35 ms, 4 branches 8.89 ms, 5 branches
+        # (TV tower on its own too) 9.76 ms.  Stream-to-stream edges between side streams crash hipGraph instantiation
+        # on ROCm 7.2, so every branch forks from / joins the caller.
+        se = self.style_encoder
+        feat = torch.cat([feat12, mel_p[:, : feat12.shape[1]]], dim=0).contiguous()
+        ti = se.tower_inputs(feat, ref_lay)
+        with Fork(side_streams(dev, 4), uses=(feat12, feat, ti["c"], ti["mel_img"], ti["ema_img"])) as side:
             with side(0):
                 a_en = self.arts_encoder.forward_packed(tok, tok_lay)
             with side(1):
-                feat = torch.cat([feat12, mel_p[:, : feat12.shape[1]]], dim=0).contiguous()
-                style = self.style_encoder.style_extractor_packed(feat, ref_lay)
+                s_mel = se.tower("mel", ti)
             with side(2):
+                s_rest = [se.tower(w, ti) for w in ("ema", "f0", "energy")]
+            with side(3):
                 duration = self.durationPredictor.forward_packed(tok, tok_lay, feat12[2:12], ref_lay)
-            side.produced(a_en, style, duration)
+            side.produced(a_en, s_mel, duration, *s_rest)
+        style = torch.cat([s_mel] + s_rest, dim=1).contiguous()
         if frames_hint is None:
             dur_i, frame_off, _ = ops.durations(duration.reshape(-1), forced, tok_lay, 0)
             off = frame_off.cpu().tolist()                                   # the one device->host sync

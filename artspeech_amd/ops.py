@@ -32,6 +32,14 @@ def _p(t):
     return t.data_ptr()
 
 
+def _settle(device):
+    """Layouts are cached and shared by branches running on different HIP streams: what one branch creates lazily on
+    its stream (offset tables, the column descriptors) must be complete before another stream can pick it up.  Created
+    once per geometry, so a host-side wait is cheap; inside a graph capture nothing new is created (warm-up did)."""
+    if isinstance(device, torch.device) and device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(device).synchronize()
+
+
 class Layout:
     """Packed-frames geometry: B utterances, utterance b is an H x widths[b] image (H = 1: a sequence)."""
 
@@ -50,6 +58,7 @@ class Layout:
         self.widths = torch.tensor(self.widths_host, dtype=torch.int32, device=device)
         self.col_off = torch.tensor(off, dtype=torch.int32, device=device)
         self._meta = None
+        _settle(device)
 
     @property
     def meta(self):
@@ -57,6 +66,7 @@ class Layout:
             m = torch.empty(max(self.N, 1), dtype=torch.int64, device=self.device)
             check(_lib.lib().as_make_meta(_p(self.widths), _p(self.col_off), self.B, self.H, self.N, _p(m), stream()),
                   "as_make_meta")
+            _settle(self.device)
             self._meta = m
         return self._meta
 
