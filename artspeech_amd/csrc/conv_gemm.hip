@@ -329,6 +329,51 @@ conv_gemm_kernel(const ConvGemmArgs a)
     epilogue<TM, TN>(a, acc, m0, n0, wm, wn, l31, lk, S);
 }
 
+// Cin = 1 (the first conv of every style tower and of the decoder's F0 / energy inputs): 9 MACs per output on a
+// 16-deep matrix-core k-block would be 2 % useful work, and the op is bound by writing Y anyway (M x N x 4 bytes: 130 MB
+// for the mel tower) -- so a direct kernel: a thread owns one column, keeps its T input taps in registers and streams the
+// M output channels (stores coalesced across the wave), weights and bias from LDS.
+#define DIRECT_MAX_M 128
+__global__ void __launch_bounds__(256)
+conv_direct_cin1_kernel(const ConvGemmArgs a)
+{
+    __shared__ float ws[AS_MAX_TAPS * DIRECT_MAX_M];       // [t][m]
+    __shared__ float bs[DIRECT_MAX_M];
+    for (int i = threadIdx.x; i < a.T * a.M; i += 256) ws[i] = a.W[(size_t)(i / a.M) * a.Kp * a.M + (i % a.M)];   // k = 0 rows
+    for (int i = threadIdx.x; i < a.M; i += 256) bs[i] = a.bias ? a.bias[i] : 0.f;
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.N) return;
+    int h = 0, w = 0, H = 1, Wj = 0x7fffffff;
+    if (a.meta) {
+        const unsigned long long md = a.meta[j];
+        h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff), H = (int)((md >> 32) & 0xffff), Wj = (int)(md >> 48);
+    }
+    float x[AS_MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < AS_MAX_TAPS; ++t) {
+        x[t] = 0.f;
+        if (t < a.T) {
+            const bool ok = !a.meta || ((unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)Wj);
+            if (ok) {
+                float v = a.X[j + a.dh[t] * (a.meta ? Wj : 0) + a.dw[t]];
+                if (a.in_act == 2) v = v > 0.f ? v : 0.2f * v;
+                x[t] = v;
+            }
+        }
+    }
+    for (int m = 0; m < a.M; ++m) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < AS_MAX_TAPS; ++t)
+            if (t < a.T) s += ws[t * a.M + m] * x[t];
+        s += bs[m];
+        if (a.act == 1) s = s > 0.f ? s : 0.f;
+        else if (a.act == 2) s = s > 0.f ? s : 0.2f * s;
+        a.Y[(size_t)m * a.ldy + j] = s;
+    }
+}
+
 // y = epi(sum_s slab[s]) in a fixed order (deterministic, unlike float atomics)
 __global__ void splitk_reduce_kernel(const ConvGemmArgs a, int S)
 {
@@ -460,6 +505,14 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if ((double)(a.transpose_out ? a.N : a.M) * a.ldy * 4.0 >= 2147483648.0 || (double)a.M * a.ldr * 4.0 >= 2147483648.0 ||
         (double)a.M * a.N * 4.0 >= 2147483648.0) return AS_EINVAL;
     if (a.N == 0) return AS_OK;
+    if (a.K == 1 && a.W && !a.res && !a.div_sqrt2 && !a.transpose_out && a.M <= DIRECT_MAX_M && !getenv("AS_GEMM_NO_DIRECT")) {
+        char tag[64];
+        snprintf(tag, sizeof(tag), "M%d N%d K1 T%d direct", a.M, a.N, a.T);
+        AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.T, 4.0 * ((double)a.T * a.M + a.N + (double)a.M * a.N), stream, tag);
+        hipLaunchKernelGGL(conv_direct_cin1_kernel, dim3(as_cdiv(a.N, 256)), dim3(256), 0, stream, a);
+        AS_CHECK_LAUNCH();
+        return AS_OK;
+    }
     const bool x6 = use_x6(a);
     const int choice = gemm_tile_choice(a.M, a.N, x6);
     int S = gemm_ksplit(a.M, a.N, a.Kp, a.T, choice, x6);

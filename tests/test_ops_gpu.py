@@ -262,3 +262,26 @@ def test_kernels_side_by_side_on_two_streams(cuda):
                 b = second()
             torch.cuda.synchronize()
             assert torch.equal(a, r1) and torch.equal(b, r2)
+
+
+@pytest.mark.parametrize("two_d", [False, True])
+def test_conv_cin1_direct_kernel(cuda, two_d):
+    """Cin = 1 convs (first layer of each tower) take the direct kernel inside as_conv_gemm_f32: bias, LeakyReLU on the
+    input and on the output, ragged batch, 1-D k=3 and 2-D 3x3."""
+    g = torch.Generator().manual_seed(21)
+    cout = 64
+    if two_d:
+        H, widths = 10, [23, 8, 40]
+        w, b = torch.randn(cout, 1, 3, 3, generator=g) / 3, torch.randn(cout, generator=g)
+        xs = [torch.randn(1, H, W, generator=g) for W in widths]
+        want = packed([F.leaky_relu(F.conv2d(F.leaky_relu(x, 0.2)[None], w, b, padding=1)[0], 0.2).reshape(cout, -1) for x in xs])
+        lay, taps, X = Layout(widths, cuda, H=H), taps_2d(3, 3), packed([x.reshape(1, -1) for x in xs])
+    else:
+        lens = [50, 13, 1, 200]
+        w, b = torch.randn(cout, 1, 3, generator=g) / 2, torch.randn(cout, generator=g)
+        xs = [torch.randn(1, L, generator=g) for L in lens]
+        want = packed([F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.2)[None], w, b, padding=1)[0], 0.2) for x in xs])
+        lay, taps, X = Layout(lens, cuda), taps_1d(3), packed(xs)
+    y = ops.conv_gemm(ops.prep_weight(w, cuda), X.to(cuda), lay, lay.new(cout), taps, bias=b.to(cuda), in_act=ops.ACT_LRELU,
+                      act=ops.ACT_LRELU)
+    assert float((y.cpu() - want).abs().max()) <= 2e-6
