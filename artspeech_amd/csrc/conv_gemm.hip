@@ -334,6 +334,73 @@ conv_gemm_kernel(const ConvGemmArgs a)
 // for the mel tower) -- so a direct kernel: a thread owns one column, keeps its T input taps in registers and streams the
 // M output channels (stores coalesced across the wave), weights and bias from LDS.
 #define DIRECT_MAX_M 128
+#define DIRECT_TP 12                                       // weights per channel in LDS: T (<= 9 on the fast path) padded to 3 x 16 bytes
+// fast form (T <= 9): a thread owns FOUR consecutive columns (one 16-byte store per channel when Y allows), three
+// 16-byte LDS reads feed 4 x T FMAs
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float ws[DIRECT_MAX_M * DIRECT_TP];   // [m][t]
+    __shared__ float bs[DIRECT_MAX_M];
+    for (int i = threadIdx.x; i < a.M * DIRECT_TP; i += 256) {
+        const int m = i / DIRECT_TP, t = i % DIRECT_TP;
+        ws[i] = t < a.T ? a.W[(size_t)t * a.Kp * a.M + m] : 0.f;      // k = 0 rows of the [T][Kp][M] image
+    }
+    for (int i = threadIdx.x; i < a.M; i += 256) bs[i] = a.bias ? a.bias[i] : 0.f;
+    __syncthreads();
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j0 >= a.N) return;
+    float x[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int j = j0 + c;
+        int h = 0, w = 0, H = 1, Wj = 0x7fffffff;
+        if (a.meta && j < a.N) {
+            const unsigned long long md = a.meta[j];
+            h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff), H = (int)((md >> 32) & 0xffff), Wj = (int)(md >> 48);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // branch-free: all 36 loads of the thread are in flight together (an invalid tap reads the column itself)
+            const int tt = t < a.T ? t : 0;
+            const bool ok = t < a.T && j < a.N &&
+                            (!a.meta || ((unsigned)(h + a.dh[tt]) < (unsigned)H && (unsigned)(w + a.dw[tt]) < (unsigned)Wj));
+            const int jj = j < a.N ? j : a.N - 1;
+            float v = a.X[ok ? jj + a.dh[tt] * (a.meta ? Wj : 0) + a.dw[tt] : jj];
+            if (a.in_act == 2) v = v > 0.f ? v : 0.2f * v;
+            x[c][t] = ok ? v : 0.f;
+        }
+    }
+    for (int m = 0; m < a.M; ++m) {
+        float wt[DIRECT_TP];
+#pragma unroll
+        for (int q = 0; q < DIRECT_TP / 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&ws[m * DIRECT_TP + 4 * q]);
+            wt[4 * q] = v[0]; wt[4 * q + 1] = v[1]; wt[4 * q + 2] = v[2]; wt[4 * q + 3] = v[3];
+        }
+        float y[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) sum += wt[t] * x[c][t];
+            sum += bs[m];
+            if (a.act == 1) sum = sum > 0.f ? sum : 0.f;
+            else if (a.act == 2) sum = sum > 0.f ? sum : 0.2f * sum;
+            y[c] = sum;
+        }
+        float* yr = a.Y + (size_t)m * a.ldy + j0;
+        if (VEC) *reinterpret_cast<f32x4*>(yr) = f32x4{y[0], y[1], y[2], y[3]};
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (j0 + c < a.N) yr[c] = y[c];
+        }
+    }
+}
+
+// general form (any T <= AS_MAX_TAPS): one column per thread
 __global__ void __launch_bounds__(256)
 conv_direct_cin1_kernel(const ConvGemmArgs a)
 {
@@ -509,7 +576,13 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
         char tag[64];
         snprintf(tag, sizeof(tag), "M%d N%d K1 T%d direct", a.M, a.N, a.T);
         AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.T, 4.0 * ((double)a.T * a.M + a.N + (double)a.M * a.N), stream, tag);
-        hipLaunchKernelGGL(conv_direct_cin1_kernel, dim3(as_cdiv(a.N, 256)), dim3(256), 0, stream, a);
+        if (a.T <= 9) {
+            const bool vec = (a.N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0;
+            if (vec) hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<true>, dim3(as_cdiv(a.N, 1024)), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<false>, dim3(as_cdiv(a.N, 1024)), dim3(256), 0, stream, a);
+        } else {
+            hipLaunchKernelGGL(conv_direct_cin1_kernel, dim3(as_cdiv(a.N, 256)), dim3(256), 0, stream, a);
+        }
         AS_CHECK_LAUNCH();
         return AS_OK;
     }
