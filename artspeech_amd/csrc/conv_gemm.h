@@ -9,6 +9,10 @@
 // host: launch the bf16x6 kernel for tile `choice` (22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64) on a grid of
 // (tiles, S); returns AS_OK or a hipError_t.  (conv_gemm_x6.hip)
 int as_conv_gemm_x6_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream);
+// host: the tap-shared bf16x6 kernel (conv_gemm_x6t.hip, tile 128x128): k-tiles it would run (0 = taps not in groups
+// of three consecutive column offsets), and its launch on a grid of (tiles, S)
+int as_conv_gemm_x6t_ktiles(const ConvGemmArgs& a);
+int as_conv_gemm_x6t_launch(const ConvGemmArgs& a, int S, hipStream_t stream);
 
 #ifdef __HIPCC__
 typedef float f32x16 __attribute__((ext_vector_type(16)));

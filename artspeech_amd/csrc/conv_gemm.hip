@@ -463,8 +463,9 @@ static void tile_dims(int choice, int* bm, int* bn)
 {
     // 22 / 21 / 12 / 11: 128x128, 128x64, 64x128, 64x64 with 4 waves; 228 / 218 / 128 (bf16x6 only): the same tiles with
     // 8 waves (two per SIMD), the extra four splitting K
-    *bm = (choice == 22 || choice == 21 || choice == 228 || choice == 218) ? 128 : 64;
-    *bn = (choice == 22 || choice == 12 || choice == 228 || choice == 128) ? 128 : 64;
+    // 223 (bf16x6 only): 128x128, 4 waves, the three taps of a group share one staged activation tile (conv_gemm_x6t.hip)
+    *bm = (choice == 22 || choice == 21 || choice == 228 || choice == 218 || choice == 223) ? 128 : 64;
+    *bn = (choice == 22 || choice == 12 || choice == 228 || choice == 128 || choice == 223) ? 128 : 64;
 }
 
 // which arithmetic: bf16x6 when the caller supplied the split weights (AS_GEMM_IMPL=f32 forces the fp32 MFMAs when
@@ -479,10 +480,11 @@ static bool use_x6(const ConvGemmArgs& a)
 // Tile and split-K choice, from sweeps on MI355X (scripts/gemm_bench.py): the kernel wants >= ~1000 workgroups
 // (4-5 per CU) so that tile quantisation over 256 CUs and the lock-step load/compute phases of co-resident
 // workgroups average out; shapes with fewer tiles get 128x64 tiles and 2-4 K slices (16 for tiny outputs).
-static int gemm_tile_choice(int M, int N, bool x6)
+static int gemm_tile_choice(int M, int N, bool x6, bool taps3 = false)
 {
     const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 22, 21, 12, 11
-    if (env && atoi(env) > 0) return atoi(env);
+    if (env && atoi(env) > 0 && (atoi(env) != 223 || (x6 && taps3))) return atoi(env);
+    if (env && atoi(env) == 223) env = nullptr;
     const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);   // a 128-row tile is not half empty
     if (x6) {
         // cost model fitted to sweeps on MI355X (scripts/gemm_bench.py): a CU runs its L = ceil(tiles / 256) tiles
@@ -519,8 +521,9 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice, bool x6)
     tile_dims(choice, &bm, &bn);
     const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
     int nkt = T * (Kp / BK);
-    const int waves = choice > 100 ? 8 : 4;
+    const int waves = (choice > 100 && choice != 223) ? 8 : 4;
     if (x6) nkt = T * as_cdiv(Kp / 16, waves * 64 * 64 / (bm * bn));   // k-tile = 16 * WK, WK = waves / (tile / 64x64)
+    if (choice == 223) nkt = (T / 3) * (Kp / 16);                       // one k-tile = a 16-deep block of three taps
     int s = 1;
     if (env && atoi(env) > 0) s = atoi(env);
     else if (x6) {
@@ -537,7 +540,7 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice, bool x6)
     // k-tiles a slice keeps: a slice pays ~6 us of prologue + epilogue and the split a reduce launch (~8 us), against
     // ~0.65 us per 32-deep k-tile; swept on the whole step (bench.py): a slice of >= 384 k (12 k-tiles of 32) is best
     const int env_min = getenv("AS_GEMM_MINKT") ? atoi(getenv("AS_GEMM_MINKT")) : 0;   // tuning/experiments only
-    const int min_kt = env_min > 0 ? env_min : x6 ? 12 * 32 / (16 * waves * 64 * 64 / (bm * bn)) : 8;
+    const int min_kt = env_min > 0 ? env_min : choice == 223 ? 8 : x6 ? 12 * 32 / (16 * waves * 64 * 64 / (bm * bn)) : 8;
     if (s > nkt / min_kt) s = nkt / min_kt;
     return s < 1 ? 1 : s;
 }
@@ -547,7 +550,7 @@ extern "C" size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host)
     if (!args_host || args_host->M <= 0 || args_host->N <= 0 || args_host->Kp <= 0 || args_host->T <= 0) return 0;
     const ConvGemmArgs& a = *args_host;
     const bool x6 = use_x6(a);
-    const int s = gemm_ksplit(a.M, a.N, a.Kp, a.T, gemm_tile_choice(a.M, a.N, x6), x6);
+    const int s = gemm_ksplit(a.M, a.N, a.Kp, a.T, gemm_tile_choice(a.M, a.N, x6, x6 && as_conv_gemm_x6t_ktiles(a) > 0), x6);
     return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
 }
 
@@ -587,7 +590,7 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
         return AS_OK;
     }
     const bool x6 = use_x6(a);
-    const int choice = gemm_tile_choice(a.M, a.N, x6);
+    const int choice = gemm_tile_choice(a.M, a.N, x6, x6 && as_conv_gemm_x6t_ktiles(a) > 0);
     int S = gemm_ksplit(a.M, a.N, a.Kp, a.T, choice, x6);
     if (S > 1 && (!a.ws || a.ws_bytes < (size_t)S * a.M * a.N * sizeof(float))) S = 1;   // no workspace: no split
     const char* envq = getenv("AS_GEMM_QUAD");           // tuning/experiments only: 0 forces the scalar staging
@@ -598,7 +601,7 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.K * a.T,
                        4.0 * ((double)a.T * a.K * a.M + (double)a.K * a.N + (double)a.M * a.N), stream, tag);
     if (x6) {
-        const int rc = as_conv_gemm_x6_launch(a, choice, S, stream);
+        const int rc = choice == 223 ? as_conv_gemm_x6t_launch(a, S, stream) : as_conv_gemm_x6_launch(a, choice, S, stream);
         if (rc != AS_OK) return rc;
     } else {
         int bm, bn;

@@ -23,7 +23,7 @@ def impl(request, monkeypatch):
 
 @pytest.mark.parametrize("cin,cout,k,lens", [(64, 128, 3, [50, 13, 1, 200]), (10, 64, 1, [7, 9]), (1, 32, 1, [33]),
                                              (96, 80, 5, [40, 41]), (130, 257, 9, [17, 300, 64]), (512, 1024, 3, [128] * 8)])
-@pytest.mark.parametrize("tile", ["", "11", "21", "22", "12", "228", "218", "128"])
+@pytest.mark.parametrize("tile", ["", "11", "21", "22", "12", "228", "218", "128", "223"])
 @pytest.mark.parametrize("quad", ["", "0"])
 def test_conv1d_gemm(cuda, monkeypatch, impl, cin, cout, k, lens, tile, quad):
     if impl == "x6" and quad:
@@ -54,8 +54,13 @@ def test_conv1d_gemm(cuda, monkeypatch, impl, cin, cout, k, lens, tile, quad):
     assert float((y2.cpu() - want).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("tile", ["", "223"])
 @pytest.mark.parametrize("widths", [[23, 8, 40], [23, 23, 23], [12, 8, 40]])
-def test_conv2d_gemm_and_transpose_out(cuda, impl, widths):
+def test_conv2d_gemm_and_transpose_out(cuda, monkeypatch, impl, widths, tile):
+    if tile:
+        monkeypatch.setenv("AS_GEMM_TILE", tile)
+    else:
+        monkeypatch.delenv("AS_GEMM_TILE", raising=False)
     g = torch.Generator().manual_seed(3)
     cin, cout, H = 16, 48, 10
     w = torch.randn(cout, cin, 3, 3, generator=g) / 12
