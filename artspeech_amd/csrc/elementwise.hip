@@ -532,21 +532,24 @@ extern "C" int as_avgpool_down_f32(const float* x, int ldx, const int32_t* in_of
 
 // im2col for the valid KxK convs that close the 2-D towers (models.py:391,399,535), with the LeakyReLU that
 // precedes them (models.py:390,398,534) applied on the fly.  col[(c*K*K + a*K + d)][out_off[b] + ho*Wo + wo]
-__global__ void im2col_valid_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off,
-                                    const int* __restrict__ in_w, int Hin, float* __restrict__ col, int ldc,
-                                    const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout, int K,
-                                    int stride, int act)
+__global__ void __launch_bounds__(256)
+im2col_valid_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off, const int* __restrict__ in_w,
+                    int Hin, float* __restrict__ col, int ldc, const int* __restrict__ out_off,
+                    const int* __restrict__ out_w, int Hout, int K, int stride, int act, int B)
 {
-    const int b = blockIdx.y, ck = blockIdx.z;              // ck = c*K*K + a*K + d
+    // one workgroup per row ck = c*K*K + a*K + d of `col`, threads over its packed output columns (the outputs of a
+    // tower's last conv are a handful of positions per utterance: a grid over (utterance, row) was 400 k tiny workgroups)
+    const int ck = blockIdx.x;
     const int c = ck / (K * K), a = (ck / K) % K, d = ck % K;
-    const int Wi = in_w[b], Wo = out_w[b];
-    const float* xr = x + (size_t)c * ldx + in_off[b];
-    float* cr = col + (size_t)ck * ldc + out_off[b];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
+    const int total = out_off[B];
+    for (int j = threadIdx.x; j < total; j += blockDim.x) {
+        int b = 0;
+        while (b + 1 < B && out_off[b + 1] <= j) ++b;
+        const int i = j - out_off[b], Wo = out_w[b], Wi = in_w[b];
         const int ho = i / Wo, wo = i - ho * Wo;
-        float v = xr[(size_t)(ho * stride + a) * Wi + wo * stride + d];
+        float v = x[(size_t)c * ldx + in_off[b] + (size_t)(ho * stride + a) * Wi + wo * stride + d];
         if (act) v = lrelu02(v);
-        cr[i] = v;
+        col[(size_t)ck * ldc + j] = v;
     }
 }
 
@@ -556,10 +559,9 @@ extern "C" int as_im2col_valid_f32(const float* x, int ldx, const int32_t* in_of
 {
     if (!x || !col || !in_off || !in_w || !out_off || !out_w || K <= 0 || stride <= 0 || B < 0 || C <= 0) return AS_EINVAL;
     if (B == 0 || max_out <= 0) return AS_OK;
-    if ((long)C * K * K > 65535) return AS_EINVAL;
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(im2col_valid_kernel, dim3(as_cdiv(max_out, 64), B, C * K * K), dim3(64), 0, (hipStream_t)stream, x,
-                       ldx, in_off, in_w, Hin, col, ldc, out_off, out_w, Hout, K, stride, lrelu);
+    hipLaunchKernelGGL(im2col_valid_kernel, dim3(C * K * K), dim3(256), 0, (hipStream_t)stream, x, ldx, in_off, in_w, Hin, col,
+                       ldc, out_off, out_w, Hout, K, stride, lrelu, B);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
