@@ -86,15 +86,15 @@ struct X6Plan {
     // the other: a slot then mixes a VALU chain (split), a scalar chain (addresses, cursors) and a memory
     // instruction, which one wave can issue back to back, where a slot holding a single dependent chain stalls on it
     // (PMC: a third of the wave's cycles were such issue stalls).  Order constraints: TAPA < TAPB < loads < XADV;
-    // ASOFF < DMA < WADV; both halves of a pair in order and before the stores; everything before the barrier.
+    // ASOFF < DMA < WADV (in slot order AND in micro-op order within a slot); both halves of a pair in order and before the stores; everything before the barrier.
     static constexpr int slot_of(int m)
     {
         if (m == M_TAPA) return 0;
         if (m == M_TAPB) return 1;
-        if (m < M_XADV) return 2 + (m - M_LD) / UB;                      // loads: slots 2..9
-        if (m == M_XADV) return 10;
-        if (m == M_ASOFF) return 10;
-        if (m < M_WADV) return 11 + ((m - M_DMA) * 6) / ACH;             // LDS-DMA pieces: slots 11..16
+        if (m < M_XADV) return 8 + (m - M_LD) / UB;                      // loads: slots 8..15
+        if (m == M_XADV) return 16;
+        if (m == M_ASOFF) return 1;
+        if (m < M_WADV) return 2 + ((m - M_DMA) * 6) / ACH;              // LDS-DMA pieces first (slots 2..7): the longest latency
         if (m == M_WADV) return 17;
         if (m < M_SP) return 6 + (m - M_FR);                             // fragment reads: slots 6..17
         if (m < M_ST) return ((m - M_SP) * 22) / (8 * UB);               // split halves: spread over slots 0..21
