@@ -24,7 +24,7 @@ AsProfScope::AsProfScope(int cls, double flops, double bytes, hipStream_t s, con
     r.tag[0] = 0;
     if (tag) { strncpy(r.tag, tag, sizeof(r.tag) - 1); r.tag[sizeof(r.tag) - 1] = 0; }
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     std::lock_guard<std::mutex> g(g_mu);
     g_recs.push_back(r);
     idx = (int)g_recs.size() - 1;
@@ -34,13 +34,13 @@ AsProfScope::~AsProfScope()
 {
     if (idx < 0) return;
     std::lock_guard<std::mutex> g(g_mu);
-    hipEventRecord(g_recs[idx].b, stream);
+    (void)hipEventRecord(g_recs[idx].b, stream);
 }
 
 extern "C" int as_prof_enable(int on)
 {
     std::lock_guard<std::mutex> g(g_mu);
-    for (auto& r : g_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_recs.clear();
     g_on = on != 0;
     return AS_OK;
