@@ -36,7 +36,8 @@ class ConvGemmArgs(ctypes.Structure):
                 ("ldx", ctypes.c_int32), ("ldy", ctypes.c_int32), ("ldr", ctypes.c_int32),
                 ("act", ctypes.c_int32), ("div_sqrt2", ctypes.c_int32), ("in_act", ctypes.c_int32),
                 ("transpose_out", ctypes.c_int32), ("quad_ok", ctypes.c_int32),
-                ("dh", ctypes.c_int32 * AS_MAX_TAPS), ("dw", ctypes.c_int32 * AS_MAX_TAPS)]
+                ("dh", ctypes.c_int32 * AS_MAX_TAPS), ("dw", ctypes.c_int32 * AS_MAX_TAPS),
+                ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float)]
 
 
 _SIGNATURES.update({

@@ -93,7 +93,8 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
                 x += v[e];
                 if (DIV) x = div_sqrt2f(x);
                 if (ACT == 1) x = x > 0.f ? x : 0.f;
-                if (ACT == 2) x = x > 0.f ? x : 0.2f * x;
+                if (ACT == 2) x = x > 0.f ? x : a.act_slope * x;
+                if (ACT == 3) x = tanhf(x);
                 v[e] = x;
             }
             if (TR) {                                        // time-major output for the LSTM: Y[col][row], 4 rows = 16 bytes
@@ -157,6 +158,7 @@ static __device__ __forceinline__ void epilogue_dispatch(const ConvGemmArgs& a, 
     else if (a.div_sqrt2) epilogue_tiles<TM, TN, true, 1, false>(a, acc, rbase, cbase, l31);
     else if (a.act == 0) epilogue_tiles<TM, TN, false, 0, false>(a, acc, rbase, cbase, l31);
     else if (a.act == 1) epilogue_tiles<TM, TN, false, 1, false>(a, acc, rbase, cbase, l31);
+    else if (a.act == 3) epilogue_tiles<TM, TN, false, 3, false>(a, acc, rbase, cbase, l31);
     else epilogue_tiles<TM, TN, false, 2, false>(a, acc, rbase, cbase, l31);
 }
 

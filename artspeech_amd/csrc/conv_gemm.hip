@@ -180,7 +180,7 @@ conv_gemm_quad_kernel(const ConvGemmArgs a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float x = ((rok[i] >> c) & 1u) ? v[c] : 0.f;
-                if (in_lrelu) x = x > 0.f ? x : 0.2f * x;  // LeakyReLU fused on the operand (models.py:89,142)
+                if (in_lrelu) x = x > 0.f ? x : a.in_slope * x;  // LeakyReLU fused on the operand (models.py:89,142)
                 v[c] = x;
             }
             *reinterpret_cast<f32x4*>(&Bs[buf][q / (BN / 4)][(q % (BN / 4)) * 4]) = v;
@@ -298,7 +298,7 @@ conv_gemm_kernel(const ConvGemmArgs a)
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             float v = rb[i];
-            if (in_lrelu) v = v > 0.f ? v : 0.2f * v;
+            if (in_lrelu) v = v > 0.f ? v : a.in_slope * v;
             Bs[buf][b_r0 + i * B_RSTEP][b_c] = v;
         }
     };
@@ -368,7 +368,7 @@ conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
                             (!a.meta || ((unsigned)(h + a.dh[tt]) < (unsigned)H && (unsigned)(w + a.dw[tt]) < (unsigned)Wj));
             const int jj = j < a.N ? j : a.N - 1;
             float v = a.X[ok ? jj + a.dh[tt] * (a.meta ? Wj : 0) + a.dw[tt] : jj];
-            if (a.in_act == 2) v = v > 0.f ? v : 0.2f * v;
+            if (a.in_act == 2) v = v > 0.f ? v : a.in_slope * v;
             x[c][t] = ok ? v : 0.f;
         }
     }
@@ -387,7 +387,8 @@ conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
             for (int t = 0; t < 9; ++t) sum += wt[t] * x[c][t];
             sum += bs[m];
             if (a.act == 1) sum = sum > 0.f ? sum : 0.f;
-            else if (a.act == 2) sum = sum > 0.f ? sum : 0.2f * sum;
+            else if (a.act == 2) sum = sum > 0.f ? sum : a.act_slope * sum;
+            else if (a.act == 3) sum = tanhf(sum);
             y[c] = sum;
         }
         float* yr = a.Y + (size_t)m * a.ldy + j0;
@@ -424,7 +425,7 @@ conv_direct_cin1_kernel(const ConvGemmArgs a)
             const bool ok = !a.meta || ((unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)Wj);
             if (ok) {
                 float v = a.X[j + a.dh[t] * (a.meta ? Wj : 0) + a.dw[t]];
-                if (a.in_act == 2) v = v > 0.f ? v : 0.2f * v;
+                if (a.in_act == 2) v = v > 0.f ? v : a.in_slope * v;
                 x[t] = v;
             }
         }
@@ -436,7 +437,8 @@ conv_direct_cin1_kernel(const ConvGemmArgs a)
             if (t < a.T) s += ws[t * a.M + m] * x[t];
         s += bs[m];
         if (a.act == 1) s = s > 0.f ? s : 0.f;
-        else if (a.act == 2) s = s > 0.f ? s : 0.2f * s;
+        else if (a.act == 2) s = s > 0.f ? s : a.act_slope * s;
+        else if (a.act == 3) s = tanhf(s);
         a.Y[(size_t)m * a.ldy + j] = s;
     }
 }
@@ -453,7 +455,8 @@ __global__ void splitk_reduce_kernel(const ConvGemmArgs a, int S)
         if (a.res) v += a.res[(size_t)row * a.ldr + col];
         if (a.div_sqrt2) v = v / 1.41421356237309504880f;
         if (a.act == 1) v = v > 0.f ? v : 0.f;
-        else if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
+        else if (a.act == 2) v = v > 0.f ? v : a.act_slope * v;
+        else if (a.act == 3) v = tanhf(v);
         if (a.transpose_out) a.Y[(size_t)col * a.ldy + row] = v;
         else a.Y[(size_t)row * a.ldy + col] = v;
     }
@@ -473,6 +476,13 @@ static void tile_dims(int choice, int* bm, int* bn)
 static bool use_x6(const ConvGemmArgs& a)
 {
     if (!a.Wx) return false;
+    // tap offsets the bf16x6 kernel can pack into a byte: |dh|, |dw| <= 7, or dh = 0 everywhere and |dw| <= 127 (dilated 1-D)
+    bool small = true, flat = true;
+    for (int t = 0; t < a.T; ++t) {
+        small &= a.dh[t] >= -7 && a.dh[t] <= 7 && a.dw[t] >= -7 && a.dw[t] <= 7;
+        flat &= a.dh[t] == 0 && a.dw[t] >= -127 && a.dw[t] <= 127;
+    }
+    if (!small && !flat) return a.W ? false : true;        // (no fp32 image to fall back to: the launch reports EINVAL)
     const char* env = getenv("AS_GEMM_IMPL");
     return !(env && env[0] == 'f' && a.W);
 }
@@ -565,7 +575,11 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!args_host) return AS_EINVAL;
-    const ConvGemmArgs& a = *args_host;
+    ConvGemmArgs norm = *args_host;
+    if (norm.in_slope == 0.f) norm.in_slope = 0.2f;
+    if (norm.act_slope == 0.f) norm.act_slope = 0.2f;
+    if (norm.act < 0 || norm.act > 3 || (norm.in_act != 0 && norm.in_act != 2)) return AS_EINVAL;
+    const ConvGemmArgs& a = norm;
     if ((!a.W && !a.Wx) || !a.X || !a.Y || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS) return AS_EINVAL;
     if (a.Kp < a.K || a.Kp % BK) return AS_EINVAL;
     if (a.ldx < a.N || a.ldy < (a.transpose_out ? a.M : a.N) || (a.res && (a.ldr < a.N || a.transpose_out))) return AS_EINVAL;

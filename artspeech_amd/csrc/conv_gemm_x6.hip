@@ -106,6 +106,7 @@ struct X6Plan {
 // word: the k loop then selects a tap with scalar ALU only (a scalar or scratch load inside it would stall the wave)
 struct X6Taps {
     unsigned long long w0, w1, w2, w3;
+    int wide;                             // 1: every dh = 0 and the byte is dw + 128 (dilated 1-D convs, |dw| <= 127)
 };
 
 // Software pipeline, per workgroup and k-tile `it` (P = it & 1):
@@ -207,7 +208,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
     auto gload_b = [&](float (&r8)[UB][8]) {
         const unsigned long long w = xb_t < 8 ? tp.w0 : xb_t < 16 ? tp.w1 : xb_t < 24 ? tp.w2 : tp.w3;
         const int byte = (int)(w >> ((xb_t & 7) * 8)) & 0xff;
-        const int src = j + ((byte >> 4) - 8) * Wj + (byte & 15) - 8;
+        const int src = tp.wide ? j + byte - 128 : j + ((byte >> 4) - 8) * Wj + (byte & 15) - 8;
         const unsigned b_voff = (((tapmask >> xb_t) & 1u) && src >= 0) ? (unsigned)src * 4u : OOB;
         // rows past K (last k-tile of a tap when K % 16 != 0, or zero-padded k-blocks): read row K-1 again -- their
         // weights are zero rows, and a clamp is two scalar instructions where a validity select is six
@@ -227,8 +228,8 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
     auto split_pair = [&](float x0, float x1, u32x4& hv, u32x4& mv, u32x4& lv, int e) {
         unsigned h, m, l;
         if (LRELU) {                                                    // LeakyReLU fused on the operand (models.py:89,142)
-            x0 = vmax(x0, 0.2f * x0);
-            x1 = vmax(x1, 0.2f * x1);
+            x0 = vmax(x0, a.in_slope * x0);
+            x1 = vmax(x1, a.in_slope * x1);
         }
 #ifdef X6_EXP_NOSPLIT
         h = __builtin_bit_cast(unsigned, x0);
@@ -318,7 +319,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
             const unsigned long long w = xb_t < 8 ? tp.w0 : xb_t < 16 ? tp.w1 : xb_t < 24 ? tp.w2 : tp.w3;
             c_byte = (int)(w >> ((xb_t & 7) * 8)) & 0xff;
         } else if constexpr (M == PL::M_TAPB) {
-            const int src = j + ((c_byte >> 4) - 8) * Wj + (c_byte & 15) - 8;
+            const int src = tp.wide ? j + c_byte - 128 : j + ((c_byte >> 4) - 8) * Wj + (c_byte & 15) - 8;
             c_voff = (((tapmask >> xb_t) & 1u) && src >= 0) ? (unsigned)src * 4u : OOB;
             c_base = (xb_kb * 16 + g0 * 8) * ldx4;
         } else if constexpr (M < PL::M_XADV) {
@@ -354,8 +355,8 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
             if constexpr (half == 0) {                                  // x = h + r
                 float x0 = rb[P][i][2 * e], x1 = rb[P][i][2 * e + 1];
                 if (LRELU) {
-                    x0 = vmax(x0, 0.2f * x0);
-                    x1 = vmax(x1, 0.2f * x1);
+                    x0 = vmax(x0, a.in_slope * x0);
+                    x1 = vmax(x1, a.in_slope * x1);
                 }
                 const unsigned h = pk_bf16(x0, x1);
                 c_r[i][e][0] = x0 - bf_lo(h);
@@ -456,11 +457,14 @@ static int launch_x6(const ConvGemmArgs& a, int S, hipStream_t stream)
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr_set = true;
     }
-    X6Taps tp = {0, 0, 0, 0};
+    X6Taps tp = {0, 0, 0, 0, 0};
     unsigned long long* w = &tp.w0;
+    for (int t = 0; t < a.T; ++t)
+        if (a.dh[t] < -7 || a.dh[t] > 7 || a.dw[t] < -7 || a.dw[t] > 7) tp.wide = 1;
     for (int t = 0; t < a.T; ++t) {
-        if (a.dh[t] < -7 || a.dh[t] > 7 || a.dw[t] < -7 || a.dw[t] > 7) return AS_EINVAL;
-        w[t >> 3] |= (unsigned long long)(((a.dh[t] + 8) << 4) | (a.dw[t] + 8)) << ((t & 7) * 8);
+        if (tp.wide && (a.dh[t] != 0 || a.dw[t] < -127 || a.dw[t] > 127)) return AS_EINVAL;
+        const int byte = tp.wide ? a.dw[t] + 128 : ((a.dh[t] + 8) << 4) | (a.dw[t] + 8);
+        w[t >> 3] |= (unsigned long long)byte << ((t & 7) * 8);
     }
     const dim3 grid(as_cdiv(a.M, C::BM) * as_cdiv(a.N, C::BN), S);
     hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WK, LRELU>), grid, dim3(C::NT), C::LDS, stream, a, tp);
@@ -470,7 +474,6 @@ static int launch_x6(const ConvGemmArgs& a, int S, hipStream_t stream)
 
 int as_conv_gemm_x6_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream)
 {
-    if (a.in_act != 0 && a.in_act != 2) return AS_EINVAL;
     const bool lr = a.in_act == 2;
     switch (choice) {
     case 228: return lr ? launch_x6<2, 2, 2, true>(a, S, stream) : launch_x6<2, 2, 2, false>(a, S, stream);   // 8 waves

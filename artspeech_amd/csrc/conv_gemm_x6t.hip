@@ -163,8 +163,8 @@ conv_gemm_x6t_kernel(const ConvGemmArgs a, const X6TGroups tg)
         if constexpr (q % 2 == 0) {
             float x0 = rb[2 * e], x1 = rb[2 * e + 1];
             if (LRELU) {
-                x0 = vmax(x0, 0.2f * x0);
-                x1 = vmax(x1, 0.2f * x1);
+                x0 = vmax(x0, a.in_slope * x0);
+                x1 = vmax(x1, a.in_slope * x1);
             }
             const unsigned h = pk_bf16(x0, x1);
             c_r[e][0] = x0 - bf_lo(h);
@@ -185,7 +185,7 @@ conv_gemm_x6t_kernel(const ConvGemmArgs a, const X6TGroups tg)
         if (tid < 4) {
             float x[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) x[q] = LRELU ? vmax(rbx[q], 0.2f * rbx[q]) : rbx[q];
+            for (int q = 0; q < 8; ++q) x[q] = LRELU ? vmax(rbx[q], a.in_slope * rbx[q]) : rbx[q];
             u32x4 h, m, l;
             split3(x, h, m, l);
             unsigned char* b = smem + stage * T_STAGE + T_B_OFF + (khx * T_ROWS + rx) * 16;

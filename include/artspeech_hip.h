@@ -89,9 +89,9 @@ typedef struct ConvGemmArgs {
     int32_t M, N, K, T;
     int32_t Kp;            /* rows per tap in W: K rounded up to a multiple of 16, the extra rows zero */
     int32_t ldx, ldy, ldr;
-    int32_t act;           /* epilogue activation: 0 none, 1 ReLU, 2 LeakyReLU(0.2) */
+    int32_t act;           /* epilogue activation: 0 none, 1 ReLU, 2 LeakyReLU(act_slope), 3 tanh */
     int32_t div_sqrt2;     /* epilogue: divide by sqrt(2) after bias and residual */
-    int32_t in_act;        /* 2 = LeakyReLU(0.2) applied to X while staging (models.py:89,142) */
+    int32_t in_act;        /* 2 = LeakyReLU(in_slope) applied to X while staging (models.py:89,142; Vocoder/vocoder.py:38,102) */
     int32_t transpose_out; /* 1 = write Y[j][m] (time-major, row stride ldy >= M) */
     int32_t quad_ok;       /* caller's promise enabling the 16-byte staging: (a) the 16 bytes in front of X are
                               readable (or no tap has a negative offset), (b) no group of 4 consecutive columns
@@ -99,6 +99,7 @@ typedef struct ConvGemmArgs {
                               dh != 0.  0 = always-correct scalar staging.  (M % 4 == 0 is checked here.) */
     int32_t dh[AS_MAX_TAPS];   /* tap row offsets (scalar-loadable) */
     int32_t dw[AS_MAX_TAPS];   /* tap column offsets */
+    float in_slope, act_slope; /* LeakyReLU slopes of in_act / act; 0 = the path's 0.2 */
 } ConvGemmArgs;
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
 /* Bytes of split-K workspace this shape wants (0 = none).  Shapes whose tile grid cannot fill the 256 CUs
