@@ -11,7 +11,7 @@ from ._lib import check, ptr, stream
 
 AS_MAX_TAPS = _lib.AS_MAX_TAPS
 KTILE = 16                      # the GEMM k-tile (BK in csrc/conv_gemm.hip): weights are zero-padded to it
-ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 
 
 ConvGemmArgs = _lib.ConvGemmArgs
@@ -158,7 +158,7 @@ def taps_2d(kh, kw):
 
 
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
-              use_meta=True):
+              use_meta=True, in_slope=0.0, act_slope=0.0):
     """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt [T][Kp][M] (prep_weight: K zero-padded to a multiple
     of 16); X [K][*]; Y [M][*] (or [N][*] transposed)."""
     T, Kp, M = Wt.shape
@@ -175,6 +175,7 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     a.ldx, a.ldy = _ld(X), _ld(Y)
     a.ldr = _ld(res) if res is not None else 0
     a.act, a.div_sqrt2, a.in_act, a.transpose_out = act, int(div_sqrt2), in_act, int(transpose_out)
+    a.in_slope, a.act_slope = in_slope, act_slope          # 0 = LeakyReLU(0.2), the acoustic path's slope
     assert len(taps) == T
     for i, (dh, dw) in enumerate(taps):
         a.dh[i], a.dw[i] = dh, dw
@@ -254,6 +255,17 @@ def rows_to_images(src, src_lay, start, H, img_lay):
     check(_lib.lib().as_rows_to_images_f32(_p(src), _ld(src), _p(src_lay.col_off), start, H, _p(dst), _p(img_lay.col_off),
                                            img_lay.B, src_lay.max_cols, stream()), "as_rows_to_images_f32")
     return dst
+
+
+def interleave_phases(Z, bias, C, u, n_in, Y):
+    check(_lib.lib().as_interleave_phases_f32(_p(Z), _ld(Z), _p(bias), C, u, n_in, _p(Y), _ld(Y), stream()),
+          "as_interleave_phases_f32")
+    return Y
+
+
+def mean3(A, B, C3, n, Y):
+    check(_lib.lib().as_mean3_f32(_p(A), _p(B), _p(C3), _ld(A), A.shape[0], n, _p(Y), _ld(Y), stream()), "as_mean3_f32")
+    return Y
 
 
 def dwconv_down(X, lin, Y, lout, w, bias, kh, lrelu):

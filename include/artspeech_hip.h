@@ -181,6 +181,17 @@ typedef struct BiLstmJob {
 } BiLstmJob;
 int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32_t* col_off, int B, int H, as_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * HiFi-GAN generator glue (Vocoder/vocoder.py:75-125).  Its convolutions run through
+ * as_conv_gemm_f32 (dilated taps, LeakyReLU slopes 0.1 / 0.01, tanh epilogue).
+ * ------------------------------------------------------------------------------------------- */
+/* ConvTranspose1d(k = 2u, stride u) = one 3-tap conv with output rows (phase r, channel m), then
+ * y[m][u*q + r] = z[r*C + m][q] + bias[m]                                     vocoder.py:84-89,102-103 */
+int as_interleave_phases_f32(const float* z, int ldz, const float* bias, int C, int u, int Nin, float* y, int ldy,
+                             as_stream_t stream);
+/* y = (a + b + c) / 3 over [C][N]                                              vocoder.py:104-110 */
+int as_mean3_f32(const float* a, const float* b, const float* c, int ld, int C, int N, float* y, int ldy, as_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -235,7 +235,33 @@ def make_text():
     print("text golden:", len(ref_md.symbols), "symbols,", len(gold), "lines")
 
 
+def make_vocoder():
+    """HiFi-GAN Generator of the reference (Vocoder/vocoder.py:75-125) on seeded synthetic weights
+    (artspeech_amd.vocoder.synth_generator_state_dict): a tiny configuration and the shipped one (Vocoder/config.json)."""
+    from Vocoder.vocoder import Generator as RefGenerator                      # the reference
+    from artspeech_amd import vocoder as V
+    inv = {}
+    for tag, c0, t_list in (("tiny", 32, (9, 16)), ("full", 512, (12,))):
+        h = Munch(dict(V.DEFAULT_H, upsample_initial_channel=c0))
+        ref = RefGenerator(h).eval()
+        inv[tag] = {k: list(v.shape) for k, v in ref.state_dict().items()}
+        assert inv[tag] == {k: list(v) for k, v in V.generator_spec(h).items()}, "generator_spec differs from the reference"
+        sd = V.synth_generator_state_dict(h, seed=3407)
+        ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        for t in t_list:
+            mel = synth.hash_tensor(f"voc/mel/{tag}/{t}", (1, 80, t), 1234, 1.0)
+            with torch.no_grad():
+                wav = ref(torch.from_numpy(mel))
+            assert wav.shape == (1, 1, 300 * t) and torch.isfinite(wav).all()
+            print("vocoder golden", tag, t, "wav abs max %.4f mean |x| %.4f" % (float(wav.abs().max()), float(wav.abs().mean())))
+            np.savez_compressed(os.path.join(HERE, f"voc_{tag}_T{t}.npz"), c0=c0, t=t, seed=3407, mel=mel[0], wav=wav[0, 0].numpy())
+    json.dump(inv, open(os.path.join(HERE, "vocoder_inventory.json"), "w"), indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["vocoder"]:
+        make_vocoder()
+        sys.exit(0)
     what = sys.argv[1:] or ["params", "mas", "net", "text"]
     if "text" in what:
         make_text()
