@@ -1,9 +1,10 @@
-"""The acoustic-model part of the reference's inference script (test.py:58-119) on the HIP path.
+"""The reference's inference script (test.py:58-135) on the HIP path, from phonemes to samples.
 
 ``test.py`` does: espeak phonemizer -> TextCleaner -> reference wav -> log-mel -> ArtsSpeech(step="test") -> HiFi-GAN.
-The phonemizer, the wav/mel front end and the vocoder are outside this path;
-this class covers test.py:75-88 (distribution, build_model, load_checkpoint) and test.py:96-113 (ids, tensor packing,
-the model call) so that a caller with phonemes and a reference mel gets the mel the reference would vocode.
+The phonemizer and the wav/mel front end are outside this path; this class covers
+test.py:75-88 (distribution, build_model, load_checkpoint), test.py:96-113 (ids, tensor packing, the model call) and
+test.py:115-125 (the generator, SURVEY.md section 8(f) N2: artspeech_amd/vocoder.py), so that a caller with phonemes and a
+reference mel gets the mel -- and, with a vocoder attached, the waveform -- the reference would produce.
 """
 import json
 
@@ -39,6 +40,29 @@ class ArtSpeech:
             models.load_checkpoint(self.model, None, ckpt, load_only_params=True)       # test.py:85
         self.textcleaner = TextCleaner()
         self.device = dev
+        self.generator = None                       # test.py:119-125: the HiFi-GAN generator (attach_vocoder)
+
+    def attach_vocoder(self, h=None, checkpoint=None):
+        """test.py:119-125: build the generator from Vocoder/config.json-style `h` and load checkpoint['generator']."""
+        from .vocoder import Generator
+        self.generator = Generator(h, device=self.device)
+        if checkpoint is not None:
+            sd = checkpoint if isinstance(checkpoint, dict) else torch.load(checkpoint, map_location="cpu")
+            self.generator.load_state_dict(sd)
+        return self.generator
+
+    @torch.no_grad()
+    def synthesis_wav(self, phonemes, ref_mel, features=None, forced_durations=None):
+        """test.py:113-116: mel from the acoustic model, then ``generator(mel).squeeze()`` -> [B, 300 * frames]
+        (one utterance: 1-D), samples beyond an utterance's own length are zero.  The packed mel goes straight into the
+        generator: no padding is ever synthesised."""
+        if self.generator is None:
+            raise RuntimeError("no vocoder attached: call attach_vocoder(h, checkpoint) first")
+        single = isinstance(phonemes, str)
+        mel = self.synthesis_mel(phonemes, ref_mel, features=features, forced_durations=forced_durations)
+        lens = self._last_frames
+        wav = self.generator(mel, lengths=lens)[:, 0]
+        return wav[0] if single else wav
 
     @torch.no_grad()
     def synthesis_mel(self, phonemes, ref_mel, features=None, forced_durations=None):
@@ -67,9 +91,11 @@ class ArtSpeech:
                 f0[b, :, : f.shape[-1]] = torch.as_tensor(f).reshape(1, -1)
                 ema[b, :, : e.shape[-1]] = torch.as_tensor(e)
             feats = (f0, ema)
-        return self.model.ArtsSpeech([text, input_lengths, mels, mel_input_length, None, None, None], None, None,
-                                     step="test", features=feats, forced_durations=forced_durations)   # test.py:113
+        mel, aux = self.model.ArtsSpeech([text, input_lengths, mels, mel_input_length, None, None, None], None, None,
+                                         step="test", features=feats, forced_durations=forced_durations, return_aux=True)   # test.py:113
+        self._last_frames = list(aux["lay2"].widths_host)
+        return mel
 
     def synthesis(self, text, ref_wav, save_path):
-        raise NotImplementedError("text -> phonemes (espeak), wav -> log-mel and mel -> wav (HiFi-GAN) are outside the "
-                                  "acoustic-model path (SURVEY.md section 2); use synthesis_mel(phonemes, ref_mel)")
+        raise NotImplementedError("text -> phonemes (espeak) and wav -> log-mel are outside this path (SURVEY.md "
+                                  "section 2); use synthesis_mel / synthesis_wav(phonemes, ref_mel)")

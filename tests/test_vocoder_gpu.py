@@ -48,3 +48,29 @@ def test_ragged_batch_equals_single(cuda, golden_dir):
         n = 300 * int(g["t"])
         assert float(np.abs(wav[b, 0, :n].cpu().numpy() - g["wav"]).max()) <= TOL
         assert float(wav[b, 0, n:].abs().max()) == 0.0 if n < 300 * tmax else True
+
+
+def test_pipeline_mel_to_wav(cuda, golden_dir):
+    """test.py's chain on the HIP path: phonemes + reference mel -> acoustic model -> generator -> samples."""
+    import json
+    from artspeech_amd import synth
+    from artspeech_amd.pipeline import ArtSpeech
+    from test_net_gpu import raw_features
+    tts = ArtSpeech(config={"model_params": {"hidden_dim": 64, "dim_in": 8, "max_conv_dim": 64}},
+                    checkpoint={"net": {"ArtsSpeech": synth.synth_state_dict(64, 8, seed=3407)}}, device=cuda)
+    h = dict(V.DEFAULT_H, upsample_initial_channel=32)
+    tts.attach_vocoder(h, V.synth_generator_state_dict(h, seed=3407))
+    with open(os.path.join(golden_dir, "text_golden.json"), encoding="utf-8") as f:
+        cases = json.load(f)["cases"]
+    ph = [cases[0]["text"][:30], cases[1]["text"][:18]]
+    mels, feats = [], []
+    for i, t in enumerate((90, 70)):
+        mel, f0_raw, ema_raw = raw_features(t, 40 + i)
+        mels.append(mel)
+        feats.append((f0_raw, ema_raw))
+    wav = tts.synthesis_wav(ph, mels, features=feats)
+    frames = tts._last_frames
+    assert wav.shape == (2, 300 * max(frames)) and bool(torch.isfinite(wav).all())
+    solo = tts.synthesis_wav(ph[1], mels[1], features=feats[1])
+    assert solo.shape == (300 * frames[1],)
+    assert float((solo - wav[1, : solo.shape[0]]).abs().max()) <= 1e-5
