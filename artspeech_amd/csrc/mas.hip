@@ -114,7 +114,8 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
             }
             if (W > 1) {
                 if (lane == 63) bnd[(y & 1) * 16 + wave] = prev[R - 1];
-                __syncthreads();
+                // LDS-only barrier: __syncthreads() would also wait for the prefetched chunk's global loads (vmcnt)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
         wsb[(size_t)c * NT + tid] = (u64)(bits[0] | (bits[1] << 16)) | ((u64)(bits[2] | (bits[3] << 16)) << 32);
@@ -166,16 +167,19 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
 // ---- host side -------------------------------------------------------------------------------------
 static int mas_geometry(int Tx, int* R, int* W)
 {
+    // rows per lane R and waves W (64 * R * W >= Tx).  A column step costs ~5 instructions per row of the lane plus,
+    // with several waves, one LDS-only barrier: measured on MI355X ([8,1024,2000]) 1 wave x 16 rows 1.24 ms, 8 x 2
+    // 0.80 ms -- so as many waves as the workgroup allows (16 at <= 128 VGPRs for R <= 4, 8 for R = 8 / 16).
     int r = 1;
     const char* env = getenv("AS_MAS_R");                  // tuning/experiments only
     if (env && atoi(env) > 0) {
         r = atoi(env);
         if (r != 1 && r != 2 && r != 4 && r != 8 && r != 16) return AS_EINVAL;
     } else {
-        while (r < 16 && 64 * r < Tx) r <<= 1;
+        while (r < 16 && 64 * r * (r <= 4 ? 16 : 8) < Tx) r <<= 1;
     }
     const int w = as_cdiv(Tx > 0 ? Tx : 1, 64 * r);
-    if (w > 8) return AS_EINVAL;                           // Tx <= 8192 at R = 16
+    if (w > (r <= 4 ? 16 : 8)) return AS_EINVAL;           // Tx <= 8192
     *R = r;
     *W = w;
     return AS_OK;
@@ -193,17 +197,18 @@ static void mas_launch(bool vec4, int B, int W, size_t smem, hipStream_t s, cons
                        const int* t_y, int Tx, int Ty, float* path, int* dur, int* rows, u64* ws, int sc)
 {
     // W == 1 (the common case, Tx <= 64*R): 64-thread workgroups may use the whole register file, which
-    // the R = 16 prefetch needs; multi-wave geometries are capped at 8 waves (256 VGPRs each).
+    // the R = 16 prefetch needs; multi-wave geometries go up to 16 waves (128 VGPRs each).
     if (W == 1) {
         if (vec4)
             hipLaunchKernelGGL((mas_kernel<R, true, TIE, 64>), dim3(B), dim3(64), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
         else
             hipLaunchKernelGGL((mas_kernel<R, false, TIE, 64>), dim3(B), dim3(64), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
     } else {
+        constexpr int MT = R <= 4 ? 1024 : 512;            // launch bound = register budget: R = 8 / 16 need 256 VGPRs
         if (vec4)
-            hipLaunchKernelGGL((mas_kernel<R, true, TIE, 512>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
+            hipLaunchKernelGGL((mas_kernel<R, true, TIE, MT>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
         else
-            hipLaunchKernelGGL((mas_kernel<R, false, TIE, 512>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
+            hipLaunchKernelGGL((mas_kernel<R, false, TIE, MT>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
     }
 }
 
