@@ -28,7 +28,7 @@ AS_MAX_TAPS = 25
 
 
 class ConvGemmArgs(ctypes.Structure):
-    _fields_ = [("W", ctypes.c_void_p), ("Wx", ctypes.c_void_p), ("X", ctypes.c_void_p), ("Y", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+    _fields_ = [("W", ctypes.c_void_p), ("Wx", ctypes.c_void_p), ("X", ctypes.c_void_p), ("Xs", ctypes.c_void_p), ("Y", ctypes.c_void_p), ("bias", ctypes.c_void_p),
                 ("res", ctypes.c_void_p), ("meta", ctypes.c_void_p),
                 ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_size_t),
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("T", ctypes.c_int32),
@@ -44,6 +44,8 @@ _SIGNATURES.update({
     "as_make_meta": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "as_conv_gemm_f32": (c_i, [ctypes.POINTER(ConvGemmArgs), c_p]),
     "as_conv_gemm_workspace_bytes": (c_sz, [ctypes.POINTER(ConvGemmArgs)]),
+    "as_split_bf16x3_bytes": (c_sz, [c_i, c_i]),
+    "as_split_bf16x3_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "as_embed_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "as_channel_layernorm_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_i, c_p]),
     "as_adain_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),

@@ -14,6 +14,11 @@ int as_conv_gemm_x6_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t
 int as_conv_gemm_x6t_ktiles(const ConvGemmArgs& a);
 int as_conv_gemm_x6t_launch(const ConvGemmArgs& a, int S, hipStream_t stream);
 
+// host: the bf16x6 kernel reading BOTH operands by LDS-DMA (conv_gemm_x6d.hip; a.Xs = pre-split activations; tiles 22, 21,
+// 12), and the launch of the kernel that makes that image (no profiling scope of its own)
+int as_conv_gemm_x6d_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream);
+int as_split_bf16x3_launch(const float* x, int ldx, int K, int N, int lrelu, float slope, uint16_t* xs, hipStream_t stream);
+
 #ifdef __HIPCC__
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -184,4 +189,9 @@ static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32
                                                                        (int)((unsigned)a.M * a.N * 4u), 0x00020000);
     slab_store<TM, TN, 0>(a, acc, rs, rbase, cbase, l31);
 }
+// (Built and measured on MI355X, not kept: issuing MFMA(activation fragment, weight fragment) so that a lane owns four
+// consecutive COLUMNS of one row -- 16-byte residual loads and output stores, 34 memory instructions per 64x64 block
+// instead of 160.  Each store instruction then touches 32 rows x 32 bytes instead of 2 rows x 128 bytes and the
+// output-heavy shapes lost more (M128 N128000 K128: 72 -> 85 us, M64 N509440 K64 T9: 379 -> 411 us) than the small
+// ones gained (M512 N1280 K512: 18.0 -> 17.4 us).)
 #endif

@@ -555,13 +555,49 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice, bool x6)
     return s < 1 ? 1 : s;
 }
 
+// What one call runs: arithmetic, tile, K slices, and whether the activations are split into bf16 parts ahead of the
+// GEMM (conv_gemm_x6d.hip) instead of inside every tile's k loop.  The pre-split kernel is 5-25 % faster than the
+// in-loop one (no split VALU, no activation registers, three LDS stages on the 128x128 tile), but the split pass costs
+// 10 bytes of HBM traffic per input element plus a launch: with the whole step as the judge (bench.py, per-shape HIP
+// events, scripts/exp/x6d_policy.py) it pays for itself only on the 64-row tiles with 9 taps (the 64-channel 3x3
+// convolutions of the style towers: 413 -> 307 us); elsewhere it is break-even or worse.  So: those shapes, and any
+// call whose caller supplies the image (ConvGemmArgs.Xs: one split shared by several convolutions, or written by the
+// kernel that produces the activations).
+struct GemmPlan {
+    bool x6, x6d;
+    int choice, S;
+    size_t slab_bytes, xs_bytes;      // workspace: split-K slabs first, then (256-byte aligned) the split activations
+};
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+static GemmPlan gemm_plan(const ConvGemmArgs& a, bool have_ws_for_xs)
+{
+    GemmPlan p = {};
+    p.x6 = use_x6(a);
+    const bool taps3 = p.x6 && as_conv_gemm_x6t_ktiles(a) > 0;
+    if (p.x6) {
+        const char* env = getenv("AS_GEMM_X6D");          // tuning/experiments only: 0 never, 1 whenever the kernel can
+        const int mode = env ? atoi(env) : -1;
+        int c = gemm_tile_choice(a.M, a.N, true, false);
+        if (a.Xs && c != 22 && c != 21 && c != 12) c = a.M > 64 ? 21 : 12;   // (a forced experiment tile the kernel lacks)
+        bool want = a.Xs != nullptr;
+        if (!want && have_ws_for_xs && mode != 0) want = mode == 1 || (c == 12 && a.T >= 9 && a.N >= 4096);
+        if (want && (c == 22 || c == 21 || c == 12)) {
+            p.x6d = true;
+            p.choice = c;
+        }
+    }
+    if (!p.x6d) p.choice = gemm_tile_choice(a.M, a.N, p.x6, taps3);
+    p.S = gemm_ksplit(a.M, a.N, a.Kp, a.T, p.choice, p.x6);
+    p.slab_bytes = p.S > 1 ? (size_t)p.S * a.M * a.N * sizeof(float) : 0;
+    p.xs_bytes = (p.x6d && !a.Xs) ? as_split_bf16x3_bytes(a.K, a.N) : 0;
+    return p;
+}
+
 extern "C" size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host)
 {
     if (!args_host || args_host->M <= 0 || args_host->N <= 0 || args_host->Kp <= 0 || args_host->T <= 0) return 0;
-    const ConvGemmArgs& a = *args_host;
-    const bool x6 = use_x6(a);
-    const int s = gemm_ksplit(a.M, a.N, a.Kp, a.T, gemm_tile_choice(a.M, a.N, x6, x6 && as_conv_gemm_x6t_ktiles(a) > 0), x6);
-    return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
+    const GemmPlan p = gemm_plan(*args_host, true);
+    return p.xs_bytes ? align256(p.slab_bytes) + p.xs_bytes : p.slab_bytes;
 }
 
 template <int TM, int TN>
@@ -603,18 +639,29 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
         AS_CHECK_LAUNCH();
         return AS_OK;
     }
-    const bool x6 = use_x6(a);
-    const int choice = gemm_tile_choice(a.M, a.N, x6, x6 && as_conv_gemm_x6t_ktiles(a) > 0);
-    int S = gemm_ksplit(a.M, a.N, a.Kp, a.T, choice, x6);
-    if (S > 1 && (!a.ws || a.ws_bytes < (size_t)S * a.M * a.N * sizeof(float))) S = 1;   // no workspace: no split
+    GemmPlan plan = gemm_plan(a, a.ws != nullptr);
+    if (plan.xs_bytes && a.ws_bytes < align256(plan.slab_bytes) + plan.xs_bytes) plan = gemm_plan(a, false);   // no room: split in the k loop
+    const bool x6 = plan.x6;
+    const int choice = plan.choice;
+    int S = plan.S;
+    if (S > 1 && (!a.ws || a.ws_bytes < plan.slab_bytes)) S = 1;         // no workspace: no K slices
     const char* envq = getenv("AS_GEMM_QUAD");           // tuning/experiments only: 0 forces the scalar staging
     const bool quad = a.quad_ok && (a.M & 3) == 0 && !(envq && atoi(envq) == 0);
     char tag[64];
-    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d S%d %s", a.M, a.N, a.K, a.T, choice, S, x6 ? "x6" : quad ? "q" : "s");
+    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d S%d %s", a.M, a.N, a.K, a.T, choice, S, plan.x6d ? "x6d" : x6 ? "x6" : quad ? "q" : "s");
     // algorithmic work of this launch: 2*M*N*K*T flop; bytes = weights + input + output once
     AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.K * a.T,
                        4.0 * ((double)a.T * a.K * a.M + (double)a.K * a.N + (double)a.M * a.N), stream, tag);
-    if (x6) {
+    if (plan.x6d) {
+        if (!a.Xs) {                                                    // split once, behind the K slabs in the workspace
+            uint16_t* xs = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(a.ws) + align256(plan.slab_bytes));
+            const int rc = as_split_bf16x3_launch(a.X, a.ldx, a.K, a.N, a.in_act == 2, a.in_slope, xs, stream);
+            if (rc != AS_OK) return rc;
+            norm.Xs = xs;
+        }
+        const int rc = as_conv_gemm_x6d_launch(a, choice, S, stream);
+        if (rc != AS_OK) return rc;
+    } else if (x6) {
         const int rc = choice == 223 ? as_conv_gemm_x6t_launch(a, S, stream) : as_conv_gemm_x6_launch(a, choice, S, stream);
         if (rc != AS_OK) return rc;
     } else {

@@ -45,28 +45,6 @@
 
 #include "x6_common.h"
 
-template <int WM, int WN, int WK>
-struct X6Cfg {
-    static constexpr int BM = 64 * WM, BN = 64 * WN;
-    static constexpr int A_BLK = 6 * BM * 16, B_BLK = 6 * BN * 16;      // bytes per 16-deep k-block
-    static constexpr int STAGE = WK * (A_BLK + B_BLK);
-    static constexpr int RED = (WK - 1) * WM * WN * 64 * 64 * 4;        // cross-wave K reduction scratch
-    static constexpr int LDS = 2 * STAGE > RED ? 2 * STAGE : RED;
-    static constexpr int NT = 64 * WM * WN * WK;                         // threads: one wave per (M, N, K) block, 4 or 8 waves
-    static constexpr int ACH = WK * 6 * BM / NT;                         // 16-byte weight chunks per thread per k-tile
-    static constexpr int UB = WK * 2 * BN / NT;                          // (column, 8 k) activation units per thread
-};
-
-#ifdef X6_EXP_STAMPS
-#define X6_STAMP(t) unsigned long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-#define X6_BAR_BEGIN { unsigned long long b0__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b0__) :: "memory");
-#define X6_BAR_END unsigned long long b1__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b1__) :: "memory"); w_bar += b1__ - b0__; }
-#else
-#define X6_STAMP(t)
-#define X6_BAR_BEGIN
-#define X6_BAR_END
-#endif
-
 // The staging work of one k-tile as a list of micro-operations with approximate instruction counts, dealt out over
 // the 24 MFMAs of the iteration in order, by cumulative weight (x6 kernel, "slots").
 template <int ACH, int UB>
@@ -100,13 +78,6 @@ struct X6Plan {
         if (m < M_ST) return ((m - M_SP) * 22) / (8 * UB);               // split halves: spread over slots 0..21
         return 22 + ((m - M_ST) * 2) / (3 * UB);                         // stores: slots 22, 23
     }
-};
-
-// tap offsets packed one byte per tap, (dh+8) << 4 | (dw+8) (|dh|, |dw| <= 7, checked by the host), eight taps per
-// word: the k loop then selects a tap with scalar ALU only (a scalar or scratch load inside it would stall the wave)
-struct X6Taps {
-    unsigned long long w0, w1, w2, w3;
-    int wide;                             // 1: every dh = 0 and the byte is dw + 128 (dilated 1-D convs, |dw| <= 127)
 };
 
 // Software pipeline, per workgroup and k-tile `it` (P = it & 1):
@@ -169,6 +140,8 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
         }
     }
 
+    const X6TapCol tcol(tp, j, Wj);
+
     const int kt_per_tap = (KB + WK - 1) / WK;
     const int nkt_all = a.T * kt_per_tap;
     const int S = gridDim.y;                                             // split-K over (tap, k-tile)
@@ -206,9 +179,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
     float rb[2][UB][8];
     const int ldx4 = a.ldx * 4, last_row = (a.K - 1) * ldx4;
     auto gload_b = [&](float (&r8)[UB][8]) {
-        const unsigned long long w = xb_t < 8 ? tp.w0 : xb_t < 16 ? tp.w1 : xb_t < 24 ? tp.w2 : tp.w3;
-        const int byte = (int)(w >> ((xb_t & 7) * 8)) & 0xff;
-        const int src = tp.wide ? j + byte - 128 : j + ((byte >> 4) - 8) * Wj + (byte & 15) - 8;
+        const int src = tcol.src(x6_tap_byte(tp, xb_t));
         const unsigned b_voff = (((tapmask >> xb_t) & 1u) && src >= 0) ? (unsigned)src * 4u : OOB;
         // rows past K (last k-tile of a tap when K % 16 != 0, or zero-padded k-blocks): read row K-1 again -- their
         // weights are zero rows, and a clamp is two scalar instructions where a validity select is six
@@ -316,10 +287,9 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
     auto micro = [&](auto m_, auto p_) {
         constexpr int M = decltype(m_)::value, P = decltype(p_)::value, Q = P ^ 1;
         if constexpr (M == PL::M_TAPA) {
-            const unsigned long long w = xb_t < 8 ? tp.w0 : xb_t < 16 ? tp.w1 : xb_t < 24 ? tp.w2 : tp.w3;
-            c_byte = (int)(w >> ((xb_t & 7) * 8)) & 0xff;
+            c_byte = x6_tap_byte(tp, xb_t);
         } else if constexpr (M == PL::M_TAPB) {
-            const int src = tp.wide ? j + c_byte - 128 : j + ((c_byte >> 4) - 8) * Wj + (c_byte & 15) - 8;
+            const int src = tcol.src(c_byte);
             c_voff = (((tapmask >> xb_t) & 1u) && src >= 0) ? (unsigned)src * 4u : OOB;
             c_base = (xb_kb * 16 + g0 * 8) * ldx4;
         } else if constexpr (M < PL::M_XADV) {
@@ -436,15 +406,8 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
                     }
     }
     epilogue<2, 2>(a, acc, m0, n0, wm, wn, l31, lk, S, wk == 0);
-#ifdef X6_EXP_STAMPS
     X6_STAMP(t3)
-    if (tid == 0) {                                  // thread 0 owns Y[m0 + 0..3][n0]: overwrite with the segment times
-        a.Y[(size_t)(m0 + 0) * a.ldy + n0] = (float)(t1 - t0);
-        a.Y[(size_t)(m0 + 1) * a.ldy + n0] = (float)(t2 - t1);
-        a.Y[(size_t)(m0 + 2) * a.ldy + n0] = (float)(t3 - t2);
-        a.Y[(size_t)(m0 + 3) * a.ldy + n0] = (float)w_bar;
-    }
-#endif
+    X6_STAMPS_OUT
 }
 
 template <int WM, int WN, int WK, bool LRELU>
@@ -457,15 +420,8 @@ static int launch_x6(const ConvGemmArgs& a, int S, hipStream_t stream)
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr_set = true;
     }
-    X6Taps tp = {0, 0, 0, 0, 0};
-    unsigned long long* w = &tp.w0;
-    for (int t = 0; t < a.T; ++t)
-        if (a.dh[t] < -7 || a.dh[t] > 7 || a.dw[t] < -7 || a.dw[t] > 7) tp.wide = 1;
-    for (int t = 0; t < a.T; ++t) {
-        if (tp.wide && (a.dh[t] != 0 || a.dw[t] < -127 || a.dw[t] > 127)) return AS_EINVAL;
-        const int byte = tp.wide ? a.dw[t] + 128 : ((a.dh[t] + 8) << 4) | (a.dw[t] + 8);
-        w[t >> 3] |= (unsigned long long)byte << ((t & 7) * 8);
-    }
+    X6Taps tp;
+    if (x6_pack_taps(a, &tp) != AS_OK) return AS_EINVAL;
     const dim3 grid(as_cdiv(a.M, C::BM) * as_cdiv(a.N, C::BN), S);
     hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WK, LRELU>), grid, dim3(C::NT), C::LDS, stream, a, tp);
     AS_CHECK_LAUNCH();

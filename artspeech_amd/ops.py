@@ -157,10 +157,21 @@ def taps_2d(kh, kw):
     return [(a - kh // 2, d - kw // 2) for a in range(kh) for d in range(kw)]
 
 
+def split_act(X, lay, in_act=0, in_slope=0.0):
+    """X [K][*] fp32 -> the bf16x6 GEMM's pre-split activation image (int16 [KBx][6][N][8], LeakyReLU applied first when
+    in_act = ACT_LRELU): pass it as conv_gemm(..., xs=) to every conv that reads the same activations."""
+    L = _lib.lib()
+    K, N = X.shape[0], lay.N
+    xs = torch.empty(max(L.as_split_bf16x3_bytes(K, N) // 2, 8), dtype=torch.int16, device=X.device)
+    check(L.as_split_bf16x3_f32(_p(X), _ld(X), K, N, in_act, in_slope, _p(xs), stream()), "as_split_bf16x3_f32")
+    return xs
+
+
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
-              use_meta=True, in_slope=0.0, act_slope=0.0):
+              use_meta=True, in_slope=0.0, act_slope=0.0, xs=None):
     """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt [T][Kp][M] (prep_weight: K zero-padded to a multiple
-    of 16); X [K][*]; Y [M][*] (or [N][*] transposed)."""
+    of 16); X [K][*]; Y [M][*] (or [N][*] transposed).  xs: split_act(X, lay, in_act, in_slope), when several convs
+    share X."""
     T, Kp, M = Wt.shape
     K = X.shape[0]
     if Kp % KTILE or not (Kp - KTILE < K <= Kp):
@@ -170,6 +181,7 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     a.W, a.X, a.Y, a.bias, a.res = _p(Wt), _p(X), _p(Y), _p(bias), _p(res)
     x6 = getattr(Wt, "x6", None) if GEMM_IMPL == "x6" else None
     a.Wx = _p(x6)
+    a.Xs = _p(xs) if x6 is not None else None
     a.meta = _p(lay.meta) if (use_meta and not (T == 1 and taps[0] == (0, 0))) else None
     a.M, a.N, a.K, a.T = M, lay.N, K, T
     a.ldx, a.ldy = _ld(X), _ld(Y)

@@ -80,11 +80,15 @@ typedef struct ConvGemmArgs {
                               weights split w = h + m + l (three bf16, exact) for the bf16x6 path -- slot p*2 + kh holds
                               part p (h, m, l) of k = 16*kb + 8*kh + 0..7; NULL = fp32 path */
     const float* X;        /* [K][ldx] */
+    const uint16_t* Xs;    /* optional: X already split for the bf16x6 path by as_split_bf16x3_f32 (in_act applied THERE;
+                              in_act here is then ignored), [KBx][6][N+1][8] bf16; NULL = the library splits (into ws when
+                              as_conv_gemm_workspace_bytes asked for the room, else inside the GEMM's k loop) */
     float* Y;              /* [M][ldy] */
     const float* bias;     /* [M] or NULL */
     const float* res;      /* [M][ldr] or NULL (may alias Y) */
     const uint64_t* meta;  /* [N] column descriptors, or NULL = every tap valid */
-    float* ws;             /* split-K partial slabs (as_conv_gemm_workspace_bytes), or NULL = never split */
+    float* ws;             /* scratch: split-K partial slabs, then the split activations (as_conv_gemm_workspace_bytes);
+                              NULL = never split K, activations split inside the GEMM */
     size_t ws_bytes;
     int32_t M, N, K, T;
     int32_t Kp;            /* rows per tap in W: K rounded up to a multiple of 16, the extra rows zero */
@@ -102,9 +106,16 @@ typedef struct ConvGemmArgs {
     float in_slope, act_slope; /* LeakyReLU slopes of in_act / act; 0 = the path's 0.2 */
 } ConvGemmArgs;
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
-/* Bytes of split-K workspace this shape wants (0 = none).  Shapes whose tile grid cannot fill the 256 CUs
- * are split along (tap, Cin) into slices; a second kernel sums the slabs in a fixed order (deterministic). */
+/* Bytes of workspace this shape wants (0 = none).  Shapes whose tile grid cannot fill the 256 CUs are split along
+ * (tap, Cin) into slices; a second kernel sums the slabs in a fixed order (deterministic).  Shapes with many output
+ * channels x taps per input element get their activations split into bf16 parts once, ahead of the GEMM. */
 size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host);
+/* X fp32 [K][ldx] (N columns) -> Xs [KBx][6][N+1][8] bf16 (column N is zero: where taps outside an utterance read), x = h + m + l exactly (three bf16, round-to-nearest-even at each
+ * step), slot p*2 + kh of k-block kb holds part p of k = 16*kb + 8*kh + 0..7, KBx = ceil(K/16) rounded up to a multiple
+ * of 4, rows >= K zero.  in_act 2 applies LeakyReLU(in_slope; 0 = 0.2) first.  One image can feed every conv reading
+ * the same activations (ConvGemmArgs.Xs).  xs must be 16-byte aligned and hold as_split_bf16x3_bytes(K, N). */
+size_t as_split_bf16x3_bytes(int K, int N);
+int as_split_bf16x3_f32(const float* x, int ldx, int K, int N, int in_act, float in_slope, uint16_t* xs, as_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Bandwidth-bound kernels on packed frames.  col_off int32 [B+1] = first column of each utterance.

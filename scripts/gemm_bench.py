@@ -1,5 +1,6 @@
 """Micro-benchmark of the conv GEMM on the path's shapes (tuning aid).  AS_LIB_PATH selects an experiment build.
-usage: gemm_bench.py [M,N,K,T,L ...]   env: IMPLS=x6,f32  TILES=,22,21,12,11  KSPLITS=,1,2,4"""
+usage: gemm_bench.py [M,N,K,T,L ...]   env: IMPLS=x6,x6d,x6ds,f32  TILES=,22,21,12,11  KSPLITS=,1,2,4
+x6 = activations split in the k loop; x6d = split kernel + pre-split GEMM (what a call costs); x6ds = pre-split GEMM alone"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +14,7 @@ SHAPES = [  # M, N(total cols), K, taps, per-utt length (1-D)
 args = [a for a in sys.argv[1:]]
 if args:
     SHAPES = [tuple(int(v) for v in s.split(",")) for s in args]
-IMPLS = os.environ.get("IMPLS", "x6,f32").split(",")
+IMPLS = os.environ.get("IMPLS", "x6,x6d,x6ds,f32").split(",")
 TILES = os.environ.get("TILES", "").split(",")
 KSPLITS = os.environ.get("KSPLITS", "").split(",")
 print("lib:", _lib.LIB_PATH)
@@ -26,7 +27,9 @@ for (M, N, K, T, L) in SHAPES:
     taps = ops.taps_1d(T)
     ref = None
     for impl in IMPLS:
-        ops.GEMM_IMPL = impl
+        ops.GEMM_IMPL = "f32" if impl == "f32" else "x6"
+        os.environ["AS_GEMM_X6D"] = "1" if impl == "x6d" else "0"
+        xs = ops.split_act(X, lay) if impl == "x6ds" else None
         for tile in TILES:
             for ks in KSPLITS:
                 os.environ.pop("AS_GEMM_TILE", None); os.environ.pop("AS_GEMM_KSPLIT", None)
@@ -34,17 +37,17 @@ for (M, N, K, T, L) in SHAPES:
                 if ks: os.environ["AS_GEMM_KSPLIT"] = ks
                 Y = lay.new(M)
                 for _ in range(3):
-                    ops.conv_gemm(wt, X, lay, Y, taps, bias=b)
+                    ops.conv_gemm(wt, X, lay, Y, taps, bias=b, xs=xs)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 n = 20
                 e0.record()
                 for _ in range(n):
-                    ops.conv_gemm(wt, X, lay, Y, taps, bias=b)
+                    ops.conv_gemm(wt, X, lay, Y, taps, bias=b, xs=xs)
                 e1.record(); torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / n
                 if ref is None:
                     ref = Y.clone()
                 d = float((Y - ref).abs().max())
-                print(f"M{M} N{lay.N} K{K} T{T} {impl:3s} tile={tile or 'auto':4s} S={ks or 'auto':4s}: {ms*1e3:8.1f} us  "
+                print(f"M{M} N{lay.N} K{K} T{T} {impl:4s} tile={tile or 'auto':4s} S={ks or 'auto':4s}: {ms*1e3:8.1f} us  "
                       f"{2.0*M*lay.N*K*T/ms/1e9:6.1f} TF/s  maxdiff vs first {d:.2e}", flush=True)

@@ -14,10 +14,12 @@ def packed(x_list):
     return torch.cat(x_list, dim=1).contiguous()
 
 
-@pytest.fixture(params=["x6", "f32"])
+@pytest.fixture(params=["x6", "x6d", "f32"])
 def impl(request, monkeypatch):
-    """both arithmetic paths of the conv GEMM: bf16x6 (default) and fp32 MFMA"""
-    monkeypatch.setattr(ops, "GEMM_IMPL", request.param)
+    """the arithmetic paths of the conv GEMM: bf16x6 with the activations split inside the k loop (x6) or ahead of the
+    GEMM (x6d: both operands by LDS-DMA), and fp32 MFMA"""
+    monkeypatch.setattr(ops, "GEMM_IMPL", "f32" if request.param == "f32" else "x6")
+    monkeypatch.setenv("AS_GEMM_X6D", "1" if request.param == "x6d" else "0")
     return request.param
 
 
@@ -26,10 +28,12 @@ def impl(request, monkeypatch):
 @pytest.mark.parametrize("tile", ["", "11", "21", "22", "12", "228", "218", "128", "223"])
 @pytest.mark.parametrize("quad", ["", "0"])
 def test_conv1d_gemm(cuda, monkeypatch, impl, cin, cout, k, lens, tile, quad):
-    if impl == "x6" and quad:
-        pytest.skip("one staging in the bf16x6 kernel")
+    if impl != "f32" and quad:
+        pytest.skip("one staging in the bf16x6 kernels")
     if impl == "f32" and len(tile) == 3:
         pytest.skip("8-wave tiles exist in the bf16x6 kernel only")
+    if impl == "x6d" and tile not in ("", "21", "22", "12"):
+        pytest.skip("the pre-split kernel has the 128x128, 128x64 and 64x128 tiles")
     if quad:
         monkeypatch.setenv("AS_GEMM_QUAD", quad)          # force the scalar staging
     if tile:
@@ -76,6 +80,46 @@ def test_conv2d_gemm_and_transpose_out(cuda, monkeypatch, impl, widths, tile):
     yt = torch.empty(lay.N, cout, device=cuda)
     ops.conv_gemm(wt, X, lay, yt, taps_2d(3, 3), bias=b.to(cuda), in_act=ops.ACT_LRELU, transpose_out=True)
     assert torch.equal(yt.t().contiguous(), y)
+
+
+@pytest.mark.parametrize("K,lens,lrelu", [(80, [50, 13, 1, 200], False), (512, [1000, 24], True), (7, [5], True), (33, [300], False)])
+def test_split_activations(cuda, K, lens, lrelu):
+    """as_split_bf16x3_f32: x = h + m + l exactly, parts laid out [kb][p*2+kh][column][8], zero rows past K and a zero column N; and a conv
+    fed with the image (xs=) equals the conv that splits inside its k loop, bit for bit."""
+    g = torch.Generator().manual_seed(K)
+    lay = Layout(lens, cuda)
+    X = lay.new(K)
+    X.copy_(torch.randn(K, lay.N, generator=g) * torch.logspace(-3, 3, K)[:, None])
+    xs = ops.split_act(X, lay, ops.ACT_LRELU if lrelu else 0, 0.1)
+    x = F.leaky_relu(X, 0.1) if lrelu else X
+    kbx = (K + 63) // 64 * 4
+    nx = lay.N + 1                                                                                 # the image's last column is zero
+    img = xs[: kbx * 6 * nx * 8].view(torch.bfloat16).reshape(kbx, 3, 2, nx, 8).float()            # [kb][p][kh][n][8]
+    parts = img.permute(1, 0, 2, 4, 3).reshape(3, kbx * 16, nx)                                    # [p][k][n]
+    assert torch.equal(parts[:, K:], torch.zeros_like(parts[:, K:])) and not parts[:, :, lay.N].any()
+    parts = parts[:, :, : lay.N]
+    h = x.to(torch.bfloat16).float()
+    m = (x - h).to(torch.bfloat16).float()
+    l = (x - h - m).to(torch.bfloat16).float()
+    assert torch.equal(parts[0, :K], h) and torch.equal(parts[1, :K], m) and torch.equal(parts[2, :K], l)
+    assert torch.equal(parts[0, :K] + parts[1, :K] + parts[2, :K], x)
+    w = ops.prep_weight(torch.randn(128, K, 3, generator=g) / np.sqrt(3 * K), cuda)
+    import os
+    old = os.environ.get("AS_GEMM_X6D")
+    try:
+        os.environ["AS_GEMM_X6D"] = "0"
+        y0 = ops.conv_gemm(w, X, lay, lay.new(128), taps_1d(3), in_act=ops.ACT_LRELU if lrelu else 0, in_slope=0.1)
+        y1 = ops.conv_gemm(w, X, lay, lay.new(128), taps_1d(3), xs=xs)
+        os.environ["AS_GEMM_X6D"] = "1"
+        y2 = ops.conv_gemm(w, X, lay, lay.new(128), taps_1d(3), in_act=ops.ACT_LRELU if lrelu else 0, in_slope=0.1)
+    finally:
+        if old is None:
+            os.environ.pop("AS_GEMM_X6D", None)
+        else:
+            os.environ["AS_GEMM_X6D"] = old
+    assert torch.equal(y1, y2)
+    # same six products per k-block, but the k loop visits them per (tap, k-block) in the same order: bit-identical
+    assert float((y1 - y0).abs().max()) <= 1e-6 * float(y0.abs().max())
 
 
 def test_mfma_layout_asymmetric(cuda, impl):
