@@ -122,26 +122,6 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
         const int c = tid + NT * i, kblk = c / (6 * BM), rem = c % (6 * BM), pk = rem / BM, row = rem % BM;
         a_voff[i] = (m0 + row) < a.M ? (unsigned)(((kblk * 6 + pk) * a.M + m0 + row) * 16) : OOB;
     }
-    // activations: unit u = tid + NT i -> column u % BN (the same for every i), k rows 8 g .. 8 g + 7, g = u / BN
-    const int j = n0 + tid % BN;
-    const int g0 = __builtin_amdgcn_readfirstlane(tid / BN);             // wave-uniform (BN >= 64)
-    unsigned tapmask = 0;
-    int Wj = 0;
-    if (j < a.N) {
-        if (a.meta) {
-            const unsigned long long md = a.meta[j];
-            const int h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff);
-            const int H = (int)((md >> 32) & 0xffff);
-            Wj = (int)(md >> 48);
-            for (int t = 0; t < a.T; ++t)
-                if ((unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)Wj) tapmask |= 1u << t;
-        } else {
-            tapmask = 0xffffffffu;
-        }
-    }
-
-    const X6TapCol tcol(tp, j, Wj);
-
     const int kt_per_tap = (KB + WK - 1) / WK;
     const int nkt_all = a.T * kt_per_tap;
     const int S = gridDim.y;                                             // split-K over (tap, k-tile)
@@ -176,6 +156,34 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
 #endif
         advance(wa_t, wa_kb);
     };
+    // activations: unit u = tid + NT i -> column u % BN (the same for every i), k rows 8 g .. 8 g + 7, g = u / BN
+    const int j = n0 + tid % BN;
+    const int g0 = __builtin_amdgcn_readfirstlane(tid / BN);             // wave-uniform (BN >= 64)
+    unsigned long long md = 0;
+    if (a.meta && j < a.N) md = a.meta[j];
+    // the weights of tiles 0 and 1 start moving now, behind the descriptor load (loads return in order: waiting for the
+    // descriptor must not mean waiting for them): their latency overlaps the tap masks below
+    dma_a(0);
+    dma_a(1);
+    unsigned tapmask = 0;
+    int Wj = 0;
+    if (j < a.N) {
+        if (a.meta) {
+            const int h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff);
+            const int H = (int)((md >> 32) & 0xffff);
+            Wj = (int)(md >> 48);
+            for (int t = 0; t < a.T; ++t) {                               // offsets from the packed bytes: no loads in this loop
+                const int byte = x6_tap_byte(tp, t);
+                const int dh = tp.wide ? 0 : (byte >> 4) - 8, dw = tp.wide ? byte - 128 : (byte & 15) - 8;
+                if ((unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)Wj) tapmask |= 1u << t;
+            }
+        } else {
+            tapmask = 0xffffffffu;
+        }
+    }
+
+    const X6TapCol tcol(tp, j, Wj);
+
     float rb[2][UB][8];
     const int ldx4 = a.ldx * 4, last_row = (a.K - 1) * ldx4;
     auto gload_b = [&](float (&r8)[UB][8]) {
@@ -260,9 +268,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
 
     X6Frags fr[2];
     // prologue: tiles 0 and 1 staged, activations of tile 2 in flight, fragments of tile 0 requested
-    dma_a(0);
     gload_b(rb[0]);
-    dma_a(1);
     gload_b(rb[1]);
     lstore_b(rb[0], 0, 0);
     lstore_b(rb[0], 0, 1);
