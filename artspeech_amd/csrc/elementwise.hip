@@ -436,6 +436,47 @@ extern "C" int as_rows_to_images_f32(const float* src, int lds, const int32_t* s
 }
 
 // ---------------------------------------------------------------------------------------------------
+// JDCNet: BatchNorm2d(eval) -> LeakyReLU -> MaxPool2d((1, k)) over the mel axis
+// (Utils/JDC/model.py:29-34 pool_block, :166-170 ResBlock.pre_conv).  Images [H = mel bins][W_b = frames].
+// ---------------------------------------------------------------------------------------------------
+__global__ void bn_lrelu_maxpool_rows_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ tok_off, int H, int k,
+                                             const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+                                             float* __restrict__ y, int ldy, int to_channels)
+{
+    const int b = blockIdx.y, c = blockIdx.z;
+    const int t0 = tok_off[b], Wb = tok_off[b + 1] - t0, Hout = H / k;
+    const float* xr = x + (size_t)c * ldx + (size_t)H * t0;
+    const float sc = scale[c], sh = shift[c];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wb; i += gridDim.x * blockDim.x) {
+        const int ho = i / Wb, w = i - ho * Wb;
+        float m = -INFINITY;
+        for (int r = 0; r < k; ++r) {
+            float v = xr[(size_t)(ho * k + r) * Wb + w] * sc + sh;
+            v = v > 0.f ? v : slope * v;
+            m = fmaxf(m, v);
+        }
+        if (to_channels) y[(size_t)(c * Hout + ho) * ldy + t0 + w] = m;
+        else y[(size_t)c * ldy + (size_t)Hout * t0 + i] = m;
+    }
+}
+
+extern "C" int as_bn_lrelu_maxpool_rows_f32(const float* x, int ldx, const int32_t* tok_off, int B, int C, int H, int k,
+                                            const float* scale, const float* shift, float slope, float* y, int ldy,
+                                            int to_channels, int total_frames, as_stream_t stream)
+{
+    if (!x || !y || !tok_off || !scale || !shift || B < 0 || C <= 0 || H <= 0 || k <= 0 || k > H) return AS_EINVAL;
+    if (B == 0 || total_frames <= 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 4.0 * C * (double)total_frames * (H + H / k), (hipStream_t)stream);
+    const int per_utt = as_cdiv((long)(H / k) * total_frames, B);          // average output pixels of an utterance
+    int gx = as_cdiv(per_utt, 256);
+    gx = gx < 1 ? 1 : gx > 64 ? 64 : gx;
+    hipLaunchKernelGGL(bn_lrelu_maxpool_rows_kernel, dim3(gx, B, C), dim3(256), 0, (hipStream_t)stream, x, ldx, tok_off, H, k, scale,
+                       shift, slope, y, ldy, to_channels);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Style-tower helpers (K10): learned / average 2x down-sampling, im2col for the valid 5x5 convs,
 // LeakyReLU + global average pool.  Images are [C][sum_b H*W_b] with per-utterance widths.
 // ---------------------------------------------------------------------------------------------------

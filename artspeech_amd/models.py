@@ -8,9 +8,9 @@ utterance, exactly what the reference computes one utterance at a time (the refe
 step="test" is batch-1 only, models.py:361-362) -- instance-norm statistics, conv zero padding and
 the reverse LSTM pass all see the utterance's own frames only.
 
-Out of scope here: the two frozen feature extractors (JDCNet, EMA_Predictor).
-Their OUTPUTS are inputs of this path: pass ``features=(f0_raw, ema_raw)`` or attach torch modules as
-``style_encoder.pitch_extractor`` / ``style_encoder.ema_extractor``.
+The two frozen feature extractors are pluggable: their OUTPUTS are inputs of this path.
+Pass ``features=(f0_raw, ema_raw)`` or attach modules as ``style_encoder.pitch_extractor`` (artspeech_amd.jdc.JDCNet is
+the HIP one) / ``style_encoder.ema_extractor``.
 """
 import math
 
@@ -369,15 +369,19 @@ class StyleEncoder(_Module):
         return feat12, style
 
     def _extract(self, mel, features):
-        if features is not None:
-            return features
-        if self.pitch_extractor is None or self.ema_extractor is None:
-            raise RuntimeError("StyleEncoder: attach pitch_extractor / ema_extractor torch modules (the reference's "
-                               "JDCNet / EMA_Predictor) or pass features=(f0_raw, ema_raw); they are outside this path")
+        """(f0_raw, ema_raw) as models.py:431-433 computes them; an entry of `features` that is given is used as is."""
+        f0, ema = features if features is not None else (None, None)
+        if f0 is not None and ema is not None:
+            return f0, ema
+        if (f0 is None and self.pitch_extractor is None) or self.ema_extractor is None and ema is None:
+            raise RuntimeError("StyleEncoder: attach pitch_extractor (artspeech_amd.jdc.JDCNet, or the reference's torch "
+                               "module) / ema_extractor (the reference's EMA_Predictor) or pass features=(f0_raw, ema_raw)")
         with torch.no_grad():
-            n_raw = torch.log(torch.exp(mel.unsqueeze(1) * 4 - 4).norm(dim=2))
-            f0 = self.pitch_extractor(mel.unsqueeze(1))
-            ema = self.ema_extractor(f0, n_raw, mel)
+            if f0 is None:
+                f0 = self.pitch_extractor(mel.unsqueeze(1))                                # models.py:432
+            if ema is None:
+                n_raw = torch.log(torch.exp(mel.unsqueeze(1) * 4 - 4).norm(dim=2))         # models.py:431, :655-660
+                ema = self.ema_extractor(f0.to(mel.device), n_raw, mel)                    # models.py:433
         return f0, ema
 
     def forward(self, mel, mel_input_length, step="second", distribution=None, epoch=20, features=None):

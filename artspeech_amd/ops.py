@@ -11,7 +11,7 @@ from ._lib import check, ptr, stream
 
 AS_MAX_TAPS = _lib.AS_MAX_TAPS
 KTILE = 16                      # the GEMM k-tile (BK in csrc/conv_gemm.hip): weights are zero-padded to it
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_ABS = 0, 1, 2, 3, 4
 
 
 ConvGemmArgs = _lib.ConvGemmArgs
@@ -259,6 +259,14 @@ def crop(src, src_lay, start, dst, dst_lay):
     check(_lib.lib().as_crop_f32(_p(src), _ld(src), _p(src_lay.col_off), start, _p(dst), _ld(dst), _p(dst_lay.col_off),
                                  dst_lay.B, src.shape[0], dst_lay.max_cols, stream()), "as_crop_f32")
     return dst
+
+
+def bn_lrelu_maxpool_rows(X, tok_lay, H, k, scale, shift, slope, Y, to_channels=False):
+    """BatchNorm(eval) -> LeakyReLU -> max over k consecutive image rows; X [C][H * frames] images of tok_lay's utterances."""
+    check(_lib.lib().as_bn_lrelu_maxpool_rows_f32(_p(X), _ld(X), _p(tok_lay.col_off), tok_lay.B, X.shape[0], H, k, _p(scale), _p(shift),
+                                                  slope, _p(Y), _ld(Y), int(to_channels), tok_lay.N, stream()),
+          "as_bn_lrelu_maxpool_rows_f32")
+    return Y
 
 
 def rows_to_images(src, src_lay, start, H, img_lay):

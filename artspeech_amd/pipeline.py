@@ -42,6 +42,16 @@ class ArtSpeech:
         self.device = dev
         self.generator = None                       # test.py:119-125: the HiFi-GAN generator (attach_vocoder)
 
+    def attach_pitch_extractor(self, checkpoint=None):
+        """models.py:377-379: ``JDCNet(num_class=1, seq_len=192)`` + ``torch.load("Utils/JDC/bst.t7")['net']``, on the HIP
+        path (artspeech_amd/jdc.py).  With it attached, ``features=(None, ema_raw)`` lets the model extract F0 itself."""
+        from .jdc import JDCNet
+        net = JDCNet(num_class=1, seq_len=192, device=self.device)
+        if checkpoint is not None:
+            net.load_state_dict(checkpoint if isinstance(checkpoint, dict) else torch.load(checkpoint, map_location="cpu"))
+        self.model.ArtsSpeech.style_encoder.pitch_extractor = net
+        return net
+
     def attach_vocoder(self, h=None, checkpoint=None):
         """test.py:119-125: build the generator from Vocoder/config.json-style `h` and load checkpoint['generator']."""
         from .vocoder import Generator
@@ -68,7 +78,7 @@ class ArtSpeech:
     def synthesis_mel(self, phonemes, ref_mel, features=None, forced_durations=None):
         """phonemes: the string the phonemizer returns (test.py:94-96) or a list of such strings; ref_mel: normalised
         log-mel [80,T] (test.py:43-47) or a list; features: (f0_raw, ema_raw) per utterance when no extractor modules
-        are attached.  Returns mel [B,80,2*max M] (what test.py:115 hands to the vocoder)."""
+        are attached; (None, ema_raw) with a pitch extractor attached (attach_pitch_extractor).  Returns mel [B,80,2*max M] (what test.py:115 hands to the vocoder)."""
         if isinstance(phonemes, str):
             phonemes, ref_mel = [phonemes], [ref_mel]
             if features is not None:
@@ -85,10 +95,11 @@ class ArtSpeech:
         mel_input_length = torch.LongTensor([m.shape[-1] for m in ref_mel])           # test.py:111
         feats = None
         if features is not None:
-            f0 = torch.zeros(B, 1, tmax)
+            f0 = None if any(f is None for f, _ in features) else torch.zeros(B, 1, tmax)     # None: the attached JDCNet
             ema = torch.zeros(B, 10, tmax)
             for b, (f, e) in enumerate(features):
-                f0[b, :, : f.shape[-1]] = torch.as_tensor(f).reshape(1, -1)
+                if f0 is not None:
+                    f0[b, :, : f.shape[-1]] = torch.as_tensor(f).reshape(1, -1)
                 ema[b, :, : e.shape[-1]] = torch.as_tensor(e)
             feats = (f0, ema)
         mel, aux = self.model.ArtsSpeech([text, input_lengths, mels, mel_input_length, None, None, None], None, None,

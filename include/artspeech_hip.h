@@ -93,7 +93,7 @@ typedef struct ConvGemmArgs {
     int32_t M, N, K, T;
     int32_t Kp;            /* rows per tap in W: K rounded up to a multiple of 16, the extra rows zero */
     int32_t ldx, ldy, ldr;
-    int32_t act;           /* epilogue activation: 0 none, 1 ReLU, 2 LeakyReLU(act_slope), 3 tanh */
+    int32_t act;           /* epilogue activation: 0 none, 1 ReLU, 2 LeakyReLU(act_slope), 3 tanh, 4 |x| (Utils/JDC/model.py:137) */
     int32_t div_sqrt2;     /* epilogue: divide by sqrt(2) after bias and residual */
     int32_t in_act;        /* 2 = LeakyReLU(in_slope) applied to X while staging (models.py:89,142; Vocoder/vocoder.py:38,102) */
     int32_t transpose_out; /* 1 = write Y[j][m] (time-major, row stride ldy >= M) */
@@ -158,6 +158,14 @@ int as_rows_to_images_f32(const float* src, int lds, const int32_t* src_off, int
 int as_dwconv_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy,
                        const int32_t* out_off, const int32_t* out_w, int Hout, const float* w, const float* bias,
                        int kh, int B, int C, int max_out, int lrelu, as_stream_t stream);
+/* JDCNet's BatchNorm2d (eval: y = x*scale[c] + shift[c]) -> LeakyReLU(slope) -> MaxPool2d over the mel axis by k, floor
+ * mode (Utils/JDC/model.py:29-34,166-170).  Images are [H rows = mel bins][W = frames of the utterance]; tok_off int32
+ * [B+1] = first frame of each utterance in a 1-D layout, image b starts at column H*tok_off[b].  Output: images of
+ * Hout = H / k rows (to_channels = 0), or the 1-D layout with C*Hout rows, row c*Hout + h (to_channels = 1: the
+ * permute(0,2,1,3).view(.., 512) of model.py:126). */
+int as_bn_lrelu_maxpool_rows_f32(const float* x, int ldx, const int32_t* tok_off, int B, int C, int H, int k, const float* scale,
+                                 const float* shift, float slope, float* y, int ldy, int to_channels, int total_frames,
+                                 as_stream_t stream);
 int as_avgpool_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy,
                         const int32_t* out_off, const int32_t* out_w, int Hout, int pool_h, const float* res, int ldr,
                         int B, int C, int max_out, as_stream_t stream);

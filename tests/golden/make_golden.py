@@ -258,9 +258,32 @@ def make_vocoder():
     json.dump(inv, open(os.path.join(HERE, "vocoder_inventory.json"), "w"), indent=0, sort_keys=True)
 
 
+def make_jdc():
+    """JDCNet of the reference (Utils/JDC/model.py, built as models.py:377 does) on seeded synthetic weights
+    (artspeech_amd.jdc.synth_jdc_state_dict): one utterance per fixture, eval mode."""
+    from Utils.JDC.model import JDCNet as RefJDC                               # the reference
+    from artspeech_amd import jdc as J
+    ref = RefJDC(num_class=1, seq_len=192).eval()
+    inv = {k: list(v.shape) for k, v in ref.state_dict().items()}
+    assert inv == {k: list(v) for k, v in J.jdc_spec(1).items()}, "jdc_spec differs from the reference"
+    sd = J.synth_jdc_state_dict(1, seed=3407)
+    ref.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    for t in (7, 66, 150):
+        mel = synth.hash_tensor(f"jdc/mel/{t}", (1, 80, t), 1234, 1.0)
+        with torch.no_grad():
+            f0 = ref(torch.from_numpy(mel).unsqueeze(1))                       # models.py:432
+        assert f0.shape == (1, 1, t) and torch.isfinite(f0).all()
+        print("jdc golden T", t, "f0 max %.4f mean %.4f" % (float(f0.max()), float(f0.mean())))
+        np.savez_compressed(os.path.join(HERE, f"jdc_T{t}.npz"), t=t, seed=3407, mel=mel[0], f0=f0[0].numpy())
+    json.dump(inv, open(os.path.join(HERE, "jdc_inventory.json"), "w"), indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["vocoder"]:
         make_vocoder()
+        sys.exit(0)
+    if sys.argv[1:] == ["jdc"]:
+        make_jdc()
         sys.exit(0)
     what = sys.argv[1:] or ["params", "mas", "net", "text"]
     if "text" in what:
