@@ -101,6 +101,7 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
                 if (ACT == 2) x = x > 0.f ? x : a.act_slope * x;
                 if (ACT == 3) x = tanhf(x);
                 if (ACT == 4) x = fabsf(x);
+                if (ACT == 5) x = x / (1.0f + expf(-x));
                 v[e] = x;
             }
             if (TR) {                                        // time-major output for the LSTM: Y[col][row], 4 rows = 16 bytes
@@ -166,6 +167,7 @@ static __device__ __forceinline__ void epilogue_dispatch(const ConvGemmArgs& a, 
     else if (a.act == 1) epilogue_tiles<TM, TN, false, 1, false>(a, acc, rbase, cbase, l31);
     else if (a.act == 3) epilogue_tiles<TM, TN, false, 3, false>(a, acc, rbase, cbase, l31);
     else if (a.act == 4) epilogue_tiles<TM, TN, false, 4, false>(a, acc, rbase, cbase, l31);
+    else if (a.act == 5) epilogue_tiles<TM, TN, false, 5, false>(a, acc, rbase, cbase, l31);
     else epilogue_tiles<TM, TN, false, 2, false>(a, acc, rbase, cbase, l31);
 }
 

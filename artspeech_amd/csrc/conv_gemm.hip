@@ -390,6 +390,7 @@ conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
             else if (a.act == 2) sum = sum > 0.f ? sum : a.act_slope * sum;
             else if (a.act == 3) sum = tanhf(sum);
             else if (a.act == 4) sum = fabsf(sum);
+            else if (a.act == 5) sum = sum / (1.0f + expf(-sum));
             y[c] = sum;
         }
         float* yr = a.Y + (size_t)m * a.ldy + j0;
@@ -441,6 +442,7 @@ conv_direct_cin1_kernel(const ConvGemmArgs a)
         else if (a.act == 2) s = s > 0.f ? s : a.act_slope * s;
         else if (a.act == 3) s = tanhf(s);
         else if (a.act == 4) s = fabsf(s);
+        else if (a.act == 5) s = s / (1.0f + expf(-s));
         a.Y[(size_t)m * a.ldy + j] = s;
     }
 }
@@ -460,6 +462,7 @@ __global__ void splitk_reduce_kernel(const ConvGemmArgs a, int S)
         else if (a.act == 2) v = v > 0.f ? v : a.act_slope * v;
         else if (a.act == 3) v = tanhf(v);
         else if (a.act == 4) v = fabsf(v);
+        else if (a.act == 5) v = v / (1.0f + expf(-v));
         if (a.transpose_out) a.Y[(size_t)col * a.ldy + row] = v;
         else a.Y[(size_t)row * a.ldy + col] = v;
     }
@@ -617,7 +620,7 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     ConvGemmArgs norm = *args_host;
     if (norm.in_slope == 0.f) norm.in_slope = 0.2f;
     if (norm.act_slope == 0.f) norm.act_slope = 0.2f;
-    if (norm.act < 0 || norm.act > 4 || (norm.in_act != 0 && norm.in_act != 2)) return AS_EINVAL;
+    if (norm.act < 0 || norm.act > 5 || (norm.in_act != 0 && norm.in_act != 2)) return AS_EINVAL;
     const ConvGemmArgs& a = norm;
     if ((!a.W && !a.Wx) || !a.X || !a.Y || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS) return AS_EINVAL;
     if (a.Kp < a.K || a.Kp % BK) return AS_EINVAL;

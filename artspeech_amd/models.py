@@ -368,27 +368,31 @@ class StyleEncoder(_Module):
         style = self.style_extractor_packed(feat, lay)
         return feat12, style
 
-    def _extract(self, mel, features):
-        """(f0_raw, ema_raw) as models.py:431-433 computes them; an entry of `features` that is given is used as is."""
+    def _extract(self, mel, features, lengths=None):
+        """(f0_raw, ema_raw) as models.py:431-433 computes them; an entry of `features` that is given is used as is.  The
+        HIP extractors (artspeech_amd.jdc / .ema) get the utterance lengths, so every item equals its B = 1 result; a
+        torch module in the slot is called exactly as the reference calls it."""
         f0, ema = features if features is not None else (None, None)
         if f0 is not None and ema is not None:
             return f0, ema
-        if (f0 is None and self.pitch_extractor is None) or self.ema_extractor is None and ema is None:
-            raise RuntimeError("StyleEncoder: attach pitch_extractor (artspeech_amd.jdc.JDCNet, or the reference's torch "
-                               "module) / ema_extractor (the reference's EMA_Predictor) or pass features=(f0_raw, ema_raw)")
+        if (f0 is None and self.pitch_extractor is None) or (ema is None and self.ema_extractor is None):
+            raise RuntimeError("StyleEncoder: attach pitch_extractor / ema_extractor (artspeech_amd.jdc.JDCNet and "
+                               "artspeech_amd.ema.EMA_Predictor, or the reference's torch modules) or pass features=(f0_raw, ema_raw)")
+        kw = lambda ext: {"lengths": lengths} if (lengths is not None and hasattr(ext, "forward_packed")) else {}
         with torch.no_grad():
             if f0 is None:
-                f0 = self.pitch_extractor(mel.unsqueeze(1))                                # models.py:432
+                f0 = self.pitch_extractor(mel.unsqueeze(1), **kw(self.pitch_extractor))    # models.py:432
             if ema is None:
-                n_raw = torch.log(torch.exp(mel.unsqueeze(1) * 4 - 4).norm(dim=2))         # models.py:431, :655-660
-                ema = self.ema_extractor(f0.to(mel.device), n_raw, mel)                    # models.py:433
+                m = mel.to(f0.device)
+                n_raw = torch.log(torch.exp(m.unsqueeze(1) * 4 - 4).norm(dim=2))           # models.py:431, :655-660
+                ema = self.ema_extractor(f0, n_raw, m, **kw(self.ema_extractor))           # models.py:433
         return f0, ema
 
     def forward(self, mel, mel_input_length, step="second", distribution=None, epoch=20, features=None):
         dev = self.W.device
         lens = [int(v) for v in mel_input_length]
         lay = layout(lens, dev)
-        f0_raw, ema_raw = self._extract(mel, features)
+        f0_raw, ema_raw = self._extract(mel, features, lens)
         stats24 = stats_vector(distribution, dev)
         feat12, style = self.forward_packed(pack(mel.to(dev), lens), pack(f0_raw.to(dev), lens),
                                             pack(ema_raw.to(dev), lens), lay, stats24)
@@ -606,7 +610,7 @@ class ArtsSpeech(_Module):
         B = len(tl)
         tok_lay, ref_lay = layout(tl, dev), layout(ml, dev)
         tok = torch.cat([texts[b, :l] for b, l in enumerate(tl)]).to(device=dev, dtype=torch.int32)
-        f0_raw, ema_raw = self.style_encoder._extract(mels, features)
+        f0_raw, ema_raw = self.style_encoder._extract(mels, features, ml)
         mel_p, f0_p, ema_p = pack(mels.to(dev), ml), pack(f0_raw.to(dev), ml), pack(ema_raw.to(dev), ml)
         forced = None
         if forced_durations is not None:

@@ -11,7 +11,7 @@ from ._lib import check, ptr, stream
 
 AS_MAX_TAPS = _lib.AS_MAX_TAPS
 KTILE = 16                      # the GEMM k-tile (BK in csrc/conv_gemm.hip): weights are zero-padded to it
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_ABS = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_ABS, ACT_SWISH = 0, 1, 2, 3, 4, 5
 
 
 ConvGemmArgs = _lib.ConvGemmArgs
@@ -322,6 +322,23 @@ def mean_pool(X, lay, lrelu, y=None):
 def relpos_attention(qkv, C, heads, window, ek, ev, lay, out):
     check(_lib.lib().as_relpos_attention_f32(_p(qkv), _ld(qkv), C, heads, window, _p(ek), _p(ev), _p(lay.col_off), lay.B,
                                              lay.max_w, _p(out), _ld(out), stream()), "as_relpos_attention_f32")
+    return out
+
+
+def xl_attention(qkv, C, heads, pos, u_bias, v_bias, inv_scale, lay, out):
+    check(_lib.lib().as_xl_attention_f32(_p(qkv), _ld(qkv), C, heads, _p(pos), _ld(pos), _p(u_bias), _p(v_bias), inv_scale,
+                                         _p(lay.col_off), lay.B, lay.max_w, _p(out), _ld(out), stream()), "as_xl_attention_f32")
+    return out
+
+
+def glu_dwconv_bn_swish(A, C, w, scale, shift, lay, Y):
+    check(_lib.lib().as_glu_dwconv_bn_swish_f32(_p(A), _ld(A), C, _p(w), w.shape[1], _p(scale), _p(shift), _p(lay.col_off), lay.B,
+                                                _p(Y), _ld(Y), stream()), "as_glu_dwconv_bn_swish_f32")
+    return Y
+
+
+def lstm_step0(gx, H, N, out):
+    check(_lib.lib().as_lstm_step0_f32(_p(gx), _ld(gx), H, N, _p(out), _ld(out), stream()), "as_lstm_step0_f32")
     return out
 
 

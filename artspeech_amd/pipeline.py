@@ -52,6 +52,16 @@ class ArtSpeech:
         self.model.ArtsSpeech.style_encoder.pitch_extractor = net
         return net
 
+    def attach_ema_extractor(self, checkpoint=None):
+        """models.py:381-383: ``EMA_Predictor()`` + ``torch.load("Utils/EMA/200000.pth.tar")['model']``, on the HIP path
+        (artspeech_amd/ema.py).  With both extractors attached ``synthesis_mel(phonemes, ref_mel)`` needs no ``features``."""
+        from .ema import EMA_Predictor
+        net = EMA_Predictor(device=self.device)
+        if checkpoint is not None:
+            net.load_state_dict(checkpoint if isinstance(checkpoint, dict) else torch.load(checkpoint, map_location="cpu"))
+        self.model.ArtsSpeech.style_encoder.ema_extractor = net
+        return net
+
     def attach_vocoder(self, h=None, checkpoint=None):
         """test.py:119-125: build the generator from Vocoder/config.json-style `h` and load checkpoint['generator']."""
         from .vocoder import Generator

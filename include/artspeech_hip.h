@@ -93,7 +93,8 @@ typedef struct ConvGemmArgs {
     int32_t M, N, K, T;
     int32_t Kp;            /* rows per tap in W: K rounded up to a multiple of 16, the extra rows zero */
     int32_t ldx, ldy, ldr;
-    int32_t act;           /* epilogue activation: 0 none, 1 ReLU, 2 LeakyReLU(act_slope), 3 tanh, 4 |x| (Utils/JDC/model.py:137) */
+    int32_t act;           /* epilogue activation: 0 none, 1 ReLU, 2 LeakyReLU(act_slope), 3 tanh, 4 |x| (Utils/JDC/model.py:137),
+                              5 swish x*sigmoid(x) (Utils/EMA/conformer/conformer/activation.py:29) */
     int32_t div_sqrt2;     /* epilogue: divide by sqrt(2) after bias and residual */
     int32_t in_act;        /* 2 = LeakyReLU(in_slope) applied to X while staging (models.py:89,142; Vocoder/vocoder.py:38,102) */
     int32_t transpose_out; /* 1 = write Y[j][m] (time-major, row stride ldy >= M) */
@@ -174,6 +175,23 @@ int as_im2col_valid_f32(const float* x, int ldx, const int32_t* in_off, const in
                         int B, int C, int max_out, as_stream_t stream);
 int as_mean_pool_f32(const float* x, int ldx, const int32_t* col_off, int B, int C, int lrelu, float* y, int ldy,
                      as_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * EMA_Predictor: what is not a GEMM in Utils/EMA/EMA_Predictor.py and its conformer blocks.
+ * as_xl_attention_f32: RelativeMultiHeadAttention.forward (conformer/attention.py:77-109) on a fused [3C][N] q/k/v
+ *   projection and pos [C][N] = pos_proj(PE[frame index]) per utterance; u_bias, v_bias [heads][64]; the reference's
+ *   _relative_shift (:111-119) is reproduced entry for entry; inv_scale = 1/sqrt(d_model).  d_head must be 64.
+ * as_glu_dwconv_bn_swish_f32: GLU -> depthwise conv1d (k odd <= 63, zero 'same' padding inside the utterance) -> BatchNorm
+ *   (eval, scale/shift) -> Swish (conformer/convolution.py:140-144); a [2C][N] -> y [C][N]; w [C][k].
+ * as_lstm_step0_f32: one LSTM step from the zero state for every column, both directions (EMA_Predictor.py:43,79: an
+ *   nn.LSTM without batch_first fed [1, T, 256] treats the T frames as a batch of length-1 sequences); gx [8H][N] -> h [2H][N].
+ * ------------------------------------------------------------------------------------------- */
+int as_xl_attention_f32(const float* qkv, int ld, int C, int heads, const float* pos, int ldp, const float* u_bias,
+                        const float* v_bias, float inv_scale, const int32_t* col_off, int B, int max_len, float* out, int ldo,
+                        as_stream_t stream);
+int as_glu_dwconv_bn_swish_f32(const float* a, int lda, int C, const float* w, int k, const float* scale, const float* shift,
+                               const int32_t* col_off, int B, float* y, int ldy, as_stream_t stream);
+int as_lstm_step0_f32(const float* gx, int ldg, int H, int N, float* h, int ldh, as_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Windowed relative-position attention (K5) on a fused [3C][N] q/k/v projection.

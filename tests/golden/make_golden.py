@@ -278,7 +278,34 @@ def make_jdc():
     json.dump(inv, open(os.path.join(HERE, "jdc_inventory.json"), "w"), indent=0, sort_keys=True)
 
 
+def make_ema():
+    """EMA_Predictor of the reference (Utils/EMA/EMA_Predictor.py + its vendored conformer blocks) on seeded synthetic
+    weights (artspeech_amd.ema.synth_ema_state_dict): one utterance per fixture (B = 1, as test.py runs it), eval mode."""
+    from Utils.EMA.EMA_Predictor import EMA_Predictor as RefEMA                # the reference
+    from artspeech_amd import ema as E
+    ref = RefEMA().eval()
+    inv = {k: list(v.shape) for k, v in ref.state_dict().items()}
+    assert inv == {k: list(v) for k, v in E.ema_spec().items()}, "ema_spec differs from the reference"
+    sd = E.synth_ema_state_dict(seed=3407)
+    pe_ref = ref.state_dict()["decoder.0.sequential.1.module.positional_encoding.pe"]
+    assert torch.equal(pe_ref, torch.from_numpy(sd["decoder.0.sequential.1.module.positional_encoding.pe"])), "PE table differs"
+    ref.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    for t in (7, 66, 150):
+        mel = synth.hash_tensor(f"ema/mel/{t}", (1, 80, t), 1234, 1.0)
+        f0 = synth.hash_tensor(f"ema/f0/{t}", (1, 1, t), 1234, 1.0)
+        n = synth.hash_tensor(f"ema/n/{t}", (1, 1, t), 1234, 1.0)
+        with torch.no_grad():
+            ema = ref(torch.from_numpy(f0), torch.from_numpy(n), torch.from_numpy(mel))   # models.py:433
+        assert ema.shape == (1, 10, t) and torch.isfinite(ema).all()
+        print("ema golden T", t, "abs max %.4f mean |x| %.4f" % (float(ema.abs().max()), float(ema.abs().mean())))
+        np.savez_compressed(os.path.join(HERE, f"ema_T{t}.npz"), t=t, seed=3407, mel=mel[0], f0=f0[0], n=n[0], ema=ema[0].numpy())
+    json.dump(inv, open(os.path.join(HERE, "ema_inventory.json"), "w"), indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["ema"]:
+        make_ema()
+        sys.exit(0)
     if sys.argv[1:] == ["vocoder"]:
         make_vocoder()
         sys.exit(0)

@@ -76,10 +76,12 @@ def test_bn_lrelu_maxpool_rows(cuda):
         assert torch.allclose(yc[:, : tok.N].cpu(), want, atol=1e-6)
 
 
-def test_pipeline_extracts_f0_with_attached_jdcnet(cuda, golden_dir):
-    """models.py:432 on the test.py surface: with the HIP JDCNet attached the model computes F0 from the reference mel
-    itself; the result equals feeding that F0 in by hand (zero-padded batch, items run at full length as the reference does)."""
+def test_pipeline_with_attached_extractors(cuda, golden_dir):
+    """models.py:431-433 on the test.py surface: with the HIP JDCNet and EMA_Predictor attached the model computes F0 and the
+    EMA trajectories from the reference mel itself (phonemes + mel in, mel out, no `features`); the result equals feeding the
+    extractors' outputs in by hand, and F0 alone can be left to the model too."""
     import json
+    from artspeech_amd import ema as E
     from artspeech_amd import synth
     from artspeech_amd.pipeline import ArtSpeech
     from test_net_gpu import raw_features
@@ -89,16 +91,27 @@ def test_pipeline_extracts_f0_with_attached_jdcnet(cuda, golden_dir):
     with open(os.path.join(golden_dir, "text_golden.json"), encoding="utf-8") as f:
         cases = json.load(f)["cases"]
     ph = [cases[0]["text"][:30], cases[1]["text"][:18]]
+    lens = (90, 70)
     mels, emas = [], []
-    for i, t in enumerate((90, 70)):
+    for i, t in enumerate(lens):
         mel, _, ema_raw = raw_features(t, 40 + i)
         mels.append(mel)
         emas.append(ema_raw)
-    mel_a = tts.synthesis_mel(ph, mels, features=[(None, e) for e in emas])
     dense = torch.zeros(2, 80, 90)
     for b, m in enumerate(mels):
         dense[b, :, : m.shape[-1]] = torch.as_tensor(m)
-    f0 = jd(dense.unsqueeze(1)).cpu()
-    mel_b = tts.synthesis_mel(ph, mels, features=[(f0[b, :, : mels[b].shape[-1]], emas[b]) for b in range(2)])
+    f0 = jd(dense.unsqueeze(1), lengths=lens)
+    # F0 from the attached JDCNet, EMA given
+    mel_a = tts.synthesis_mel(ph, mels, features=[(None, e) for e in emas])
+    mel_b = tts.synthesis_mel(ph, mels, features=[(f0[b, :, : lens[b]].cpu(), emas[b]) for b in range(2)])
     assert mel_a.shape == mel_b.shape and bool(torch.isfinite(mel_a).all())
     assert float((mel_a - mel_b).abs().max()) <= 1e-6
+    # both extractors attached: nothing but phonemes and the reference mel
+    em = tts.attach_ema_extractor({"model": E.synth_ema_state_dict(seed=3407)})
+    n_raw = torch.log(torch.exp(dense.to(cuda).unsqueeze(1) * 4 - 4).norm(dim=2))
+    ema = em(f0, n_raw, dense, lengths=lens)
+    mel_c = tts.synthesis_mel(ph, mels)
+    mel_d = tts.synthesis_mel(ph, mels, features=[(f0[b, :, : lens[b]].cpu(), ema[b, :, : lens[b]].cpu()) for b in range(2)])
+    assert bool(torch.isfinite(mel_c).all()) and float((mel_c - mel_d).abs().max()) <= 1e-6
+    solo = tts.synthesis_mel(ph[1], mels[1])
+    assert float((solo[0] - mel_c[1, :, : solo.shape[-1]]).abs().max()) <= 1e-5
