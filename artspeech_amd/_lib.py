@@ -49,6 +49,7 @@ _SIGNATURES.update({
     "as_embed_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "as_channel_layernorm_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_i, c_p]),
     "as_adain_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
+    "as_adain_split_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "as_linear_rows_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "as_durations_f32": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p]),
     "as_expand_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p]),

@@ -490,7 +490,7 @@ static bool use_x6(const ConvGemmArgs& a)
     }
     if (!small && !flat) return a.W ? false : true;        // (no fp32 image to fall back to: the launch reports EINVAL)
     const char* env = getenv("AS_GEMM_IMPL");
-    return !(env && env[0] == 'f' && a.W);
+    return !(env && env[0] == 'f' && a.W && a.X);
 }
 
 // Tile and split-K choice, from sweeps on MI355X (scripts/gemm_bench.py): the kernel wants >= ~1000 workgroups
@@ -622,7 +622,7 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if (norm.act_slope == 0.f) norm.act_slope = 0.2f;
     if (norm.act < 0 || norm.act > 5 || (norm.in_act != 0 && norm.in_act != 2)) return AS_EINVAL;
     const ConvGemmArgs& a = norm;
-    if ((!a.W && !a.Wx) || !a.X || !a.Y || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS) return AS_EINVAL;
+    if ((!a.W && !a.Wx) || (!a.X && !(a.Xs && a.Wx)) || !a.Y || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS) return AS_EINVAL;
     if (a.Kp < a.K || a.Kp % BK) return AS_EINVAL;
     if (a.ldx < a.N || a.ldy < (a.transpose_out ? a.M : a.N) || (a.res && (a.ldr < a.N || a.transpose_out))) return AS_EINVAL;
     // 32-bit byte offsets inside the buffer descriptors
@@ -631,7 +631,7 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if ((double)(a.transpose_out ? a.N : a.M) * a.ldy * 4.0 >= 2147483648.0 || (double)a.M * a.ldr * 4.0 >= 2147483648.0 ||
         (double)a.M * a.N * 4.0 >= 2147483648.0) return AS_EINVAL;
     if (a.N == 0) return AS_OK;
-    if (a.K == 1 && a.W && !a.res && !a.div_sqrt2 && !a.transpose_out && a.M <= DIRECT_MAX_M && !getenv("AS_GEMM_NO_DIRECT")) {
+    if (a.K == 1 && a.W && a.X && !a.res && !a.div_sqrt2 && !a.transpose_out && a.M <= DIRECT_MAX_M && !getenv("AS_GEMM_NO_DIRECT")) {
         char tag[64];
         snprintf(tag, sizeof(tag), "M%d N%d K1 T%d direct", a.M, a.N, a.T);
         AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.T, 4.0 * ((double)a.T * a.M + a.N + (double)a.M * a.N), stream, tag);

@@ -375,3 +375,83 @@ extern "C" int as_split_bf16x3_f32(const float* x, int ldx, int K, int N, int in
     AsProfScope prof__(AS_CLS_OTHER, 0, 10.0 * K * (double)N, (hipStream_t)stream);
     return as_split_bf16x3_launch(x, ldx, K, N, in_act == 2, in_slope == 0.f ? 0.2f : in_slope, xs, (hipStream_t)stream);
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// AdaIN + LeakyReLU written DIRECTLY as the split image (the output of models.py:189-197's norm -> actv feeds nothing but
+// the following conv, so the fp32 activations never exist): per-(channel, utterance) statistics exactly as
+// adain_kernel (elementwise.hip) computes them -- one wave per channel, the same summation order -- then a thread takes
+// 8 channels of one column, normalises, applies LeakyReLU(0.2), splits and stores three 16-byte rows.
+// Workgroup = (8-channel group = one (k-block, k-half) of the image, utterance).
+// ----------------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float xd_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+adain_split_kernel(const float* __restrict__ x, int ldx, int C, const float* __restrict__ gb, int ldgb,
+                   const int* __restrict__ col_off, int N, int act, u32x4* __restrict__ xs)
+{
+    __shared__ float st[8][4];                                          // mean, rstd, 1 + gamma, beta
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int c0 = g * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t NX = (size_t)N + 1;
+    const size_t plane = ((size_t)(g >> 1) * 6 + (g & 1)) * NX;         // part h of this (k-block, k-half); m at + 2 NX, l at + 4 NX
+    if (b == 0 && threadIdx.x < 3) xs[plane + (size_t)threadIdx.x * 2 * NX + N] = u32x4{0u, 0u, 0u, 0u};   // the zero column
+    const int o0 = col_off[b], L = col_off[b + 1] - o0;
+    if (L <= 0) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = c0 + wave * 2 + q;
+        if (c < C) {                                                    // wave-uniform
+            const float* xr = x + (size_t)c * ldx + o0;
+            float s = 0.f;
+            for (int i = lane; i < L; i += 64) s += xr[i];
+            const float mean = xd_wave_sum(s) / (float)L;
+            float v = 0.f;
+            for (int i = lane; i < L; i += 64) { const float d = xr[i] - mean; v += d * d; }
+            const float var = xd_wave_sum(v) / (float)L;
+            if (lane == 0) {
+                st[wave * 2 + q][0] = mean;
+                st[wave * 2 + q][1] = 1.0f / sqrtf(var + 1e-5f);
+                st[wave * 2 + q][2] = 1.0f + gb[(size_t)b * ldgb + c];
+                st[wave * 2 + q][3] = gb[(size_t)b * ldgb + C + c];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += 256) {
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float o = 0.f;
+            if (c0 + r < C) {
+                o = st[r][2] * ((x[(size_t)(c0 + r) * ldx + o0 + i] - st[r][0]) * st[r][1]) + st[r][3];
+                if (act) o = o > 0.f ? o : 0.2f * o;
+            }
+            t[r] = o;
+        }
+        u32x4 h, m, l;
+        split3(t, h, m, l);
+        const size_t at = plane + o0 + i;
+        xs[at] = h;
+        xs[at + 2 * NX] = m;
+        xs[at + 4 * NX] = l;
+    }
+}
+
+extern "C" int as_adain_split_f32(const float* x, int ldx, int C, const float* gamma_beta, int ldgb, const int32_t* col_off, int B,
+                                  int N, int lrelu, uint16_t* xs, as_stream_t stream)
+{
+    if (!x || !gamma_beta || !col_off || !xs || C <= 0 || B <= 0 || N < 0 || ldgb < 2 * C) return AS_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(xs) & 15) != 0) return AS_EINVAL;
+    const int KBx = (((C + 15) >> 4) + 3) & ~3;
+    AsProfScope prof__(AS_CLS_ADAIN, 0, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(adain_split_kernel, dim3(2 * KBx, B), dim3(256), 0, (hipStream_t)stream, x, ldx, C, gamma_beta, ldgb, col_off, N,
+                       lrelu, reinterpret_cast<u32x4*>(xs));
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}

@@ -116,6 +116,7 @@ def conv1d(W, name, X, lay, k, Y=None, **kw):
 import os as _os
 
 SHORTCUT_FORK = _os.environ.get("AS_SHORTCUT_FORK", "0") != "0"     # experiment (no gain measured): 1x1 shortcut on a side stream
+ADAIN_SPLIT = _os.environ.get("AS_ADAIN_SPLIT", "1") != "0"         # AdaIN writes the following conv's pre-split operand image
 
 
 def adain_gb(W, p, style):
@@ -163,17 +164,25 @@ def adain_resblk1d(W, p, X, lay, style, out=None, upsample=False, gb=None, fork_
         h = lay2.new(din)
         sc = lay2.new(din)
         ops.adain(X, gb1, lay, h, True, W.dw(p + ".pool"), W.vec(p + ".pool.bias"), sc)
-    else:
-        h = ops.adain(X, gb1, lay, lay.new(din), True)
+    split = ADAIN_SPLIT and ops.GEMM_IMPL == "x6"      # norm -> actv feeds only the conv: store it as that conv's operand image
+    if not upsample:
         sc = X
-    h = conv1d(W, p + ".conv1", h, lay2, 3)
-    h2 = ops.adain(h, gb2, lay2, lay2.new(dout), True)
+    if upsample or not split:
+        if not upsample:
+            h = ops.adain(X, gb1, lay, lay.new(din), True)
+        h = conv1d(W, p + ".conv1", h, lay2, 3)
+    else:
+        h = conv1d(W, p + ".conv1", None, lay2, 3, xs=ops.adain_split(X, gb1, lay), K=din)
+    h2 = None if split else ops.adain(h, gb2, lay2, lay2.new(dout), True)
     if fork is not None:
         fork.__exit__(None, None, None)
         sc = out
     elif has_sc:
         sc = conv1d(W, p + ".conv1x1", sc, lay2, 1, Y=out)
-    conv1d(W, p + ".conv2", h2, lay2, 3, Y=out, res=sc, div_sqrt2=True)
+    if split:
+        conv1d(W, p + ".conv2", None, lay2, 3, Y=out, res=sc, div_sqrt2=True, xs=ops.adain_split(h, gb2, lay2), K=dout)
+    else:
+        conv1d(W, p + ".conv2", h2, lay2, 3, Y=out, res=sc, div_sqrt2=True)
     return out, lay2
 
 

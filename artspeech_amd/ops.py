@@ -167,13 +167,28 @@ def split_act(X, lay, in_act=0, in_slope=0.0):
     return xs
 
 
+def adain_split(X, gb, lay, lrelu=True):
+    """AdaIN1d + LeakyReLU of X [C][N], stored only as the pre-split operand image of the conv that follows (conv_gemm(Wt, None,
+    ..., xs=, K=C))."""
+    L = _lib.lib()
+    C = X.shape[0]
+    xs = torch.empty(max(L.as_split_bf16x3_bytes(C, lay.N) // 2, 8), dtype=torch.int16, device=X.device)
+    check(L.as_adain_split_f32(_p(X), _ld(X), C, _p(gb), _ld(gb), _p(lay.col_off), lay.B, lay.N, int(lrelu), _p(xs), stream()),
+          "as_adain_split_f32")
+    return xs
+
+
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
-              use_meta=True, in_slope=0.0, act_slope=0.0, xs=None):
+              use_meta=True, in_slope=0.0, act_slope=0.0, xs=None, K=None):
     """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt [T][Kp][M] (prep_weight: K zero-padded to a multiple
     of 16); X [K][*]; Y [M][*] (or [N][*] transposed).  xs: split_act(X, lay, in_act, in_slope), when several convs
     share X."""
     T, Kp, M = Wt.shape
-    K = X.shape[0]
+    if X is None:
+        if xs is None or K is None or GEMM_IMPL != "x6":
+            raise ValueError("conv_gemm: X may be omitted only with xs= and K= on the bf16x6 path")
+    else:
+        K = X.shape[0]
     if Kp % KTILE or not (Kp - KTILE < K <= Kp):
         raise ValueError(f"conv_gemm: weight rows {Kp} do not match input channels {K} (use ops.prep_weight)")
     a = ConvGemmArgs()
@@ -184,14 +199,14 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     a.Xs = _p(xs) if x6 is not None else None
     a.meta = _p(lay.meta) if (use_meta and not (T == 1 and taps[0] == (0, 0))) else None
     a.M, a.N, a.K, a.T = M, lay.N, K, T
-    a.ldx, a.ldy = _ld(X), _ld(Y)
+    a.ldx, a.ldy = (_ld(X) if X is not None else lay.N), _ld(Y)
     a.ldr = _ld(res) if res is not None else 0
     a.act, a.div_sqrt2, a.in_act, a.transpose_out = act, int(div_sqrt2), in_act, int(transpose_out)
     a.in_slope, a.act_slope = in_slope, act_slope          # 0 = LeakyReLU(0.2), the acoustic path's slope
     assert len(taps) == T
     for i, (dh, dw) in enumerate(taps):
         a.dh[i], a.dw[i] = dh, dw
-    front_ok = X.storage_offset() >= 4 or all(dh >= 0 and dw >= 0 for dh, dw in taps)
+    front_ok = X is not None and (X.storage_offset() >= 4 or all(dh >= 0 and dw >= 0 for dh, dw in taps))
     a.quad_ok = int(front_ok and (lay.quads_regular() or all(dh == 0 for dh, _ in taps)))
     L = _lib.lib()
     nbytes = L.as_conv_gemm_workspace_bytes(ctypes.byref(a))

@@ -79,7 +79,7 @@ typedef struct ConvGemmArgs {
     const uint16_t* Wx;    /* [T][KBx][6][M][8] bf16, KBx = Kp/16 rounded up to a multiple of 4 (zero blocks): the same
                               weights split w = h + m + l (three bf16, exact) for the bf16x6 path -- slot p*2 + kh holds
                               part p (h, m, l) of k = 16*kb + 8*kh + 0..7; NULL = fp32 path */
-    const float* X;        /* [K][ldx] */
+    const float* X;        /* [K][ldx]; may be NULL when Xs is given (bf16x6 path only) */
     const uint16_t* Xs;    /* optional: X already split for the bf16x6 path by as_split_bf16x3_f32 (in_act applied THERE;
                               in_act here is then ignored), [KBx][6][N+1][8] bf16; NULL = the library splits (into ws when
                               as_conv_gemm_workspace_bytes asked for the room, else inside the GEMM's k loop) */
@@ -134,6 +134,10 @@ int as_channel_layernorm_f32(const float* x, int ldx, int C, int N, const float*
 int as_adain_f32(const float* x, int ldx, int C, const float* gamma_beta, int ldgb, const int32_t* col_off, int B,
                  float* y, int ldy, int lrelu, const float* pool_w, const float* pool_b, float* x_up, int ld_up,
                  as_stream_t stream);
+/* The same AdaIN1d + LeakyReLU(0.2) written as the bf16x6 operand image of the conv that follows (as_split_bf16x3_f32's
+ * layout, N = total columns; pass it as ConvGemmArgs.Xs): the fp32 activations are never stored. */
+int as_adain_split_f32(const float* x, int ldx, int C, const float* gamma_beta, int ldgb, const int32_t* col_off, int B, int N,
+                       int lrelu, uint16_t* xs, as_stream_t stream);
 /* y[b][m] = bias[m] + W[m][:] . x[b][:]       nn.Linear on per-utterance vectors (models.py:237,412-415,538) */
 int as_linear_rows_f32(const float* x, int ldx, const float* w, const float* bias, int B, int M, int K, float* y,
                        int ldy, as_stream_t stream);

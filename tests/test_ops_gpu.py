@@ -122,6 +122,25 @@ def test_split_activations(cuda, K, lens, lrelu):
     assert float((y1 - y0).abs().max()) <= 1e-6 * float(y0.abs().max())
 
 
+@pytest.mark.parametrize("C,lens", [(80, [50, 13, 1, 200]), (512, [100, 24]), (7, [5])])
+def test_adain_split_equals_adain_then_split(cuda, C, lens):
+    """as_adain_split_f32 (AdaIN + LeakyReLU stored only as the next conv's operand image) is bit-identical to as_adain_f32
+    followed by as_split_bf16x3_f32, and a conv fed with it (no fp32 activations at all) to the conv on the fp32 activations."""
+    g = torch.Generator().manual_seed(C)
+    lay = Layout(lens, cuda)
+    X = lay.new(C)
+    X.copy_(torch.randn(C, lay.N, generator=g) * 2 + 0.3)
+    gb = torch.randn(len(lens), 2 * C, generator=g).to(cuda) * 0.3
+    y = ops.adain(X, gb, lay, lay.new(C), True)
+    want = ops.split_act(y, lay)
+    got = ops.adain_split(X, gb, lay)
+    assert torch.equal(got, want)
+    w = ops.prep_weight(torch.randn(96, C, 3, generator=g) / np.sqrt(3 * C), cuda)
+    y0 = ops.conv_gemm(w, y, lay, lay.new(96), taps_1d(3), xs=want)
+    y1 = ops.conv_gemm(w, None, lay, lay.new(96), taps_1d(3), xs=got, K=C)
+    assert torch.equal(y0, y1)
+
+
 def test_mfma_layout_asymmetric(cuda, impl):
     """A = I with an asymmetric B: catches a transposed C fragment (guide section 3)."""
     n = 64
