@@ -215,7 +215,8 @@ def main():
         gemm_kernel, gemm_peak = "conv_gemm_quad_kernel / conv_gemm_kernel (fp32 MFMA implicit-GEMM conv)", PEAK_F32_MFMA_TFLOPS
         gemm_peak_basis = "dense v_mfma_f32_32x32x2_f32"
     else:
-        gemm_kernel, gemm_peak = "conv_gemm_x6_kernel (implicit-GEMM conv, bf16x6 split operands on the bf16 MFMAs)", PEAK_X6_TFLOPS
+        gemm_kernel, gemm_peak = ("conv_gemm_x6_kernel / conv_gemm_x6d_kernel (implicit-GEMM conv, bf16x6 split operands on the bf16 MFMAs; "
+                                  "activations split in the k loop / pre-split by the producer)"), PEAK_X6_TFLOPS
         gemm_peak_basis = "dense bf16 MFMA 2516.6 TFLOP/s / 6 partial products per fp32 product (achieved = algorithmic fp32 flop)"
     frames_per_step = B * FRAMES_PER_UTT
     ms_per_step = elapsed / args.steps * 1e3

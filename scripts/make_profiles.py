@@ -38,7 +38,7 @@ for k in sorted(f, key=lambda k: -f[k])[:14]:
     fe = f[k] * 1024 / nf[k]; wr = w.get(k, 0) * 1024 / max(nw.get(k, 1), 1)
     tr[k] = dict(launches=nf[k], fetch_bytes_per_launch_raw=round(fe), fetch_bytes_per_launch_x2=round(2 * fe), write_bytes_per_launch=round(wr))
 for k in f:
-    if k.startswith("conv_gemm") or k.startswith("splitk_reduce"):
+    if k.startswith("conv_gemm") or k.startswith("splitk_reduce") or k.startswith("split_bf16x3"):
         gem_f += f[k] * 1024; gem_w += w.get(k, 0) * 1024
         if k.startswith("conv_gemm"): gem_n += nf[k]
 json.dump(tr, open(f"{P}/{tag}_pmc_traffic.json", "w"), indent=1)
