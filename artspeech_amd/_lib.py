@@ -57,6 +57,9 @@ _SIGNATURES.update({
     "as_crop_f32": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "as_rows_to_images_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p]),
     "as_dwconv_down_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "as_frame_signal_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "as_spec_power_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "as_log_norm_f32": (c_i, [c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_i, c_p]),
     "as_xl_attention_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_i, c_i, c_p, c_i, c_p]),
     "as_glu_dwconv_bn_swish_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "as_lstm_step0_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),

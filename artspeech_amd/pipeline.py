@@ -62,6 +62,31 @@ class ArtSpeech:
         self.model.ArtsSpeech.style_encoder.ema_extractor = net
         return net
 
+    def attach_frontend(self):
+        """test.py:40-47: the MelSpectrogram + log normalisation that turns the reference wave into ``mels`` (artspeech_amd/frontend.py)."""
+        from .frontend import LogMel
+        self.frontend = LogMel(device=self.device)
+        return self.frontend
+
+    @torch.no_grad()
+    def synthesis_from_wave(self, phonemes, ref_wave, features=None, forced_durations=None):
+        """test.py:94-116 from the phonemizer's output and the (already loaded, trimmed, 24 kHz) reference wave on: log-mel front
+        end -> [JDCNet, EMA_Predictor] -> acoustic model -> generator.  Returns the samples (mel frames if no vocoder is attached).
+        Loading / trimming / resampling the file (librosa, test.py:99-106) and espeak stay with the caller."""
+        if getattr(self, "frontend", None) is None:
+            self.attach_frontend()
+        single = isinstance(phonemes, str)
+        if single:
+            mels = [self.frontend(ref_wave)[0]]
+            phonemes = [phonemes]
+            features = None if features is None else [features]
+        else:
+            mel, lens = self.frontend(list(ref_wave))
+            mels = [mel[b, :, :n] for b, n in enumerate(lens)]
+        fn = self.synthesis_wav if self.generator is not None else self.synthesis_mel
+        out = fn(phonemes, mels, features=features, forced_durations=forced_durations)
+        return out[0] if single and out.dim() > 1 and self.generator is not None else out
+
     def attach_vocoder(self, h=None, checkpoint=None):
         """test.py:119-125: build the generator from Vocoder/config.json-style `h` and load checkpoint['generator']."""
         from .vocoder import Generator
@@ -118,5 +143,5 @@ class ArtSpeech:
         return mel
 
     def synthesis(self, text, ref_wav, save_path):
-        raise NotImplementedError("text -> phonemes (espeak) and wav -> log-mel are outside this path (SURVEY.md "
-                                  "section 2); use synthesis_mel / synthesis_wav(phonemes, ref_mel)")
+        raise NotImplementedError("text -> phonemes (espeak) and reading / trimming the wav file (librosa) are outside this path "
+                                  "(SURVEY.md section 2); use synthesis_from_wave(phonemes, wave) / synthesis_wav(phonemes, ref_mel)")

@@ -181,6 +181,18 @@ int as_mean_pool_f32(const float* x, int ldx, const int32_t* col_off, int B, int
                      as_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * wav -> normalised log-mel front end, test.py:40-47: torchaudio MelSpectrogram(n_mels 80, n_fft 2048,
+ * win 1200, hop 300) = framing (centre, reflect padding) -> windowed DFT (a conv GEMM with the basis as weights) -> power ->
+ * mel filterbank (a conv GEMM) -> (log(1e-5 + mel) + 4) / 4.
+ * as_frame_signal_f32: wave = utterances back to back (wav_off int32 [B+1]); X [n_fft][N] frames, utterance b's at columns
+ *   frame_off[b] .. frame_off[b+1] (1 + L_b / hop of them).  as_spec_power_f32: Y [2F][N] (real rows, then imaginary) -> P [F][N].
+ * ------------------------------------------------------------------------------------------- */
+int as_frame_signal_f32(const float* wave, const int32_t* wav_off, const int32_t* frame_off, int B, int max_frames, int n_fft, int hop,
+                        float* X, int ldx, as_stream_t stream);
+int as_spec_power_f32(const float* Y, int ldy, int F, int N, float* P, int ldp, as_stream_t stream);
+int as_log_norm_f32(const float* x, int ldx, int C, int N, float eps, float mean, float std, float* y, int ldy, as_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * EMA_Predictor: what is not a GEMM in Utils/EMA/EMA_Predictor.py and its conformer blocks.
  * as_xl_attention_f32: RelativeMultiHeadAttention.forward (conformer/attention.py:77-109) on a fused [3C][N] q/k/v
  *   projection and pos [C][N] = pos_proj(PE[frame index]) per utterance; u_bias, v_bias [heads][64]; the reference's
