@@ -251,3 +251,66 @@ extern "C" int as_mas_f32(const float* value, const int* t_x, const int* t_y, in
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// SURVEY.md section 8(f) N4 -- the training scripts' producer of K1 (train_second.py:181-184, train_first.py:171-177):
+//   s2s_attn = softmax(s2s_attn_feat, dim = -1 | 1);  mask_ST = mask_from_lens(...);  mono = maximum_path(s2s_attn, mask_ST);
+//   d_gt = mono.sum(-1)
+// as one entry point that takes the LENGTHS (no dense mask is built): a softmax kernel over the whole [Tx][Ty] slab of every
+// item (as the reference: no masking before the softmax in train_second.py), then the MAS kernels above on it.
+// ----------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+softmax_last_kernel(const float* __restrict__ x, int Ty, float* __restrict__ y)
+{
+    __shared__ float red[4];
+    const float* xr = x + (size_t)blockIdx.x * Ty;
+    float* yr = y + (size_t)blockIdx.x * Ty;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < Ty; i += 256) m = fmaxf(m, xr[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = threadIdx.x; i < Ty; i += 256) s += expf(xr[i] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int i = threadIdx.x; i < Ty; i += 256) yr[i] = expf(xr[i] - m) / s;
+}
+
+// softmax over dim 1 (the Tx axis): one thread per (item, column), two passes over the column (coalesced across threads)
+__global__ void softmax_dim1_kernel(const float* __restrict__ x, int Tx, int Ty, float* __restrict__ y)
+{
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Ty) return;
+    const float* xb = x + (size_t)b * Tx * Ty + j;
+    float* yb = y + (size_t)b * Tx * Ty + j;
+    float m = -INFINITY;
+    for (int i = 0; i < Tx; ++i) m = fmaxf(m, xb[(size_t)i * Ty]);
+    float s = 0.f;
+    for (int i = 0; i < Tx; ++i) s += expf(xb[(size_t)i * Ty] - m);
+    for (int i = 0; i < Tx; ++i) yb[(size_t)i * Ty] = expf(xb[(size_t)i * Ty] - m) / s;
+}
+
+extern "C" int as_softmax_mas_f32(const float* feat, const int* t_x, const int* t_y, int B, int Tx, int Ty, int softmax_dim,
+                                  int tie_mode, float* attn, float* path, int* dur, int* rows, void* ws, size_t ws_bytes,
+                                  as_stream_t stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!feat || !attn || (softmax_dim != 1 && softmax_dim != 2) || B < 0 || Tx <= 0 || Ty <= 0) return AS_EINVAL;
+    if (B == 0) return AS_OK;
+    {
+        AsProfScope prof__(AS_CLS_MAS, 0, 8.0 * B * (double)Tx * Ty, stream);
+        if (softmax_dim == 2) hipLaunchKernelGGL(softmax_last_kernel, dim3(B * Tx), dim3(256), 0, stream, feat, Ty, attn);
+        else hipLaunchKernelGGL(softmax_dim1_kernel, dim3(as_cdiv(Ty, 256), B), dim3(256), 0, stream, feat, Tx, Ty, attn);
+        AS_CHECK_LAUNCH();
+    }
+    return as_mas_f32(attn, t_x, t_y, B, Tx, Ty, tie_mode, path, dur, rows, ws, ws_bytes, stream_);
+}

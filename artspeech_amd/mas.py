@@ -74,6 +74,40 @@ def maximum_path_lens(value, x_lens, y_lens, tie="stay", want=("path",)):
 
 
 @torch.no_grad()
+def soft_maximum_path(feat, symbol_lens, mel_lens, dim=-1, tie="stay"):
+    """train_second.py:181-185 (train_first.py:171-177) in one call on the GPU, from lengths:
+        s2s_attn = F.softmax(feat, dim);  mono = maximum_path(s2s_attn, mask_from_lens(s2s_attn, symbol_lens, mel_lens));
+        d_gt = mono.sum(-1)
+    feat fp32 [B, S, T]; returns (s2s_attn [B,S,T], s2s_attn_mono [B,S,T], d_gt int32 [B,S])."""
+    if feat.dim() != 3:
+        raise ValueError("feat must be [B, S, T]")
+    if not feat.is_cuda:
+        raise _lib.HipLibraryError("soft_maximum_path: feat must live in GPU memory (no CPU fallback)")
+    feat = feat.contiguous().float()
+    B, Tx, Ty = feat.shape
+    dev = feat.device
+    sdim = {-1: 2, 2: 2, 1: 1, -2: 1}.get(dim)
+    if sdim is None:
+        raise ValueError("dim must be 1 or -1")
+    tx = symbol_lens.to(device=dev, dtype=torch.int32).contiguous()
+    ty = mel_lens.to(device=dev, dtype=torch.int32).contiguous()
+    attn, path = torch.empty_like(feat), torch.empty_like(feat)
+    dur = torch.empty((B, Tx), dtype=torch.int32, device=dev)
+    if B == 0 or Tx == 0 or Ty == 0:
+        return attn, path.zero_(), dur.zero_()
+    L = _lib.lib()
+    nbytes = L.as_mas_workspace_bytes(B, Tx, Ty)
+    if nbytes == 0:
+        raise ValueError(f"soft_maximum_path: unsupported lattice shape {tuple(feat.shape)} (Tx <= 8192)")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.as_softmax_mas_f32(_lib.ptr(feat), _lib.ptr(tx), _lib.ptr(ty), B, Tx, Ty, sdim, {"stay": TIE_STAY, "move": TIE_MOVE}[tie],
+                                  _lib.ptr(attn), _lib.ptr(path), _lib.ptr(dur), None, _lib.ptr(ws), nbytes, _lib.stream())
+    _lib.check(rc, "as_softmax_mas_f32")
+    return attn, path, dur
+
+
+@torch.no_grad()
 def maximum_path(value, mask, tie="stay"):
     """Drop-in for S_monotonic_align.maximum_path2 (tie="stay", also the Triton rule) or
     maximum_path1 (tie="move").  Lengths are recovered from the mask exactly as the reference does

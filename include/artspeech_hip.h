@@ -52,6 +52,13 @@ size_t as_mas_workspace_bytes(int B, int Tx, int Ty);
 int as_mas_f32(const float* value, const int32_t* t_x, const int32_t* t_y, int B, int Tx, int Ty,
                int tie_mode, float* path, int32_t* dur, int32_t* rows,
                void* workspace, size_t workspace_bytes, as_stream_t stream);
+/* The training scripts' producer of K1 in one call (train_second.py:181-184; train_first.py:171-177 without its masked_fill):
+ * attn = softmax(feat, dim = softmax_dim) over the whole [Tx][Ty] slab (2 = the last axis, 1 = the Tx axis), then as_mas_f32 on
+ * attn with the LENGTHS (what mask_from_lens + maximum_path do through a dense mask); dur = d_gt (train_second.py:185).
+ * attn fp32 [B][Tx][Ty] is an output (s2s_attn is used downstream) and must not alias feat. */
+int as_softmax_mas_f32(const float* feat, const int32_t* t_x, const int32_t* t_y, int B, int Tx, int Ty, int softmax_dim,
+                       int tie_mode, float* attn, float* path, int32_t* dur, int32_t* rows, void* workspace,
+                       size_t workspace_bytes, as_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Packed-frames layout (DESIGN.md "Data layout").  An activation is fp32 [C][N] (row stride ld >= N)

@@ -302,7 +302,30 @@ def make_ema():
     json.dump(inv, open(os.path.join(HERE, "ema_inventory.json"), "w"), indent=0, sort_keys=True)
 
 
+def make_softmax_mas():
+    """train_second.py:181-185 with the reference's own functions: softmax -> mask_from_lens -> maximum_path1/2 -> d_gt."""
+    import torch.nn.functional as F
+    import S_monotonic_align as ref
+    out = {}
+    for tag, (B, S, T, dim) in {"last": (5, 23, 61, -1), "dim1": (4, 17, 90, 1)}.items():
+        feat = torch.from_numpy(synth.hash_tensor(f"smas/{tag}", (B, S, T), 1234, 3.0))
+        sl = torch.tensor([S - (2 * i) % (S - 1) for i in range(B)])
+        ml = torch.tensor([T - 3 * i for i in range(B)])
+        attn = F.softmax(feat, dim=dim)
+        mask = ref.mask_from_lens(attn, sl, ml)
+        p2 = ref.maximum_path2(attn, mask)
+        p1 = ref.maximum_path1(attn, mask)
+        out.update({f"{tag}_feat": feat.numpy(), f"{tag}_sl": sl.numpy(), f"{tag}_ml": ml.numpy(), f"{tag}_attn": attn.numpy(),
+                    f"{tag}_path2": p2.numpy().astype(np.uint8), f"{tag}_path1": p1.numpy().astype(np.uint8),
+                    f"{tag}_dgt2": p2.sum(-1).numpy().astype(np.int32), f"{tag}_dim": np.int32(dim)})
+        print("softmax+mas golden", tag, "d_gt sum", int(p2.sum()))
+    np.savez_compressed(os.path.join(HERE, "softmax_mas.npz"), **out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["softmax_mas"]:
+        make_softmax_mas()
+        sys.exit(0)
     if sys.argv[1:] == ["ema"]:
         make_ema()
         sys.exit(0)

@@ -100,3 +100,26 @@ def test_forced_rows_per_lane(cuda, monkeypatch):
         monkeypatch.setenv("AS_MAS_R", r)
         got = mas.maximum_path(torch.from_numpy(value).to(cuda), torch.from_numpy(mask).to(cuda))
         assert np.array_equal(got.cpu().numpy(), want), r
+
+
+@pytest.mark.parametrize("tag", ["last", "dim1"])
+def test_softmax_mas_fused(cuda, golden_dir, tag):
+    """as_softmax_mas_f32 (train_second.py:181-185 from lengths): softmax within 1e-6 of the reference's, the path bit-exact
+    with the oracle's MAS on the SAME probabilities (decisions compare fp32 sums, so the input must be identical), d_gt =
+    path.sum(-1); on this fixture the path also equals the reference's own maximum_path1/2 output."""
+    import os
+    from artspeech_amd import mas
+    from oracle import mas as omas
+    g = np.load(os.path.join(golden_dir, "softmax_mas.npz"))
+    feat, sl, ml, dim = torch.from_numpy(g[f"{tag}_feat"]), torch.from_numpy(g[f"{tag}_sl"]), torch.from_numpy(g[f"{tag}_ml"]), int(g[f"{tag}_dim"])
+    for tie, key in (("stay", "path2"), ("move", "path1")):
+        attn, path, dgt = mas.soft_maximum_path(feat.to(cuda), sl, ml, dim=dim, tie=tie)
+        assert float((attn.cpu() - torch.from_numpy(g[f"{tag}_attn"])).abs().max()) <= 1e-6
+        a = attn.cpu().numpy()
+        want = omas.maximum_path_np(a, omas.mask_from_lens(a.shape, sl.numpy(), ml.numpy()), tie == "move")
+        assert np.array_equal(path.cpu().numpy(), want.astype(np.float32))
+        assert np.array_equal(dgt.cpu().numpy(), want.sum(-1).astype(np.int32))
+        same = np.array_equal(path.cpu().numpy().astype(np.uint8), g[f"{tag}_{key}"])
+        print(tag, tie, "path equals the reference's:", same)
+        assert same
+    assert np.array_equal(mas.soft_maximum_path(feat.to(cuda), sl, ml, dim=dim)[2].cpu().numpy(), g[f"{tag}_dgt2"])
