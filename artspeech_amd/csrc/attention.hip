@@ -161,6 +161,141 @@ relpos_attention_kernel(const float* __restrict__ qkv, int ld, int C, int heads,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Short utterances (every utterance <= 64 tokens: the text side of the path at 40 tokens per utterance).  The kernel
+// above gives such an utterance three 16-query workgroups that each stage the same K/V tile and walk run-time-bounded
+// loops (79 us per launch on 32 x 40 tokens, 10 launches per step).  Here ONE workgroup owns (utterance, head): Q, K, V
+// are staged once with compile-time trip counts, a wave takes every fourth group of four queries, scores for all keys sit in
+// lanes, probabilities go through LDS to the PV phase (lane = channel).  Same arithmetic order per output as above
+// (dot products accumulate over d ascending, PV over keys ascending then the relative taps ascending).
+// ---------------------------------------------------------------------------------------------------
+#define SN 64
+#define SPAD 65
+template <int DK>
+__global__ void __launch_bounds__(256)
+relpos_attention_small_kernel(const float* __restrict__ qkv, int ld, int C, int window, const float* __restrict__ emb_k,
+                              const float* __restrict__ emb_v, const int* __restrict__ col_off, float* __restrict__ out, int ldo)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Ks = sm;                              // [DK][SPAD]   (reused for the output transpose)
+    float* Vs = Ks + DK * SPAD;                  // [DK][SPAD]
+    float* Qs = Vs + DK * SPAD;                  // [DK][SPAD]: Qs[d][q]
+    float* Ps = Qs + DK * SPAD;                  // [SN queries][SPAD keys]
+    float* Rk = Ps + SN * SPAD;                  // [SN][MAXREL]
+    float* Ek = Rk + SN * MAXREL;                // [MAXREL][DK]
+    float* Ev = Ek + MAXREL * DK;                // [MAXREL][DK]
+
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int o0 = col_off[b], N = col_off[b + 1] - o0;
+    if (N <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrel = 2 * window + 1;
+    const float scale = sqrtf((float)DK);
+    const float* Qg = qkv + (size_t)(h * DK) * ld + o0;
+    const float* Kg = qkv + (size_t)(C + h * DK) * ld + o0;
+    const float* Vg = qkv + (size_t)(2 * C + h * DK) * ld + o0;
+
+    // stage Q, K, V: thread (column = lane, rows wave + 4 i); all loads of a batch of 16 rows are issued before their stores
+    const bool colok = lane < N;
+#pragma unroll
+    for (int i0 = 0; i0 < DK / 4; i0 += 16) {
+        float q[16], k[16], v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int d = wave + 4 * (i0 + i);
+            q[i] = colok ? Qg[(size_t)d * ld + lane] : 0.f;
+            k[i] = colok ? Kg[(size_t)d * ld + lane] : 0.f;
+            v[i] = colok ? Vg[(size_t)d * ld + lane] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int d = wave + 4 * (i0 + i);
+            Qs[d * SPAD + lane] = q[i];
+            Ks[d * SPAD + lane] = k[i];
+            Vs[d * SPAD + lane] = v[i];
+        }
+    }
+    for (int i = tid; i < nrel * DK; i += 256) { Ek[i] = emb_k[i]; Ev[i] = emb_v[i]; }
+    __syncthreads();
+    // Rk[q][r] = q . Ek[r] / scale: thread (query = lane, taps wave, wave + 4, wave + 8)
+    for (int r = wave; r < nrel; r += 4) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < DK; ++d) s += Qs[d * SPAD + lane] * Ek[r * DK + d];
+        Rk[lane * MAXREL + r] = s / scale;
+    }
+    __syncthreads();
+    // scores + softmax: a wave takes the query groups g = wave, wave + 4, ... of four queries; lane = key
+    const int ngroups = (N + 3) / 4;
+    for (int g = wave; g < ngroups; g += 4) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int d = 0; d < DK; ++d) {
+            const float kv = Ks[d * SPAD + lane];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) s[qq] += Qs[d * SPAD + 4 * g + qq] * kv;
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int qi = 4 * g + qq;
+            float sc = s[qq] / scale;
+            const int r = lane - qi + window;
+            if (r >= 0 && r < nrel && qi < SN) sc += Rk[qi * MAXREL + r];
+            if (lane >= N) sc = -INFINITY;
+            const float mx = wmax(sc);
+            const float p = (lane < N) ? expf(sc - mx) : 0.f;
+            const float l = wsum(p);
+            // the general kernel's online softmax with a single key tile: p = exp(sc - max), divided by the sum at the very end
+            Ps[qi * SPAD + lane] = p;
+            if (lane == 0) Ps[qi * SPAD + SN] = l;           // the row's sum rides in its padding slot
+        }
+    }
+    __syncthreads();
+    // PV: lane = channels d0 = lane, d1 = lane + 64
+    float* Os = Ks;                                          // [DK][SPAD]: output transposed for row-contiguous stores
+    const int d0 = lane, d1 = lane + 64;
+    for (int g = wave; g < ngroups; g += 4) {
+        float acc[4][2];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) { acc[qq][0] = 0.f; acc[qq][1] = 0.f; }
+        for (int j = 0; j < N; ++j) {
+            const float v0 = Vs[d0 * SPAD + j];
+            const float v1 = DK > 64 ? Vs[d1 * SPAD + j] : 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const float p = Ps[(4 * g + qq) * SPAD + j];
+                acc[qq][0] += p * v0;
+                acc[qq][1] += p * v1;
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int qi = 4 * g + qq;
+            for (int r = 0; r < nrel; ++r) {
+                const int jg = qi + r - window;
+                if (jg < 0 || jg >= N) continue;
+                const float p = Ps[qi * SPAD + jg];
+                acc[qq][0] += p * Ev[r * DK + d0];
+                if (DK > 64) acc[qq][1] += p * Ev[r * DK + d1];
+            }
+        }
+        // (Os aliases Ks, which nobody reads after the barrier above)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int qi = 4 * g + qq;
+            const float l = Ps[qi * SPAD + SN];
+            Os[d0 * SPAD + qi] = acc[qq][0] / l;
+            if (DK > 64) Os[d1 * SPAD + qi] = acc[qq][1] / l;
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < DK / 4; ++i) {
+        const int d = wave + 4 * i;
+        if (lane < N) out[(size_t)(h * DK + d) * ldo + o0 + lane] = Os[d * SPAD + lane];
+    }
+}
+
 extern "C" int as_relpos_attention_f32(const float* qkv, int ld, int C, int heads, int window, const float* emb_rel_k,
                                        const float* emb_rel_v, const int32_t* col_off, int B, int max_len, float* out,
                                        int ldo, as_stream_t stream)
@@ -169,6 +304,20 @@ extern "C" int as_relpos_attention_f32(const float* qkv, int ld, int C, int head
     const int dk = C / heads;
     if (dk > MAXDK || 2 * window + 1 > MAXREL || window < 0 || B < 0) return AS_EINVAL;
     if (B == 0 || max_len <= 0) return AS_OK;
+    if (max_len <= SN && dk == 128 && !getenv("AS_ATTN_GENERAL")) {            // short utterances: one workgroup per (utterance, head)
+        const size_t sm_small = sizeof(float) * ((size_t)3 * 128 * SPAD + SN * SPAD + SN * MAXREL + 2 * MAXREL * 128);
+        static bool attr_small = false;
+        if (!attr_small) {
+            AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_small_kernel<128>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_small = true;
+        }
+        AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
+        hipLaunchKernelGGL(relpos_attention_small_kernel<128>, dim3(heads, B), dim3(256), sm_small, (hipStream_t)stream, qkv, ld, C,
+                           window, emb_rel_k, emb_rel_v, col_off, out, ldo);
+        AS_CHECK_LAUNCH();
+        return AS_OK;
+    }
     const size_t smem = sizeof(float) * ((size_t)2 * dk * KPAD + QT * dk + 4 * KT * 4 + QT * MAXREL + 2 * MAXREL * dk);
     static bool attr_set = false;                          // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_set) {

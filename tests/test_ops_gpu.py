@@ -202,7 +202,7 @@ def test_durations_expand(cuda):
     assert torch.equal(y.cpu(), x.repeat_interleave(want.long(), dim=1).repeat_interleave(2, dim=1))
 
 
-@pytest.mark.parametrize("lens,C", [([40, 33, 7], 64), ([150], 512), ([1, 2, 70, 64, 65], 64)])
+@pytest.mark.parametrize("lens,C", [([40, 33, 7], 64), ([150], 512), ([1, 2, 70, 64, 65], 64), ([40, 33, 7, 64, 1, 63], 512), ([40] * 32, 512)])
 def test_relpos_attention(cuda, lens, C):
     from oracle import acoustic
     g = torch.Generator().manual_seed(sum(lens) + C)
@@ -330,6 +330,37 @@ def test_kernels_side_by_side_on_two_streams(cuda):
                 b = second()
             torch.cuda.synchronize()
             assert torch.equal(a, r1) and torch.equal(b, r2)
+
+
+def test_short_attention_side_by_side_and_equal_to_general(cuda, monkeypatch):
+    """The one-workgroup-per-(utterance, head) kernel for utterances of <= 64 tokens: equal to the general kernel (same
+    arithmetic order) and stable when it shares the chip with a GEMM on another stream."""
+    B, N, C = 32, 40, 512
+    lay = ops.layout([N] * (B - 2) + [64, 1], cuda)
+    g = torch.Generator().manual_seed(2)
+    qkv = lay.new(3 * C)
+    qkv.copy_(torch.randn(3 * C, lay.N, generator=g))
+    ek, ev = (torch.randn(9, 128, generator=g) * 0.1).to(cuda), (torch.randn(9, 128, generator=g) * 0.1).to(cuda)
+    att = lambda: ops.relpos_attention(qkv, C, 4, 4, ek, ev, lay, lay.new(C))
+    ref = att().clone()
+    monkeypatch.setenv("AS_ATTN_GENERAL", "1")
+    general = att().clone()
+    monkeypatch.delenv("AS_ATTN_GENERAL")
+    assert float((ref - general).abs().max()) <= 1e-6
+    w = ops.prep_weight(torch.randn(1024, 512, 9, generator=g) / 68, cuda)
+    X = lay.new(512)
+    X.copy_(torch.randn(512, lay.N, generator=g))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            a = att()
+        with torch.cuda.stream(s2):
+            ops.conv_gemm(w, X, lay, lay.new(1024), taps_1d(9))
+        with torch.cuda.stream(s1):
+            a2 = att()
+        torch.cuda.synchronize()
+        assert torch.equal(a, ref) and torch.equal(a2, ref)
 
 
 @pytest.mark.parametrize("two_d", [False, True])
