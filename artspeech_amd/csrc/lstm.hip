@@ -131,6 +131,136 @@ bilstm_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B, int H
     }
 }
 
+// H = 256 (duration predictor, models.py:526; JDCNet's classifier, Utils/JDC/model.py:62-64): a direction's W_hh is 1 MB, twice
+// the CU's register file, and streaming ALL of it from L2 every step (the kernel above: 11 us per step, latency-bound with 8
+// loads in flight per thread) is the whole step time.  Here 512 threads own TWO gate rows each (rows t and t + 2H), keep the
+// first KREG entries of both in registers, the next KLDS rows of W_hh^T live in LDS (144 KB), and the remaining rows are
+// streamed per step, double-buffered.  Swept on MI355X (JDCNet, 200 steps): KREG 32 / 48 / 64 -> 1.98 / 2.36 / 3.1 ms against
+// 2.33 for the kernel above -- hipcc spills beyond ~32 resident entries per row -- so this is a 15 % step, not the fix; the fix is
+// W_hh split over several workgroups (DESIGN.md "next").  The accumulation order over k is unchanged (ascending).
+template <int H, int KREG, int KLDS>
+__global__ void __launch_bounds__(2 * H)
+bilstm_big_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B)
+{
+    #ifndef LSTM_SB
+#define LSTM_SB 4
+#endif
+    constexpr int G = 4 * H, NT = 2 * H, KS = H - KREG - KLDS, SB = LSTM_SB;   // SB: streamed rows per batch
+    static_assert(KS >= 0 && KS % SB == 0, "split of the k range");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* hs = sm;                         // [2][H][NB]
+    float* gs = hs + 2 * H * NB;            // [4H][NB]
+    float* wl = gs + G * NB;                // [KLDS][G]
+    __shared__ int s_off[NB], s_len[NB];
+
+    const BiLstmJob job = jobs.j[blockIdx.z];
+    const int dir = blockIdx.y;
+    const int u0 = blockIdx.x * NB;
+    const int tid = threadIdx.x;            // gate rows tid and tid + NT
+    if (tid < NB) {
+        const int u = u0 + tid;
+        s_off[tid] = u < B ? col_off[u] : 0;
+        s_len[tid] = u < B ? col_off[u + 1] - col_off[u] : 0;
+    }
+    for (int i = tid; i < 2 * H * NB; i += NT) hs[i] = 0.f;
+    const float* w = job.whh_t + (size_t)dir * H * G + tid;
+    float wa[KREG], wb[KREG];
+#pragma unroll
+    for (int k = 0; k < KREG; ++k) {
+        wa[k] = w[(size_t)k * G];
+        wb[k] = w[(size_t)k * G + NT];
+    }
+#pragma unroll 4
+    for (int k = 0; k < KLDS; ++k) {
+        wl[k * G + tid] = w[(size_t)(KREG + k) * G];
+        wl[k * G + NT + tid] = w[(size_t)(KREG + k) * G + NT];
+    }
+    const float* ws = w + (size_t)(KREG + KLDS) * G;
+    __syncthreads();
+    int Lmax = 0;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) Lmax = s_len[u] > Lmax ? s_len[u] : Lmax;
+    const int unit = tid % H, q = tid / H;  // cell-update role: (unit, utterance q); NT = H * NB threads
+    float c = 0.f;
+
+    auto load_gx = [&](int t, float (&ga)[NB], float (&gb)[NB]) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int L = s_len[u];
+            const int pos = dir ? L - 1 - t : t;
+            const float* p = job.gx_tm + (size_t)(s_off[u] + pos) * job.ldg + dir * G + tid;
+            ga[u] = (t < L) ? p[0] : 0.f;
+            gb[u] = (t < L) ? p[NT] : 0.f;
+        }
+    };
+    float gna[NB], gnb[NB];
+    load_gx(0, gna, gnb);
+
+    for (int t = 0; t < Lmax; ++t) {
+        asm volatile("" ::: "memory");      // the LDS-resident and streamed weights are loop invariant: without this hipcc hoists them into (spilled) registers
+        const float* hc = hs + (t & 1) * H * NB;
+        float* hn = hs + ((t + 1) & 1) * H * NB;
+        float a0 = gna[0], a1 = gna[1], b0 = gnb[0], b1 = gnb[1];
+        if (t + 1 < Lmax) load_gx(t + 1, gna, gnb);
+        float ka[SB], kb[SB];                                  // the first streamed rows start moving before the resident part runs
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            ka[i] = ws[(size_t)i * G];
+            kb[i] = ws[(size_t)i * G + NT];
+        }
+#pragma unroll
+        for (int k = 0; k < KREG; ++k) {
+            const float2 h2 = *reinterpret_cast<const float2*>(hc + k * NB);
+            a0 += wa[k] * h2.x; a1 += wa[k] * h2.y;
+            b0 += wb[k] * h2.x; b1 += wb[k] * h2.y;
+            if ((k & 7) == 7) asm volatile("" ::: "memory");   // keeps hipcc from hoisting all 96 h reads up front (it spilled ~1000 registers)
+        }
+#pragma unroll 4
+        for (int k = 0; k < KLDS; ++k) {
+            const float va = wl[k * G + tid], vb = wl[k * G + NT + tid];
+            const float2 h2 = *reinterpret_cast<const float2*>(hc + (KREG + k) * NB);
+            a0 += va * h2.x; a1 += va * h2.y;
+            b0 += vb * h2.x; b1 += vb * h2.y;
+        }
+        for (int k0 = 0; k0 < KS; k0 += SB) {
+            float na[SB], nb[SB];
+            const int kn = k0 + SB < KS ? k0 + SB : k0;       // (the last batch re-loads itself: branch-free)
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                na[i] = ws[(size_t)(kn + i) * G];
+                nb[i] = ws[(size_t)(kn + i) * G + NT];
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const float2 h2 = *reinterpret_cast<const float2*>(hc + (KREG + KLDS + k0 + i) * NB);
+                a0 += ka[i] * h2.x; a1 += ka[i] * h2.y;
+                b0 += kb[i] * h2.x; b1 += kb[i] * h2.y;
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) { ka[i] = na[i]; kb[i] = nb[i]; }
+        }
+        *reinterpret_cast<float2*>(gs + tid * NB) = make_float2(a0, a1);
+        *reinterpret_cast<float2*>(gs + (NT + tid) * NB) = make_float2(b0, b1);
+        lds_barrier();
+        {                                    // every thread updates one (unit, utterance) cell
+            const int u = q;
+            const int L = s_len[u];
+            if (t < L) {
+                const float ig = sigmoidf_(gs[(unit)*NB + u]);
+                const float fg = sigmoidf_(gs[(H + unit) * NB + u]);
+                const float gg = tanhf_(gs[(2 * H + unit) * NB + u]);
+                const float og = sigmoidf_(gs[(3 * H + unit) * NB + u]);
+                c = fg * c + ig * gg;
+                const float hv = og * tanhf_(c);
+                hn[unit * NB + u] = hv;
+                const int pos = dir ? L - 1 - t : t;
+                job.out[(size_t)(dir * H + unit) * job.ldo + s_off[u] + pos] = hv;
+            }
+        }
+        lds_barrier();
+    }
+}
+
 // H <= 128: thread = (hidden unit, K quarter).  A thread keeps the W_hh entries of ALL FOUR gates of its unit for its
 // quarter of the hidden vector in registers (4 * H/4 = H VGPRs), accumulates 8 independent chains (4 gates x 2
 // utterances) -- instruction-level parallelism instead of one 128-long dependent chain -- and the four quarters are
@@ -239,6 +369,22 @@ extern "C" int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32
     case 32: hipLaunchKernelGGL(bilstm_quad_kernel<32>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B); break;
     case 64: hipLaunchKernelGGL(bilstm_quad_kernel<64>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B); break;
     case 128: hipLaunchKernelGGL(bilstm_quad_kernel<128>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B); break;
+    case 256: {
+#ifndef LSTM_KREG
+#define LSTM_KREG 32
+#endif
+        constexpr int KREG = LSTM_KREG, KLDS = 36;                    
+        const size_t sm_big = smem + sizeof(float) * (size_t)KLDS * 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_big_kernel<256, KREG, KLDS>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big));   // (+ 16 bytes static: 160 KB would be refused)
+            attr_set = true;
+        }
+        if (getenv("AS_LSTM_STREAM")) hipLaunchKernelGGL(bilstm_kernel<0>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H);
+        else hipLaunchKernelGGL((bilstm_big_kernel<256, KREG, KLDS>), grid, dim3(512), sm_big, (hipStream_t)stream, jobs, col_off, B);
+        break;
+    }
     default: hipLaunchKernelGGL(bilstm_kernel<0>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H); break;
     }
     AS_CHECK_LAUNCH();
