@@ -490,7 +490,16 @@ class Decoder(_Module):
     def __init__(self, W, prefix="decoder"):
         self.W, self.p = W, prefix
 
-    def forward_packed(self, asr_up, lay2, style, f0, n, ema, out=None):
+    def adain_params(self, style):
+        """gamma/beta of every AdaIN of the decoder (two batched launches over ~40 MB of fc weights): depends on the style
+        vector only, so the caller can run it beside the predictors instead of at the head of the decoder."""
+        W, p = self.W, self.p
+        mel_style = style[:, :256].contiguous()
+        gbs = adain_fc_batch(W, [p + ".encode"] + [f"{p}.decode.{i}" for i in (0, 1, 2)], style)
+        gbs.update(adain_fc_batch(W, [f"{p}.decode.{i}" for i in (3, 4, 5)], mel_style))
+        return gbs
+
+    def forward_packed(self, asr_up, lay2, style, f0, n, ema, out=None, gbs=None):
         """asr_up: [C][2M-frames] (already nearest-x2, models.py:500)."""
         W, p = self.W, self.p
         C = asr_up.shape[0]
@@ -502,8 +511,8 @@ class Decoder(_Module):
         conv1d(W, p + ".EMA_conv", ema, lay2, 1, Y=x0[C + 64:C + 128])
         bott = 2 * C
         cat_a, cat_b = lay2.new(bott + 64 + 128), lay2.new(bott + 64 + 128)
-        gbs = adain_fc_batch(W, [p + ".encode"] + [f"{p}.decode.{i}" for i in (0, 1, 2)], style)
-        gbs.update(adain_fc_batch(W, [f"{p}.decode.{i}" for i in (3, 4, 5)], mel_style))
+        if gbs is None:
+            gbs = self.adain_params(style)
         adain_resblk1d(W, p + ".encode", x0, lay2, style, out=cat_a[:bott], gb=gbs[p + ".encode"], fork_shortcut=True)
         conv1d(W, p + ".asr_res.0", asr_up, lay2, 1, Y=cat_a[bott:bott + 64])
         cat_a[bott + 64:].copy_(x0[C:])
@@ -670,15 +679,16 @@ class ArtsSpeech(_Module):
         dur_i, frame_off, tof = ops.durations(duration.reshape(-1), forced, tok_lay, lay1.N)
         # The text encoder feeds only the decoder: it is deferred to run beside the articulatory predictors, whose
         # three branches and sequential LSTM recurrences leave most of the chip idle (critical path: scripts/phase_bench.py).
-        with Fork(side_streams(dev, 1, "text_encoder")) as side:
+        with Fork(side_streams(dev, 1, "text_encoder"), uses=(style,)) as side:
             with side(0):
                 t_en = self.text_encoder.forward_packed(tok, tok_lay)
+                dec_gbs = self.decoder.adain_params(style)                   # style-only work of the decoder, off its critical path
             C = a_en.shape[0]
             a_ex = ops.expand(a_en, tof, lay1.N, 1, lay1.new(C))
             f0, n, ema, lay2 = self.artsPredictor.forward_packed(a_ex, lay1, style)
-            side.produced(t_en)
+            side.produced(t_en, *[t for v in dec_gbs.values() for t in v])
         t_up = ops.expand(t_en, tof, lay1.N, 2, lay2.new(C))
-        mel = self.decoder.forward_packed(t_up, lay2, style, f0, n, ema)
+        mel = self.decoder.forward_packed(t_up, lay2, style, f0, n, ema, gbs=dec_gbs)
         return dict(mel=mel, lay2=lay2, lay1=lay1, t_en=t_en, a_en=a_en, feat12=feat12, style=style,
                     duration=duration, dur_i=dur_i, F0=f0, N=n, EMA=ema)
 
