@@ -301,13 +301,16 @@ static int launch_x6d(const ConvGemmArgs& a, int S, hipStream_t stream)
     return AS_OK;
 }
 
+#ifndef LSTAGE12
+#define LSTAGE12 2          // (three 37 KB stages on the 64x128 tile leave one workgroup per CU: 249 -> 313 us on M64 N509440 K64 T9)
+#endif
 int as_conv_gemm_x6d_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream)
 {
     if ((double)(((a.Kp >> 4) + 3) & ~3) * 6.0 * (a.N + 1.0) * 16.0 >= 2147483648.0) return AS_EINVAL;   // 32-bit offsets in the descriptor
     switch (choice) {
     case 22: return launch_x6d<2, 2, 1, 3>(a, S, stream);    // 3 x 24.5 KB of LDS: two workgroups per CU
     case 21: return launch_x6d<2, 1, 2, 2>(a, S, stream);    // (a third 37 KB stage would leave one workgroup per CU)
-    case 12: return launch_x6d<1, 2, 2, 2>(a, S, stream);
+    case 12: return launch_x6d<1, 2, 2, LSTAGE12>(a, S, stream);
     default: return AS_EINVAL;
     }
 }
