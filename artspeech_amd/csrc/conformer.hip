@@ -95,23 +95,37 @@ xl_attention_kernel(const float* __restrict__ qkv, int ld, int C, const float* _
         __syncthreads();
         // ---- scores: lane = key
         const int kj = k0 + lane;
-        float sc[4], sp[4];
+        // content and position sums; the position term of query q uses q's own vector for keys at or before it (e < T) and the
+        // NEXT query's for the wrapped entries (e > T): both sums run (five broadcast rows serve the wave's four queries), the
+        // lane picks one at the end.  Q rows are read four d at a time (one ds_read_b128 per row and four d).
+        float sc[4], sa[4], sb[4];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) { sc[qq] = 0.f; sp[qq] = 0.f; }
-        bool wrap[4];
+        for (int qq = 0; qq < 4; ++qq) { sc[qq] = 0.f; sa[qq] = 0.f; sb[qq] = 0.f; }
+#pragma unroll 2
+        for (int d = 0; d < XDK; d += 4) {
+            float4 qu[4], qv[5];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) wrap[qq] = (T - 1 - (q0 + wave * 4 + qq) + kj) > T;
-#pragma unroll 4
-        for (int d = 0; d < XDK; ++d) {
-            const float kv = Ks[d * XPAD + lane];
+            for (int qq = 0; qq < 4; ++qq) qu[qq] = *reinterpret_cast<const float4*>(Qu + (wave * 4 + qq) * XDK + d);
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int q = wave * 4 + qq;
-                sc[qq] += Qu[q * XDK + d] * kv;
-                const float qsel = wrap[qq] ? Qv[(q + 1) * XDK + d] : Qv[q * XDK + d];
-                sp[qq] += qsel * Pe[d * XPP + (XQT - 1 - q) + lane];
+            for (int qq = 0; qq < 5; ++qq) qv[qq] = *reinterpret_cast<const float4*>(Qv + (wave * 4 + qq) * XDK + d);
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const float kv = Ks[(d + dd) * XPAD + lane];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float pe = Pe[(d + dd) * XPP + (XQT - 1 - (wave * 4 + qq)) + lane];
+                    const float u = dd == 0 ? qu[qq].x : dd == 1 ? qu[qq].y : dd == 2 ? qu[qq].z : qu[qq].w;
+                    const float va = dd == 0 ? qv[qq].x : dd == 1 ? qv[qq].y : dd == 2 ? qv[qq].z : qv[qq].w;
+                    const float vb = dd == 0 ? qv[qq + 1].x : dd == 1 ? qv[qq + 1].y : dd == 2 ? qv[qq + 1].z : qv[qq + 1].w;
+                    sc[qq] += u * kv;
+                    sa[qq] += va * pe;
+                    sb[qq] += vb * pe;
+                }
             }
         }
+        float sp[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) sp[qq] = (T - 1 - (q0 + wave * 4 + qq) + kj) > T ? sb[qq] : sa[qq];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             float s = (sc[qq] + sp[qq]) * inv_scale;
