@@ -116,6 +116,7 @@ def conv1d(W, name, X, lay, k, Y=None, **kw):
 import os as _os
 
 SHORTCUT_FORK = _os.environ.get("AS_SHORTCUT_FORK", "0") != "0"     # experiment (no gain measured): 1x1 shortcut on a side stream
+TOWER_BRANCHES = int(_os.environ.get("AS_TOWER_BRANCHES", "1"))     # streams for the TV / F0 / energy towers (1: back to back on one)
 ADAIN_SPLIT = _os.environ.get("AS_ADAIN_SPLIT", "1") != "0"         # AdaIN writes the following conv's pre-split operand image
 
 
@@ -537,11 +538,13 @@ class Decoder(_Module):
 _STREAMS = {}
 
 
-def side_streams(device, n, tag=""):
-    key = str(device) + "/" + tag
+def side_streams(device, n, tag="", priorities=None):
+    """n pooled side streams; priorities: per-stream HIP priority (-1 = high) -- part of the pool key."""
+    key = str(device) + "/" + tag + ("/" + ",".join(str(p) for p in priorities) if priorities else "")
     pool = _STREAMS.setdefault(key, [])
     while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=device))
+        pr = priorities[len(pool)] if priorities else 0
+        pool.append(torch.cuda.Stream(device=device, priority=pr))
     return pool[:n]
 
 
@@ -655,18 +658,26 @@ class ArtsSpeech(_Module):
         # Measured on MI355X (bench.py, C3): 3 branches (all towers in one) 9.35 ms, 4 branches 8.89 ms, 5 branches
         # (TV tower on its own too) 9.76 ms.  Stream-to-stream edges between side streams crash hipGraph instantiation
         # on ROCm 7.2, so every branch forks from / joins the caller.
+        # Re-measured at the end of round 1 (scripts/phase_bench.py, each case its own hipGraph): the branches alone take
+        # 1.02 + 1.81 + 0.98 + 1.67 = 5.5 ms, together 4.1 ms (one graph queue: 5.6; two: 4.35; four or eight: 4.1): most of
+        # their kernels fill the 256 CUs on their own, so overlap only hides the small ones.  More queues with more branches
+        # (GPU_MAX_HW_QUEUES=8, TV / F0 / energy towers on three streams: 12 ms per step), high-priority streams for the
+        # small-kernel branches (10.4 ms) and the mel tower before / after / beside the others (+-0.1 ms) do not help.
         se = self.style_encoder
         feat = torch.cat([feat12, mel_p[:, : feat12.shape[1]]], dim=0).contiguous()
         ti = se.tower_inputs(feat, ref_lay)
-        with Fork(side_streams(dev, 4), uses=(feat12, feat, ti["c"], ti["mel_img"], ti["ema_img"])) as side:
+        nb = TOWER_BRANCHES
+        with Fork(side_streams(dev, 3 + nb), uses=(feat12, feat, ti["c"], ti["mel_img"], ti["ema_img"])) as side:
             with side(0):
                 a_en = self.arts_encoder.forward_packed(tok, tok_lay)
             with side(1):
                 s_mel = se.tower("mel", ti)
             with side(2):
-                s_rest = [se.tower(w, ti) for w in ("ema", "f0", "energy")]
-            with side(3):
                 duration = self.durationPredictor.forward_packed(tok, tok_lay, feat12[2:12], ref_lay)
+            s_rest = [None, None, None]
+            for i, w in enumerate(("ema", "f0", "energy")):
+                with side(3 + i % nb):
+                    s_rest[i] = se.tower(w, ti)
             side.produced(a_en, s_mel, duration, *s_rest)
         style = torch.cat([s_mel] + s_rest, dim=1).contiguous()
         if frames_hint is None:

@@ -16,10 +16,14 @@ models.CONCURRENT = False
 out = net.forward_packed(g["tok"], g["tok_lay"], g["mel"], g["f0"], g["ema"], g["ref_lay"], forced=g["forced"], frames_hint=g["frames"])
 torch.cuda.synchronize()
 feat12, style = out["feat12"], out["style"]
+FEAT = torch.cat([feat12, g["mel"][:, : feat12.shape[1]]], dim=0).contiguous()
+TI = net.style_encoder.tower_inputs(FEAT, g["ref_lay"])
 case = os.environ.get("CASE", "dur")
 fn = {"dur": lambda: net.durationPredictor.forward_packed(g["tok"], g["tok_lay"], feat12[2:12], g["ref_lay"]),
       "arts": lambda: net.arts_encoder.forward_packed(g["tok"], g["tok_lay"]),
       "dec": lambda: net.decoder.forward_packed(ops.expand(out["t_en"], ops.durations(out["duration"].reshape(-1), g["forced"], g["tok_lay"], out["lay1"].N)[2], out["lay1"].N, 2, out["lay2"].new(512)), out["lay2"], style, out["F0"], out["N"], out["EMA"]),
+      "towers": lambda: [net.style_encoder.tower(w, TI) for w in ("ema", "f0", "energy")],
+      "mel": lambda: net.style_encoder.tower("mel", TI),
       }[case]
 fn(); torch.cuda.synchronize()
 L = _lib.lib()

@@ -25,29 +25,45 @@ a_ex = ops.expand(a_en, tof, lay1.N, 1, lay1.new(C))
 t_up = ops.expand(t_en, tof, lay1.N, 2, lay2.new(C))
 f0, n, ema = out["F0"], out["N"], out["EMA"]
 
-def style_branch():
-    feat = torch.cat([feat12, g["mel"][:, : feat12.shape[1]]], dim=0).contiguous()
-    return net.style_encoder.style_extractor_packed(feat, g["ref_lay"])
+se = net.style_encoder
+feat = torch.cat([feat12, g["mel"][:, : feat12.shape[1]]], dim=0).contiguous()
+ti = se.tower_inputs(feat, g["ref_lay"])
+torch.cuda.synchronize()
 
-def phase_a():
-    f12 = net.style_encoder.features_packed(g["mel"], g["f0"], g["ema"], g["ref_lay"], stats24)
-    with Fork(side_streams(dev, 4), uses=(f12,)) as side:
-        with side(0): a = net.text_encoder.forward_packed(g["tok"], g["tok_lay"])
-        with side(1): b = net.arts_encoder.forward_packed(g["tok"], g["tok_lay"])
-        with side(2):
-            feat = torch.cat([f12, g["mel"][:, : f12.shape[1]]], dim=0).contiguous()
-            c = net.style_encoder.style_extractor_packed(feat, g["ref_lay"])
-        with side(3): d = net.durationPredictor.forward_packed(g["tok"], g["tok_lay"], f12[2:12], g["ref_lay"])
-        side.produced(a, b, c, d)
+
+def phase1():
+    with Fork(side_streams(dev, 4), uses=(feat12, feat, ti["c"], ti["mel_img"], ti["ema_img"])) as side:
+        with side(0): a = net.arts_encoder.forward_packed(g["tok"], g["tok_lay"])
+        with side(1): b = se.tower("mel", ti)
+        with side(2): c = [se.tower(w, ti) for w in ("ema", "f0", "energy")]
+        with side(3): d = net.durationPredictor.forward_packed(g["tok"], g["tok_lay"], feat12[2:12], g["ref_lay"])
+        side.produced(a, b, d, *c)
     return a, b, c, d
 
+
+def phase2():
+    with Fork(side_streams(dev, 1, "text_encoder"), uses=(style,)) as side:
+        with side(0):
+            t = net.text_encoder.forward_packed(g["tok"], g["tok_lay"])
+            gb = net.decoder.adain_params(style)
+        r = net.artsPredictor.forward_packed(a_ex, lay1, style)
+        side.produced(t, *[x for v in gb.values() for x in v])
+    return t, r, gb
+
+
 cases = {
-    "phase A (4 concurrent branches)": phase_a,
-    "  text_encoder alone": lambda: net.text_encoder.forward_packed(g["tok"], g["tok_lay"]),
-    "  style towers alone": style_branch,
+    "phase 1 (4 concurrent branches)": phase1,
+    "  arts encoder alone": lambda: net.arts_encoder.forward_packed(g["tok"], g["tok_lay"]),
+    "  mel tower alone": lambda: se.tower("mel", ti),
+    "  TV + F0 + energy towers alone": lambda: [se.tower(w, ti) for w in ("ema", "f0", "energy")],
+    "    TV tower alone": lambda: se.tower("ema", ti),
+    "    F0 tower alone": lambda: se.tower("f0", ti),
+    "    energy tower alone": lambda: se.tower("energy", ti),
     "  duration predictor alone": lambda: net.durationPredictor.forward_packed(g["tok"], g["tok_lay"], feat12[2:12], g["ref_lay"]),
-    "phase B (predictor: 3 branches + LSTM)": lambda: net.artsPredictor.forward_packed(a_ex, lay1, style),
-    "phase C (decoder)": lambda: net.decoder.forward_packed(t_up, lay2, style, f0, n, ema),
+    "phase 2 (text encoder || predictor)": phase2,
+    "  text encoder (+ decoder AdaIN fc) alone": lambda: (net.text_encoder.forward_packed(g["tok"], g["tok_lay"]), net.decoder.adain_params(style)),
+    "  predictor alone (3 branches + LSTM)": lambda: net.artsPredictor.forward_packed(a_ex, lay1, style),
+    "phase 3 (decoder)": lambda: net.decoder.forward_packed(t_up, lay2, style, f0, n, ema),
     "whole step": lambda: net.forward_packed(g["tok"], g["tok_lay"], g["mel"], g["f0"], g["ema"], g["ref_lay"], forced=g["forced"], frames_hint=g["frames"]),
 }
 sel = os.environ.get('CASE')
