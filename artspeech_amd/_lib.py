@@ -38,7 +38,8 @@ class ConvGemmArgs(ctypes.Structure):
                 ("act", ctypes.c_int32), ("div_sqrt2", ctypes.c_int32), ("in_act", ctypes.c_int32),
                 ("transpose_out", ctypes.c_int32), ("quad_ok", ctypes.c_int32),
                 ("dh", ctypes.c_int32 * AS_MAX_TAPS), ("dw", ctypes.c_int32 * AS_MAX_TAPS),
-                ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float)]
+                ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float),
+                ("W2", ctypes.c_void_p), ("Wx2", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("n_split", ctypes.c_int32)]
 
 
 _SIGNATURES.update({
@@ -47,6 +48,9 @@ _SIGNATURES.update({
     "as_conv_gemm_workspace_bytes": (c_sz, [ctypes.POINTER(ConvGemmArgs)]),
     "as_split_bf16x3_bytes": (c_sz, [c_i, c_i]),
     "as_split_bf16x3_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "as_embed_groups_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
+    "as_channel_layernorm_groups_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_i, c_p]),
+    "as_relpos_attention_groups_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, c_p]),
     "as_embed_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "as_channel_layernorm_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_i, c_p]),
     "as_adain_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),

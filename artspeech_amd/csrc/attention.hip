@@ -39,9 +39,12 @@ static __device__ __forceinline__ float wsum(float v)
 
 __global__ void __launch_bounds__(256)
 relpos_attention_kernel(const float* __restrict__ qkv, int ld, int C, int heads, int window,
-                        const float* __restrict__ emb_k, const float* __restrict__ emb_v,
-                        const int* __restrict__ col_off, float* __restrict__ out, int ldo)
+                        const float* __restrict__ emb_k1, const float* __restrict__ emb_v1, const float* __restrict__ emb_k2,
+                        const float* __restrict__ emb_v2, int b_split, const int* __restrict__ col_off, float* __restrict__ out, int ldo)
 {
+    const bool second = emb_k2 && (int)blockIdx.z >= b_split;           // utterances >= b_split: the second encoder's tables
+    const float* emb_k = second ? emb_k2 : emb_k1;
+    const float* emb_v = second ? emb_v2 : emb_v1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int dk = C / heads;
     const int nrel = 2 * window + 1;
@@ -173,9 +176,13 @@ relpos_attention_kernel(const float* __restrict__ qkv, int ld, int C, int heads,
 #define SPAD 65
 template <int DK>
 __global__ void __launch_bounds__(256)
-relpos_attention_small_kernel(const float* __restrict__ qkv, int ld, int C, int window, const float* __restrict__ emb_k,
-                              const float* __restrict__ emb_v, const int* __restrict__ col_off, float* __restrict__ out, int ldo)
+relpos_attention_small_kernel(const float* __restrict__ qkv, int ld, int C, int window, const float* __restrict__ emb_k1,
+                              const float* __restrict__ emb_v1, const float* __restrict__ emb_k2, const float* __restrict__ emb_v2,
+                              int b_split, const int* __restrict__ col_off, float* __restrict__ out, int ldo)
 {
+    const bool second = emb_k2 && (int)blockIdx.y >= b_split;
+    const float* emb_k = second ? emb_k2 : emb_k1;
+    const float* emb_v = second ? emb_v2 : emb_v1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Ks = sm;                              // [DK][SPAD]   (reused for the output transpose)
     float* Vs = Ks + DK * SPAD;                  // [DK][SPAD]
@@ -296,10 +303,11 @@ relpos_attention_small_kernel(const float* __restrict__ qkv, int ld, int C, int 
     }
 }
 
-extern "C" int as_relpos_attention_f32(const float* qkv, int ld, int C, int heads, int window, const float* emb_rel_k,
-                                       const float* emb_rel_v, const int32_t* col_off, int B, int max_len, float* out,
-                                       int ldo, as_stream_t stream)
+extern "C" int as_relpos_attention_groups_f32(const float* qkv, int ld, int C, int heads, int window, const float* emb_rel_k,
+                                              const float* emb_rel_v, const float* emb_rel_k2, const float* emb_rel_v2, int b_split,
+                                              const int32_t* col_off, int B, int max_len, float* out, int ldo, as_stream_t stream)
 {
+    if ((emb_rel_k2 == nullptr) != (emb_rel_v2 == nullptr)) return AS_EINVAL;
     if (!qkv || !emb_rel_k || !emb_rel_v || !col_off || !out || C <= 0 || heads <= 0 || C % heads) return AS_EINVAL;
     const int dk = C / heads;
     if (dk > MAXDK || 2 * window + 1 > MAXREL || window < 0 || B < 0) return AS_EINVAL;
@@ -314,7 +322,7 @@ extern "C" int as_relpos_attention_f32(const float* qkv, int ld, int C, int head
         }
         AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
         hipLaunchKernelGGL(relpos_attention_small_kernel<128>, dim3(heads, B), dim3(256), sm_small, (hipStream_t)stream, qkv, ld, C,
-                           window, emb_rel_k, emb_rel_v, col_off, out, ldo);
+                           window, emb_rel_k, emb_rel_v, emb_rel_k2, emb_rel_v2, b_split, col_off, out, ldo);
         AS_CHECK_LAUNCH();
         return AS_OK;
     }
@@ -327,7 +335,15 @@ extern "C" int as_relpos_attention_f32(const float* qkv, int ld, int C, int head
     }
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(relpos_attention_kernel, dim3(as_cdiv(max_len, QT), heads, B), dim3(256), smem, (hipStream_t)stream,
-                       qkv, ld, C, heads, window, emb_rel_k, emb_rel_v, col_off, out, ldo);
+                       qkv, ld, C, heads, window, emb_rel_k, emb_rel_v, emb_rel_k2, emb_rel_v2, b_split, col_off, out, ldo);
     AS_CHECK_LAUNCH();
     return AS_OK;
+}
+
+extern "C" int as_relpos_attention_f32(const float* qkv, int ld, int C, int heads, int window, const float* emb_rel_k,
+                                       const float* emb_rel_v, const int32_t* col_off, int B, int max_len, float* out,
+                                       int ldo, as_stream_t stream)
+{
+    return as_relpos_attention_groups_f32(qkv, ld, C, heads, window, emb_rel_k, emb_rel_v, nullptr, nullptr, 0, col_off, B, max_len, out,
+                                          ldo, stream);
 }

@@ -60,8 +60,9 @@ template <int TM, int TN, bool DIV, int ACT, bool TR>
 static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int rbase, int cbase,
                                                       int l31)
 {
-    const __amdgpu_buffer_rsrc_t rsB =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
+    // (cbase is 64-aligned inside a tile that starts at a multiple of 64 and n_split is a multiple of 128: a wave's columns are all on one side)
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>((a.n_split > 0 && cbase >= a.n_split) ? a.bias2 : a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.res), 0, a.res ? (int)((unsigned)a.M * a.ldr * 4u) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY =

@@ -85,7 +85,7 @@ conv_gemm_quad_kernel(const ConvGemmArgs a)
     const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
 
     const __amdgpu_buffer_rsrc_t rsW =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, (int)((unsigned)a.T * a.Kp * a.M * 4u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((a.n_split > 0 && n0 >= a.n_split) ? a.W2 : a.W), 0, (int)((unsigned)a.T * a.Kp * a.M * 4u), 0x00020000);
     // X descriptor starts 16 bytes in front of X (quad_ok promises they are readable): a quad whose first column
     // is masked may start at column -1..-4 of row 0 without its offset wrapping
     const __amdgpu_buffer_rsrc_t rsX =
@@ -234,7 +234,7 @@ conv_gemm_kernel(const ConvGemmArgs a)
     const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
 
     const __amdgpu_buffer_rsrc_t rsW =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, (int)((unsigned)a.T * a.Kp * a.M * 4u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((a.n_split > 0 && n0 >= a.n_split) ? a.W2 : a.W), 0, (int)((unsigned)a.T * a.Kp * a.M * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((unsigned)a.K * a.ldx * 4u), 0x00020000);
 
@@ -455,7 +455,7 @@ __global__ void splitk_reduce_kernel(const ConvGemmArgs a, int S)
         const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
         float v = 0.f;
         for (int s = 0; s < S; ++s) v += a.ws[(size_t)s * total + i];
-        if (a.bias) v += a.bias[row];
+        if (a.bias) v += ((a.n_split > 0 && col >= a.n_split) ? a.bias2 : a.bias)[row];
         if (a.res) v += a.res[(size_t)row * a.ldr + col];
         if (a.div_sqrt2) v = v / 1.41421356237309504880f;
         if (a.act == 1) v = v > 0.f ? v : 0.f;
@@ -579,7 +579,7 @@ static GemmPlan gemm_plan(const ConvGemmArgs& a, bool have_ws_for_xs)
 {
     GemmPlan p = {};
     p.x6 = use_x6(a);
-    const bool taps3 = p.x6 && as_conv_gemm_x6t_ktiles(a) > 0;
+    const bool taps3 = p.x6 && a.n_split == 0 && as_conv_gemm_x6t_ktiles(a) > 0;     // (the tap-shared kernel has no second weight set)
     if (p.x6) {
         const char* env = getenv("AS_GEMM_X6D");          // tuning/experiments only: 0 never, 1 whenever the kernel can
         const int mode = env ? atoi(env) : -1;
@@ -624,6 +624,7 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     const ConvGemmArgs& a = norm;
     if ((!a.W && !a.Wx) || (!a.X && !(a.Xs && a.Wx)) || !a.Y || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS) return AS_EINVAL;
     if (a.Kp < a.K || a.Kp % BK) return AS_EINVAL;
+    if (a.n_split < 0 || (a.n_split > 0 && (a.n_split % 128 || (a.W && !a.W2) || (a.Wx && !a.Wx2) || (a.bias && !a.bias2) || a.K == 1))) return AS_EINVAL;
     if (a.ldx < a.N || a.ldy < (a.transpose_out ? a.M : a.N) || (a.res && (a.ldr < a.N || a.transpose_out))) return AS_EINVAL;
     // 32-bit byte offsets inside the buffer descriptors
     if ((double)a.T * (a.Kp + 48) * a.M * 6.0 >= 4294967296.0 || (double)a.K * a.ldx * 4.0 + 16.0 >= 4294967296.0) return AS_EINVAL;

@@ -110,7 +110,7 @@ conv_gemm_x6_kernel(const ConvGemmArgs a, const X6Taps tp)
     const int KBx = (KB + 3) & ~3;                                       // k-blocks per tap in the image (zero padded)
 
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(a.Wx), 0, X6_EXP_W((int)((unsigned)a.T * KBx * 6u * a.M * 16u)), 0x00020000);
+        const_cast<uint16_t*>((a.n_split > 0 && n0 >= a.n_split) ? a.Wx2 : a.Wx), 0, X6_EXP_W((int)((unsigned)a.T * KBx * 6u * a.M * 16u)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, X6_EXP_X((int)((unsigned)a.K * a.ldx * 4u)), 0x00020000);
 

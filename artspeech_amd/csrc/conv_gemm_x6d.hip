@@ -62,7 +62,7 @@ conv_gemm_x6d_kernel(const ConvGemmArgs a, const X6Taps tp)
     const int NX = a.N + 1;                                              // columns of the activation image (the last one is zero)
 
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(a.Wx), 0, (int)((unsigned)a.T * KBx * 6u * a.M * 16u), 0x00020000);
+        const_cast<uint16_t*>((a.n_split > 0 && n0 >= a.n_split) ? a.Wx2 : a.Wx), 0, (int)((unsigned)a.T * KBx * 6u * a.M * 16u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.Xs), 0, (int)((unsigned)KBx * 6u * NX * 16u), 0x00020000);
 

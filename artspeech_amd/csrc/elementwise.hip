@@ -45,27 +45,35 @@ extern "C" int as_make_meta(const int32_t* widths, const int32_t* col_off, int B
 // ---------------------------------------------------------------------------------------------------
 // Embedding * sqrt(C), transposed to [C][N]   (RelTransformerEnc.py:373-374)
 // ---------------------------------------------------------------------------------------------------
-__global__ void embed_kernel(const int* __restrict__ tok, const float* __restrict__ emb, int C, int N, int V,
-                             float scale, float* __restrict__ y, int ldy)
+// (emb2, n_split: columns >= n_split take their rows from a second table -- two encoders run as one double-width launch)
+__global__ void embed_kernel(const int* __restrict__ tok, const float* __restrict__ emb, const float* __restrict__ emb2, int n_split,
+                             int C, int N, int V, float scale, float* __restrict__ y, int ldy)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (j >= N) return;
     int t = tok[j];
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-    y[(size_t)c * ldy + j] = emb[(size_t)t * C + c] * scale;
+    const float* e = (emb2 && j >= n_split) ? emb2 : emb;
+    y[(size_t)c * ldy + j] = e[(size_t)t * C + c] * scale;
+}
+
+extern "C" int as_embed_groups_f32(const int32_t* tokens, const float* emb, const float* emb2, int n_split, int C, int N, int V,
+                                   float scale, float* y, int ldy, as_stream_t stream)
+{
+    if (!tokens || !emb || !y || C <= 0 || N < 0 || V <= 0 || ldy < N) return AS_EINVAL;
+    if (N == 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(embed_kernel, dim3(as_cdiv(N, 64), C), dim3(64), 0, (hipStream_t)stream, tokens, emb, emb2, n_split, C, N, V,
+                       scale, y, ldy);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
 }
 
 extern "C" int as_embed_f32(const int32_t* tokens, const float* emb, int C, int N, int V, float scale, float* y,
                             int ldy, as_stream_t stream)
 {
-    if (!tokens || !emb || !y || C <= 0 || N < 0 || V <= 0 || ldy < N) return AS_EINVAL;
-    if (N == 0) return AS_OK;
-    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(embed_kernel, dim3(as_cdiv(N, 64), C), dim3(64), 0, (hipStream_t)stream, tokens, emb, C, N, V,
-                       scale, y, ldy);
-    AS_CHECK_LAUNCH();
-    return AS_OK;
+    return as_embed_groups_f32(tokens, emb, nullptr, 0, C, N, V, scale, y, ldy, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -77,13 +85,17 @@ extern "C" int as_embed_f32(const int32_t* tokens, const float* emb, int C, int 
 #define LN_PARTS 32
 #define LN_MAXV 16
 __global__ void __launch_bounds__(1024)
-channel_ln_kernel(const float* __restrict__ x, int ldx, int C, int N, const float* __restrict__ gamma,
-                  const float* __restrict__ beta, float eps, int relu, float* __restrict__ y, int ldy)
+channel_ln_kernel(const float* __restrict__ x, int ldx, int C, int N, const float* __restrict__ gamma1,
+                  const float* __restrict__ beta1, const float* __restrict__ gamma2, const float* __restrict__ beta2, int n_split,
+                  float eps, int relu, float* __restrict__ y, int ldy)
 {
     __shared__ float red[LN_PARTS][LN_COLS + 1];
     const int col = threadIdx.x % LN_COLS, part = threadIdx.x / LN_COLS;
     const int j = blockIdx.x * LN_COLS + col;
     const bool ok = j < N;
+    const bool second = gamma2 && j >= n_split;          // columns >= n_split: the second encoder's affine parameters
+    const float* gamma = second ? gamma2 : gamma1;
+    const float* beta = second ? beta2 : beta1;
     float v[LN_MAXV];
     float s = 0.f;
 #pragma unroll
@@ -134,16 +146,23 @@ channel_ln_kernel(const float* __restrict__ x, int ldx, int C, int N, const floa
     }
 }
 
-extern "C" int as_channel_layernorm_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta,
-                                        float eps, int relu, float* y, int ldy, as_stream_t stream)
+extern "C" int as_channel_layernorm_groups_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta,
+                                               const float* gamma2, const float* beta2, int n_split, float eps, int relu, float* y,
+                                               int ldy, as_stream_t stream)
 {
-    if (!x || !y || !gamma || !beta || C <= 0 || N < 0 || ldx < N || ldy < N) return AS_EINVAL;
+    if (!x || !y || !gamma || !beta || C <= 0 || N < 0 || ldx < N || ldy < N || ((gamma2 == nullptr) != (beta2 == nullptr))) return AS_EINVAL;
     if (N == 0) return AS_OK;
     AsProfScope prof__(AS_CLS_LN, 8.0 * C * N, 8.0 * C * N, (hipStream_t)stream);
     hipLaunchKernelGGL(channel_ln_kernel, dim3(as_cdiv(N, LN_COLS)), dim3(1024), 0, (hipStream_t)stream, x, ldx, C, N, gamma,
-                       beta, eps, relu, y, ldy);
+                       beta, gamma2, beta2, n_split, eps, relu, y, ldy);
     AS_CHECK_LAUNCH();
     return AS_OK;
+}
+
+extern "C" int as_channel_layernorm_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta,
+                                        float eps, int relu, float* y, int ldy, as_stream_t stream)
+{
+    return as_channel_layernorm_groups_f32(x, ldx, C, N, gamma, beta, nullptr, nullptr, 0, eps, relu, y, ldy, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

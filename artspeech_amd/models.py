@@ -116,6 +116,7 @@ def conv1d(W, name, X, lay, k, Y=None, **kw):
 import os as _os
 
 SHORTCUT_FORK = _os.environ.get("AS_SHORTCUT_FORK", "0") != "0"     # experiment (no gain measured): 1x1 shortcut on a side stream
+ENC_PAIR = _os.environ.get("AS_ENC_PAIR", "1") != "0"               # text + articulatory encoders as one double-width encoder
 TOWER_BRANCHES = int(_os.environ.get("AS_TOWER_BRANCHES", "1"))     # streams for the TV / F0 / energy towers (1: back to back on one)
 ADAIN_SPLIT = _os.environ.get("AS_ADAIN_SPLIT", "1") != "0"         # AdaIN writes the following conv's pre-split operand image
 
@@ -204,33 +205,61 @@ def bilstm_many(W, items, lay):
     return ops.bilstm(jobs, lay, H)
 
 
-def rel_encoder(W, p, tokens_i32, lay, n_layers):
-    """RelTransformerEncoder.forward (RelTransformerEnc.py:371-380) on packed tokens -> [C][N]."""
+def rel_encoder(W, p, tokens_i32, lay, n_layers, p2=None, n_split=0, b_split=0):
+    """RelTransformerEncoder.forward (RelTransformerEnc.py:371-380) on packed tokens -> [C][N].
+    p2: a SECOND encoder of the same shape (the text and articulatory encoders are twins on the same tokens) whose weights
+    serve the columns >= n_split / utterances >= b_split of `lay`: both run as one double-width launch sequence."""
     emb = W.vec(p + ".emb.weight")
     C = emb.shape[1]
-    x = ops.embed(tokens_i32, emb, math.sqrt(C), lay.new(C))
+    pair = p2 is not None
+
+    def g_conv(name):                       # second weight set of a conv (conv1d's group2=)
+        return (W.conv(p2 + name), W.bias(p2 + name), n_split) if pair else None
+
+    def g_ln(name):
+        return (W.vec(f"{p2}{name}.gamma"), W.vec(f"{p2}{name}.beta"), n_split) if pair else None
+
+    x = ops.embed(tokens_i32, emb, math.sqrt(C), lay.new(C), group2=(W.vec(p2 + ".emb.weight"), n_split) if pair else None)
     h = x
     for i in range(3):                                                    # ConvReluNorm :318-325
-        h = conv1d(W, f"{p}.pre.conv_layers.{i}", h, lay, 5)
+        h = conv1d(W, f"{p}.pre.conv_layers.{i}", h, lay, 5, group2=g_conv(f".pre.conv_layers.{i}"))
         h = ops.channel_layernorm(h, lay.N, W.vec(f"{p}.pre.norm_layers.{i}.gamma"),
-                                  W.vec(f"{p}.pre.norm_layers.{i}.beta"), lay.new(C), relu=True)
-    x = conv1d(W, p + ".pre.proj", h, lay, 1, res=x)
+                                  W.vec(f"{p}.pre.norm_layers.{i}.beta"), lay.new(C), relu=True, group2=g_ln(f".pre.norm_layers.{i}"))
+    x = conv1d(W, p + ".pre.proj", h, lay, 1, res=x, group2=g_conv(".pre.proj"))
     e = p + ".encoder"
     for i in range(n_layers):                                             # Encoder.forward :66-90
         y = ops.channel_layernorm(x, lay.N, W.vec(f"{e}.norm_layers_1.{i}.gamma"), W.vec(f"{e}.norm_layers_1.{i}.beta"),
-                                  lay.new(C))
+                                  lay.new(C), group2=g_ln(f".encoder.norm_layers_1.{i}"))
         a = f"{e}.attn_layers.{i}"
         wqkv, bqkv = W.qkv(a)
-        qkv = ops.conv_gemm(wqkv, y, lay, lay.new(3 * C), [(0, 0)], bias=bqkv)
-        att = ops.relpos_attention(qkv, C, N_HEADS, WINDOW, W.vec(a + ".emb_rel_k"), W.vec(a + ".emb_rel_v"), lay,
-                                   lay.new(C))
-        x = conv1d(W, a + ".conv_o", att, lay, 1, res=x)
+        a2 = f"{p2}.encoder.attn_layers.{i}" if pair else None
+        qkv = ops.conv_gemm(wqkv, y, lay, lay.new(3 * C), [(0, 0)], bias=bqkv, group2=W.qkv(a2) + (n_split,) if pair else None)
+        att = ops.relpos_attention(qkv, C, N_HEADS, WINDOW, W.vec(a + ".emb_rel_k"), W.vec(a + ".emb_rel_v"), lay, lay.new(C),
+                                   group2=(W.vec(a2 + ".emb_rel_k"), W.vec(a2 + ".emb_rel_v"), b_split) if pair else None)
+        x = conv1d(W, a + ".conv_o", att, lay, 1, res=x, group2=g_conv(f".encoder.attn_layers.{i}.conv_o"))
         y = ops.channel_layernorm(x, lay.N, W.vec(f"{e}.norm_layers_2.{i}.gamma"), W.vec(f"{e}.norm_layers_2.{i}.beta"),
-                                  lay.new(C))
+                                  lay.new(C), group2=g_ln(f".encoder.norm_layers_2.{i}"))
         f = f"{e}.ffn_layers.{i}"
-        y = conv1d(W, f + ".conv_1", y, lay, 9, act=ACT_RELU)
-        x = conv1d(W, f + ".conv_2", y, lay, 1, res=x)
-    return ops.channel_layernorm(x, lay.N, W.vec(e + ".last_ln.gamma"), W.vec(e + ".last_ln.beta"), lay.new(C))
+        y = conv1d(W, f + ".conv_1", y, lay, 9, act=ACT_RELU, group2=g_conv(f".encoder.ffn_layers.{i}.conv_1"))
+        x = conv1d(W, f + ".conv_2", y, lay, 1, res=x, group2=g_conv(f".encoder.ffn_layers.{i}.conv_2"))
+    return ops.channel_layernorm(x, lay.N, W.vec(e + ".last_ln.gamma"), W.vec(e + ".last_ln.beta"), lay.new(C),
+                                 group2=g_ln(".encoder.last_ln"))
+
+
+def rel_encoder_pair(W, p1, p2, tokens_i32, lay, n_layers):
+    """Two encoders of the same shape on the same tokens (text_encoder / arts_encoder, models.py:358-359) as ONE double-width
+    encoder: the tokens are laid out twice, [utterances | filler up to a multiple of 128 columns | utterances], and every kernel
+    picks its parameter set by column (ConvGemmArgs.n_split, the *_groups_* entry points).  Half the launches, twice the columns
+    per launch.  Returns (out1, out2), views [C][N] of the double-width result."""
+    dev = tokens_i32.device
+    lens = [int(v) for v in lay.widths_host]
+    N = lay.N
+    pad = (-N) % 128
+    fill = [pad] if pad else []
+    lay2 = layout(lens + fill + lens, dev)
+    tok2 = torch.cat([tokens_i32[:N], tokens_i32.new_zeros(pad), tokens_i32[:N]])
+    y = rel_encoder(W, p1, tok2, lay2, n_layers, p2=p2, n_split=N + pad, b_split=len(lens) + len(fill))
+    return y[:, :N], y[:, N + pad: 2 * N + pad]
 
 
 def resblk_down(W, p, X, lay, kind, one_d=False):
@@ -669,7 +698,10 @@ class ArtsSpeech(_Module):
         nb = TOWER_BRANCHES
         with Fork(side_streams(dev, 3 + nb), uses=(feat12, feat, ti["c"], ti["mel_img"], ti["ema_img"])) as side:
             with side(0):
-                a_en = self.arts_encoder.forward_packed(tok, tok_lay)
+                if ENC_PAIR:
+                    a_en, t_en = rel_encoder_pair(self.W, "arts_encoder", "text_encoder", tok, tok_lay, 4)
+                else:
+                    a_en, t_en = self.arts_encoder.forward_packed(tok, tok_lay), None
             with side(1):
                 s_mel = se.tower("mel", ti)
             with side(2):
@@ -679,6 +711,8 @@ class ArtsSpeech(_Module):
                 with side(3 + i % nb):
                     s_rest[i] = se.tower(w, ti)
             side.produced(a_en, s_mel, duration, *s_rest)
+            if t_en is not None:
+                side.produced(t_en)
         style = torch.cat([s_mel] + s_rest, dim=1).contiguous()
         if frames_hint is None:
             dur_i, frame_off, _ = ops.durations(duration.reshape(-1), forced, tok_lay, 0)
@@ -692,7 +726,8 @@ class ArtsSpeech(_Module):
         # three branches and sequential LSTM recurrences leave most of the chip idle (critical path: scripts/phase_bench.py).
         with Fork(side_streams(dev, 1, "text_encoder"), uses=(style,)) as side:
             with side(0):
-                t_en = self.text_encoder.forward_packed(tok, tok_lay)
+                if t_en is None:
+                    t_en = self.text_encoder.forward_packed(tok, tok_lay)
                 dec_gbs = self.decoder.adain_params(style)                   # style-only work of the decoder, off its critical path
             C = a_en.shape[0]
             a_ex = ops.expand(a_en, tof, lay1.N, 1, lay1.new(C))

@@ -179,7 +179,7 @@ def adain_split(X, gb, lay, lrelu=True):
 
 
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
-              use_meta=True, in_slope=0.0, act_slope=0.0, xs=None, K=None):
+              use_meta=True, in_slope=0.0, act_slope=0.0, xs=None, K=None, group2=None):
     """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt [T][Kp][M] (prep_weight: K zero-padded to a multiple
     of 16); X [K][*]; Y [M][*] (or [N][*] transposed).  xs: split_act(X, lay, in_act, in_slope), when several convs
     share X."""
@@ -197,6 +197,12 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     x6 = getattr(Wt, "x6", None) if GEMM_IMPL == "x6" else None
     a.Wx = _p(x6)
     a.Xs = _p(xs) if x6 is not None else None
+    if group2 is not None:                           # (Wt2, bias2, n_split): columns >= n_split use the second layer's weights
+        Wt2, bias2, n_split = group2
+        if Wt2.shape != Wt.shape or (bias is None) != (bias2 is None) or n_split % 128:
+            raise ValueError("conv_gemm: the second weight set must match the first; n_split a multiple of 128")
+        a.W2, a.bias2, a.n_split = _p(Wt2), _p(bias2), n_split
+        a.Wx2 = _p(getattr(Wt2, "x6", None)) if x6 is not None else None
     a.meta = _p(lay.meta) if (use_meta and not (T == 1 and taps[0] == (0, 0))) else None
     a.M, a.N, a.K, a.T = M, lay.N, K, T
     a.ldx, a.ldy = (_ld(X) if X is not None else lay.N), _ld(Y)
@@ -217,16 +223,20 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     return Y
 
 
-def embed(tokens_i32, emb, scale, Y):
+def embed(tokens_i32, emb, scale, Y, group2=None):
+    """group2 = (emb2, n_split): token columns >= n_split look their rows up in the second table."""
     V, C = emb.shape
-    check(_lib.lib().as_embed_f32(_p(tokens_i32), _p(emb), C, tokens_i32.numel(), V, scale, _p(Y), _ld(Y), stream()),
-          "as_embed_f32")
+    emb2, n_split = group2 if group2 is not None else (None, 0)
+    check(_lib.lib().as_embed_groups_f32(_p(tokens_i32), _p(emb), _p(emb2), n_split, C, tokens_i32.numel(), V, scale, _p(Y), _ld(Y),
+                                         stream()), "as_embed_groups_f32")
     return Y
 
 
-def channel_layernorm(X, N, gamma, beta, Y, relu=False, eps=1e-4):
-    check(_lib.lib().as_channel_layernorm_f32(_p(X), _ld(X), X.shape[0], N, _p(gamma), _p(beta), eps, int(relu), _p(Y),
-                                              _ld(Y), stream()), "as_channel_layernorm_f32")
+def channel_layernorm(X, N, gamma, beta, Y, relu=False, eps=1e-4, group2=None):
+    """group2 = (gamma2, beta2, n_split): columns >= n_split use the second affine pair."""
+    g2, b2, n_split = group2 if group2 is not None else (None, None, 0)
+    check(_lib.lib().as_channel_layernorm_groups_f32(_p(X), _ld(X), X.shape[0], N, _p(gamma), _p(beta), _p(g2), _p(b2), n_split, eps,
+                                                     int(relu), _p(Y), _ld(Y), stream()), "as_channel_layernorm_groups_f32")
     return Y
 
 
@@ -334,9 +344,12 @@ def mean_pool(X, lay, lrelu, y=None):
     return y
 
 
-def relpos_attention(qkv, C, heads, window, ek, ev, lay, out):
-    check(_lib.lib().as_relpos_attention_f32(_p(qkv), _ld(qkv), C, heads, window, _p(ek), _p(ev), _p(lay.col_off), lay.B,
-                                             lay.max_w, _p(out), _ld(out), stream()), "as_relpos_attention_f32")
+def relpos_attention(qkv, C, heads, window, ek, ev, lay, out, group2=None):
+    """group2 = (ek2, ev2, b_split): utterances >= b_split use the second pair of relative-position tables."""
+    ek2, ev2, b_split = group2 if group2 is not None else (None, None, 0)
+    check(_lib.lib().as_relpos_attention_groups_f32(_p(qkv), _ld(qkv), C, heads, window, _p(ek), _p(ev), _p(ek2), _p(ev2), b_split,
+                                                    _p(lay.col_off), lay.B, lay.max_w, _p(out), _ld(out), stream()),
+          "as_relpos_attention_groups_f32")
     return out
 
 

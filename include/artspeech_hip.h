@@ -112,6 +112,12 @@ typedef struct ConvGemmArgs {
     int32_t dh[AS_MAX_TAPS];   /* tap row offsets (scalar-loadable) */
     int32_t dw[AS_MAX_TAPS];   /* tap column offsets */
     float in_slope, act_slope; /* LeakyReLU slopes of in_act / act; 0 = the path's 0.2 */
+    /* Two layers of the same shape as ONE launch (the text and articulatory encoders, RelTransformerEnc.py: identical
+     * stacks on the same tokens): columns >= n_split use the second weight set.  n_split = 0: off; else a multiple of 128. */
+    const float* W2;
+    const uint16_t* Wx2;
+    const float* bias2;
+    int32_t n_split;
 } ConvGemmArgs;
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
 /* Bytes of workspace this shape wants (0 = none).  Shapes whose tile grid cannot fill the 256 CUs are split along
@@ -131,6 +137,15 @@ int as_split_bf16x3_f32(const float* x, int ldx, int K, int N, int in_act, float
 /* emb(x)*sqrt(C), transposed to [C][N]      RelTransformerEnc.py:373-374 */
 int as_embed_f32(const int32_t* tokens, const float* emb, int C, int N, int V, float scale, float* y, int ldy,
                  as_stream_t stream);
+/* the *_groups_* variants: columns >= n_split (utterances >= b_split) take the SECOND parameter set -- two encoders of the same
+ * shape run as one double-width launch (ConvGemmArgs.n_split is the GEMM's counterpart); NULL second set = the plain call */
+int as_embed_groups_f32(const int32_t* tokens, const float* emb, const float* emb2, int n_split, int C, int N, int V, float scale,
+                        float* y, int ldy, as_stream_t stream);
+int as_channel_layernorm_groups_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta, const float* gamma2,
+                                    const float* beta2, int n_split, float eps, int relu, float* y, int ldy, as_stream_t stream);
+int as_relpos_attention_groups_f32(const float* qkv, int ld, int C, int heads, int window, const float* emb_rel_k,
+                                   const float* emb_rel_v, const float* emb_rel_k2, const float* emb_rel_v2, int b_split,
+                                   const int32_t* col_off, int B, int max_len, float* out, int ldo, as_stream_t stream);
 /* channel LayerNorm (eps 1e-4) (+ReLU)       RelTransformerEnc.py:272-290, :322-323 */
 int as_channel_layernorm_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta, float eps,
                              int relu, float* y, int ldy, as_stream_t stream);

@@ -41,6 +41,20 @@ def phase1():
     return a, b, c, d
 
 
+tok2 = torch.cat([g["tok"], g["tok"]]).contiguous()
+lay2x = ops.layout(list(g["tok_lay"].widths_host) * 2, dev)
+
+
+def phase1_wide():                          # what a grouped (text + articulatory) double-width encoder would cost in phase 1
+    with Fork(side_streams(dev, 4), uses=(feat12, feat, ti["c"], ti["mel_img"], ti["ema_img"])) as side:
+        with side(0): a = net.arts_encoder.forward_packed(tok2, lay2x)
+        with side(1): b = se.tower("mel", ti)
+        with side(2): c = [se.tower(w, ti) for w in ("ema", "f0", "energy")]
+        with side(3): d = net.durationPredictor.forward_packed(g["tok"], g["tok_lay"], feat12[2:12], g["ref_lay"])
+        side.produced(a, b, d, *c)
+    return a, b, c, d
+
+
 def phase2():
     with Fork(side_streams(dev, 1, "text_encoder"), uses=(style,)) as side:
         with side(0):
@@ -63,6 +77,8 @@ cases = {
     "phase 2 (text encoder || predictor)": phase2,
     "  text encoder (+ decoder AdaIN fc) alone": lambda: (net.text_encoder.forward_packed(g["tok"], g["tok_lay"]), net.decoder.adain_params(style)),
     "  predictor alone (3 branches + LSTM)": lambda: net.artsPredictor.forward_packed(a_ex, lay1, style),
+    "phase 1 with a double-width encoder": phase1_wide,
+    "  double-width encoder alone": lambda: net.arts_encoder.forward_packed(tok2, lay2x),
     "phase 3 (decoder)": lambda: net.decoder.forward_packed(t_up, lay2, style, f0, n, ema),
     "whole step": lambda: net.forward_packed(g["tok"], g["tok_lay"], g["mel"], g["f0"], g["ema"], g["ref_lay"], forced=g["forced"], frames_hint=g["frames"]),
 }

@@ -190,3 +190,20 @@ def test_pipeline_surface(cuda, golden_dir):
     assert float((solo[0] - out[1, :, : solo.shape[2]]).abs().max()) <= 5e-5
     with pytest.raises(NotImplementedError):
         tts.synthesis("hello", "ref.wav", "out.wav")
+
+
+def test_paired_encoders_equal_separate(cuda):
+    """rel_encoder_pair (text + articulatory encoders as one double-width launch sequence, per-column parameter sets) against the two
+    encoders run one after the other, on a ragged batch whose column count needs the 128-column filler."""
+    from artspeech_amd import models, synth
+    from artspeech_amd.weights import fold_state_dict
+    W = models.Weights(fold_state_dict(synth.synth_state_dict(64, 8, seed=3407)), cuda)
+    lens = [40, 17, 5, 33]
+    lay = models.layout(lens, cuda)
+    tok = torch.from_numpy(np.concatenate([synth.synth_tokens(n, 3 + i) for i, n in enumerate(lens)])).to(device=cuda, dtype=torch.int32)
+    a1 = models.rel_encoder(W, "arts_encoder", tok, lay, 4)
+    t1 = models.rel_encoder(W, "text_encoder", tok, lay, 4)
+    a2, t2 = models.rel_encoder_pair(W, "arts_encoder", "text_encoder", tok, lay, 4)
+    assert a2.shape == a1[:, : lay.N].shape and float((a2 - a1[:, : lay.N]).abs().max()) <= 2e-5
+    assert float((t2 - t1[:, : lay.N]).abs().max()) <= 2e-5
+    assert float((a1[:, : lay.N] - t1[:, : lay.N]).abs().max()) > 1e-3          # (the two encoders do differ)
