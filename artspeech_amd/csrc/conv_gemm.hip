@@ -543,10 +543,19 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice, bool x6)
     int s = 1;
     if (env && atoi(env) > 0) s = atoi(env);
     else if (x6) {
+        const double gflop = 2e-9 * M * N * (double)Kp * T;
         if (tiles < 256) {
             s = as_cdiv(512, tiles);
             const int cap = (long)M * N >= 262144 ? 4 : 16;
             if (s > cap) s = cap;
+            // more than half the CUs busy already and a short GEMM: the reduce pass (~9 us + a launch) costs more than the
+            // slices gain (M512 N2560 K1024: 28 us unsplit, 32 us in two slices)
+            if (tiles >= 128 && gflop < 3.0) s = 1;
+        } else if (tiles < 384 && gflop >= 12.0) {
+            // 256-383 tiles leave the second round of workgroups mostly empty (two fit a CU: 512 slots); a long GEMM is
+            // worth slicing for that alone (M1024 N2560 K512 T9, 320 tiles: 172 us unsplit, 145 us in four slices; with
+            // 400 tiles and more the slices only add their overhead)
+            s = 4;
         }
     } else if (tiles < 1000) {
         s = as_cdiv(1200, tiles);
