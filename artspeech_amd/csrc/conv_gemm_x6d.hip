@@ -39,12 +39,21 @@ struct X6dPlan {                                        // staging pieces of one
 // the iteration that issued it (measured: a lone workgroup then waits ~270 of its ~1 200 cycles per k-tile at the
 // barrier); with three the tile is read during it + 2 and the end-of-iteration wait is vmcnt(this iteration's DMAs),
 // i.e. only for the PREVIOUS iteration's.  Three stages of the 128x128 tile are 74 KB: two workgroups per CU still fit.
-template <int WM, int WN, int WK, int NS>
-__global__ void __launch_bounds__(64 * WM * WN * WK)
+//
+// OCC ("occupancy") variant: no software pipelining of the fragments at all -- an iteration reads its 12 fragments from
+// the landed stage, issues the LDS-DMA of the NEXT tile into the other stage and multiplies; one fragment set instead of two
+// keeps a wave under 170 registers, so THREE workgroups share a CU (two stages of the 128x128 tile are 49 KB) and cover each
+// other's fragment latency and barriers, where the pipelined variant covers them inside one workgroup with twice the registers.
+// Measured on MI355X (AS_X6D_OCC=1, kernel alone): 5-8 % SLOWER than the three-stage pipelined variant on every shape tried
+// (M1024 N6400 K1024 T3: 244 vs 233 us; M128 N128000 K128 T9, four workgroups per CU available: 205 vs 189 us), so it stays an
+// experiment: hiding latency inside the workgroup beats hiding it with occupancy here.
+template <int WM, int WN, int WK, int NS, bool OCC = false>
+__global__ void __launch_bounds__(64 * WM * WN * WK, OCC ? 3 : 1)
 conv_gemm_x6d_kernel(const ConvGemmArgs a, const X6Taps tp)
 {
     using C = X6Cfg<WM, WN, WK>;
     static_assert(NS == 2 || NS == 3, "stages");
+    static_assert(!OCC || NS == 2, "the occupancy variant has two stages");
     constexpr int BM = C::BM, BN = C::BN, ACH = C::ACH, NT = C::NT;
     constexpr int BCH = WK * 6 * BN / NT;                                // 16-byte activation chunks per thread per k-tile
     static_assert((NT == 256 || NT == 512) && ACH * NT == WK * 6 * BM && BCH * NT == WK * 6 * BN, "tile shape");
@@ -171,8 +180,8 @@ conv_gemm_x6d_kernel(const ConvGemmArgs a, const X6Taps tp)
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
     using I0 = std::integral_constant<int, 0>;
-    // prologue: tiles 0 .. NS-1 staged, fragments of tile 0 in set 0
-    for (int st = 0; st < NS; ++st) {
+    // prologue: tiles 0 .. NS-1 staged, fragments of tile 0 in set 0 (OCC: tile 0 staged, nothing read yet)
+    for (int st = 0; st < (OCC ? 1 : NS); ++st) {
         tap_word();
         tap_byte();
         tap_col();
@@ -181,8 +190,10 @@ conv_gemm_x6d_kernel(const ConvGemmArgs a, const X6Taps tp)
         advance(c_t, c_kb);
     }
     __syncthreads();
-    x6_for<0, 12>([&](auto q_) { read_frag(q_, I0{}, 0); });
-    __syncthreads();          // every wave holds its fragments of tile 0 before the first iteration restages stage 0
+    if constexpr (!OCC) {
+        x6_for<0, 12>([&](auto q_) { read_frag(q_, I0{}, 0); });
+        __syncthreads();      // every wave holds its fragments of tile 0 before the first iteration restages stage 0
+    }
 
     using PL = X6dPlan<ACH, BCH>;
     // iteration `it`: stage P = it % NS holds tile it, whose fragments are in register set F = it % 2; the fragments of
@@ -192,10 +203,10 @@ conv_gemm_x6d_kernel(const ConvGemmArgs a, const X6Taps tp)
         if constexpr (M == PL::M_TAP0) tap_word();
         else if constexpr (M == PL::M_TAP1) tap_byte();
         else if constexpr (M == PL::M_TAP2) tap_col();
-        else if constexpr (M < PL::M_DMA_B) dma_a(std::integral_constant<int, M - PL::M_DMA_A>{}, P);
-        else if constexpr (M < PL::M_ADV) dma_b(std::integral_constant<int, M - PL::M_DMA_B>{}, P);
+        else if constexpr (M < PL::M_DMA_B) dma_a(std::integral_constant<int, M - PL::M_DMA_A>{}, OCC ? PN : P);
+        else if constexpr (M < PL::M_ADV) dma_b(std::integral_constant<int, M - PL::M_DMA_B>{}, OCC ? PN : P);
         else if constexpr (M == PL::M_ADV) advance(c_t, c_kb);
-        else read_frag(std::integral_constant<int, M - PL::M_FR>{}, std::integral_constant<int, F ^ 1>{}, PN);
+        else if constexpr (!OCC) read_frag(std::integral_constant<int, M - PL::M_FR>{}, std::integral_constant<int, F ^ 1>{}, PN);
     };
     // MFMA n of the iteration: six groups of four, smallest terms first: (A part, B part) = (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
     auto step = [&](auto n_, auto p_, auto f_) {
@@ -212,9 +223,11 @@ conv_gemm_x6d_kernel(const ConvGemmArgs a, const X6Taps tp)
     // end of an iteration: the tile the NEXT iteration reads fragments from has landed (this wave's share) and everybody
     // is done with the stage the next iteration restages.  Not __syncthreads(): its fence waits for vmcnt(0).
     constexpr int PEND = NS == 2 ? 0 : ACH + BCH;                      // LDS-DMAs that may stay in flight across the barrier
+    // OCC: this iteration's fragments first, in the order the MFMAs want them (weights h, activations l, ...)
 #define X6D_ITER(U)                                                                                               \
     {                                                                                                             \
-        x6_for<0, 24>([&](auto n_) { step(n_, std::integral_constant<int, (U) % NS>{}, std::integral_constant<int, (U) % 2>{}); }); \
+        if constexpr (OCC) x6_for<0, 12>([&](auto q_) { read_frag(q_, I0{}, (U) % 2); });                         \
+        x6_for<0, 24>([&](auto n_) { step(n_, std::integral_constant<int, (U) % NS>{}, std::integral_constant<int, OCC ? 0 : (U) % 2>{}); }); \
         X6_BAR_BEGIN                                                                                              \
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PEND) : "memory");                       \
         X6_BAR_END                                                                                                \
@@ -282,21 +295,21 @@ conv_gemm_x6d_kernel(const ConvGemmArgs a, const X6Taps tp)
     X6_STAMPS_OUT
 }
 
-template <int WM, int WN, int WK, int NS>
+template <int WM, int WN, int WK, int NS, bool OCC = false>
 static int launch_x6d(const ConvGemmArgs& a, int S, hipStream_t stream)
 {
     using C = X6Cfg<WM, WN, WK>;
     constexpr int LDS = NS * C::STAGE > C::RED ? NS * C::STAGE : C::RED;
     static bool attr_set = false;
     if (!attr_set) {
-        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6d_kernel<WM, WN, WK, NS>),
+        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6d_kernel<WM, WN, WK, NS, OCC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     X6Taps tp;
     if (x6_pack_taps(a, &tp) != AS_OK) return AS_EINVAL;
     const dim3 grid(as_cdiv(a.M, C::BM) * as_cdiv(a.N, C::BN), S);
-    hipLaunchKernelGGL((conv_gemm_x6d_kernel<WM, WN, WK, NS>), grid, dim3(C::NT), LDS, stream, a, tp);
+    hipLaunchKernelGGL((conv_gemm_x6d_kernel<WM, WN, WK, NS, OCC>), grid, dim3(C::NT), LDS, stream, a, tp);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
@@ -308,7 +321,9 @@ int as_conv_gemm_x6d_launch(const ConvGemmArgs& a, int choice, int S, hipStream_
 {
     if ((double)(((a.Kp >> 4) + 3) & ~3) * 6.0 * (a.N + 1.0) * 16.0 >= 2147483648.0) return AS_EINVAL;   // 32-bit offsets in the descriptor
     switch (choice) {
-    case 22: return launch_x6d<2, 2, 1, 3>(a, S, stream);    // 3 x 24.5 KB of LDS: two workgroups per CU
+    case 22:
+        if (getenv("AS_X6D_OCC")) return launch_x6d<2, 2, 1, 2, true>(a, S, stream);   // experiment: three workgroups per CU, no fragment pipelining
+        return launch_x6d<2, 2, 1, 3>(a, S, stream);    // 3 x 24.5 KB of LDS: two workgroups per CU
     case 21: return launch_x6d<2, 1, 2, 2>(a, S, stream);    // (a third 37 KB stage would leave one workgroup per CU)
     case 12: return launch_x6d<1, 2, 2, LSTAGE12>(a, S, stream);
     default: return AS_EINVAL;
