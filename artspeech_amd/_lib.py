@@ -50,6 +50,7 @@ _SIGNATURES.update({
     "as_split_bf16x3_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "as_embed_groups_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "as_channel_layernorm_groups_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_i, c_p]),
+    "as_channel_layernorm_split_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_p]),
     "as_relpos_attention_groups_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, c_p]),
     "as_embed_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "as_channel_layernorm_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_i, c_p]),

@@ -473,3 +473,107 @@ extern "C" int as_adain_split_f32(const float* x, int ldx, int C, const float* g
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// Channel LayerNorm (+ReLU) written DIRECTLY as the split image: in the encoders the LayerNorm output feeds nothing but the
+// following conv (RelTransformerEnc.py:72-87: norm_layers_1 -> attention's q/k/v convs, norm_layers_2 -> the FFN's first
+// conv; :321-323 the prenet).  Same arithmetic as channel_ln_kernel (elementwise.hip: two-pass statistics over the channel
+// axis, per-part partial sums reduced in the same order), but a thread owns 8 CONSECUTIVE channels per register group --
+// one 16-byte row of the image -- instead of channels strided by 32.  Columns >= n_split take the second affine pair.
+// ----------------------------------------------------------------------------------------------------------------
+#define LNS_COLS 32
+#define LNS_PARTS 32
+#define LNS_MAXG 4                       // 8-channel groups per thread held in registers: C <= 8 * 32 * 4 = 1024
+__global__ void __launch_bounds__(1024)
+channel_ln_split_kernel(const float* __restrict__ x, int ldx, int C, int N, const float* __restrict__ gamma1,
+                        const float* __restrict__ beta1, const float* __restrict__ gamma2, const float* __restrict__ beta2, int n_split,
+                        float eps, int relu, u32x4* __restrict__ xs, int KBx)
+{
+    __shared__ float red[LNS_PARTS][LNS_COLS + 1];
+    const int col = threadIdx.x % LNS_COLS, part = threadIdx.x / LNS_COLS;
+    const int j = blockIdx.x * LNS_COLS + col;
+    const bool ok = j < N;
+    const bool second = gamma2 && j >= n_split;
+    const float* gamma = second ? gamma2 : gamma1;
+    const float* beta = second ? beta2 : beta1;
+    const int ngroups = 2 * KBx;                                         // 8-channel groups of the image (zero beyond C)
+    float v[LNS_MAXG][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNS_MAXG; ++i)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c = 8 * (part + i * LNS_PARTS) + r;
+            v[i][r] = (ok && c < C) ? x[(size_t)c * ldx + j] : 0.f;
+            s += v[i][r];
+        }
+    red[part][col] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < LNS_PARTS; ++q) tot += red[q][col];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNS_MAXG; ++i)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c = 8 * (part + i * LNS_PARTS) + r;
+            const float d = v[i][r] - mean;
+            if (c < C) q2 += d * d;
+        }
+    red[part][col] = q2;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < LNS_PARTS; ++q) tot += red[q][col];
+    const float rs = 1.0f / sqrtf(tot / (float)C + eps);
+    const size_t NX = (size_t)N + 1;
+    if (blockIdx.x == 0 && col == 0) {                                   // the zero column N of every plane this thread's groups own
+#pragma unroll
+        for (int i = 0; i < LNS_MAXG; ++i) {
+            const int g = part + i * LNS_PARTS;
+            if (g < ngroups)
+                for (int p = 0; p < 3; ++p) xs[((size_t)(g >> 1) * 6 + (g & 1) + 2 * p) * NX + N] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    if (!ok) return;
+#pragma unroll
+    for (int i = 0; i < LNS_MAXG; ++i) {
+        const int g = part + i * LNS_PARTS;
+        if (g >= ngroups) continue;
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c = 8 * g + r;
+            float o = 0.f;
+            if (c < C) {
+                o = (v[i][r] - mean) * rs * gamma[c] + beta[c];
+                if (relu) o = o > 0.f ? o : 0.f;
+            }
+            t[r] = o;
+        }
+        u32x4 h, m, l;
+        split3(t, h, m, l);
+        const size_t at = ((size_t)(g >> 1) * 6 + (g & 1)) * NX + j;
+        xs[at] = h;
+        xs[at + 2 * NX] = m;
+        xs[at + 4 * NX] = l;
+    }
+}
+
+extern "C" int as_channel_layernorm_split_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta,
+                                              const float* gamma2, const float* beta2, int n_split, float eps, int relu, uint16_t* xs,
+                                              as_stream_t stream)
+{
+    if (!x || !xs || !gamma || !beta || C <= 0 || C > 8 * LNS_PARTS * LNS_MAXG || N <= 0 || ldx < N ||
+        ((gamma2 == nullptr) != (beta2 == nullptr)) || (reinterpret_cast<uintptr_t>(xs) & 15) != 0)
+        return AS_EINVAL;
+    const int KBx = (((C + 15) >> 4) + 3) & ~3;
+    AsProfScope prof__(AS_CLS_LN, 8.0 * C * N, 10.0 * C * N, (hipStream_t)stream);
+    hipLaunchKernelGGL(channel_ln_split_kernel, dim3(as_cdiv(N, LNS_COLS)), dim3(1024), 0, (hipStream_t)stream, x, ldx, C, N, gamma, beta,
+                       gamma2, beta2, n_split, eps, relu, reinterpret_cast<u32x4*>(xs), KBx);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}

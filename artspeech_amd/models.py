@@ -116,6 +116,7 @@ def conv1d(W, name, X, lay, k, Y=None, **kw):
 import os as _os
 
 SHORTCUT_FORK = _os.environ.get("AS_SHORTCUT_FORK", "0") != "0"     # experiment (no gain measured): 1x1 shortcut on a side stream
+LN_SPLIT = _os.environ.get("AS_LN_SPLIT", "1") != "0"               # encoder LayerNorms write the following conv's pre-split operand image
 ENC_PAIR = _os.environ.get("AS_ENC_PAIR", "1") != "0"               # text + articulatory encoders as one double-width encoder
 TOWER_BRANCHES = int(_os.environ.get("AS_TOWER_BRANCHES", "1"))     # streams for the TV / F0 / energy towers (1: back to back on one)
 ADAIN_SPLIT = _os.environ.get("AS_ADAIN_SPLIT", "1") != "0"         # AdaIN writes the following conv's pre-split operand image
@@ -220,28 +221,38 @@ def rel_encoder(W, p, tokens_i32, lay, n_layers, p2=None, n_split=0, b_split=0):
         return (W.vec(f"{p2}{name}.gamma"), W.vec(f"{p2}{name}.beta"), n_split) if pair else None
 
     x = ops.embed(tokens_i32, emb, math.sqrt(C), lay.new(C), group2=(W.vec(p2 + ".emb.weight"), n_split) if pair else None)
-    h = x
-    for i in range(3):                                                    # ConvReluNorm :318-325
-        h = conv1d(W, f"{p}.pre.conv_layers.{i}", h, lay, 5, group2=g_conv(f".pre.conv_layers.{i}"))
-        h = ops.channel_layernorm(h, lay.N, W.vec(f"{p}.pre.norm_layers.{i}.gamma"),
-                                  W.vec(f"{p}.pre.norm_layers.{i}.beta"), lay.new(C), relu=True, group2=g_ln(f".pre.norm_layers.{i}"))
-    x = conv1d(W, p + ".pre.proj", h, lay, 1, res=x, group2=g_conv(".pre.proj"))
+    split = LN_SPLIT and ops.GEMM_IMPL == "x6"      # a LayerNorm here feeds only the next conv: store it as that conv's operand image
+
+    def ln_conv(xin, ln, relu, conv, k, **kw):
+        """conv(LayerNorm(xin)) -- the normalised activations exist only as the conv's pre-split operand when `split`."""
+        g, b = W.vec(f"{p}{ln}.gamma"), W.vec(f"{p}{ln}.beta")
+        if split:
+            xs_ = ops.channel_layernorm_split(xin, lay, g, b, relu=relu, group2=g_ln(ln))
+            return conv(None, xs=xs_, K=C, **kw)
+        return conv(ops.channel_layernorm(xin, lay.N, g, b, lay.new(C), relu=relu, group2=g_ln(ln)), **kw)
+
+    h = conv1d(W, f"{p}.pre.conv_layers.0", x, lay, 5, group2=g_conv(".pre.conv_layers.0"))                # ConvReluNorm :318-325
+    for i in range(3):
+        nxt = f".pre.conv_layers.{i + 1}" if i < 2 else ".pre.proj"
+        kk, extra = (5, {}) if i < 2 else (1, {"res": x})
+        h = ln_conv(h, f".pre.norm_layers.{i}", True,
+                    lambda X_, _n=nxt, _k=kk, **kw: conv1d(W, p + _n, X_, lay, _k, group2=g_conv(_n), **kw), kk, **extra)
+    x = h
     e = p + ".encoder"
     for i in range(n_layers):                                             # Encoder.forward :66-90
-        y = ops.channel_layernorm(x, lay.N, W.vec(f"{e}.norm_layers_1.{i}.gamma"), W.vec(f"{e}.norm_layers_1.{i}.beta"),
-                                  lay.new(C), group2=g_ln(f".encoder.norm_layers_1.{i}"))
         a = f"{e}.attn_layers.{i}"
         wqkv, bqkv = W.qkv(a)
         a2 = f"{p2}.encoder.attn_layers.{i}" if pair else None
-        qkv = ops.conv_gemm(wqkv, y, lay, lay.new(3 * C), [(0, 0)], bias=bqkv, group2=W.qkv(a2) + (n_split,) if pair else None)
+        qkv = ln_conv(x, f".encoder.norm_layers_1.{i}", False,
+                      lambda X_, **kw: ops.conv_gemm(wqkv, X_, lay, lay.new(3 * C), [(0, 0)], bias=bqkv,
+                                                     group2=W.qkv(a2) + (n_split,) if pair else None, **kw), 1)
         att = ops.relpos_attention(qkv, C, N_HEADS, WINDOW, W.vec(a + ".emb_rel_k"), W.vec(a + ".emb_rel_v"), lay, lay.new(C),
                                    group2=(W.vec(a2 + ".emb_rel_k"), W.vec(a2 + ".emb_rel_v"), b_split) if pair else None)
         x = conv1d(W, a + ".conv_o", att, lay, 1, res=x, group2=g_conv(f".encoder.attn_layers.{i}.conv_o"))
-        y = ops.channel_layernorm(x, lay.N, W.vec(f"{e}.norm_layers_2.{i}.gamma"), W.vec(f"{e}.norm_layers_2.{i}.beta"),
-                                  lay.new(C), group2=g_ln(f".encoder.norm_layers_2.{i}"))
-        f = f"{e}.ffn_layers.{i}"
-        y = conv1d(W, f + ".conv_1", y, lay, 9, act=ACT_RELU, group2=g_conv(f".encoder.ffn_layers.{i}.conv_1"))
-        x = conv1d(W, f + ".conv_2", y, lay, 1, res=x, group2=g_conv(f".encoder.ffn_layers.{i}.conv_2"))
+        f = f".encoder.ffn_layers.{i}"
+        y = ln_conv(x, f".encoder.norm_layers_2.{i}", False,
+                    lambda X_, _f=f, **kw: conv1d(W, p + _f + ".conv_1", X_, lay, 9, act=ACT_RELU, group2=g_conv(_f + ".conv_1"), **kw), 9)
+        x = conv1d(W, p + f + ".conv_2", y, lay, 1, res=x, group2=g_conv(f + ".conv_2"))
     return ops.channel_layernorm(x, lay.N, W.vec(e + ".last_ln.gamma"), W.vec(e + ".last_ln.beta"), lay.new(C),
                                  group2=g_ln(".encoder.last_ln"))
 

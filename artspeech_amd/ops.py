@@ -344,6 +344,18 @@ def mean_pool(X, lay, lrelu, y=None):
     return y
 
 
+def channel_layernorm_split(X, lay, gamma, beta, relu=False, eps=1e-4, group2=None):
+    """channel LayerNorm (+ReLU) of X [C][N] stored only as the pre-split operand image of the conv that follows
+    (conv_gemm(Wt, None, ..., xs=, K=C))."""
+    L = _lib.lib()
+    C = X.shape[0]
+    g2, b2, n_split = group2 if group2 is not None else (None, None, 0)
+    xs = torch.empty(max(L.as_split_bf16x3_bytes(C, lay.N) // 2, 8), dtype=torch.int16, device=X.device)
+    check(L.as_channel_layernorm_split_f32(_p(X), _ld(X), C, lay.N, _p(gamma), _p(beta), _p(g2), _p(b2), n_split, eps, int(relu), _p(xs),
+                                           stream()), "as_channel_layernorm_split_f32")
+    return xs
+
+
 def relpos_attention(qkv, C, heads, window, ek, ev, lay, out, group2=None):
     """group2 = (ek2, ev2, b_split): utterances >= b_split use the second pair of relative-position tables."""
     ek2, ev2, b_split = group2 if group2 is not None else (None, None, 0)

@@ -143,6 +143,10 @@ int as_embed_groups_f32(const int32_t* tokens, const float* emb, const float* em
                         float* y, int ldy, as_stream_t stream);
 int as_channel_layernorm_groups_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta, const float* gamma2,
                                     const float* beta2, int n_split, float eps, int relu, float* y, int ldy, as_stream_t stream);
+/* Channel LayerNorm (+ReLU) written as the bf16x6 operand image of the conv that follows (as_split_bf16x3_f32's layout; pass it as
+ * ConvGemmArgs.Xs): in the encoders a LayerNorm's output feeds nothing but that conv.  C <= 1024; second affine pair as above. */
+int as_channel_layernorm_split_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta, const float* gamma2,
+                                   const float* beta2, int n_split, float eps, int relu, uint16_t* xs, as_stream_t stream);
 int as_relpos_attention_groups_f32(const float* qkv, int ld, int C, int heads, int window, const float* emb_rel_k,
                                    const float* emb_rel_v, const float* emb_rel_k2, const float* emb_rel_v2, int b_split,
                                    const int32_t* col_off, int B, int max_len, float* out, int ldo, as_stream_t stream);

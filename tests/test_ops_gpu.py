@@ -141,6 +141,28 @@ def test_adain_split_equals_adain_then_split(cuda, C, lens):
     assert torch.equal(y0, y1)
 
 
+@pytest.mark.parametrize("C,lens,relu", [(512, [40, 33, 7], False), (64, [50, 1, 200], True), (1024, [17], False)])
+def test_layernorm_split_equals_layernorm_then_split(cuda, C, lens, relu):
+    """as_channel_layernorm_split_f32: the parts sum to the LayerNorm output (to summation order), layout as the split image,
+    second affine pair for the columns >= n_split."""
+    g = torch.Generator().manual_seed(C + len(lens))
+    lay = Layout(lens, cuda)
+    X = lay.new(C)
+    X.copy_(torch.randn(C, lay.N, generator=g) * 3 + 1)
+    ga, be = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+    ga2, be2 = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+    n_split = lay.N // 2
+    grp = (ga2, be2, n_split)
+    want = ops.channel_layernorm(X, lay.N, ga, be, lay.new(C), relu=relu, group2=grp)[:, : lay.N]
+    xs = ops.channel_layernorm_split(X, lay, ga, be, relu=relu, group2=grp)
+    kbx, nx = (C + 63) // 64 * 4, lay.N + 1
+    img = xs[: kbx * 6 * nx * 8].view(torch.bfloat16).reshape(kbx, 3, 2, nx, 8).float()
+    parts = img.permute(1, 0, 2, 4, 3).reshape(3, kbx * 16, nx)
+    assert not parts[:, :, lay.N].any() and not parts[:, C:].any()
+    got = parts[0, :C, : lay.N] + parts[1, :C, : lay.N] + parts[2, :C, : lay.N]
+    assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+
+
 def test_mfma_layout_asymmetric(cuda, impl):
     """A = I with an asymmetric B: catches a transposed C fragment (guide section 3)."""
     n = 64
