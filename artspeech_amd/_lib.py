@@ -29,25 +29,27 @@ AS_MAX_TAPS = 25
 
 
 class ConvGemmArgs(ctypes.Structure):
-    _fields_ = [("W", ctypes.c_void_p), ("Wx", ctypes.c_void_p), ("X", ctypes.c_void_p), ("Xs", ctypes.c_void_p), ("Y", ctypes.c_void_p), ("bias", ctypes.c_void_p),
-                ("res", ctypes.c_void_p), ("meta", ctypes.c_void_p),
+    _fields_ = [("Wh", ctypes.c_void_p), ("W", ctypes.c_void_p), ("X", ctypes.c_void_p), ("Xh", ctypes.c_void_p), ("Y", ctypes.c_void_p),
+                ("Yh", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p), ("meta", ctypes.c_void_p),
                 ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_size_t),
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("T", ctypes.c_int32),
                 ("Kp", ctypes.c_int32),
                 ("ldx", ctypes.c_int32), ("ldy", ctypes.c_int32), ("ldr", ctypes.c_int32),
                 ("act", ctypes.c_int32), ("div_sqrt2", ctypes.c_int32), ("in_act", ctypes.c_int32),
-                ("transpose_out", ctypes.c_int32), ("quad_ok", ctypes.c_int32),
+                ("transpose_out", ctypes.c_int32), ("yh_lrelu", ctypes.c_int32), ("n_prod", ctypes.c_int32),
                 ("dh", ctypes.c_int32 * AS_MAX_TAPS), ("dw", ctypes.c_int32 * AS_MAX_TAPS),
-                ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float),
-                ("W2", ctypes.c_void_p), ("Wx2", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("n_split", ctypes.c_int32)]
+                ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float), ("acc_scale", ctypes.c_float),
+                ("n_groups", ctypes.c_int32), ("group_cols", ctypes.c_int32)]
 
 
 _SIGNATURES.update({
     "as_make_meta": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "as_conv_gemm_f32": (c_i, [ctypes.POINTER(ConvGemmArgs), c_p]),
     "as_conv_gemm_workspace_bytes": (c_sz, [ctypes.POINTER(ConvGemmArgs)]),
-    "as_split_bf16x3_bytes": (c_sz, [c_i, c_i]),
-    "as_split_bf16x3_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "as_split_f16x2_bytes": (c_sz, [c_i, c_i]),
+    "as_split_f16x2_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "as_prep_weight_f16x2_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "as_prep_weight_f16x2_host": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "as_embed_groups_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "as_channel_layernorm_groups_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_i, c_p]),
     "as_channel_layernorm_split_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_p]),
@@ -127,4 +129,6 @@ def ptr(t):
 
 
 def stream():
+    """the current HIP stream of the current device.  Tensors of another device are rejected by device_guard (models.py runs
+    every forward under `torch.cuda.device(model device)`), so a launch never mixes a stream of one GPU with memory of another."""
     return torch.cuda.current_stream().cuda_stream

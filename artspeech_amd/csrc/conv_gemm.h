@@ -1,4 +1,5 @@
-// Internal pieces shared by the two conv-GEMM arithmetic paths (conv_gemm.hip: fp32 MFMA; conv_gemm_x6.hip: bf16x6).
+// Internal pieces of the conv GEMM (conv_gemm.hip: dispatch, split-K reduce, Cin = 1 direct kernel; conv_gemm_h3.hip: the
+// f16x3 matrix-core kernel and the writers of its operand images).
 #pragma once
 #include "artspeech_hip.h"
 #include "common.h"
@@ -6,23 +7,22 @@
 #define OOB 0xFFFFFFFFu
 #define OOBH 0x80000000u   /* epilogue: out of range for every descriptor (< 2 GiB, host-checked) even after adding an in-range offset */
 
-// host: launch the bf16x6 kernel for tile `choice` (22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64) on a grid of
-// (tiles, S); returns AS_OK or a hipError_t.  (conv_gemm_x6.hip)
-int as_conv_gemm_x6_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream);
-// host: the tap-shared bf16x6 kernel (conv_gemm_x6t.hip, tile 128x128): k-tiles it would run (0 = taps not in groups
-// of three consecutive column offsets), and its launch on a grid of (tiles, S)
-int as_conv_gemm_x6t_ktiles(const ConvGemmArgs& a);
-int as_conv_gemm_x6t_launch(const ConvGemmArgs& a, int S, hipStream_t stream);
+// host: launch the f16x3 kernel for tile `choice` (22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64; 4 waves each) on a
+// grid of (tiles, S); returns AS_OK or a hipError_t.  (conv_gemm_h3.hip)
+int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream);
+// host: the kernel that writes the split image of X (no profiling scope of its own)
+int as_split_f16x2_launch(const float* x, int ldx, int K, int N, int lrelu, float slope, uint16_t* xh, hipStream_t stream);
 
-// host: the bf16x6 kernel reading BOTH operands by LDS-DMA (conv_gemm_x6d.hip; a.Xs = pre-split activations; tiles 22, 21,
-// 12), and the launch of the kernel that makes that image (no profiling scope of its own)
-int as_conv_gemm_x6d_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream);
-int as_split_bf16x3_launch(const float* x, int ldx, int K, int N, int lrelu, float slope, uint16_t* xs, hipStream_t stream);
+static inline __host__ __device__ int as_kbx(int K) { return (((K + 15) >> 4) + 3) & ~3; }      // k-blocks of a split image: a multiple of 4
 
 #ifdef __HIPCC__
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 static __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
 {
@@ -41,13 +41,27 @@ static __device__ __forceinline__ int logical_tile()
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
 }
 
-// Accumulator tiles -> Y.  A 32x32 MFMA accumulator holds C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31];
-// a wave owns TM x TN of them at rows m0 + wm*32*TM, columns n0 + wn*32*TN.  S > 1: raw partial sums into this
-// slice's slab (splitk_reduce_kernel applies the epilogue).
-// Branch-free: every access is a raw BUFFER access whose per-lane offset carries the whole (row, column) position, so
-// rows >= M fall past the descriptor's end (loads return 0, stores are dropped by the range check) and columns >= N
-// get an out-of-range offset -- no exec-mask branches, no 64-bit address arithmetic per element (the branchy
-// version of this function took 20-40k cycles per 128x128 tile, a third of a small GEMM).
+// two fp32 -> (h, l) fp16 pairs with x = h + l to 22 bits: v_cvt_pk_f16_f32 (RNE), the residual is exact in fp32
+static __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l)
+{
+    const f32x2 v = {x0, x1};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);
+    const f32x2 r = v - __builtin_convertvector(hh, f32x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+// 8 fp32 (consecutive k of one column) -> two 16-byte rows of 8 fp16
+static __device__ __forceinline__ void split2(const float (&x)[8], u32x4_t& h, u32x4_t& l)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned hu, lu;
+        split2_pair(x[2 * e], x[2 * e + 1], hu, lu);
+        h[e] = hu;
+        l[e] = lu;
+    }
+}
+
 static __device__ __forceinline__ float div_sqrt2f(float x)
 {
     // x / sqrt(2), correctly rounded without the division sequence: q = x*(1/c), one Newton correction in fma
@@ -56,17 +70,75 @@ static __device__ __forceinline__ float div_sqrt2f(float x)
     return __builtin_fmaf(__builtin_fmaf(-q, c, x), rc, q);
 }
 
+template <int ACT>
+static __device__ __forceinline__ float epi_act(float x, float slope)
+{
+    if (ACT == 1) x = x > 0.f ? x : 0.f;
+    if (ACT == 2) x = x > 0.f ? x : slope * x;
+    if (ACT == 3) x = tanhf(x);
+    if (ACT == 4) x = fabsf(x);
+    if (ACT == 5) x = x / (1.0f + expf(-x));
+    return x;
+}
+
+// One 32x32 result tile as rows of the consumer's split image.  A lane holds column `col`, rows row0 + (e&3) + 8(e>>2) + 4 lk:
+// half of each of the tile's four 8-row groups.  v_permlane32_swap hands lane (col, lk = 0) the other half of groups 0 and 2
+// and lane (col, lk = 1) that of groups 1 and 3, so every lane stores whole 16-byte rows: 8 swaps, 4 stores per tile.
+static __device__ __forceinline__ void yh_store_tile(const ConvGemmArgs& a, __amdgpu_buffer_rsrc_t rsH, const float (&v)[16], int row0,
+                                                     int col, int lk)
+{
+    const unsigned NXy = (unsigned)a.N + 1u;
+    const int groups = 2 * as_kbx(a.M);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x0 = v[8 * pr + r], x1 = v[8 * pr + 4 + r];
+            if (a.yh_lrelu) {
+                x0 = x0 > 0.f ? x0 : a.in_slope * x0;
+                x1 = x1 > 0.f ? x1 : a.in_slope * x1;
+            }
+            const u32x2_t s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0), __builtin_bit_cast(unsigned, x1), false, false);
+            t[r] = __builtin_bit_cast(float, s[0]);
+            t[4 + r] = __builtin_bit_cast(float, s[1]);
+        }
+        u32x4_t h, l;
+        split2(t, h, l);
+        const int g = (row0 >> 3) + 2 * pr + lk;                        // 8-row group: k-block g / 2, k-half g % 2
+        const bool ok = col < a.N && g < groups;
+        const unsigned off = ok ? ((unsigned)((g >> 1) * 4 + (g & 1)) * NXy + (unsigned)col) * 16u : OOBH;
+        __builtin_amdgcn_raw_buffer_store_b128(h, rsH, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(l, rsH, off + 2u * NXy * 16u, 0, 0);
+        if (col == 0 && g < groups) {                                   // the zero column N, once per (group, part)
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            const unsigned offz = ((unsigned)((g >> 1) * 4 + (g & 1)) * NXy + (unsigned)a.N) * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(z, rsH, offz, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(z, rsH, offz + 2u * NXy * 16u, 0, 0);
+        }
+    }
+}
+
+// Accumulator tiles -> Y / Yh.  A 32x32 MFMA accumulator holds C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31];
+// a wave owns TM x TN of them at rows m0 + wm*32*TM, columns n0 + wn*32*TN.
+// Branch-free: every access is a raw BUFFER access whose per-lane offset carries the whole (row, column) position, so
+// rows >= M fall past the descriptor's end (loads return 0, stores are dropped by the range check) and columns >= N
+// get an out-of-range offset -- no exec-mask branches, no 64-bit address arithmetic per element.
 template <int TM, int TN, bool DIV, int ACT, bool TR>
 static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int rbase, int cbase,
-                                                      int l31)
+                                                      int l31, int lk)
 {
-    // (cbase is 64-aligned inside a tile that starts at a multiple of 64 and n_split is a multiple of 128: a wave's columns are all on one side)
+    // (cbase is 64-aligned inside a tile that starts at a multiple of 64 and group_cols is a multiple of 128: a wave's columns are all in one group)
+    const int grp = a.n_groups > 1 ? cbase / a.group_cols : 0;
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>((a.n_split > 0 && cbase >= a.n_split) ? a.bias2 : a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
+        const_cast<float*>(a.bias ? a.bias + (size_t)grp * a.M : nullptr), 0, a.bias ? a.M * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.res), 0, a.res ? (int)((unsigned)a.M * a.ldr * 4u) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY =
-        __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, (int)((unsigned)(TR ? a.N : a.M) * a.ldy * 4u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, a.Y ? (int)((unsigned)(TR ? a.N : a.M) * a.ldy * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(
+        a.Yh, 0, a.Yh ? (int)((unsigned)as_kbx(a.M) * 4u * ((unsigned)a.N + 1u) * 16u) : 0, 0x00020000);
+    const float sc = a.acc_scale;
     float bv[TM][16];                                      // loads first: Y may alias res, so program order is kept
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -95,15 +167,10 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float x = acc[i][jn][e] + bv[i][e];
+                float x = __builtin_fmaf(acc[i][jn][e], sc, bv[i][e]);
                 x += v[e];
                 if (DIV) x = div_sqrt2f(x);
-                if (ACT == 1) x = x > 0.f ? x : 0.f;
-                if (ACT == 2) x = x > 0.f ? x : a.act_slope * x;
-                if (ACT == 3) x = tanhf(x);
-                if (ACT == 4) x = fabsf(x);
-                if (ACT == 5) x = x / (1.0f + expf(-x));
-                v[e] = x;
+                v[e] = epi_act<ACT>(x, a.act_slope);
             }
             if (TR) {                                        // time-major output for the LSTM: Y[col][row], 4 rows = 16 bytes
                 const bool quad = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 && row0 + 28 <= a.M;
@@ -123,17 +190,20 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
                     }
                 }
             } else {
-                const unsigned off = col < a.N ? (unsigned)(row0 * a.ldy + col) * 4u : OOBH;
+                if (a.Y) {
+                    const unsigned off = col < a.N ? (unsigned)(row0 * a.ldy + col) * 4u : OOBH;
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rsY,
-                                                          off + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.ldy * 4), 0, 0);
+                    for (int e = 0; e < 16; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rsY,
+                                                              off + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.ldy * 4), 0, 0);
+                }
+                if (a.Yh) yh_store_tile(a, rsH, v, row0 - 4 * lk, col, lk);
             }
         }
     }
 }
 
-template <int TM, int TN, int AUX>
+template <int TM, int TN>
 static __device__ __forceinline__ void slab_store(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], __amdgpu_buffer_rsrc_t rs,
                                                   int rbase, int cbase, int l31)
 {
@@ -150,34 +220,31 @@ static __device__ __forceinline__ void slab_store(const ConvGemmArgs& a, const f
                 float t = acc[i][jn][e];
                 asm volatile("" : "+v"(t));
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rs,
-                                                      v0 + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.N * 4), 0, AUX);
+                                                      v0 + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.N * 4), 0, 0);
             }
         }
 }
 
 template <int TM, int TN>
 static __device__ __forceinline__ void epilogue_dispatch(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int rbase, int cbase,
-                                                         int l31)
+                                                         int l31, int lk)
 {
     // one lean copy per (divide, activation, transposed) combination the path uses
-    if (a.transpose_out) epilogue_tiles<TM, TN, false, 0, true>(a, acc, rbase, cbase, l31);
-    else if (a.div_sqrt2 && a.act == 0) epilogue_tiles<TM, TN, true, 0, false>(a, acc, rbase, cbase, l31);
-    else if (a.div_sqrt2 && a.act == 2) epilogue_tiles<TM, TN, true, 2, false>(a, acc, rbase, cbase, l31);
-    else if (a.div_sqrt2) epilogue_tiles<TM, TN, true, 1, false>(a, acc, rbase, cbase, l31);
-    else if (a.act == 0) epilogue_tiles<TM, TN, false, 0, false>(a, acc, rbase, cbase, l31);
-    else if (a.act == 1) epilogue_tiles<TM, TN, false, 1, false>(a, acc, rbase, cbase, l31);
-    else if (a.act == 3) epilogue_tiles<TM, TN, false, 3, false>(a, acc, rbase, cbase, l31);
-    else if (a.act == 4) epilogue_tiles<TM, TN, false, 4, false>(a, acc, rbase, cbase, l31);
-    else if (a.act == 5) epilogue_tiles<TM, TN, false, 5, false>(a, acc, rbase, cbase, l31);
-    else epilogue_tiles<TM, TN, false, 2, false>(a, acc, rbase, cbase, l31);
+    if (a.transpose_out) epilogue_tiles<TM, TN, false, 0, true>(a, acc, rbase, cbase, l31, lk);
+    else if (a.div_sqrt2 && a.act == 0) epilogue_tiles<TM, TN, true, 0, false>(a, acc, rbase, cbase, l31, lk);
+    else if (a.div_sqrt2 && a.act == 2) epilogue_tiles<TM, TN, true, 2, false>(a, acc, rbase, cbase, l31, lk);
+    else if (a.div_sqrt2) epilogue_tiles<TM, TN, true, 1, false>(a, acc, rbase, cbase, l31, lk);
+    else if (a.act == 0) epilogue_tiles<TM, TN, false, 0, false>(a, acc, rbase, cbase, l31, lk);
+    else if (a.act == 1) epilogue_tiles<TM, TN, false, 1, false>(a, acc, rbase, cbase, l31, lk);
+    else if (a.act == 3) epilogue_tiles<TM, TN, false, 3, false>(a, acc, rbase, cbase, l31, lk);
+    else if (a.act == 4) epilogue_tiles<TM, TN, false, 4, false>(a, acc, rbase, cbase, l31, lk);
+    else if (a.act == 5) epilogue_tiles<TM, TN, false, 5, false>(a, acc, rbase, cbase, l31, lk);
+    else epilogue_tiles<TM, TN, false, 2, false>(a, acc, rbase, cbase, l31, lk);
 }
 
 // S > 1 (split-K): this slice's raw partial sums go to its slab; splitk_reduce_kernel sums the slabs in a fixed order
 // and applies the epilogue.  (Combining inside this kernel -- per-tile arrival counters, the last slice reduces -- was
-// built and measured on MI355X: slower.  With agent-scope release/acquire fences the whole step went from 9.9 to
-// 12.5 ms (every fence writes back / invalidates an L2), with write-through slabs and sc1 loads to 11.5 ms (the last
-// arriver reads S slabs serially while the reduce kernel is wide and short), and keeping the accumulators live across
-// the hand-off cost 56 VGPRs = one wave per SIMD for every launch.)
+// built and measured on MI355X in round 1: slower, see DESIGN.md.)
 // `active` = this wave holds a result (false for the waves of a K group that already folded theirs into group 0).
 template <int TM, int TN>
 static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
@@ -187,16 +254,11 @@ static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32
     const int rbase = m0 + wm * 32 * TM + 4 * lk;          // this lane's first row; element e adds i*32 + (e&3) + 8*(e>>2)
     const int cbase = n0 + wn * 32 * TN;
     if (S == 1) {
-        epilogue_dispatch<TM, TN>(a, acc, rbase, cbase, l31);
+        epilogue_dispatch<TM, TN>(a, acc, rbase, cbase, l31, lk);
         return;
     }
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.ws + (size_t)blockIdx.y * a.M * a.N, 0,
-                                                                       (int)((unsigned)a.M * a.N * 4u), 0x00020000);
-    slab_store<TM, TN, 0>(a, acc, rs, rbase, cbase, l31);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<float*>(a.ws) + (size_t)blockIdx.y * a.M * a.N, 0, (int)((unsigned)a.M * a.N * 4u), 0x00020000);
+    slab_store<TM, TN>(a, acc, rs, rbase, cbase, l31);
 }
-// (Built and measured on MI355X, not kept: issuing MFMA(activation fragment, weight fragment) so that a lane owns four
-// consecutive COLUMNS of one row -- 16-byte residual loads and output stores, 34 memory instructions per 64x64 block
-// instead of 160.  Each store instruction then touches 32 rows x 32 bytes instead of 2 rows x 128 bytes and the
-// output-heavy shapes lost more (M128 N128000 K128: 72 -> 85 us, M64 N509440 K64 T9: 379 -> 411 us) than the small
-// ones gained (M512 N1280 K512: 18.0 -> 17.4 us).)
 #endif

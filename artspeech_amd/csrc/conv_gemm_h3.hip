@@ -1,0 +1,683 @@
+// K3/K4/K8/K10 -- every dense convolution / linear layer of the path as ONE implicit-GEMM kernel on the fp16 matrix cores,
+// fp32-accurate through a two-way operand split ("f16x3"):
+//
+//   Y[m][j] = epilogue( sum_t sum_k  W[t][k][m] * X[k][ j + dh[t]*Wj + dw[t] ] )      m < M, j < N
+//
+//   x = h + l,  h = fp16(x), l = fp16(x - h)  (22 significand bits);   x*w ~= h_x*l_w + l_x*h_w + h_x*h_w
+//   on v_mfma_f32_32x32x16_f16 (32 cycles, K = 16), fp32 accumulation, smallest terms first.  The dropped l*l term is below
+//   2^-22 |x w|; weights are pre-scaled by a power of two so their l parts are normal numbers (ConvGemmArgs.acc_scale undoes
+//   it).  scripts/exp/f16x3_numerics.py runs the whole path this way on the CPU: the mel lands 6e-6 from the reference's
+//   golden vectors, where exact fp32 products land 5e-6 (bound 1e-4).  Three matrix-core products per fp32 product instead of
+//   round 1's six bf16 ones (bf16x6), and 4 bytes of operand image per element instead of 6.
+//
+// Both operands arrive by LDS-DMA (buffer_load_dwordx4 ... lds) from images that are stored in staging order:
+//   Wh[tap][kb = k/16][q = p*2 + kh][m][8]       fp16, p = 0 (h) / 1 (l), kh = k-half     (as_prep_weight_f16x2_host)
+//   Xh[kb][q][column 0..N][8]                     fp16, column N = 0                        (split_f16x2_kernel and the producers)
+// so the k loop holds no conversion, no masking and no activation registers: a tap shifts the SOURCE column of a lane's
+// 16-byte row (per-lane source addresses are what LDS-DMA offers); a tap that is invalid for an output column (conv zero
+// padding / utterance wall) reads the zero column N.  Per 16-deep k-block a wave issues 4 LDS-DMAs (128x128 tile), 8
+// ds_read_b128 fragment reads and 12 MFMAs.
+//
+// Workgroup = 4 waves, each a 64x64 output block (2x2 MFMA tiles, 64 accumulator registers): WM x WN x WK waves along M, N, K;
+// tiles 128x128 <2,2,1>, 128x64 <2,1,2>, 64x128 <1,2,2>, 64x64 <1,1,4>; with WK > 1 the waves split K and sum their
+// accumulators through LDS at the end in a fixed order.  KT k-blocks per wave and iteration (one barrier per iteration), NS
+// LDS stages: with three, the tile staged in iteration `it` is read in it + 2 and the end-of-iteration wait is
+// vmcnt(this iteration's DMAs) -- only the PREVIOUS iteration's must have landed -- followed by a raw s_barrier
+// (__syncthreads() would wait for vmcnt(0)).
+#include "conv_gemm.h"
+#include <type_traits>
+
+#define H3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int I, int N, typename F>
+static __device__ __forceinline__ void h3_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        h3_for<I + 1, N>(f);
+    }
+}
+
+// tap offsets packed one byte per tap, (dh+8) << 4 | (dw+8) (|dh|, |dw| <= 7, checked by the host), eight taps per
+// word: the k loop then selects a tap with scalar ALU only (a scalar or scratch load inside it would stall the wave)
+struct H3Taps {
+    unsigned long long w0, w1, w2, w3;
+    int wide;                             // 1: every dh = 0 and the byte is dw + 128 (dilated 1-D convs, |dw| <= 127)
+};
+
+// host: pack the tap offsets of `a` for the kernel (AS_EINVAL if they do not fit a byte)
+static inline int h3_pack_taps(const ConvGemmArgs& a, H3Taps* out)
+{
+    H3Taps tp = {0, 0, 0, 0, 0};
+    unsigned long long* w = &tp.w0;
+    for (int t = 0; t < a.T; ++t)
+        if (a.dh[t] < -7 || a.dh[t] > 7 || a.dw[t] < -7 || a.dw[t] > 7) tp.wide = 1;
+    for (int t = 0; t < a.T; ++t) {
+        if (tp.wide && (a.dh[t] != 0 || a.dw[t] < -127 || a.dw[t] > 127)) return AS_EINVAL;
+        const int byte = tp.wide ? a.dw[t] + 128 : ((a.dh[t] + 8) << 4) | (a.dw[t] + 8);
+        w[t >> 3] |= (unsigned long long)byte << ((t & 7) * 8);
+    }
+    *out = tp;
+    return AS_OK;
+}
+
+// Byte of tap t.  Written with masks: as a select chain hipcc turns it into scalar BRANCHES inside the k loop.
+static __device__ __forceinline__ unsigned long long h3_tap_word(const H3Taps& tp, int t)
+{
+    const int s = t >> 3;
+    const unsigned long long m0 = 0ull - (unsigned long long)(s == 0), m1 = 0ull - (unsigned long long)(s == 1),
+                             m2 = 0ull - (unsigned long long)(s == 2), m3 = 0ull - (unsigned long long)(s == 3);
+    return (tp.w0 & m0) | (tp.w1 & m1) | (tp.w2 & m2) | (tp.w3 & m3);
+}
+
+template <int WM, int WN, int WK, int KT, int NS, int NP>
+struct H3Cfg {
+    static constexpr int QP = NP == 1 ? 2 : 4;                           // planes staged per k-block (h only / h and l)
+    static constexpr int BM = 64 * WM, BN = 64 * WN;
+    static constexpr int KBS = WK * KT;                                  // k-blocks per stage
+    static constexpr int A_BLK = QP * BM * 16, B_BLK = QP * BN * 16;     // bytes per 16-deep k-block
+    static constexpr int A_ST = KBS * A_BLK;                             // weight part of a stage
+    static constexpr int STAGE = KBS * (A_BLK + B_BLK);
+    static constexpr int RED = (WK - 1) * WM * WN * 64 * 64 * 4;         // cross-wave K reduction scratch
+    static constexpr int LDS = NS * STAGE > RED ? NS * STAGE : RED;
+    static constexpr int NT = 64 * WM * WN * WK;                         // threads
+    static constexpr int ACH = KBS * QP * BM / NT;                       // 16-byte weight chunks per thread per iteration
+    static constexpr int BCH = KBS * QP * BN / NT;                       // 16-byte activation chunks per thread per iteration
+    static constexpr int NMF = 4 * NP;                                   // MFMAs per k-block
+    static constexpr int NFR = 4 * (NP == 1 ? 1 : 2);                    // fragment reads per k-block
+};
+
+template <int WM, int WN, int WK, int KT, int NS, int NP>
+__global__ void __launch_bounds__(64 * WM * WN * WK)
+conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
+{
+    using C = H3Cfg<WM, WN, WK, KT, NS, NP>;
+    static_assert(NS == 2 || NS == 3, "stages");
+    constexpr int BM = C::BM, BN = C::BN, ACH = C::ACH, BCH = C::BCH, NT = C::NT, QP = C::QP, KBS = C::KBS;
+    static_assert(NT == 256 && ACH * NT == KBS * QP * BM && BCH * NT == KBS * QP * BN && ACH >= 1 && BCH >= 1, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn % WM, wn = wmn / WM;
+    const int l31 = lane & 31, lk = lane >> 5;
+    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tile = logical_tile();
+    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+    const int KB = a.Kp >> 4, KBx = (KB + 3) & ~3;
+    const int NX = a.N + 1;                                              // columns of the activation image (the last one is zero)
+    const int grp = a.n_groups > 1 ? n0 / a.group_cols : 0;
+
+    const unsigned w_bytes = (unsigned)a.T * KBx * 4u * a.M * 16u;       // one weight set
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.Wh) + (size_t)grp * w_bytes), 0, (int)w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.Xh), 0, (int)((unsigned)KBx * 4u * NX * 16u), 0x00020000);
+
+    (void)rsW;
+    (void)rsX;      // (the host pass does not see the LDS-DMA builtins that use them)
+    // chunk c = tid + NT i of an iteration's image [kblk][plane][row] -> LDS offset 16 c (both operands).  The global image
+    // always has four planes per k-block; with NP = 1 only planes 0, 1 (the h parts) are staged.
+    unsigned a_voff[ACH];
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        const int c = tid + NT * i, kblk = c / (QP * BM), rem = c % (QP * BM), pk = rem / BM, row = rem % BM;
+        a_voff[i] = (m0 + row) < a.M ? (unsigned)(((kblk * 4 + pk) * a.M + m0 + row) * 16) : OOB;
+    }
+    unsigned b_plane[BCH];                                               // (kblk*4 + pk) * NX * 16: plane of chunk i
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int c = tid + NT * i, kblk = c / (QP * BN), pk = (c % (QP * BN)) / BN;
+        b_plane[i] = (unsigned)((kblk * 4 + pk) * NX) * 16u;
+    }
+    const int j = n0 + tid % BN;                                         // the column this thread stages (same for every chunk)
+    unsigned tapmask = 0;                                                // taps that are valid for column j
+    int Wj = 0;
+    if (j < a.N) {
+        if (a.meta) {
+            const unsigned long long md = a.meta[j];
+            const int h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff);
+            const int H = (int)((md >> 32) & 0xffff);
+            Wj = (int)(md >> 48);
+            for (int t = 0; t < a.T; ++t) {
+                const int byte = (int)(h3_tap_word(tp, t) >> ((t & 7) * 8)) & 0xff;
+                const int dh = tp.wide ? 0 : (byte >> 4) - 8, dw = tp.wide ? byte - 128 : (byte & 15) - 8;
+                if ((unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)Wj) tapmask |= 1u << t;
+            }
+        } else {
+            tapmask = 0xffffffffu;
+        }
+    }
+    // source column of a tap for this thread's column, one formula for both encodings:
+    //   src = j + (byte >> 4) * tA + (byte & 15) + tC;  narrow: tA = Wj, tC = -8 Wj - 8;  wide: tA = 16, tC = -128
+    const int tA = tp.wide ? 16 : Wj, tC = j + (tp.wide ? -128 : -8 * Wj - 8);
+
+    // iterations: an iteration covers KBS k-blocks of one tap (the tail of a tap re-reads zero blocks: KBx is a multiple of 4
+    // and the weights' zero rows make them harmless as long as KBS divides 4 or the cursor clamps -- see advance)
+    const int it_per_tap = (KB + KBS - 1) / KBS;
+    const int nit_all = a.T * it_per_tap;
+    const int S = gridDim.y;
+    const int it_lo = (int)((long)nit_all * blockIdx.y / S);
+    const int n_it = (int)((long)nit_all * (blockIdx.y + 1) / S) - it_lo;
+
+    // cursor of the next tile to stage; past the end it stays on the last tile (loading it again into a stage nobody
+    // reads is harmless)
+    int c_t = it_lo / it_per_tap, c_kb = (it_lo - c_t * it_per_tap) * KBS;
+    auto advance = [&](int& t, int& kb) {
+        int nkb = kb + KBS, nt = t;
+        if (nkb >= KB) { nkb = 0; nt += 1; }
+        const bool ok = nt < a.T;
+        kb = ok ? nkb : kb;
+        t = ok ? nt : t;
+    };
+    unsigned c_col = 0;                                                  // source column * 16 of this thread's rows, staged tap
+    int c_asoff = 0, c_bsoff = 0, c_byte = 0;
+    unsigned long long c_word = 0;
+    auto tap_word = [&]() {
+        c_word = h3_tap_word(tp, c_t);
+        asm volatile("" : "+s"(c_word));                                 // computed HERE (hipcc otherwise sinks it into a branch)
+    };
+    auto tap_byte = [&]() {
+        c_byte = (int)(c_word >> ((c_t & 7) * 8)) & 0xff;
+        c_asoff = (c_t * KBx + c_kb) * 4 * a.M * 16;
+        c_bsoff = c_kb * 4 * NX * 16;
+        asm volatile("" : "+s"(c_byte), "+s"(c_asoff), "+s"(c_bsoff));
+    };
+    auto tap_col = [&]() {                                               // an invalid tap reads the zero column N
+        const unsigned ok = 0u - ((tapmask >> c_t) & 1u);                // all ones / zero: arithmetic select, no exec branch
+        const unsigned src = ((unsigned)((c_byte >> 4) * tA + (c_byte & 15) + tC) & ok) | ((unsigned)a.N & ~ok);
+        c_col = src * 16u;
+    };
+    (void)c_col;
+    auto dma_a = [&](auto i_, int stage) {
+#if __HIP_DEVICE_COMPILE__   // (device pass only: with this builtin in the body hipcc 7.2's HOST pass drops the kernel's launch stub)
+        constexpr int i = decltype(i_)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(smem + stage * C::STAGE + wave * 1024 + i * (NT * 16)), 16, a_voff[i],
+                                                 c_asoff, 0, 0);
+#endif
+    };
+    auto dma_b = [&](auto i_, int stage) {
+#if __HIP_DEVICE_COMPILE__
+        constexpr int i = decltype(i_)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(smem + stage * C::STAGE + C::A_ST + wave * 1024 + i * (NT * 16)), 16,
+                                                 b_plane[i] + c_col, c_bsoff, 0, 0);
+#endif
+    };
+    // fragments: [set][32-row / 32-column tile][part]
+    f16x8 fa[2][2][2], fb[2][2][2];
+    const int a_frag = (wk * KT * QP + lk) * BM * 16 + (wm * 64 + l31) * 16;
+    const int b_frag = C::A_ST + (wk * KT * QP + lk) * BN * 16 + (wn * 64 + l31) * 16;
+    // fragment read q of k-block step s of stage `stage` into register set `set`: q = ab*NFR/2 + p*2 + i
+    auto read_frag = [&](auto q_, auto set_, auto s_, int stage) {
+        constexpr int q = decltype(q_)::value, set = decltype(set_)::value, s = decltype(s_)::value;
+        constexpr int half = C::NFR / 2, ab = q / half, p = (q % half) / 2, i = q % 2;
+        const unsigned char* st = smem + stage * C::STAGE;
+        if constexpr (ab == 0) fa[set][i][p] = *reinterpret_cast<const f16x8*>(st + a_frag + (s * QP + p * 2) * BM * 16 + i * 32 * 16);
+        else fb[set][i][p] = *reinterpret_cast<const f16x8*>(st + b_frag + (s * QP + p * 2) * BN * 16 + i * 32 * 16);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    using I0 = std::integral_constant<int, 0>;
+    // Look-ahead L: iteration `it` stages tile it + L into stage (it + L) % NS.  KT = 1: L = NS -- the iteration's own stage,
+    // whose fragments were all read during iteration it - 1, before the barrier.  KT > 1: steps 1.. of an iteration still read
+    // the iteration's own stage, so the target is the stage of tile it - 1: L = NS - 1.
+    constexpr int L = KT == 1 ? NS : NS - 1;
+    static_assert(L >= 2, "KT > 1 needs three stages");
+    // prologue: tiles 0 .. L-1 staged, fragments of (tile 0, step 0) in set 0
+    for (int st = 0; st < L; ++st) {
+        tap_word();
+        tap_byte();
+        tap_col();
+        h3_for<0, ACH>([&](auto i_) { dma_a(i_, st); });
+        h3_for<0, BCH>([&](auto i_) { dma_b(i_, st); });
+        advance(c_t, c_kb);
+    }
+    __syncthreads();
+    h3_for<0, C::NFR>([&](auto q_) { read_frag(q_, I0{}, I0{}, 0); });
+    __syncthreads();      // every wave holds its fragments of tile 0 before the first iteration restages stage 0
+
+    // Iteration `it` (stage P = it % NS holds its tile): step s multiplies k-block s from register set F = (it KT + s) % 2
+    // while the fragments of the next step -- k-block s + 1 of the same stage, or k-block 0 of stage P + 1 -- are read into
+    // the other set, and the staging of tile it + L is dealt out behind the MFMAs: a wave issues about one instruction per
+    // 4 cycles and an MFMA holds the matrix core for 32.
+    constexpr int NMI = KT * C::NMF;                                     // MFMAs per iteration
+    // staging micro-operations of an iteration: tap decode (3), ACH + BCH DMAs, cursor advance
+    constexpr int M_DMA = 3, M_ADV = M_DMA + ACH + BCH, NMS = M_ADV + 1;
+    constexpr int SLOT0 = 0;
+    auto stage_micro = [&](auto m_, auto p_) {
+        constexpr int Mi = decltype(m_)::value, P = (decltype(p_)::value + L) % NS;
+        if constexpr (Mi == 0) tap_word();
+        else if constexpr (Mi == 1) tap_byte();
+        else if constexpr (Mi == 2) tap_col();
+        else if constexpr (Mi < M_DMA + ACH) dma_a(std::integral_constant<int, Mi - M_DMA>{}, P);
+        else if constexpr (Mi < M_ADV) dma_b(std::integral_constant<int, Mi - M_DMA - ACH>{}, P);
+        else advance(c_t, c_kb);
+    };
+    // slot of staging micro-op m: spread evenly over [SLOT0, NMI)
+    auto slot_of_stage = [](int m) constexpr { return SLOT0 + (m * (NMI - SLOT0)) / NMS; };
+    // slot of fragment read q of step s (reads of the NEXT step): spread over the first NMF - 2 slots of the step
+    auto slot_of_frag = [](int s, int q) constexpr { return s * C::NMF + (q * (C::NMF - 2)) / C::NFR + (C::NMF > 4 ? 1 : 0); };
+    // MFMA n of a step: groups of four, smallest terms first: (A part, B part) = (h,l) (l,h) (h,h); NP = 1: (h,h)
+    auto step = [&](auto n_, auto s_, auto p_, auto f_) {
+        constexpr int Nn = decltype(n_)::value, Ss = decltype(s_)::value, P = decltype(p_)::value, F = decltype(f_)::value;
+        constexpr int grp_ = Nn / 4, i = (Nn % 4) / 2, jn = Nn % 2;
+        constexpr int PA = NP == 1 ? 0 : (grp_ == 1 ? 1 : 0);
+        constexpr int PB = NP == 1 ? 0 : (grp_ == 0 ? 1 : 0);
+        acc[i][jn] = H3_MFMA(fa[F][i][PA], fb[F][jn][PB], acc[i][jn]);
+        constexpr int slot = Ss * C::NMF + Nn;
+        h3_for<0, NMS>([&](auto m_) {
+            if constexpr (slot_of_stage(decltype(m_)::value) == slot) stage_micro(m_, p_);
+        });
+        h3_for<0, C::NFR>([&](auto q_) {
+            if constexpr (slot_of_frag(Ss, decltype(q_)::value) == slot) {
+                if constexpr (Ss + 1 < KT) read_frag(q_, std::integral_constant<int, F ^ 1>{}, std::integral_constant<int, Ss + 1>{}, P);
+                else read_frag(q_, std::integral_constant<int, F ^ 1>{}, I0{}, (P + 1) % NS);
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // end of an iteration: the tile the NEXT iteration reads fragments from has landed (this wave's share) and everybody
+    // is done with the stage the next iteration restages.  Not __syncthreads(): its fence waits for vmcnt(0).
+    constexpr int PEND = (L - 2) * (ACH + BCH);                          // LDS-DMAs that may stay in flight across the barrier: tiles it + 3 .. it + L
+#define H3_ITER(U)                                                                                                \
+    {                                                                                                             \
+        h3_for<0, KT>([&](auto s_) {                                                                              \
+            h3_for<0, C::NMF>([&](auto n_) {                                                                      \
+                step(n_, s_, std::integral_constant<int, (U) % NS>{},                                             \
+                     std::integral_constant<int, ((U) * KT + decltype(s_)::value) % 2>{});                        \
+            });                                                                                                   \
+        });                                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PEND) : "memory");                       \
+    }
+    // stage = it % NS, first register set = (it KT) % 2: period lcm(NS, KT odd ? 2 : 1)
+    constexpr int PERIOD = (KT % 2 == 0) ? NS : (NS % 2 == 0 ? NS : 2 * NS);
+    int it = 0;
+    for (; it + PERIOD <= n_it; it += PERIOD) {
+        h3_for<0, PERIOD>([&](auto u_) { H3_ITER(decltype(u_)::value) });
+    }
+    h3_for<0, PERIOD - 1>([&](auto u_) {
+        if (it + decltype(u_)::value < n_it) H3_ITER(decltype(u_)::value)
+    });
+#undef H3_ITER
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");       // re-staged tail tiles have landed before LDS is reused
+
+    if (WK > 1) {                                                       // sum the K groups: wk = 0 += wk = 1, 2, 3 in order
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        f32x4 v = {acc[i][jn][4 * e4], acc[i][jn][4 * e4 + 1], acc[i][jn][4 * e4 + 2], acc[i][jn][4 * e4 + 3]};
+                        red[((((wk - 1) * (WM * WN) + wmn) * 4 + i * 2 + jn) * 4 + e4) * 64 + lane] = v;
+                    }
+        }
+        __syncthreads();
+        if (wk == 0)
+#pragma unroll
+            for (int s = 1; s < WK; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const f32x4 v = red[((((s - 1) * (WM * WN) + wmn) * 4 + i * 2 + jn) * 4 + e4) * 64 + lane];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[i][jn][4 * e4 + c] += v[c];
+                        }
+    }
+    epilogue<2, 2>(a, acc, m0, n0, wm, wn, l31, lk, S, wk == 0);
+}
+
+template <int WM, int WN, int WK, int KT, int NS, int NP>
+static int launch_h3(const ConvGemmArgs& a, int S, hipStream_t stream)
+{
+    using C = H3Cfg<WM, WN, WK, KT, NS, NP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        attr_set = true;
+    }
+    H3Taps tp;
+    if (h3_pack_taps(a, &tp) != AS_OK) return AS_EINVAL;
+    const dim3 grid(as_cdiv(a.M, C::BM) * as_cdiv(a.N, C::BN), S);
+    hipLaunchKernelGGL((conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP>), grid, dim3(C::NT), C::LDS, stream, a, tp);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// Pipeline shape per tile (k-blocks per wave and iteration, LDS stages): AS_H3_KT / AS_H3_NS select the alternatives
+// that are compiled in (tuning runs only)
+#ifndef H3_KT
+#define H3_KT 1
+#endif
+template <int WM, int WN, int WK>
+static int launch_h3_tile(const ConvGemmArgs& a, int S, hipStream_t stream)
+{
+    const char *ekt = getenv("AS_H3_KT"), *ens = getenv("AS_H3_NS");
+    const int kt = ekt ? atoi(ekt) : H3_KT, ns = ens ? atoi(ens) : 3;
+    if (a.n_prod == 1) return launch_h3<WM, WN, WK, 1, 3, 1>(a, S, stream);
+    if constexpr (H3Cfg<WM, WN, WK, 2, 3, 3>::LDS <= 160 * 1024) {
+        if (kt == 2) return launch_h3<WM, WN, WK, 2, 3, 3>(a, S, stream);
+    }
+    return ns == 2 ? launch_h3<WM, WN, WK, 1, 2, 3>(a, S, stream) : launch_h3<WM, WN, WK, 1, 3, 3>(a, S, stream);
+}
+
+int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream)
+{
+    if ((double)as_kbx(a.K) * 4.0 * (a.N + 1.0) * 16.0 >= 2147483648.0) return AS_EINVAL;   // 32-bit offsets in the descriptor
+    switch (choice) {
+    case 22: return launch_h3_tile<2, 2, 1>(a, S, stream);
+    case 21: return launch_h3_tile<2, 1, 2>(a, S, stream);
+    case 12: return launch_h3_tile<1, 2, 2>(a, S, stream);
+    case 11: return launch_h3_tile<1, 1, 4>(a, S, stream);
+    default: return AS_EINVAL;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// X fp32 [K][ldx] -> Xh[(K/16 up to a multiple of 4)][p*2 + kh][N + 1][8] fp16, x = h + l; optional LeakyReLU first;
+// column N and rows >= K are zero.
+// A thread owns 4 consecutive columns x 8 consecutive k: eight 16-byte loads (range-checked buffer loads: the last
+// quad of a row may reach past N, and past the allocation on the last row), eight 16-byte stores.
+__global__ void __launch_bounds__(256)
+split_f16x2_kernel(const float* __restrict__ x, int ldx, int K, int N, int lrelu, float slope, u32x4_t* __restrict__ xh)
+{
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int g = blockIdx.y;                                           // 8-row group: kb = g / 2, kh = g % 2
+    if (col > N) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(((unsigned)(K - 1) * ldx + N) * 4u), 0x00020000);
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | ((uintptr_t)ldx * 4)) & 15) == 0;   // 16-byte loads need aligned rows
+    f32x4 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = g * 8 + r;
+        const unsigned off = k < K ? (unsigned)(k * ldx + col) * 4u : OOB;
+        if (al) v[r] = buf_load4(rs, off, 0);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[r][c] = buf_load1(rs, k < K ? off + 4u * c : OOB, 0);
+        }
+    }
+    const size_t NX = (size_t)N + 1;
+    const size_t base = ((size_t)(g >> 1) * 4 + (g & 1)) * NX + col;    // plane p*2 + kh of k-block kb
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (col + c > N) break;
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float e = col + c < N ? v[r][c] : 0.f;                      // column N: the zero column
+            if (lrelu) e = e > 0.f ? e : slope * e;
+            t[r] = e;
+        }
+        u32x4_t h, l;
+        split2(t, h, l);
+        xh[base + c] = h;
+        xh[base + c + 2 * NX] = l;
+    }
+}
+
+extern "C" size_t as_split_f16x2_bytes(int K, int N)
+{
+    if (K <= 0 || N <= 0) return 0;
+    return (size_t)as_kbx(K) * 4 * ((size_t)N + 1) * 16;
+}
+
+int as_split_f16x2_launch(const float* x, int ldx, int K, int N, int lrelu, float slope, uint16_t* xh, hipStream_t stream)
+{
+    if ((double)K * ldx * 4.0 >= 2147483648.0) return AS_EINVAL;        // 32-bit offsets in the buffer descriptor
+    hipLaunchKernelGGL(split_f16x2_kernel, dim3(as_cdiv(N + 1, 1024), 2 * as_kbx(K)), dim3(256), 0, stream, x, ldx, K, N, lrelu, slope,
+                       reinterpret_cast<u32x4_t*>(xh));
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+extern "C" int as_split_f16x2_f32(const float* x, int ldx, int K, int N, int in_act, float in_slope, uint16_t* xh, as_stream_t stream)
+{
+    if (!x || !xh || K <= 0 || N < 0 || ldx < N || (in_act != 0 && in_act != 2)) return AS_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(xh) & 15) != 0) return AS_EINVAL;
+    if (N == 0) return AS_OK;
+    AsProfScope prof__(AS_CLS_OTHER, 0, 8.0 * K * (double)N, (hipStream_t)stream);
+    return as_split_f16x2_launch(x, ldx, K, N, in_act == 2, in_slope == 0.f ? 0.2f : in_slope, xh, (hipStream_t)stream);
+}
+
+// host-side weight preparation (see the header)
+extern "C" size_t as_prep_weight_f16x2_bytes(int G, int Cout, int Cin, int T)
+{
+    if (G <= 0 || Cout <= 0 || Cin <= 0 || T <= 0) return 0;
+    return (size_t)G * T * as_kbx(Cin) * 4 * (size_t)Cout * 16;
+}
+
+extern "C" int as_prep_weight_f16x2_host(const float* w, int G, int Cout, int Cin, int T, uint16_t* wh, float* scale_out)
+{
+    if (!w || !wh || !scale_out || G <= 0 || Cout <= 0 || Cin <= 0 || T <= 0) return AS_EINVAL;
+    const size_t n = (size_t)G * Cout * Cin * T;
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) {
+        const float v = w[i] < 0 ? -w[i] : w[i];
+        if (!(v <= 3.0e38f)) return AS_EINVAL;                           // NaN / inf
+        mx = v > mx ? v : mx;
+    }
+    int e = 0;
+    float scale = 1.0f;
+    if (mx > 0.f) {
+        frexpf(mx, &e);                                                  // mx = f * 2^e, f in [0.5, 1): mx in [2^(e-1), 2^e)
+        scale = ldexpf(1.0f, 14 - e);                                    // max |w| * scale in [2^13, 2^14)
+    }
+    const int KBx = as_kbx(Cin);
+    const size_t total = as_prep_weight_f16x2_bytes(G, Cout, Cin, T) / 2;
+    for (size_t i = 0; i < total; ++i) wh[i] = 0;
+    for (int g = 0; g < G; ++g)
+        for (int m = 0; m < Cout; ++m)
+            for (int k = 0; k < Cin; ++k)
+                for (int t = 0; t < T; ++t) {
+                    const float x = w[(((size_t)g * Cout + m) * Cin + k) * T + t] * scale;
+                    const _Float16 h = (_Float16)x;
+                    const _Float16 l = (_Float16)(x - (float)h);
+                    const int kb = k >> 4, kh = (k >> 3) & 1, e8 = k & 7;
+                    const size_t base = ((((size_t)g * T + t) * KBx + kb) * 4) * (size_t)Cout * 8;
+                    uint16_t hb, lb;
+                    __builtin_memcpy(&hb, &h, 2);
+                    __builtin_memcpy(&lb, &l, 2);
+                    wh[base + ((size_t)(0 * 2 + kh) * Cout + m) * 8 + e8] = hb;
+                    wh[base + ((size_t)(1 * 2 + kh) * Cout + m) * 8 + e8] = lb;
+                }
+    *scale_out = scale;
+    return AS_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// AdaIN + LeakyReLU written DIRECTLY as the split image (the output of models.py:189-197's norm -> actv feeds nothing but
+// the following conv, so the fp32 activations never exist): per-(channel, utterance) statistics exactly as
+// adain_kernel (elementwise.hip) computes them -- one wave per channel, the same summation order -- then a thread takes
+// 8 channels of one column, normalises, applies LeakyReLU(0.2), splits and stores three 16-byte rows.
+// Workgroup = (8-channel group = one (k-block, k-half) of the image, utterance).
+// ----------------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float h3_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+adain_split_kernel(const float* __restrict__ x, int ldx, int C, const float* __restrict__ gb, int ldgb,
+                   const int* __restrict__ col_off, int N, int act, u32x4_t* __restrict__ xs)
+{
+    __shared__ float st[8][4];                                          // mean, rstd, 1 + gamma, beta
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int c0 = g * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t NX = (size_t)N + 1;
+    const size_t plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;         // part h of this (k-block, k-half); l at + 2 NX
+    if (b == 0 && threadIdx.x < 2) xs[plane + (size_t)threadIdx.x * 2 * NX + N] = u32x4_t{0u, 0u, 0u, 0u};   // the zero column
+    const int o0 = col_off[b], L = col_off[b + 1] - o0;
+    if (L <= 0) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = c0 + wave * 2 + q;
+        if (c < C) {                                                    // wave-uniform
+            const float* xr = x + (size_t)c * ldx + o0;
+            float s = 0.f;
+            for (int i = lane; i < L; i += 64) s += xr[i];
+            const float mean = h3_wave_sum(s) / (float)L;
+            float v = 0.f;
+            for (int i = lane; i < L; i += 64) { const float d = xr[i] - mean; v += d * d; }
+            const float var = h3_wave_sum(v) / (float)L;
+            if (lane == 0) {
+                st[wave * 2 + q][0] = mean;
+                st[wave * 2 + q][1] = 1.0f / sqrtf(var + 1e-5f);
+                st[wave * 2 + q][2] = 1.0f + gb[(size_t)b * ldgb + c];
+                st[wave * 2 + q][3] = gb[(size_t)b * ldgb + C + c];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += 256) {
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float o = 0.f;
+            if (c0 + r < C) {
+                o = st[r][2] * ((x[(size_t)(c0 + r) * ldx + o0 + i] - st[r][0]) * st[r][1]) + st[r][3];
+                if (act) o = o > 0.f ? o : 0.2f * o;
+            }
+            t[r] = o;
+        }
+        u32x4_t h, l;
+        split2(t, h, l);
+        const size_t at = plane + o0 + i;
+        xs[at] = h;
+        xs[at + 2 * NX] = l;
+    }
+}
+
+extern "C" int as_adain_split_f32(const float* x, int ldx, int C, const float* gamma_beta, int ldgb, const int32_t* col_off, int B,
+                                  int N, int lrelu, uint16_t* xs, as_stream_t stream)
+{
+    if (!x || !gamma_beta || !col_off || !xs || C <= 0 || B <= 0 || N < 0 || ldgb < 2 * C) return AS_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(xs) & 15) != 0) return AS_EINVAL;
+    if (N == 0) return AS_OK;
+    const int KBx = as_kbx(C);
+    AsProfScope prof__(AS_CLS_ADAIN, 0, 8.0 * C * (double)N, (hipStream_t)stream);
+    hipLaunchKernelGGL(adain_split_kernel, dim3(2 * KBx, B), dim3(256), 0, (hipStream_t)stream, x, ldx, C, gamma_beta, ldgb, col_off, N,
+                       lrelu, reinterpret_cast<u32x4_t*>(xs));
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Channel LayerNorm (+ReLU) written DIRECTLY as the split image: in the encoders the LayerNorm output feeds nothing but the
+// following conv (RelTransformerEnc.py:72-87: norm_layers_1 -> attention's q/k/v convs, norm_layers_2 -> the FFN's first
+// conv; :321-323 the prenet).  Same arithmetic as channel_ln_kernel (elementwise.hip: two-pass statistics over the channel
+// axis, per-part partial sums reduced in the same order), but a thread owns 8 CONSECUTIVE channels per register group --
+// one 16-byte row of the image -- instead of channels strided by 32.  Columns >= n_split take the second affine pair.
+// ----------------------------------------------------------------------------------------------------------------
+#define LNS_COLS 32
+#define LNS_PARTS 32
+#define LNS_MAXG 4                       // 8-channel groups per thread held in registers: C <= 8 * 32 * 4 = 1024
+__global__ void __launch_bounds__(1024)
+channel_ln_split_kernel(const float* __restrict__ x, int ldx, int C, int N, const float* __restrict__ gamma1,
+                        const float* __restrict__ beta1, const float* __restrict__ gamma2, const float* __restrict__ beta2, int n_split,
+                        float eps, int relu, u32x4_t* __restrict__ xs, int KBx)
+{
+    __shared__ float red[LNS_PARTS][LNS_COLS + 1];
+    const int col = threadIdx.x % LNS_COLS, part = threadIdx.x / LNS_COLS;
+    const int j = blockIdx.x * LNS_COLS + col;
+    const bool ok = j < N;
+    const bool second = gamma2 && j >= n_split;
+    const float* gamma = second ? gamma2 : gamma1;
+    const float* beta = second ? beta2 : beta1;
+    const int ngroups = 2 * KBx;                                         // 8-channel groups of the image (zero beyond C)
+    float v[LNS_MAXG][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNS_MAXG; ++i)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c = 8 * (part + i * LNS_PARTS) + r;
+            v[i][r] = (ok && c < C) ? x[(size_t)c * ldx + j] : 0.f;
+            s += v[i][r];
+        }
+    red[part][col] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < LNS_PARTS; ++q) tot += red[q][col];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNS_MAXG; ++i)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c = 8 * (part + i * LNS_PARTS) + r;
+            const float d = v[i][r] - mean;
+            if (c < C) q2 += d * d;
+        }
+    red[part][col] = q2;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < LNS_PARTS; ++q) tot += red[q][col];
+    const float rs = 1.0f / sqrtf(tot / (float)C + eps);
+    const size_t NX = (size_t)N + 1;
+    if (blockIdx.x == 0 && col == 0) {                                   // the zero column N of every plane this thread's groups own
+#pragma unroll
+        for (int i = 0; i < LNS_MAXG; ++i) {
+            const int g = part + i * LNS_PARTS;
+            if (g < ngroups)
+                for (int p = 0; p < 2; ++p) xs[((size_t)(g >> 1) * 4 + (g & 1) + 2 * p) * NX + N] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+    }
+    if (!ok) return;
+#pragma unroll
+    for (int i = 0; i < LNS_MAXG; ++i) {
+        const int g = part + i * LNS_PARTS;
+        if (g >= ngroups) continue;
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c = 8 * g + r;
+            float o = 0.f;
+            if (c < C) {
+                o = (v[i][r] - mean) * rs * gamma[c] + beta[c];
+                if (relu) o = o > 0.f ? o : 0.f;
+            }
+            t[r] = o;
+        }
+        u32x4_t h, l;
+        split2(t, h, l);
+        const size_t at = ((size_t)(g >> 1) * 4 + (g & 1)) * NX + j;
+        xs[at] = h;
+        xs[at + 2 * NX] = l;
+    }
+}
+
+extern "C" int as_channel_layernorm_split_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta,
+                                              const float* gamma2, const float* beta2, int n_split, float eps, int relu, uint16_t* xs,
+                                              as_stream_t stream)
+{
+    if (!x || !xs || !gamma || !beta || C <= 0 || C > 8 * LNS_PARTS * LNS_MAXG || N <= 0 || ldx < N ||
+        ((gamma2 == nullptr) != (beta2 == nullptr)) || (reinterpret_cast<uintptr_t>(xs) & 15) != 0)
+        return AS_EINVAL;
+    const int KBx = as_kbx(C);
+    AsProfScope prof__(AS_CLS_LN, 8.0 * C * N, 8.0 * C * (double)N, (hipStream_t)stream);
+    hipLaunchKernelGGL(channel_ln_split_kernel, dim3(as_cdiv(N, LNS_COLS)), dim3(1024), 0, (hipStream_t)stream, x, ldx, C, N, gamma, beta,
+                       gamma2, beta2, n_split, eps, relu, reinterpret_cast<u32x4_t*>(xs), KBx);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}

@@ -59,22 +59,30 @@ class Weights:
             self._cache[name] = self.raw[name].to(self.device).contiguous()
         return self._cache[name]
 
-    def conv(self, name):
-        """conv weight [Cout,Cin,k] or [Cout,Cin,kh,kw] -> [taps][Cin][Cout]."""
-        key = "T:" + name
+    def conv(self, name, name2=None):
+        """conv weight [Cout,Cin,k] or [Cout,Cin,kh,kw] -> the GEMM's operand image (ops.GemmWeight).  name2: a second layer of
+        the same shape stacked behind it (a grouped launch: the twin encoders)."""
+        key = "T:" + name + ("|" + name2 if name2 else "")
         if key not in self._cache:
-            self._cache[key] = ops.prep_weight(self.raw[name + ".weight"], self.device)
+            self._cache[key] = ops.prep_weight(self.raw[name + ".weight"], self.device,
+                                               stack=[self.raw[name2 + ".weight"]] if name2 else None)
         return self._cache[key]
 
-    def bias(self, name):
-        return self.vec(name + ".bias") if self.has(name + ".bias") else None
+    def bias(self, name, name2=None):
+        if not self.has(name + ".bias"):
+            return None
+        if name2 is None:
+            return self.vec(name + ".bias")
+        return self.cached("B2:" + name + "|" + name2, lambda: torch.stack([self.raw[name + ".bias"], self.raw[name2 + ".bias"]], 0)
+                           .contiguous().to(self.device))
 
-    def qkv(self, p):
-        key = "QKV:" + p
+    def qkv(self, p, p2=None):
+        key = "QKV:" + p + ("|" + p2 if p2 else "")
         if key not in self._cache:
-            w = torch.cat([self.raw[f"{p}.conv_{n}.weight"] for n in "qkv"], 0)      # [3C, C, 1]
-            b = torch.cat([self.raw[f"{p}.conv_{n}.bias"] for n in "qkv"], 0)
-            self._cache[key] = (ops.prep_weight(w, self.device), b.to(self.device))
+            ws = [torch.cat([self.raw[f"{q}.conv_{n}.weight"] for n in "qkv"], 0) for q in ([p, p2] if p2 else [p])]      # [3C, C, 1]
+            bs = [torch.cat([self.raw[f"{q}.conv_{n}.bias"] for n in "qkv"], 0) for q in ([p, p2] if p2 else [p])]
+            self._cache[key] = (ops.prep_weight(ws[0], self.device, stack=ws[1:]),
+                                (torch.stack(bs, 0) if p2 else bs[0]).contiguous().to(self.device))
         return self._cache[key]
 
     def lstm(self, p):
@@ -106,11 +114,11 @@ class Weights:
 # ------------------------------------------------------------------------------------------------
 # building blocks on packed frames
 # ------------------------------------------------------------------------------------------------
-def conv1d(W, name, X, lay, k, Y=None, **kw):
-    Wt = W.conv(name)
+def conv1d(W, name, X, lay, k, Y=None, name2=None, **kw):
+    Wt = W.conv(name, name2)
     if Y is None:
         Y = lay.new(Wt.shape[2])
-    return ops.conv_gemm(Wt, X, lay, Y, taps_1d(k), bias=W.bias(name), **kw)
+    return ops.conv_gemm(Wt, X, lay, Y, taps_1d(k), bias=W.bias(name, name2), **kw)
 
 
 import os as _os
@@ -167,7 +175,7 @@ def adain_resblk1d(W, p, X, lay, style, out=None, upsample=False, gb=None, fork_
         h = lay2.new(din)
         sc = lay2.new(din)
         ops.adain(X, gb1, lay, h, True, W.dw(p + ".pool"), W.vec(p + ".pool.bias"), sc)
-    split = ADAIN_SPLIT and ops.GEMM_IMPL == "x6"      # norm -> actv feeds only the conv: store it as that conv's operand image
+    split = ADAIN_SPLIT                                # norm -> actv feeds only the conv: store it as that conv's operand image
     if not upsample:
         sc = X
     if upsample or not split:
@@ -214,14 +222,14 @@ def rel_encoder(W, p, tokens_i32, lay, n_layers, p2=None, n_split=0, b_split=0):
     C = emb.shape[1]
     pair = p2 is not None
 
-    def g_conv(name):                       # second weight set of a conv (conv1d's group2=)
-        return (W.conv(p2 + name), W.bias(p2 + name), n_split) if pair else None
+    def g_conv(name):                       # second weight set of a conv (conv1d's name2= / group_cols=)
+        return dict(name2=p2 + name, group_cols=n_split) if pair else {}
 
     def g_ln(name):
         return (W.vec(f"{p2}{name}.gamma"), W.vec(f"{p2}{name}.beta"), n_split) if pair else None
 
     x = ops.embed(tokens_i32, emb, math.sqrt(C), lay.new(C), group2=(W.vec(p2 + ".emb.weight"), n_split) if pair else None)
-    split = LN_SPLIT and ops.GEMM_IMPL == "x6"      # a LayerNorm here feeds only the next conv: store it as that conv's operand image
+    split = LN_SPLIT                                # a LayerNorm here feeds only the next conv: store it as that conv's operand image
 
     def ln_conv(xin, ln, relu, conv, k, **kw):
         """conv(LayerNorm(xin)) -- the normalised activations exist only as the conv's pre-split operand when `split`."""
@@ -231,28 +239,28 @@ def rel_encoder(W, p, tokens_i32, lay, n_layers, p2=None, n_split=0, b_split=0):
             return conv(None, xs=xs_, K=C, **kw)
         return conv(ops.channel_layernorm(xin, lay.N, g, b, lay.new(C), relu=relu, group2=g_ln(ln)), **kw)
 
-    h = conv1d(W, f"{p}.pre.conv_layers.0", x, lay, 5, group2=g_conv(".pre.conv_layers.0"))                # ConvReluNorm :318-325
+    h = conv1d(W, f"{p}.pre.conv_layers.0", x, lay, 5, **g_conv(".pre.conv_layers.0"))                # ConvReluNorm :318-325
     for i in range(3):
         nxt = f".pre.conv_layers.{i + 1}" if i < 2 else ".pre.proj"
         kk, extra = (5, {}) if i < 2 else (1, {"res": x})
         h = ln_conv(h, f".pre.norm_layers.{i}", True,
-                    lambda X_, _n=nxt, _k=kk, **kw: conv1d(W, p + _n, X_, lay, _k, group2=g_conv(_n), **kw), kk, **extra)
+                    lambda X_, _n=nxt, _k=kk, **kw: conv1d(W, p + _n, X_, lay, _k, **g_conv(_n), **kw), kk, **extra)
     x = h
     e = p + ".encoder"
     for i in range(n_layers):                                             # Encoder.forward :66-90
         a = f"{e}.attn_layers.{i}"
-        wqkv, bqkv = W.qkv(a)
         a2 = f"{p2}.encoder.attn_layers.{i}" if pair else None
+        wqkv, bqkv = W.qkv(a, a2)
         qkv = ln_conv(x, f".encoder.norm_layers_1.{i}", False,
                       lambda X_, **kw: ops.conv_gemm(wqkv, X_, lay, lay.new(3 * C), [(0, 0)], bias=bqkv,
-                                                     group2=W.qkv(a2) + (n_split,) if pair else None, **kw), 1)
+                                                     group_cols=n_split if pair else 0, **kw), 1)
         att = ops.relpos_attention(qkv, C, N_HEADS, WINDOW, W.vec(a + ".emb_rel_k"), W.vec(a + ".emb_rel_v"), lay, lay.new(C),
                                    group2=(W.vec(a2 + ".emb_rel_k"), W.vec(a2 + ".emb_rel_v"), b_split) if pair else None)
-        x = conv1d(W, a + ".conv_o", att, lay, 1, res=x, group2=g_conv(f".encoder.attn_layers.{i}.conv_o"))
+        x = conv1d(W, a + ".conv_o", att, lay, 1, res=x, **g_conv(f".encoder.attn_layers.{i}.conv_o"))
         f = f".encoder.ffn_layers.{i}"
         y = ln_conv(x, f".encoder.norm_layers_2.{i}", False,
-                    lambda X_, _f=f, **kw: conv1d(W, p + _f + ".conv_1", X_, lay, 9, act=ACT_RELU, group2=g_conv(_f + ".conv_1"), **kw), 9)
-        x = conv1d(W, p + f + ".conv_2", y, lay, 1, res=x, group2=g_conv(f + ".conv_2"))
+                    lambda X_, _f=f, **kw: conv1d(W, p + _f + ".conv_1", X_, lay, 9, act=ACT_RELU, **g_conv(_f + ".conv_1"), **kw), 9)
+        x = conv1d(W, p + f + ".conv_2", y, lay, 1, res=x, **g_conv(f + ".conv_2"))
     return ops.channel_layernorm(x, lay.N, W.vec(e + ".last_ln.gamma"), W.vec(e + ".last_ln.beta"), lay.new(C),
                                  group2=g_ln(".encoder.last_ln"))
 
@@ -472,7 +480,7 @@ class DurationPredictor(_Module):
         for i in range(3):
             d, _ = adain_resblk1d(W, f"{p}.duration.{i}", d, tok_lay, ds, gb=gbs[f"{p}.duration.{i}"])
         x = bilstm(W, p + ".LSTM", d, tok_lay)
-        wt = W.cached("DP:" + p, lambda: W.raw[p + ".duration_proj.linear_layer.weight"].t().contiguous()[None].to(W.device))
+        wt = W.cached("DP:" + p, lambda: ops.prep_weight(W.raw[p + ".duration_proj.linear_layer.weight"][:, :, None], W.device))
         return ops.conv_gemm(wt, x, tok_lay, tok_lay.new(1), [(0, 0)], bias=W.vec(p + ".duration_proj.linear_layer.bias"))
 
     def forward_packed(self, tokens_i32, tok_lay, ema_p, ref_lay):

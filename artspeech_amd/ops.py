@@ -71,16 +71,9 @@ class Layout:
         return self._meta
 
     def new(self, C):
-        """[C][N] activation with 4 floats of slack in front of it: the GEMM's 16-byte staging may start a quad
-        up to 3 columns before the tensor (those columns are masked, but the bytes must be readable)."""
+        """[C][N] fp32 activation"""
         n = max(self.N, 1)
-        return torch.empty(C * n + 4, dtype=torch.float32, device=self.device)[4:].view(C, n)
-
-    def quads_regular(self):
-        """no aligned group of 4 columns straddles two images of different width (2-D layouts only matter)"""
-        if self.H == 1 or len(set(self.widths_host)) <= 1:
-            return True
-        return all((self.H * w) % 4 == 0 for w in self.widths_host)
+        return torch.empty((C, n), dtype=torch.float32, device=self.device)
 
     def scaled(self, k):
         return layout([w * k for w in self.widths_host], self.device, self.H)
@@ -110,43 +103,63 @@ def layout(widths, device, H=1):
     return lay
 
 
-# arithmetic of the conv GEMM: "x6" = bf16 matrix cores, three-way split operands, fp32-accurate (default);
-# "f32" = fp32 MFMAs (exact fp32 products).  Both run on the GPU through the same entry point.
-GEMM_IMPL = os.environ.get("AS_GEMM_IMPL", "x6")
+# arithmetic of the conv GEMM: "h3" = fp16 matrix cores, two-way split operands, three products, fp32-accurate (default);
+# "h1" = plain fp16 operands (the h parts only, one product): the 16-bit-operand mode BASELINE.md names for config C2.
+GEMM_IMPL = os.environ.get("AS_GEMM_IMPL", "h3")
 
 
-def split_bf16x3(wt):
-    """fp32 GEMM image [T][Kp][M] -> the bf16x6 kernel's image [T][KBx][6][M][8] (int16 bit patterns), KBx = Kp/16
-    rounded up to a multiple of 4 (zero blocks): w = h + m + l with h, m, l bf16 (round-to-nearest-even at each
-    step, exact sum); slot p*2 + kh holds part p of k = 16*kb + 8*kh + 0..7 (csrc/conv_gemm_x6.hip)."""
-    T, Kp, M = wt.shape
-    kx = (Kp + 63) // 64 * 64
-    if kx != Kp:
-        wt = torch.cat([wt, wt.new_zeros(T, kx - Kp, M)], dim=1)
-    h = wt.to(torch.bfloat16)
-    r = wt - h.float()
-    m = r.to(torch.bfloat16)
-    l = (r - m.float()).to(torch.bfloat16)
-    parts = torch.stack([h, m, l], dim=0)                                   # [3][T][kx][M]
-    img = parts.reshape(3, T, kx // 16, 2, 8, M).permute(1, 2, 0, 3, 5, 4)   # [T][kb][p][kh][M][8]
-    return img.contiguous().view(torch.int16).reshape(T, kx // 16, 6, M, 8)
+def kbx(K):
+    """k-blocks of a split image: ceil(K / 16) rounded up to a multiple of 4."""
+    return (((K + 15) >> 4) + 3) & ~3
 
 
-def prep_weight(w, device=None):
-    """conv / linear weight [Cout, Cin, *kernel] -> the GEMM's [taps][Kp][Cout] image: transposed so that output
-    channels are contiguous, input channels zero-padded to a multiple of 16 (one k-tile).  The returned tensor
-    carries `.x6`, the same weights split for the bf16x6 arithmetic (split_bf16x3)."""
+class GemmWeight:
+    """A conv / linear weight prepared for the GEMM: `wh` = the split fp16 image [G][T][KBx][4][M][8] (int16 bit patterns) on
+    the device, `scale` = the power of two it was multiplied by, `w32` = the fp32 [T][Kp][M] image (Cin = 1 only: the
+    direct kernel reads it), `shape` = (T, Kp, M) of one weight set, `G` = weight sets stacked for a grouped launch."""
+
+    def __init__(self, wh, scale, shape, G, w32=None):
+        self.wh, self.scale, self.shape, self.G, self.w32 = wh, scale, shape, G, w32
+
+
+def split_f16x2_weight(w4):
+    """w4 fp32 [G][Cout][Cin][T] (CPU) -> (image int16 [G][T][KBx][4][Cout][8], scale).  The same arithmetic as the library's
+    as_prep_weight_f16x2_host (tests/test_abi_cpu.py compares them bit for bit): scale = the power of two that puts max |w| in
+    [2^13, 2^14); h = fp16(w * scale), l = fp16(w * scale - h); plane p*2 + kh of k-block kb holds part p of k = 16 kb + 8 kh + 0..7."""
+    G, M, K, T = w4.shape
+    mx = float(w4.abs().max())
+    scale = 1.0
+    if mx > 0:
+        import math
+        _, e = math.frexp(mx)
+        scale = math.ldexp(1.0, 14 - e)
+    ws = w4.float() * scale
+    h = ws.half()
+    l = (ws - h.float()).half()
+    kx = kbx(K) * 16
+    parts = torch.stack([h, l], 0)                                          # [2][G][M][K][T]
+    if kx != K:
+        parts = torch.cat([parts, parts.new_zeros(2, G, M, kx - K, T)], dim=3)
+    img = parts.reshape(2, G, M, kx // 16, 2, 8, T).permute(1, 6, 3, 0, 4, 2, 5)   # [G][T][kb][p][kh][M][8]
+    return img.contiguous().view(torch.int16).reshape(G, T, kx // 16, 4, M, 8), scale
+
+
+def prep_weight(w, device=None, stack=None):
+    """conv / linear weight [Cout, Cin, *kernel] -> GemmWeight.  stack: further weights of the same shape (a grouped launch:
+    weight set g serves the columns [g * group_cols, (g+1) * group_cols))."""
+    ws = [w] + list(stack or [])
     cout, cin = w.shape[0], w.shape[1]
-    wt = w.reshape(cout, cin, -1).permute(2, 1, 0)
+    w4 = torch.stack([x.reshape(cout, cin, -1).float() for x in ws], 0).cpu()
+    T = w4.shape[3]
     kp = (cin + KTILE - 1) // KTILE * KTILE
-    if kp != cin:
-        wt = torch.cat([wt, wt.new_zeros(wt.shape[0], kp - cin, cout)], dim=1)
-    wt = wt.contiguous()
-    x6 = split_bf16x3(wt)
+    img, scale = split_f16x2_weight(w4)
+    w32 = None
+    if cin == 1 and len(ws) == 1:
+        w32 = torch.cat([w4[0].permute(2, 1, 0), w4.new_zeros(T, kp - cin, cout)], dim=1).contiguous()   # [T][Kp][M]
     if device is not None:
-        wt, x6 = wt.to(device), x6.to(device)
-    wt.x6 = x6                                       # a plain attribute: tensor ops on `wt` drop it
-    return wt
+        img = img.to(device)
+        w32 = w32.to(device) if w32 is not None else None
+    return GemmWeight(img, scale, (T, kp, cout), len(ws), w32)
 
 
 def taps_1d(k):
@@ -157,70 +170,69 @@ def taps_2d(kh, kw):
     return [(a - kh // 2, d - kw // 2) for a in range(kh) for d in range(kw)]
 
 
+def new_image(K, N, device):
+    """uninitialised split image for K channels x N columns"""
+    return torch.empty(max(_lib.lib().as_split_f16x2_bytes(K, N) // 2, 8), dtype=torch.int16, device=device)
+
+
 def split_act(X, lay, in_act=0, in_slope=0.0):
-    """X [K][*] fp32 -> the bf16x6 GEMM's pre-split activation image (int16 [KBx][6][N][8], LeakyReLU applied first when
+    """X [K][*] fp32 -> the GEMM's split activation image (int16 [KBx][4][N+1][8], LeakyReLU applied first when
     in_act = ACT_LRELU): pass it as conv_gemm(..., xs=) to every conv that reads the same activations."""
-    L = _lib.lib()
     K, N = X.shape[0], lay.N
-    xs = torch.empty(max(L.as_split_bf16x3_bytes(K, N) // 2, 8), dtype=torch.int16, device=X.device)
-    check(L.as_split_bf16x3_f32(_p(X), _ld(X), K, N, in_act, in_slope, _p(xs), stream()), "as_split_bf16x3_f32")
+    xs = new_image(K, N, X.device)
+    check(_lib.lib().as_split_f16x2_f32(_p(X), _ld(X), K, N, in_act, in_slope, _p(xs), stream()), "as_split_f16x2_f32")
     return xs
 
 
 def adain_split(X, gb, lay, lrelu=True):
-    """AdaIN1d + LeakyReLU of X [C][N], stored only as the pre-split operand image of the conv that follows (conv_gemm(Wt, None,
+    """AdaIN1d + LeakyReLU of X [C][N], stored only as the split operand image of the conv that follows (conv_gemm(Wt, None,
     ..., xs=, K=C))."""
-    L = _lib.lib()
     C = X.shape[0]
-    xs = torch.empty(max(L.as_split_bf16x3_bytes(C, lay.N) // 2, 8), dtype=torch.int16, device=X.device)
-    check(L.as_adain_split_f32(_p(X), _ld(X), C, _p(gb), _ld(gb), _p(lay.col_off), lay.B, lay.N, int(lrelu), _p(xs), stream()),
+    xs = new_image(C, lay.N, X.device)
+    check(_lib.lib().as_adain_split_f32(_p(X), _ld(X), C, _p(gb), _ld(gb), _p(lay.col_off), lay.B, lay.N, int(lrelu), _p(xs), stream()),
           "as_adain_split_f32")
     return xs
 
 
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
-              use_meta=True, in_slope=0.0, act_slope=0.0, xs=None, K=None, group2=None):
-    """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt [T][Kp][M] (prep_weight: K zero-padded to a multiple
-    of 16); X [K][*]; Y [M][*] (or [N][*] transposed).  xs: split_act(X, lay, in_act, in_slope), when several convs
-    share X."""
+              use_meta=True, in_slope=0.0, act_slope=0.0, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None):
+    """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt: prep_weight(...); X [K][*] fp32 or None with xs= (the split image of
+    X: split_act / adain_split / channel_layernorm_split / another conv's yh=) and K=; Y [M][*] (or [N][*] transposed) or None
+    when only yh (the output as the next conv's split image, new_image(M, N)) is wanted.  group_cols: Wt holds Wt.G weight
+    sets (and bias [G][M]); columns [g * group_cols, (g+1) * group_cols) use set g."""
     T, Kp, M = Wt.shape
     if X is None:
-        if xs is None or K is None or GEMM_IMPL != "x6":
-            raise ValueError("conv_gemm: X may be omitted only with xs= and K= on the bf16x6 path")
+        if xs is None or K is None:
+            raise ValueError("conv_gemm: X may be omitted only with xs= and K=")
     else:
         K = X.shape[0]
     if Kp % KTILE or not (Kp - KTILE < K <= Kp):
         raise ValueError(f"conv_gemm: weight rows {Kp} do not match input channels {K} (use ops.prep_weight)")
+    if (Wt.G > 1) != (group_cols > 0):
+        raise ValueError("conv_gemm: stacked weights need group_cols (and only they)")
     a = ConvGemmArgs()
     a.Kp = Kp
-    a.W, a.X, a.Y, a.bias, a.res = _p(Wt), _p(X), _p(Y), _p(bias), _p(res)
-    x6 = getattr(Wt, "x6", None) if GEMM_IMPL == "x6" else None
-    a.Wx = _p(x6)
-    a.Xs = _p(xs) if x6 is not None else None
-    if group2 is not None:                           # (Wt2, bias2, n_split): columns >= n_split use the second layer's weights
-        Wt2, bias2, n_split = group2
-        if Wt2.shape != Wt.shape or (bias is None) != (bias2 is None) or n_split % 128:
-            raise ValueError("conv_gemm: the second weight set must match the first; n_split a multiple of 128")
-        a.W2, a.bias2, a.n_split = _p(Wt2), _p(bias2), n_split
-        a.Wx2 = _p(getattr(Wt2, "x6", None)) if x6 is not None else None
+    a.Wh, a.W, a.X, a.Xh, a.Y, a.Yh, a.bias, a.res = _p(Wt.wh), _p(Wt.w32), _p(X), _p(xs), _p(Y), _p(yh), _p(bias), _p(res)
+    a.acc_scale = 1.0 / Wt.scale
+    a.n_groups, a.group_cols = Wt.G, group_cols
     a.meta = _p(lay.meta) if (use_meta and not (T == 1 and taps[0] == (0, 0))) else None
     a.M, a.N, a.K, a.T = M, lay.N, K, T
-    a.ldx, a.ldy = (_ld(X) if X is not None else lay.N), _ld(Y)
+    a.ldx, a.ldy = (_ld(X) if X is not None else lay.N), (_ld(Y) if Y is not None else lay.N)
     a.ldr = _ld(res) if res is not None else 0
     a.act, a.div_sqrt2, a.in_act, a.transpose_out = act, int(div_sqrt2), in_act, int(transpose_out)
+    a.yh_lrelu = int(yh_lrelu)
+    a.n_prod = n_prod if n_prod is not None else (1 if GEMM_IMPL == "h1" else 3)
     a.in_slope, a.act_slope = in_slope, act_slope          # 0 = LeakyReLU(0.2), the acoustic path's slope
     assert len(taps) == T
     for i, (dh, dw) in enumerate(taps):
         a.dh[i], a.dw[i] = dh, dw
-    front_ok = X is not None and (X.storage_offset() >= 4 or all(dh >= 0 and dw >= 0 for dh, dw in taps))
-    a.quad_ok = int(front_ok and (lay.quads_regular() or all(dh == 0 for dh, _ in taps)))
     L = _lib.lib()
     nbytes = L.as_conv_gemm_workspace_bytes(ctypes.byref(a))
-    if nbytes:                                       # small grid: split-K partial slabs (caller-owned scratch)
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=Y.device)
+    if nbytes:                                       # split-K partial slabs, the split image of X (caller-owned scratch)
+        ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=(Y if Y is not None else yh).device)
         a.ws, a.ws_bytes = ws.data_ptr(), nbytes
     check(L.as_conv_gemm_f32(ctypes.byref(a), stream()), "as_conv_gemm_f32")
-    return Y
+    return Y if Y is not None else yh
 
 
 def embed(tokens_i32, emb, scale, Y, group2=None):
@@ -350,7 +362,7 @@ def channel_layernorm_split(X, lay, gamma, beta, relu=False, eps=1e-4, group2=No
     L = _lib.lib()
     C = X.shape[0]
     g2, b2, n_split = group2 if group2 is not None else (None, None, 0)
-    xs = torch.empty(max(L.as_split_bf16x3_bytes(C, lay.N) // 2, 8), dtype=torch.int16, device=X.device)
+    xs = new_image(C, lay.N, X.device)
     check(L.as_channel_layernorm_split_f32(_p(X), _ld(X), C, lay.N, _p(gamma), _p(beta), _p(g2), _p(b2), n_split, eps, int(relu), _p(xs),
                                            stream()), "as_channel_layernorm_split_f32")
     return xs

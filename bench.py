@@ -36,9 +36,10 @@ FRAMES_PER_UTT = 2 * M_HALF
 FRAME_SEC = 300.0 / 24000.0                          # hop 300 @ 24 kHz (test.py:40)
 WEIGHT_SEED, DATA_SEED = 3407, 1234
 PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 (64 cycles per SIMD)
-# bf16x6: every fp32 product is six bf16 MFMA products; dense bf16 peak 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz = 2516.6
-PEAK_BF16_MFMA_TFLOPS = 2516.6
-PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0         # fp32-equivalent ceiling of the split-operand GEMM: 419.4
+# f16x3: every fp32 product is three fp16 MFMA products; dense fp16/bf16 peak 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz = 2516.6
+PEAK_F16_MFMA_TFLOPS = 2516.6
+PEAK_H3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0          # fp32-equivalent ceiling of the two-way-split GEMM: 838.9
+PEAK_X6_TFLOPS = PEAK_F16_MFMA_TFLOPS / 6.0          # round 1's arithmetic (bf16x6): 419.4 -- kept for comparison across rounds
 CLASSES = ["conv_gemm", "adain", "layernorm", "attention", "lstm", "mas", "other"]
 
 
@@ -211,13 +212,11 @@ def main():
 
     from artspeech_amd import ops as _ops
     gemm_impl = _ops.GEMM_IMPL
-    if gemm_impl == "f32":
-        gemm_kernel, gemm_peak = "conv_gemm_quad_kernel / conv_gemm_kernel (fp32 MFMA implicit-GEMM conv)", PEAK_F32_MFMA_TFLOPS
-        gemm_peak_basis = "dense v_mfma_f32_32x32x2_f32"
-    else:
-        gemm_kernel, gemm_peak = ("conv_gemm_x6_kernel / conv_gemm_x6d_kernel (implicit-GEMM conv, bf16x6 split operands on the bf16 MFMAs; "
-                                  "activations split in the k loop / pre-split by the producer)"), PEAK_X6_TFLOPS
-        gemm_peak_basis = "dense bf16 MFMA 2516.6 TFLOP/s / 6 partial products per fp32 product (achieved = algorithmic fp32 flop)"
+    n_prod = 1 if gemm_impl == "h1" else 3
+    gemm_kernel = ("conv_gemm_h3_kernel (implicit-GEMM conv, fp16 matrix cores, two-way split operands h + l, %d product%s per fp32 "
+                   "product, fp32 accumulate; both operands pre-split and staged by LDS-DMA)" % (n_prod, "" if n_prod == 1 else "s"))
+    gemm_peak = PEAK_F16_MFMA_TFLOPS / n_prod
+    gemm_peak_basis = f"dense fp16 MFMA 2516.6 TFLOP/s / {n_prod} matrix-core products per fp32 product (achieved = algorithmic fp32 flop)"
     frames_per_step = B * FRAMES_PER_UTT
     ms_per_step = elapsed / args.steps * 1e3
     value = world * frames_per_step * args.steps / elapsed
@@ -225,7 +224,8 @@ def main():
         "metric": "mel frames/sec (whole job; per-GPU = value / n_gpus), acoustic-model inference path, batch 32 x 200-frame utterances",
         "value": value, "unit": "mel frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if gemm_impl == "f32" else "f32 (bf16x6 split-operand MFMA, fp32 accumulate)", "data": "synthetic",
+        "dtype": "f16 operands, f32 accumulate (AS_GEMM_IMPL=h1)" if n_prod == 1 else "f32 (f16x3 split-operand MFMA, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": "C3: LibriTTS-like batch=32 per GPU, 40 tokens -> 200 mel frames per utterance, T_ref=200, "
                                "full predictor+decoder path, forced integer durations, synthetic weights seed 3407",
                    "global_batch": B * world, "frames_per_utt": FRAMES_PER_UTT, "parallelism": f"batch-shard x{world}, no collectives",
@@ -235,6 +235,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": gemm_kernel, "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s",
                      "frac": gemm_tflops / gemm_peak, "peak_basis": gemm_peak_basis,
                      "frac_of_fp32_mfma_peak": gemm_tflops / PEAK_F32_MFMA_TFLOPS,
+                     "frac_of_round1_bf16x6_ceiling": gemm_tflops / PEAK_X6_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_ms": gemm_ms, "launches_per_step": int(cnt[0] // prof_steps),
                      "algorithmic_gflop_per_step": fl[0] / prof_steps / 1e9},

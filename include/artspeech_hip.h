@@ -72,64 +72,75 @@ int as_make_meta(const int32_t* widths, const int32_t* col_off, int B, int H, in
                  uint64_t* meta, as_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Dense convolution / linear layer as implicit GEMM on the fp32 matrix cores (K3, K4, K8, K10).
+ * Dense convolution / linear layer as implicit GEMM on the matrix cores (K3, K4, K8, K10).
  *   Y[m][j] = epi( sum_t sum_k Wt[t][k][m] * X[k][j + dh[t]*W_j + dw[t]] ),   tap valid iff inside
  *   the column's own H x W image (zero padding otherwise).
  * Replaces nn.Conv1d (RelTransformerEnc.py:110-118,257-258,306-314; models.py:176-181,480-495,592-594),
  * nn.Conv2d 3x3/1x1 stride 1 (models.py:71-77,385-399,530-535) and nn.Linear over rows.
- * epi: +bias[m], +res[m][j], /sqrt(2) (models.py:201, :100, :156), then act (0 none, 1 ReLU,
- * 2 LeakyReLU(0.2)).  Wt is the folded weight transposed to [tap][Cin][Cout].
+ * epi: *acc_scale, +bias[m], +res[m][j], /sqrt(2) (models.py:201, :100, :156), then act.
+ *
+ * Arithmetic ("f16x3"): every fp32 operand is split into two fp16 numbers, x = h + l (round-to-nearest-even twice: 22
+ * significand bits), and a product is accumulated in fp32 from h*l + l*h + h*h on v_mfma_f32_32x32x16_f16 -- the dropped
+ * l*l term is below 2^-22 |x w|.  Weights are scaled by a power of two before the split (as_prep_weight_f16x2 chooses it,
+ * acc_scale undoes it) so that their l parts stay out of the fp16 subnormal range.  Operands must be finite and below
+ * 65504 in magnitude.  n_prod = 1 keeps h*h only (plain fp16 operands: the "16-bit operand" mode of BASELINE.md C2).
+ *
+ * Operand images ("split images"), both staged global -> LDS by LDS-DMA in exactly this order:
+ *   activations Xh [KBx][4][N+1][8] fp16: k-block kb = k/16, plane q = p*2 + kh holds part p (0 = h, 1 = l) of
+ *       k = 16 kb + 8 kh + 0..7 for every column; column N is all zeros (where a tap outside the utterance reads);
+ *       KBx = ceil(K/16) rounded up to a multiple of 4 (zero blocks).  4 bytes per element: the size of the fp32 tensor.
+ *       Written by as_split_f16x2_f32, by the producers that feed only convolutions (as_adain_split_f32,
+ *       as_channel_layernorm_split_f32, ...) or by the previous GEMM's epilogue (ConvGemmArgs.Yh).
+ *   weights Wh [G][T][KBx][4][M][8] fp16 (as_prep_weight_f16x2), G = weight sets of a grouped launch.
  * ------------------------------------------------------------------------------------------- */
 #define AS_MAX_TAPS 25
 typedef struct ConvGemmArgs {
-    const float* W;        /* [T][Kp][M] fp32 (the fp32-MFMA path), or NULL when Wx is given */
-    const uint16_t* Wx;    /* [T][KBx][6][M][8] bf16, KBx = Kp/16 rounded up to a multiple of 4 (zero blocks): the same
-                              weights split w = h + m + l (three bf16, exact) for the bf16x6 path -- slot p*2 + kh holds
-                              part p (h, m, l) of k = 16*kb + 8*kh + 0..7; NULL = fp32 path */
-    const float* X;        /* [K][ldx]; may be NULL when Xs is given (bf16x6 path only) */
-    const uint16_t* Xs;    /* optional: X already split for the bf16x6 path by as_split_bf16x3_f32 (in_act applied THERE;
-                              in_act here is then ignored), [KBx][6][N+1][8] bf16; NULL = the library splits (into ws when
-                              as_conv_gemm_workspace_bytes asked for the room, else inside the GEMM's k loop) */
-    float* Y;              /* [M][ldy] */
-    const float* bias;     /* [M] or NULL */
+    const uint16_t* Wh;    /* split weights [G][T][KBx][4][M][8] fp16 */
+    const float* W;        /* optional fp32 [T][Kp][M] image: only the Cin = 1 direct kernel reads it (K == 1 launches) */
+    const float* X;        /* fp32 [K][ldx], or NULL when Xh is given */
+    const uint16_t* Xh;    /* split activations [KBx][4][N+1][8] fp16 (in_act already applied by its writer), or NULL:
+                              the library splits X into ws first (as_conv_gemm_workspace_bytes asks for the room) */
+    float* Y;              /* fp32 [M][ldy] output, or NULL when only Yh is wanted */
+    uint16_t* Yh;          /* optional: the output ALSO (or only) as the split image [KBy][4][N+1][8] of the convolution
+                              that consumes it (KBy from M as KBx from K; rows >= M and column N zero) */
+    const float* bias;     /* [G][M] or NULL */
     const float* res;      /* [M][ldr] or NULL (may alias Y) */
     const uint64_t* meta;  /* [N] column descriptors, or NULL = every tap valid */
-    float* ws;             /* scratch: split-K partial slabs, then the split activations (as_conv_gemm_workspace_bytes);
-                              NULL = never split K, activations split inside the GEMM */
+    void* ws;              /* scratch: split-K partial slabs, then the split activations; NULL = neither */
     size_t ws_bytes;
     int32_t M, N, K, T;
-    int32_t Kp;            /* rows per tap in W: K rounded up to a multiple of 16, the extra rows zero */
+    int32_t Kp;            /* K rounded up to a multiple of 16 (rows of zeros) */
     int32_t ldx, ldy, ldr;
     int32_t act;           /* epilogue activation: 0 none, 1 ReLU, 2 LeakyReLU(act_slope), 3 tanh, 4 |x| (Utils/JDC/model.py:137),
                               5 swish x*sigmoid(x) (Utils/EMA/conformer/conformer/activation.py:29) */
     int32_t div_sqrt2;     /* epilogue: divide by sqrt(2) after bias and residual */
-    int32_t in_act;        /* 2 = LeakyReLU(in_slope) applied to X while staging (models.py:89,142; Vocoder/vocoder.py:38,102) */
+    int32_t in_act;        /* 2 = LeakyReLU(in_slope) applied to X while it is split (models.py:89,142; Vocoder/vocoder.py:38,102);
+                              ignored when Xh is given */
     int32_t transpose_out; /* 1 = write Y[j][m] (time-major, row stride ldy >= M) */
-    int32_t quad_ok;       /* caller's promise enabling the 16-byte staging: (a) the 16 bytes in front of X are
-                              readable (or no tap has a negative offset), (b) no group of 4 consecutive columns
-                              starting at a multiple of 4 straddles two images of different width while a tap has
-                              dh != 0.  0 = always-correct scalar staging.  (M % 4 == 0 is checked here.) */
-    int32_t dh[AS_MAX_TAPS];   /* tap row offsets (scalar-loadable) */
+    int32_t yh_lrelu;      /* 1 = the image Yh holds LeakyReLU(in_slope)(y) (the consumer's in_act) while Y stays plain */
+    int32_t n_prod;        /* 0 or 3 = f16x3 (fp32-accurate); 1 = h*h only */
+    int32_t dh[AS_MAX_TAPS];   /* tap row offsets */
     int32_t dw[AS_MAX_TAPS];   /* tap column offsets */
     float in_slope, act_slope; /* LeakyReLU slopes of in_act / act; 0 = the path's 0.2 */
-    /* Two layers of the same shape as ONE launch (the text and articulatory encoders, RelTransformerEnc.py: identical
-     * stacks on the same tokens): columns >= n_split use the second weight set.  n_split = 0: off; else a multiple of 128. */
-    const float* W2;
-    const uint16_t* Wx2;
-    const float* bias2;
-    int32_t n_split;
+    float acc_scale;           /* multiplies the accumulator: 1 / (weight scale of as_prep_weight_f16x2); 0 = 1 */
+    /* Grouped launch: G layers of the same shape side by side along the column axis (the text and articulatory encoders,
+     * RelTransformerEnc.py; the F0 / energy / TV branches of ArtsPredictor, models.py:606-618): columns
+     * [g * group_cols, (g+1) * group_cols) use weight set g.  n_groups <= 1: off; group_cols a multiple of 128. */
+    int32_t n_groups, group_cols;
 } ConvGemmArgs;
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
-/* Bytes of workspace this shape wants (0 = none).  Shapes whose tile grid cannot fill the 256 CUs are split along
- * (tap, Cin) into slices; a second kernel sums the slabs in a fixed order (deterministic).  Shapes with many output
- * channels x taps per input element get their activations split into bf16 parts once, ahead of the GEMM. */
+/* Bytes of workspace this shape wants (0 = none): split-K slabs for shapes whose tile grid cannot fill the 256 CUs (a second
+ * kernel sums the slabs in a fixed order: deterministic), then the split image of X when Xh is NULL. */
 size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host);
-/* X fp32 [K][ldx] (N columns) -> Xs [KBx][6][N+1][8] bf16 (column N is zero: where taps outside an utterance read), x = h + m + l exactly (three bf16, round-to-nearest-even at each
- * step), slot p*2 + kh of k-block kb holds part p of k = 16*kb + 8*kh + 0..7, KBx = ceil(K/16) rounded up to a multiple
- * of 4, rows >= K zero.  in_act 2 applies LeakyReLU(in_slope; 0 = 0.2) first.  One image can feed every conv reading
- * the same activations (ConvGemmArgs.Xs).  xs must be 16-byte aligned and hold as_split_bf16x3_bytes(K, N). */
-size_t as_split_bf16x3_bytes(int K, int N);
-int as_split_bf16x3_f32(const float* x, int ldx, int K, int N, int in_act, float in_slope, uint16_t* xs, as_stream_t stream);
+/* X fp32 [K][ldx] (N columns) -> Xh (layout above).  in_act 2 applies LeakyReLU(in_slope; 0 = 0.2) first.  One image can
+ * feed every conv reading the same activations.  xh: 16-byte aligned, as_split_f16x2_bytes(K, N) bytes. */
+size_t as_split_f16x2_bytes(int K, int N);
+int as_split_f16x2_f32(const float* x, int ldx, int K, int N, int in_act, float in_slope, uint16_t* xh, as_stream_t stream);
+/* Host-side weight preparation (no GPU work): w fp32 [G][Cout][Cin][T] (a folded nn.Conv / nn.Linear weight; T = product of
+ * the kernel dims) -> wh [G][T][KBx][4][Cout][8] fp16 in HOST memory (as_prep_weight_f16x2_bytes(G, Cout, Cin, T) bytes),
+ * scaled by *scale_out = the power of two that puts max |w| in [2^13, 2^14).  Pass ConvGemmArgs.acc_scale = 1 / *scale_out. */
+size_t as_prep_weight_f16x2_bytes(int G, int Cout, int Cin, int T);
+int as_prep_weight_f16x2_host(const float* w_host, int G, int Cout, int Cin, int T, uint16_t* wh_host, float* scale_out);
 
 /* ---------------------------------------------------------------------------------------------
  * Bandwidth-bound kernels on packed frames.  col_off int32 [B+1] = first column of each utterance.
@@ -138,13 +149,13 @@ int as_split_bf16x3_f32(const float* x, int ldx, int K, int N, int in_act, float
 int as_embed_f32(const int32_t* tokens, const float* emb, int C, int N, int V, float scale, float* y, int ldy,
                  as_stream_t stream);
 /* the *_groups_* variants: columns >= n_split (utterances >= b_split) take the SECOND parameter set -- two encoders of the same
- * shape run as one double-width launch (ConvGemmArgs.n_split is the GEMM's counterpart); NULL second set = the plain call */
+ * shape run as one double-width launch (ConvGemmArgs.n_groups is the GEMM's counterpart); NULL second set = the plain call */
 int as_embed_groups_f32(const int32_t* tokens, const float* emb, const float* emb2, int n_split, int C, int N, int V, float scale,
                         float* y, int ldy, as_stream_t stream);
 int as_channel_layernorm_groups_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta, const float* gamma2,
                                     const float* beta2, int n_split, float eps, int relu, float* y, int ldy, as_stream_t stream);
-/* Channel LayerNorm (+ReLU) written as the bf16x6 operand image of the conv that follows (as_split_bf16x3_f32's layout; pass it as
- * ConvGemmArgs.Xs): in the encoders a LayerNorm's output feeds nothing but that conv.  C <= 1024; second affine pair as above. */
+/* Channel LayerNorm (+ReLU) written as the split operand image of the conv that follows (as_split_f16x2_f32's layout; pass it as
+ * ConvGemmArgs.Xh): in the encoders a LayerNorm's output feeds nothing but that conv.  C <= 1024; second affine pair as above. */
 int as_channel_layernorm_split_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta, const float* gamma2,
                                    const float* beta2, int n_split, float eps, int relu, uint16_t* xs, as_stream_t stream);
 int as_relpos_attention_groups_f32(const float* qkv, int ld, int C, int heads, int window, const float* emb_rel_k,
@@ -160,8 +171,8 @@ int as_channel_layernorm_f32(const float* x, int ldx, int C, int N, const float*
 int as_adain_f32(const float* x, int ldx, int C, const float* gamma_beta, int ldgb, const int32_t* col_off, int B,
                  float* y, int ldy, int lrelu, const float* pool_w, const float* pool_b, float* x_up, int ld_up,
                  as_stream_t stream);
-/* The same AdaIN1d + LeakyReLU(0.2) written as the bf16x6 operand image of the conv that follows (as_split_bf16x3_f32's
- * layout, N = total columns; pass it as ConvGemmArgs.Xs): the fp32 activations are never stored. */
+/* The same AdaIN1d + LeakyReLU(0.2) written as the split operand image of the conv that follows (as_split_f16x2_f32's
+ * layout, N = total columns; pass it as ConvGemmArgs.Xh): the fp32 activations are never stored. */
 int as_adain_split_f32(const float* x, int ldx, int C, const float* gamma_beta, int ldgb, const int32_t* col_off, int B, int N,
                        int lrelu, uint16_t* xs, as_stream_t stream);
 /* y[b][m] = bias[m] + W[m][:] . x[b][:]       nn.Linear on per-utterance vectors (models.py:237,412-415,538) */

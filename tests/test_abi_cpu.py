@@ -38,3 +38,31 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.as_mas_f32(None, None, None, 1, 4, 4, 0, None, None, None, None, 0, None) == -1
     assert L.as_conv_gemm_f32(None, None) == -1
     assert L.as_bilstm_f32(None, 1, None, 1, 128, None) == -1
+
+
+def test_weight_preparation_host_matches_python():
+    """as_prep_weight_f16x2_host (what a C host calls, and what as_model_create runs) and ops.split_f16x2_weight (what the Python
+    mirror runs) produce the same split fp16 weight image and the same power-of-two scale -- host arithmetic only, no GPU."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from artspeech_amd import ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    for G, M, K, T, amp in [(1, 80, 130, 3, 0.02), (2, 64, 16, 1, 3.0), (3, 7, 1, 9, 1e-4), (1, 128, 64, 5, 40.0)]:
+        w = torch.randn(G, M, K, T, generator=g) * amp
+        img, scale = ops.split_f16x2_weight(w)
+        n = L.as_prep_weight_f16x2_bytes(G, M, K, T)
+        assert n == img.numel() * 2
+        out = np.zeros(n // 2, np.int16)
+        sc = ctypes.c_float(0)
+        wn = np.ascontiguousarray(w.numpy())
+        assert L.as_prep_weight_f16x2_host(wn.ctypes.data, G, M, K, T, out.ctypes.data, ctypes.byref(sc)) == 0
+        assert sc.value == scale and 2.0 ** 13 <= float(w.abs().max()) * scale < 2.0 ** 14
+        assert np.array_equal(out, img.numpy().reshape(-1))
+        # the parts reproduce the scaled weights to 2^-22
+        parts = img.view(torch.float16).reshape(G, T, -1, 2, 2, M, 8).float()            # [G][T][kb][p][kh][M][8]
+        back = (parts[:, :, :, 0] + parts[:, :, :, 1]).permute(0, 4, 2, 3, 5, 1).reshape(G, M, -1, T)[:, :, :K]
+        assert float((back / scale - w).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
