@@ -99,9 +99,12 @@ static __device__ __forceinline__ void yh_store_tile(const ConvGemmArgs& a, __am
                 x0 = x0 > 0.f ? x0 : a.in_slope * x0;
                 x1 = x1 > 0.f ? x1 : a.in_slope * x1;
             }
-            const u32x2_t s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0), __builtin_bit_cast(unsigned, x1), false, false);
-            t[r] = __builtin_bit_cast(float, s[0]);
-            t[4 + r] = __builtin_bit_cast(float, s[1]);
+            // x0.hi <-> x1.lo.  Inline asm: with __builtin_amdgcn_permlane32_swap hipcc 7.2 uses the FIRST result for both
+            // elements of the returned pair in this loop (found in the ISA: rows 4..7 of every group repeated rows 0..3); the
+            // s_nop covers the VALU-write -> permlane-read hazard the compiler would otherwise pad itself.
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(x1));
+            t[r] = x0;
+            t[4 + r] = x1;
         }
         u32x4_t h, l;
         split2(t, h, l);

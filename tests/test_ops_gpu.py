@@ -165,9 +165,9 @@ def test_small_operands_are_not_flushed(cuda):
     lay = Layout([L], cuda)
     y = ops.conv_gemm(ops.prep_weight(w, cuda), x.to(cuda), lay, lay.new(cout), [(0, 0)])
     err = float((y.cpu().double() - want).abs().max())
-    # representation error of a subnormal h is <= 2^-25 per element: sum over 64 products of |w| ~ 0.8 => ~2e-7 worst case;
-    # a flush would lose the whole product: ~1e-6 * 0.8 * sqrt(64) = 6e-6
-    assert err <= 5e-7, err
+    # representation error of a subnormal h is <= 2^-25 per element: over 64 products of |w| ~ 0.8 that is ~2e-7 typical,
+    # ~6e-7 at the worst of 8192 outputs (measured 5.5e-7); a flush would lose whole products: ~1e-6 * 0.8 * sqrt(64) = 6e-6
+    assert err <= 1.5e-6, err
 
 
 @pytest.mark.parametrize("C,lens", [(80, [50, 13, 1, 200]), (512, [100, 24]), (7, [5])])
