@@ -82,6 +82,43 @@ _SIGNATURES.update({
 })
 
 
+class ModelCfg(ctypes.Structure):
+    _fields_ = [("hidden_dim", ctypes.c_int32), ("dim_in", ctypes.c_int32), ("style_dim", ctypes.c_int32), ("n_mels", ctypes.c_int32),
+                ("n_token", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stats", ctypes.c_float * 24)]
+
+
+class Batch(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("tok_lens", ctypes.POINTER(ctypes.c_int32)), ("ref_lens", ctypes.POINTER(ctypes.c_int32)),
+                ("frames", ctypes.POINTER(ctypes.c_int32))]
+
+
+class ForwardIO(ctypes.Structure):
+    _fields_ = [("tokens", c_p), ("mel", c_p), ("ld_mel", ctypes.c_int32), ("f0_raw", c_p), ("ema_raw", c_p), ("ld_ema", ctypes.c_int32),
+                ("forced_dur", c_p), ("mel_out", c_p), ("ld_out", ctypes.c_int32), ("duration", c_p), ("dur_i", c_p), ("frame_off", c_p),
+                ("style", c_p), ("feat12", c_p), ("ld_feat", ctypes.c_int32), ("t_en", c_p), ("a_en", c_p), ("ld_en", ctypes.c_int32),
+                ("F0", c_p), ("N", c_p), ("EMA", c_p), ("ld_pred", ctypes.c_int32)]
+
+
+AS_MOD_FORWARD_A, AS_MOD_FORWARD_B, AS_MOD_ENCODER, AS_MOD_STYLE, AS_MOD_DURATION, AS_MOD_ARTS, AS_MOD_DECODER = range(7)
+_pB, _pIO = ctypes.POINTER(Batch), ctypes.POINTER(ForwardIO)
+_SIGNATURES.update({
+    "as_model_create": (c_i, [c_p, c_sz, ctypes.POINTER(ModelCfg), ctypes.POINTER(c_p)]),
+    "as_model_destroy": (c_i, [c_p]),
+    "as_plan_create": (c_i, [c_p, ctypes.POINTER(c_p)]),
+    "as_plan_destroy": (c_i, [c_p]),
+    "as_plan_set_serial": (c_i, [c_p, c_i]),
+    "as_module_workspace_bytes": (c_sz, [c_p, c_p, c_i, _pB]),
+    "as_encoder_forward": (c_i, [c_p, c_p, c_i, _pB, c_p, c_p, c_i, c_p, c_sz, c_p]),
+    "as_style_forward": (c_i, [c_p, c_p, _pB, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_sz, c_p]),
+    "as_duration_forward": (c_i, [c_p, c_p, _pB, c_p, c_p, c_i, c_p, c_p, c_sz, c_p]),
+    "as_arts_forward": (c_i, [c_p, c_p, _pB, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_sz, c_p]),
+    "as_decoder_forward": (c_i, [c_p, c_p, _pB, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_sz, c_p]),
+    "as_forward_test_begin": (c_i, [c_p, c_p, _pB, _pIO, c_p, c_sz, c_p]),
+    "as_forward_test_finish": (c_i, [c_p, c_p, _pB, _pIO, c_p, c_sz, c_p, c_sz, c_p]),
+    "as_forward_test": (c_i, [c_p, c_p, _pB, _pIO, c_p, c_sz, c_p, c_sz, ctypes.POINTER(ctypes.c_int32), c_p]),
+})
+
+
 AS_MAX_LSTM_JOBS = 4
 
 
@@ -113,7 +150,7 @@ def lib():
 
 def check(rc, what):
     if rc != 0:
-        kind = "invalid argument" if rc < 0 else f"hipError_t {rc}"
+        kind = "an output buffer or workspace is too small" if rc == -2 else "invalid argument" if rc < 0 else f"hipError_t {rc}"
         raise HipLibraryError(f"{what} failed: {kind}")
 
 

@@ -1,0 +1,1635 @@
+// Module-level C ABI (include/artspeech_hip.h, "Module-level entry points"): the acoustic model behind an opaque handle.
+//
+//   as_model_create   reads the checkpoint blob, folds weight_norm / spectral_norm (what the reference's modules do implicitly
+//                     on every forward, models.py:685-701), lays every weight out for the kernels and uploads it
+//   as_*_forward      the launch sequences of RelTransformerEncoder / StyleEncoder / DurationPredictor / ArtsPredictor / Decoder
+//   as_forward_test   ArtsSpeech.forward(step="test"), models.py:356-371, batched on packed frames
+//
+// This file holds no kernels: it is the host side that orders the launches of the other files of this library, owns the
+// batch geometry tables and hands out workspace memory.  One code path serves three passes over the same function:
+//   prepare (as_model_create: every weight the sequence touches is built and uploaded; nothing launched),
+//   count   (as_module_workspace_bytes: the bump allocator only adds up), and
+//   run     (kernels are enqueued; nothing is allocated, nothing synchronises once the geometry's tables exist).
+#include "common.h"
+#include "conv_gemm.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+constexpr int N_HEADS = 4;      // RelTransformerEnc.py:333
+constexpr int WINDOW = 4;       // RelTransformerEnc.py:335
+constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2;
+
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// device memory that lives as long as its owner (weights of a model, geometry tables of a plan)
+// ------------------------------------------------------------------------------------------------------------------
+struct DevPool {
+    std::vector<void*> chunks;
+    char* cur = nullptr;
+    size_t left = 0, chunk_bytes;
+    explicit DevPool(size_t chunk) : chunk_bytes(chunk) {}
+    void* alloc(size_t n)
+    {
+        n = align256(n ? n : 1);
+        if (n > left) {
+            const size_t c = n > chunk_bytes ? n : chunk_bytes;
+            void* p = nullptr;
+            if (hipMalloc(&p, c) != hipSuccess) return nullptr;
+            chunks.push_back(p);
+            cur = static_cast<char*>(p);
+            left = c;
+        }
+        void* r = cur;
+        cur += n;
+        left -= n;
+        return r;
+    }
+    void release()
+    {
+        for (void* p : chunks) (void)hipFree(p);
+        chunks.clear();
+        cur = nullptr;
+        left = 0;
+    }
+};
+
+struct HostT {
+    std::vector<int> dims;
+    std::vector<float> v;
+    size_t numel() const { return v.size(); }
+    int dim(int i) const { return i < (int)dims.size() ? dims[i] : 1; }
+};
+
+struct GemmW {                  // a conv / linear weight prepared for as_conv_gemm_f32
+    uint16_t* wh = nullptr;     // [G][T][KBx][4][M][8] fp16 split image
+    float* w32 = nullptr;       // [T][Kp][M] fp32 (Cin = 1: the direct kernel)
+    float scale = 1.f;
+    int T = 0, Kp = 0, M = 0, K = 0, G = 1;
+};
+struct Vec {
+    float* p = nullptr;
+    size_t n = 0;
+};
+struct FcCat {                  // the AdaIN fc layers of several blocks sharing a style vector, rows concatenated
+    float* w = nullptr;         // [Mtot][S]
+    float* b = nullptr;         // [Mtot]
+    int Mtot = 0, S = 0;
+    std::vector<int> off;       // row offset of (block i, norm1 / norm2): off[2 i], off[2 i + 1]
+};
+struct LstmW {
+    const GemmW* wih = nullptr; // [8H][I] both directions
+    float* bias = nullptr;      // [8H] b_ih + b_hh
+    float* whh_t = nullptr;     // [2][H][4H]
+    int H = 0;
+};
+
+}  // namespace
+
+struct as_model {
+    as_model_cfg cfg;
+    int device = 0;
+    std::unordered_map<std::string, HostT> raw;             // folded fp32 host tensors, reference names with plain ".weight"
+    mutable std::unordered_map<std::string, GemmW> gemm;    // filled while !frozen (as_model_create), read-only afterwards
+    mutable std::unordered_map<std::string, Vec> vecs;
+    mutable std::unordered_map<std::string, FcCat> fcs;
+    mutable std::unordered_map<std::string, LstmW> lstms;
+    mutable DevPool pool{(size_t)256 << 20};
+    mutable bool frozen = false;
+    mutable int err = 0;
+
+    bool has(const std::string& n) const { return raw.find(n) != raw.end(); }
+    const HostT* host(const std::string& n) const
+    {
+        auto it = raw.find(n);
+        if (it == raw.end()) { if (!err) { err = AS_EINVAL; fprintf(stderr, "artspeech_hip: checkpoint has no tensor '%s'\n", n.c_str()); } return nullptr; }
+        return &it->second;
+    }
+    float* upload(const float* h, size_t n) const
+    {
+        float* d = static_cast<float*>(pool.alloc(n * sizeof(float)));
+        if (!d || hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { if (!err) err = (int)hipErrorOutOfMemory; return nullptr; }
+        return d;
+    }
+    // a weight given as host data [G][Cout][Cin][T]
+    const GemmW* gemm_from(const std::string& key, const float* w, int G, int Cout, int Cin, int T) const
+    {
+        GemmW g;
+        g.T = T; g.K = Cin; g.Kp = (Cin + 15) / 16 * 16; g.M = Cout; g.G = G;
+        const size_t bytes = as_prep_weight_f16x2_bytes(G, Cout, Cin, T);
+        std::vector<uint16_t> img(bytes / 2);
+        if (as_prep_weight_f16x2_host(w, G, Cout, Cin, T, img.data(), &g.scale) != AS_OK) { if (!err) err = AS_EINVAL; return nullptr; }
+        g.wh = static_cast<uint16_t*>(pool.alloc(bytes));
+        if (!g.wh || hipMemcpy(g.wh, img.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { if (!err) err = (int)hipErrorOutOfMemory; return nullptr; }
+        if (Cin == 1 && G == 1) {                                          // the direct kernel's fp32 image [T][Kp][M]
+            std::vector<float> w32((size_t)T * g.Kp * Cout, 0.f);
+            for (int m = 0; m < Cout; ++m)
+                for (int t = 0; t < T; ++t) w32[((size_t)t * g.Kp) * Cout + m] = w[(size_t)m * T + t];
+            g.w32 = upload(w32.data(), w32.size());
+        }
+        return &(gemm[key] = g);
+    }
+    // conv weight `name` ([Cout][Cin][k...]), optionally stacked with a second layer of the same shape (grouped launch)
+    const GemmW* conv(const std::string& name, const std::string& name2 = std::string()) const
+    {
+        const std::string key = name2.empty() ? name : name + "|" + name2;
+        auto it = gemm.find(key);
+        if (it != gemm.end()) return &it->second;
+        if (frozen) { if (!err) err = AS_EINVAL; return nullptr; }
+        const HostT* a = host(name + ".weight");
+        const HostT* b = name2.empty() ? nullptr : host(name2 + ".weight");
+        if (!a || (!name2.empty() && (!b || b->dims != a->dims))) { if (!err) err = AS_EINVAL; return nullptr; }
+        const int Cout = a->dim(0), Cin = a->dim(1), T = (int)(a->numel() / ((size_t)Cout * Cin));
+        if (!b) return gemm_from(key, a->v.data(), 1, Cout, Cin, T);
+        std::vector<float> w(a->v);
+        w.insert(w.end(), b->v.begin(), b->v.end());
+        return gemm_from(key, w.data(), 2, Cout, Cin, T);
+    }
+    // a raw tensor (bias, gamma, table ...) on the device; name2: a second one of the same size stacked behind it
+    const float* vec(const std::string& name, const std::string& name2 = std::string()) const
+    {
+        const std::string key = name2.empty() ? name : name + "|" + name2;
+        auto it = vecs.find(key);
+        if (it != vecs.end()) return it->second.p;
+        if (frozen) { if (!err) { err = AS_EINVAL; fprintf(stderr, "artspeech_hip: '%s' was not prepared by as_model_create\n", key.c_str()); } return nullptr; }
+        const HostT* a = host(name);
+        if (!a) return nullptr;
+        std::vector<float> v(a->v);
+        if (!name2.empty()) {
+            const HostT* b = host(name2);
+            if (!b || b->numel() != a->numel()) { if (!err) err = AS_EINVAL; return nullptr; }
+            v.insert(v.end(), b->v.begin(), b->v.end());
+        }
+        Vec d;
+        d.n = v.size();
+        d.p = upload(v.data(), v.size());
+        vecs[key] = d;
+        return d.p;
+    }
+    const float* bias(const std::string& name, const std::string& name2 = std::string()) const
+    {
+        if (!has(name + ".bias")) return nullptr;
+        return vec(name + ".bias", name2.empty() ? name2 : name2 + ".bias");
+    }
+    // q / k / v projections of one attention layer as one [3C] GEMM (RelTransformerEnc.py:128-133)
+    const GemmW* qkv(const std::string& p, const std::string& p2, const float** bias_out) const
+    {
+        const std::string key = "QKV:" + p + "|" + p2;
+        auto it = gemm.find(key);
+        if (it == gemm.end()) {
+            if (frozen) { if (!err) err = AS_EINVAL; return nullptr; }
+            std::vector<float> w, b;
+            int C = 0, G = 0;
+            for (const std::string& q : {p, p2}) {
+                if (q.empty()) continue;
+                ++G;
+                for (const char* n : {"q", "k", "v"}) {
+                    const HostT* wt = host(q + ".conv_" + n + ".weight");
+                    const HostT* bt = host(q + ".conv_" + n + ".bias");
+                    if (!wt || !bt) return nullptr;
+                    C = wt->dim(1);
+                    w.insert(w.end(), wt->v.begin(), wt->v.end());
+                    b.insert(b.end(), bt->v.begin(), bt->v.end());
+                }
+            }
+            if (!gemm_from(key, w.data(), G, 3 * C, C, 1)) return nullptr;
+            Vec d;
+            d.n = b.size();
+            d.p = upload(b.data(), b.size());
+            vecs[key] = d;
+            it = gemm.find(key);
+        }
+        *bias_out = vecs[key].p;
+        return &it->second;
+    }
+    // nn.LSTM(bidirectional): input projection of both directions as one GEMM, biases summed, W_hh transposed
+    const LstmW* lstm(const std::string& p) const
+    {
+        auto it = lstms.find(p);
+        if (it != lstms.end()) return &it->second;
+        if (frozen) { if (!err) err = AS_EINVAL; return nullptr; }
+        const HostT *wi = host(p + ".weight_ih_l0"), *wir = host(p + ".weight_ih_l0_reverse"), *wh = host(p + ".weight_hh_l0"),
+                    *whr = host(p + ".weight_hh_l0_reverse"), *bi = host(p + ".bias_ih_l0"), *bh = host(p + ".bias_hh_l0"),
+                    *bir = host(p + ".bias_ih_l0_reverse"), *bhr = host(p + ".bias_hh_l0_reverse");
+        if (!wi || !wir || !wh || !whr || !bi || !bh || !bir || !bhr) return nullptr;
+        LstmW L;
+        L.H = wh->dim(1);
+        const int H = L.H, I = wi->dim(1);
+        std::vector<float> w(wi->v);
+        w.insert(w.end(), wir->v.begin(), wir->v.end());
+        L.wih = gemm_from("LSTM:" + p, w.data(), 1, 8 * H, I, 1);
+        std::vector<float> b(8 * H);
+        for (int i = 0; i < 4 * H; ++i) { b[i] = bi->v[i] + bh->v[i]; b[4 * H + i] = bir->v[i] + bhr->v[i]; }
+        L.bias = upload(b.data(), b.size());
+        std::vector<float> t((size_t)2 * H * 4 * H);
+        for (int d = 0; d < 2; ++d) {
+            const std::vector<float>& src = d ? whr->v : wh->v;                   // [4H][H] -> [H][4H]
+            for (int r = 0; r < 4 * H; ++r)
+                for (int k = 0; k < H; ++k) t[((size_t)d * H + k) * 4 * H + r] = src[(size_t)r * H + k];
+        }
+        L.whh_t = upload(t.data(), t.size());
+        return &(lstms[p] = L);
+    }
+    // fc layers of the AdaIN1d norms of `blocks` (all fed by the same style vector): one GEMV over the concatenated rows
+    const FcCat* fccat(const std::vector<std::string>& blocks) const
+    {
+        std::string key;
+        for (const auto& b : blocks) key += b + "|";
+        auto it = fcs.find(key);
+        if (it != fcs.end()) return &it->second;
+        if (frozen) { if (!err) err = AS_EINVAL; return nullptr; }
+        FcCat f;
+        std::vector<float> w, b;
+        for (const auto& blk : blocks)
+            for (const char* n : {".norm1", ".norm2"}) {
+                const HostT *wt = host(blk + n + ".fc.weight"), *bt = host(blk + n + ".fc.bias");
+                if (!wt || !bt) return nullptr;
+                f.S = wt->dim(1);
+                f.off.push_back(f.Mtot);
+                f.Mtot += wt->dim(0);
+                w.insert(w.end(), wt->v.begin(), wt->v.end());
+                b.insert(b.end(), bt->v.begin(), bt->v.end());
+            }
+        f.w = upload(w.data(), w.size());
+        f.b = upload(b.data(), b.size());
+        return &(fcs[key] = f);
+    }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// packed-frames geometry: B utterances, utterance b is an H x w[b] image (H = 1: a sequence)
+// ------------------------------------------------------------------------------------------------------------------
+struct Lay {
+    int B = 0, H = 1, N = 0, max_w = 0;
+    std::vector<int> w, off;
+    int32_t *d_w = nullptr, *d_off = nullptr;
+    uint64_t* d_meta = nullptr;
+    int max_cols() const { return H * max_w; }
+};
+
+}  // namespace
+
+struct as_plan {
+    const as_model* model = nullptr;
+    std::map<std::pair<std::vector<int>, int>, std::unique_ptr<Lay>> lays;
+    DevPool pool{(size_t)8 << 20};
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> events;
+    size_t next_event = 0;
+    bool serial = false;                  // run the independent branches back to back on the calling stream (profiling)
+    std::vector<int> frames_host;         // as_forward_test with unknown frame counts reads them here
+
+    hipEvent_t event()
+    {
+        if (next_event == events.size()) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            events.push_back(e);
+        }
+        return events[next_event++];
+    }
+    hipStream_t stream(int i)
+    {
+        while ((int)side.size() <= i) {
+            hipStream_t s;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+            side.push_back(s);
+        }
+        return side[i];
+    }
+};
+
+namespace {
+
+struct Ctx {
+    const as_model& m;
+    as_plan& p;
+    hipStream_t s;                // the stream launches go to (a side stream inside a Fork)
+    char* base;                   // workspace (nullptr when counting)
+    size_t cap, off = 0;
+    bool launch;                  // false: allocate only (count pass; prepare pass; the first half of as_forward_test_finish)
+    bool count;                   // true: nothing behind the arena, geometry tables stay on the host
+    int rc = 0;
+
+    Ctx(const as_model& m_, as_plan& p_, hipStream_t s_, void* ws, size_t ws_bytes, bool launch_, bool count_)
+        : m(m_), p(p_), s(s_), base(static_cast<char*>(ws)), cap(ws_bytes), launch(launch_), count(count_) {}
+    void fail(int r, const char* what = nullptr, int line = 0)
+    {
+        if (!rc) {
+            rc = r;
+            if (getenv("AS_DEBUG")) fprintf(stderr, "artspeech_hip: model.hip:%d: rc %d %s\n", line, r, what ? what : "");
+        }
+    }
+    void* raw_alloc(size_t bytes)
+    {
+        const size_t o = off;
+        off += align256(bytes ? bytes : 1);
+        if (count) return nullptr;
+        if (off > cap) { fail(AS_ENOSPC); return nullptr; }
+        return base + o;
+    }
+    float* f32(size_t n) { return static_cast<float*>(raw_alloc(n * sizeof(float))); }
+    int32_t* i32(size_t n) { return static_cast<int32_t*>(raw_alloc(n * sizeof(int32_t))); }
+    uint16_t* image(int K, int N) { return static_cast<uint16_t*>(raw_alloc(as_split_f16x2_bytes(K, N > 0 ? N : 1))); }
+    bool go() const { return launch && rc == 0 && m.err == 0; }
+
+    // geometry (cached in the plan; device tables created on first real use: a blocking upload)
+    const Lay* lay(const std::vector<int>& widths, int H = 1)
+    {
+        auto key = std::make_pair(widths, H);
+        auto it = p.lays.find(key);
+        Lay* L;
+        if (it == p.lays.end()) {
+            auto u = std::make_unique<Lay>();
+            L = u.get();
+            L->B = (int)widths.size();
+            L->H = H;
+            L->w = widths;
+            L->off.resize(L->B + 1);
+            L->off[0] = 0;
+            for (int b = 0; b < L->B; ++b) {
+                if (widths[b] < 0 || widths[b] > 65535) { fail(AS_EINVAL); return nullptr; }
+                L->off[b + 1] = L->off[b] + H * widths[b];
+                L->max_w = std::max(L->max_w, widths[b]);
+            }
+            L->N = L->off[L->B];
+            if (p.lays.size() > 4096) p.lays.clear();          // (device tables stay in the pool until the plan dies)
+            p.lays[key] = std::move(u);
+        } else {
+            L = it->second.get();
+        }
+        if (!count && launch && !L->d_off) {
+            L->d_w = static_cast<int32_t*>(p.pool.alloc((L->B + 1) * sizeof(int32_t)));
+            L->d_off = static_cast<int32_t*>(p.pool.alloc((L->B + 1) * sizeof(int32_t)));
+            if (!L->d_w || !L->d_off || hipMemcpy(L->d_w, L->w.data(), L->B * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(L->d_off, L->off.data(), (L->B + 1) * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+                fail((int)hipErrorOutOfMemory);
+                return nullptr;
+            }
+        }
+        return L;
+    }
+    const uint64_t* meta(const Lay* L)
+    {
+        if (!L || count || !launch) return nullptr;
+        Lay* M = const_cast<Lay*>(L);
+        if (!M->d_meta) {
+            M->d_meta = static_cast<uint64_t*>(p.pool.alloc((size_t)std::max(L->N, 1) * sizeof(uint64_t)));
+            if (!M->d_meta) { fail((int)hipErrorOutOfMemory); return nullptr; }
+            const int r = as_make_meta(L->d_w, L->d_off, L->B, L->H, L->N, M->d_meta, s);
+            if (r != AS_OK || hipStreamSynchronize(s) != hipSuccess) { fail(r ? r : (int)hipErrorUnknown); return nullptr; }
+        }
+        return M->d_meta;
+    }
+    const Lay* scaled(const Lay* L, int k)
+    {
+        std::vector<int> w(L->w);
+        for (int& v : w) v *= k;
+        return lay(w, L->H);
+    }
+    const Lay* halved(const Lay* L, bool h_too)                 // W -> ceil(W/2); H -> H/2 when h_too
+    {
+        std::vector<int> w(L->w);
+        for (int& v : w) v = (v + 1) / 2;
+        return lay(w, h_too ? L->H / 2 : L->H);
+    }
+    const Lay* valid_conv(const Lay* L, int K, int stride)
+    {
+        std::vector<int> w(L->w);
+        for (int& v : w) v = v >= K ? (v - K) / stride + 1 : 0;
+        return lay(w, L->H >= K ? (L->H - K) / stride + 1 : 0);
+    }
+};
+
+#define RUN(c, call)                                   \
+    do {                                               \
+        if ((c).go()) {                                \
+            const int r__ = (call);                    \
+            if (r__ != AS_OK) (c).fail(r__, #call, __LINE__); \
+        }                                              \
+    } while (0)
+
+// Fork / join of independent branches over the plan's side streams: every branch first waits for the calling stream, the
+// calling stream then waits for every branch (hipGraph capture records them as parallel nodes).
+struct Fork {
+    Ctx& c;
+    hipStream_t main;
+    int n, first;
+    bool on_side;
+    Fork(Ctx& c_, int n_, int first_) : c(c_), main(c_.s), n(n_), first(first_), on_side(c_.go() && !c_.p.serial)
+    {
+        if (!on_side) return;
+        hipEvent_t e = c.p.event();
+        if (!e || hipEventRecord(e, main) != hipSuccess) { c.fail((int)hipErrorUnknown); return; }
+        for (int i = 0; i < n; ++i) {
+            hipStream_t st = c.p.stream(first + i);
+            if (!st || hipStreamWaitEvent(st, e, 0) != hipSuccess) { c.fail((int)hipErrorUnknown); return; }
+        }
+    }
+    void branch(int i) { c.s = on_side ? c.p.stream(first + i) : main; }
+    void back() { c.s = main; }            // continue on the calling stream while the branches run; join() later
+    void join()
+    {
+        c.s = main;
+        if (!on_side) return;
+        for (int i = 0; i < n; ++i) {
+            hipEvent_t e = c.p.event();
+            if (!e || hipEventRecord(e, c.p.stream(first + i)) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) {
+                c.fail((int)hipErrorUnknown);
+                return;
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------------------------
+struct Taps {
+    int n = 0;
+    int dh[AS_MAX_TAPS], dw[AS_MAX_TAPS];
+};
+Taps taps_1d(int k)
+{
+    Taps t;
+    t.n = k;
+    for (int i = 0; i < k; ++i) { t.dh[i] = 0; t.dw[i] = i - k / 2; }
+    return t;
+}
+Taps taps_2d(int kh, int kw)
+{
+    Taps t;
+    t.n = kh * kw;
+    for (int a = 0; a < kh; ++a)
+        for (int d = 0; d < kw; ++d) { t.dh[a * kw + d] = a - kh / 2; t.dw[a * kw + d] = d - kw / 2; }
+    return t;
+}
+
+struct ConvOpt {
+    const float* bias = nullptr;
+    const float* res = nullptr;
+    int ldr = 0;
+    int act = ACT_NONE;
+    bool div_sqrt2 = false;
+    int in_act = 0;
+    bool transpose_out = false;
+    int group_cols = 0;
+    bool want_yh = false;         // also / only write the output as the next conv's operand image `yh`
+    uint16_t* yh = nullptr;
+    bool yh_lrelu = false;
+    bool in_image = false;        // set by conv(): the input is an operand image (xh), not fp32
+};
+
+// Y = epi(conv(W, X)); the input is fp32 X [K][ldx] (split by the library into the workspace) or the operand image xh
+void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* xh, int K, const Lay* lay, const Taps& taps, float* Y,
+               int ldy, const ConvOpt& o)
+{
+    if (!w || !lay) { c.fail(AS_EINVAL); return; }
+    if (w->T != taps.n || K > w->Kp || K <= w->Kp - 16) { c.fail(AS_EINVAL); return; }
+    const bool in_image = o.in_image;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Wh = w->wh; a.W = w->w32; a.X = X; a.Xh = xh; a.Y = Y; a.Yh = o.yh;
+    a.bias = o.bias; a.res = o.res;
+    a.M = w->M; a.N = lay->N; a.K = K; a.T = w->T; a.Kp = w->Kp;
+    a.ldx = X ? ldx : lay->N; a.ldy = ldy; a.ldr = o.ldr;
+    a.act = o.act; a.div_sqrt2 = o.div_sqrt2; a.in_act = o.in_act; a.transpose_out = o.transpose_out; a.yh_lrelu = o.yh_lrelu;
+    a.acc_scale = 1.0f / w->scale;
+    a.n_groups = w->G; a.group_cols = o.group_cols;
+    for (int i = 0; i < taps.n; ++i) { a.dh[i] = taps.dh[i]; a.dw[i] = taps.dw[i]; }
+    const bool pointwise = taps.n == 1 && taps.dh[0] == 0 && taps.dw[0] == 0;
+    if (lay->N == 0) return;
+    // pointers that are null only because this pass does not run kernels must not change the plan the library makes
+    ConvGemmArgs q = a;
+    q.X = in_image ? nullptr : reinterpret_cast<const float*>(16);
+    q.Xh = in_image ? reinterpret_cast<const uint16_t*>(16) : nullptr;
+    q.Yh = o.want_yh ? reinterpret_cast<uint16_t*>(16) : nullptr;
+    const size_t wsb = as_conv_gemm_workspace_bytes(&q);
+    a.ws = wsb ? c.raw_alloc(wsb) : nullptr;
+    a.ws_bytes = wsb;
+    if (!c.go()) return;
+    a.meta = pointwise ? nullptr : c.meta(lay);
+    RUN(c, as_conv_gemm_f32(&a, c.s));
+}
+
+// fp32 input X [K][ldx]
+void conv_x(Ctx& c, const GemmW* w, const float* X, int ldx, int K, const Lay* lay, const Taps& taps, float* Y, int ldy, ConvOpt o)
+{
+    o.in_image = false;
+    conv_impl(c, w, X, ldx, nullptr, K, lay, taps, Y, ldy, o);
+}
+// operand-image input xh (K channels)
+void conv_h(Ctx& c, const GemmW* w, const uint16_t* xh, int K, const Lay* lay, const Taps& taps, float* Y, int ldy, ConvOpt o)
+{
+    o.in_image = true;
+    conv_impl(c, w, nullptr, 0, xh, K, lay, taps, Y, ldy, o);
+}
+float* conv_x_new(Ctx& c, const GemmW* w, const float* X, int ldx, int K, const Lay* lay, const Taps& taps, const ConvOpt& o)
+{
+    if (!w || !lay) { c.fail(AS_EINVAL); return nullptr; }
+    float* Y = c.f32((size_t)w->M * std::max(lay->N, 1));
+    conv_x(c, w, X, ldx, K, lay, taps, Y, lay->N, o);
+    return Y;
+}
+float* conv_h_new(Ctx& c, const GemmW* w, const uint16_t* xh, int K, const Lay* lay, const Taps& taps, const ConvOpt& o)
+{
+    if (!w || !lay) { c.fail(AS_EINVAL); return nullptr; }
+    float* Y = c.f32((size_t)w->M * std::max(lay->N, 1));
+    conv_h(c, w, xh, K, lay, taps, Y, lay->N, o);
+    return Y;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// building blocks (the launch sequences of the reference's modules)
+// ------------------------------------------------------------------------------------------------------------------
+struct GB {                      // gamma / beta rows of one AdaIN1d: [B][ld], gamma first
+    const float* p = nullptr;
+    int ld = 0;
+};
+
+// all AdaIN fc layers of `blocks` (sharing the style vector `style` [B][lds], S entries used) in one launch
+std::vector<GB> adain_fc(Ctx& c, const std::vector<std::string>& blocks, const float* style, int lds, int B)
+{
+    std::vector<GB> out(2 * blocks.size());
+    const FcCat* f = c.m.fccat(blocks);
+    if (!f) { c.fail(AS_EINVAL); return out; }
+    float* gb = c.f32((size_t)B * f->Mtot);
+    RUN(c, as_linear_rows_f32(style, lds, f->w, f->b, B, f->Mtot, f->S, gb, f->Mtot, c.s));
+    for (size_t i = 0; i < out.size(); ++i) { out[i].p = gb ? gb + f->off[i] : nullptr; out[i].ld = f->Mtot; }
+    return out;
+}
+
+struct Act {                     // fp32 activation [C][ld] on a layout
+    float* p = nullptr;
+    int C = 0, ld = 0;
+    const Lay* lay = nullptr;
+};
+
+// AdainResBlk1d.forward (models.py:189-202).  X [din][N] -> [dout][N or 2N]; out: where to put it (row stride ldo), or null.
+Act adain_resblk1d(Ctx& c, const std::string& p, const Act& X, GB gb1, GB gb2, float* out, int ldo, bool upsample)
+{
+    const as_model& m = c.m;
+    const Lay* lay = X.lay;
+    const int din = X.C, B = lay->B;
+    const GemmW *w1 = m.conv(p + ".conv1"), *w2 = m.conv(p + ".conv2");
+    const bool has_sc = m.has(p + ".conv1x1.weight");
+    Act Y;
+    if (!w1 || !w2) { c.fail(AS_EINVAL); return Y; }
+    const int dout = w1->M;
+    const Lay* lay2 = upsample ? c.scaled(lay, 2) : lay;
+    if (!lay2) return Y;
+    const int N2 = std::max(lay2->N, 1);
+    if (!out) { out = c.f32((size_t)dout * N2); ldo = lay2->N; }
+    const Taps k3 = taps_1d(3), k1 = taps_1d(1);
+    const float* sc = X.p;
+    int ldsc = X.ld;
+    float* h1;
+    if (upsample) {
+        // norm1 -> LeakyReLU -> depthwise ConvTranspose1d x2 (models.py:172,195), shortcut = nearest x2 (models.py:184,261-270)
+        float* h = c.f32((size_t)din * N2);
+        float* up = c.f32((size_t)din * N2);
+        const float *pw = m.vec(p + ".pool.weight"), *pb = m.vec(p + ".pool.bias");      // (looked up outside RUN: the prepare pass builds them)
+        RUN(c, as_adain_f32(X.p, X.ld, din, gb1.p, gb1.ld, lay->d_off, B, h, lay2->N, 1, pw, pb, up, lay2->N, c.s));
+        ConvOpt o;
+        o.bias = m.bias(p + ".conv1");
+        h1 = conv_x_new(c, w1, h, lay2->N, din, lay2, k3, o);
+        sc = up;
+        ldsc = lay2->N;
+    } else {
+        uint16_t* xs = c.image(din, lay->N);
+        RUN(c, as_adain_split_f32(X.p, X.ld, din, gb1.p, gb1.ld, lay->d_off, B, lay->N, 1, xs, c.s));
+        ConvOpt o;
+        o.bias = m.bias(p + ".conv1");
+        h1 = conv_h_new(c, w1, xs, din, lay2, k3, o);
+    }
+    if (has_sc) {                                                       // learned shortcut (models.py:185-186), no bias
+        ConvOpt o;
+        conv_x(c, m.conv(p + ".conv1x1"), sc, ldsc, din, lay2, k1, out, ldo, o);
+        sc = out;
+        ldsc = ldo;
+    }
+    uint16_t* xs2 = c.image(dout, lay2->N);
+    RUN(c, as_adain_split_f32(h1, lay2->N, dout, gb2.p, gb2.ld, lay2->d_off, B, lay2->N, 1, xs2, c.s));
+    ConvOpt o;
+    o.bias = m.bias(p + ".conv2");
+    o.res = sc;
+    o.ldr = ldsc;
+    o.div_sqrt2 = true;                                                 // (res + sc) / sqrt(2), models.py:201
+    conv_h(c, w2, xs2, dout, lay2, k3, out, ldo, o);
+    Y.p = out; Y.C = dout; Y.ld = ldo; Y.lay = lay2;
+    return Y;
+}
+
+// nn.LSTM(bidirectional) x n on packed [I][N] inputs over one layout: one hoisted input GEMM each, ONE recurrence launch
+std::vector<Act> bilstm_many(Ctx& c, const std::vector<std::string>& names, const std::vector<Act>& xs)
+{
+    std::vector<Act> out(names.size());
+    if (names.empty() || names.size() > AS_MAX_LSTM_JOBS) { c.fail(AS_EINVAL); return out; }
+    const Lay* lay = xs[0].lay;
+    BiLstmJob jobs[AS_MAX_LSTM_JOBS];
+    int H = 0;
+    for (size_t i = 0; i < names.size(); ++i) {
+        const LstmW* L = c.m.lstm(names[i]);
+        if (!L || !L->wih) { c.fail(AS_EINVAL); return out; }
+        H = L->H;
+        float* gx = c.f32((size_t)std::max(lay->N, 1) * 8 * H);
+        ConvOpt o;
+        o.bias = L->bias;
+        o.transpose_out = true;
+        conv_x(c, L->wih, xs[i].p, xs[i].ld, xs[i].C, lay, taps_1d(1), gx, 8 * H, o);
+        float* y = c.f32((size_t)2 * H * std::max(lay->N, 1));
+        jobs[i].gx_tm = gx; jobs[i].whh_t = L->whh_t; jobs[i].out = y; jobs[i].ldg = 8 * H; jobs[i].ldo = lay->N;
+        out[i].p = y; out[i].C = 2 * H; out[i].ld = lay->N; out[i].lay = lay;
+    }
+    if (lay->N > 0) RUN(c, as_bilstm_f32(jobs, (int)names.size(), lay->d_off, lay->B, H, c.s));
+    return out;
+}
+
+// RelTransformerEncoder.forward (RelTransformerEnc.py:371-380) on packed tokens -> [C][N].
+// p2: a SECOND encoder of the same shape whose weights serve the columns >= n_split / utterances >= b_split of `lay`
+// (the text and articulatory encoders are twins on the same tokens): both run as one double-width launch sequence.
+float* rel_encoder(Ctx& c, const std::string& p, const int32_t* tokens, const Lay* lay, int n_layers, const std::string& p2 = std::string(),
+                   int n_split = 0, int b_split = 0)
+{
+    const as_model& m = c.m;
+    const bool pair = !p2.empty();
+    const HostT* emb_h = m.host(p + ".emb.weight");
+    if (!emb_h || !lay) { c.fail(AS_EINVAL); return nullptr; }
+    const int V = emb_h->dim(0), C = emb_h->dim(1), N = lay->N, Nn = std::max(N, 1);
+    auto n2 = [&](const std::string& suffix) { return pair ? p2 + suffix : std::string(); };
+    const int gc = pair ? n_split : 0;
+    float* x = c.f32((size_t)C * Nn);
+    // every weight is looked up OUTSIDE the RUN(...) arguments: the prepare pass (as_model_create) runs this code with
+    // launches disabled and must still see each name
+    const float *emb1 = m.vec(p + ".emb.weight"), *emb2 = pair ? m.vec(p2 + ".emb.weight") : nullptr;
+    if (N > 0) RUN(c, as_embed_groups_f32(tokens, emb1, emb2, n_split, C, N, V, sqrtf((float)C), x, N, c.s));
+    // conv(LayerNorm(xin)): the normalised activations exist only as the conv's operand image
+    auto ln_image = [&](const float* xin, const std::string& ln, bool relu) {
+        uint16_t* xs = c.image(C, N);
+        const float *g1 = m.vec(p + ln + ".gamma"), *b1 = m.vec(p + ln + ".beta");
+        const float *g2 = pair ? m.vec(p2 + ln + ".gamma") : nullptr, *b2 = pair ? m.vec(p2 + ln + ".beta") : nullptr;
+        if (N > 0) RUN(c, as_channel_layernorm_split_f32(xin, N, C, N, g1, b1, g2, b2, n_split, 1e-4f, relu, xs, c.s));
+        return xs;
+    };
+    auto cw = [&](const std::string& name) { return m.conv(p + name, n2(name)); };
+    auto cb = [&](const std::string& name) { return m.bias(p + name, n2(name)); };
+    const Taps k5 = taps_1d(5), k1 = taps_1d(1), k9 = taps_1d(9);
+    float* h;
+    {                                                                          // ConvReluNorm, RelTransformerEnc.py:318-325
+        ConvOpt o;
+        o.bias = cb(".pre.conv_layers.0");
+        o.group_cols = gc;
+        h = conv_x_new(c, cw(".pre.conv_layers.0"), x, N, C, lay, k5, o);
+        for (int i = 0; i < 3; ++i) {
+            uint16_t* xs = ln_image(h, ".pre.norm_layers." + std::to_string(i), true);
+            const std::string nxt = i < 2 ? ".pre.conv_layers." + std::to_string(i + 1) : std::string(".pre.proj");
+            ConvOpt q;
+            q.bias = cb(nxt);
+            q.group_cols = gc;
+            if (i == 2) { q.res = x; q.ldr = N; }
+            h = conv_h_new(c, cw(nxt), xs, C, lay, i < 2 ? k5 : k1, q);
+        }
+    }
+    x = h;
+    const std::string e = ".encoder";
+    for (int i = 0; i < n_layers; ++i) {                                       // Encoder.forward, RelTransformerEnc.py:66-90
+        const std::string a = e + ".attn_layers." + std::to_string(i), f = e + ".ffn_layers." + std::to_string(i);
+        const float* bqkv = nullptr;
+        const GemmW* wqkv = m.qkv(p + a, pair ? p2 + a : std::string(), &bqkv);
+        ConvOpt o;
+        o.bias = bqkv;
+        o.group_cols = gc;
+        float* qkv = conv_h_new(c, wqkv, ln_image(x, e + ".norm_layers_1." + std::to_string(i), false), C, lay, k1, o);
+        float* att = c.f32((size_t)C * Nn);
+        const float *ek = m.vec(p + a + ".emb_rel_k"), *ev = m.vec(p + a + ".emb_rel_v");
+        const float *ek2 = pair ? m.vec(p2 + a + ".emb_rel_k") : nullptr, *ev2 = pair ? m.vec(p2 + a + ".emb_rel_v") : nullptr;
+        if (N > 0)
+            RUN(c, as_relpos_attention_groups_f32(qkv, N, C, N_HEADS, WINDOW, ek, ev, ek2, ev2, b_split, lay->d_off, lay->B, lay->max_w, att, N, c.s));
+        ConvOpt oo;
+        oo.bias = cb(a + ".conv_o");
+        oo.res = x;
+        oo.ldr = N;
+        oo.group_cols = gc;
+        x = conv_x_new(c, cw(a + ".conv_o"), att, N, C, lay, k1, oo);
+        // FFN (RelTransformerEnc.py:261-269): conv k9 -> ReLU exists only as the 1x1 conv's operand image
+        const GemmW* w1 = cw(f + ".conv_1");
+        if (!w1) { c.fail(AS_EINVAL); return nullptr; }
+        uint16_t* yh = c.image(w1->M, N);
+        ConvOpt o1;
+        o1.bias = cb(f + ".conv_1");
+        o1.act = ACT_RELU;
+        o1.group_cols = gc;
+        o1.want_yh = true;
+        o1.yh = yh;
+        conv_h(c, w1, ln_image(x, e + ".norm_layers_2." + std::to_string(i), false), C, lay, k9, nullptr, N, o1);
+        ConvOpt o2;
+        o2.bias = cb(f + ".conv_2");
+        o2.res = x;
+        o2.ldr = N;
+        o2.group_cols = gc;
+        x = conv_h_new(c, cw(f + ".conv_2"), yh, w1->M, lay, k1, o2);
+    }
+    float* y = c.f32((size_t)C * Nn);
+    const float *lg = m.vec(p + e + ".last_ln.gamma"), *lb = m.vec(p + e + ".last_ln.beta");
+    const float *lg2 = pair ? m.vec(p2 + e + ".last_ln.gamma") : nullptr, *lb2 = pair ? m.vec(p2 + e + ".last_ln.beta") : nullptr;
+    if (N > 0) RUN(c, as_channel_layernorm_groups_f32(x, N, C, N, lg, lb, lg2, lb2, n_split, 1e-4f, 0, y, N, c.s));
+    return y;
+}
+
+// Two encoders of the same shape on the same tokens (text_encoder / arts_encoder, models.py:358-359) as ONE double-width
+// encoder: the tokens are laid out twice, [utterances | filler up to a multiple of 128 columns | utterances].
+// Returns the double-width result [C][ld]; encoder 1 at column 0, encoder 2 at column *second.
+float* rel_encoder_pair(Ctx& c, const std::string& p1, const std::string& p2, const int32_t* tokens, const Lay* lay, int n_layers, int* second,
+                        int* ld)
+{
+    const int N = lay->N, pad = (128 - N % 128) % 128;
+    std::vector<int> w(lay->w);
+    if (pad) w.push_back(pad);
+    w.insert(w.end(), lay->w.begin(), lay->w.end());
+    const Lay* lay2 = c.lay(w);
+    if (!lay2) return nullptr;
+    int32_t* tok2 = c.i32((size_t)std::max(lay2->N, 1));
+    if (c.go() && N > 0) {
+        if (hipMemsetAsync(tok2, 0, (size_t)lay2->N * 4, c.s) != hipSuccess ||
+            hipMemcpyAsync(tok2, tokens, (size_t)N * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess ||
+            hipMemcpyAsync(tok2 + N + pad, tokens, (size_t)N * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess)
+            c.fail((int)hipErrorUnknown);
+    }
+    *second = N + pad;
+    *ld = lay2->N;
+    return rel_encoder(c, p1, tok2, lay2, n_layers, p2, N + pad, lay->B + (pad ? 1 : 0));
+}
+
+// ResBlk (models.py:79-100) / ResBlk1d(downsample=True) (models.py:127-156)
+Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_d)
+{
+    const as_model& m = c.m;
+    const Lay* lay = X.lay;
+    Act Y;
+    const Lay* lay2 = c.halved(lay, half);
+    if (!lay2) return Y;
+    const int cin = X.C, B = lay->B, N2 = std::max(lay2->N, 1);
+    const Taps taps = one_d ? taps_1d(3) : taps_2d(3, 3);
+    ConvOpt o;
+    o.bias = m.bias(p + ".conv1");
+    o.in_act = ACT_LRELU;
+    float* r = conv_x_new(c, m.conv(p + ".conv1"), X.p, X.ld, cin, lay, taps, o);
+    const std::string dname = p + (one_d ? ".pool" : ".downsample_res.conv");
+    float* r2 = c.f32((size_t)cin * N2);
+    const float *dww = m.vec(dname + ".weight"), *dwb = m.vec(dname + ".bias");
+    RUN(c, as_dwconv_down_f32(r, lay->N, lay->d_off, lay->d_w, lay->H, r2, lay2->N, lay2->d_off, lay2->d_w, lay2->H, dww, dwb, half ? 3 : 1, B, cin,
+                              lay2->max_cols(), 1, c.s));
+    const GemmW* w2 = m.conv(p + ".conv2");
+    if (!w2) { c.fail(AS_EINVAL); return Y; }
+    ConvOpt o2;
+    o2.bias = m.bias(p + ".conv2");
+    float* r3 = conv_x_new(c, w2, r2, lay2->N, cin, lay2, taps, o2);
+    float* out;
+    if (m.has(p + ".conv1x1.weight")) {
+        // shortcut = avgpool(conv1x1(x)) (models.py:79-84).  Both are linear and the 1x1 conv has no bias, so it is evaluated as
+        // conv1x1(avgpool(x)): a quarter of the columns, and the merge (x + r)/sqrt(2) becomes the GEMM's epilogue.
+        float* xs = c.f32((size_t)cin * N2);
+        RUN(c, as_avgpool_down_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, xs, lay2->N, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, nullptr, 0, B,
+                                   cin, lay2->max_cols(), c.s));
+        ConvOpt o3;
+        o3.res = r3;
+        o3.ldr = lay2->N;
+        o3.div_sqrt2 = true;
+        out = conv_x_new(c, m.conv(p + ".conv1x1"), xs, lay2->N, cin, lay2, taps_1d(1), o3);
+    } else {
+        out = c.f32((size_t)w2->M * N2);
+        RUN(c, as_avgpool_down_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, out, lay2->N, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, r3, lay2->N,
+                                   B, cin, lay2->max_cols(), c.s));
+    }
+    Y.p = out; Y.C = w2->M; Y.ld = lay2->N; Y.lay = lay2;
+    return Y;
+}
+
+// Mel_block / EMA_block / dur_block + their Linear (models.py:385-401,412-413,530-538) -> y [B][ldy] (M entries per row)
+void tower2d(Ctx& c, const std::string& p, const float* X, const Lay* lay, const std::vector<bool>& halves, int last_idx, int last_stride,
+             const std::string& linear, float* y, int ldy)
+{
+    const as_model& m = c.m;
+    ConvOpt o;
+    o.bias = m.bias(p + ".0");
+    const GemmW* w0 = m.conv(p + ".0");
+    if (!w0 || !lay) { c.fail(AS_EINVAL); return; }
+    Act x;
+    x.p = conv_x_new(c, w0, X, lay->N, 1, lay, taps_2d(3, 3), o);
+    x.C = w0->M; x.ld = lay->N; x.lay = lay;
+    for (size_t i = 0; i < halves.size(); ++i) {
+        x = resblk_down(c, p + "." + std::to_string(i + 1), x, halves[i], false);
+        if (!x.lay) return;
+    }
+    const int K = 5, C = x.C;
+    const Lay* lout = c.valid_conv(x.lay, K, last_stride);
+    if (!lout) return;
+    if (lout->H < 1 || *std::min_element(lout->w.begin(), lout->w.end()) < 1) {
+        // reference utterance too short for the 5x5 valid conv (T_ref >= 66)
+        c.fail(AS_EINVAL);
+        return;
+    }
+    const std::string ln = p + "." + std::to_string(last_idx);
+    const HostT* wraw = m.host(ln + ".weight");
+    if (!wraw) return;
+    const GemmW* wl = nullptr;
+    {
+        const std::string key = "IM2COL:" + p;                              // [Cout][C][5][5] -> one tap with K = C*25 (im2col row order)
+        auto it = m.gemm.find(key);
+        wl = it != m.gemm.end() ? &it->second : (m.frozen ? nullptr : m.gemm_from(key, wraw->v.data(), 1, wraw->dim(0), C * K * K, 1));
+        if (!wl) { c.fail(AS_EINVAL); return; }
+    }
+    float* col = c.f32((size_t)C * K * K * lout->N);
+    RUN(c, as_im2col_valid_f32(x.p, x.ld, x.lay->d_off, x.lay->d_w, x.lay->H, col, lout->N, lout->d_off, lout->d_w, lout->H, K, last_stride, 1,
+                               lay->B, C, lout->max_cols(), c.s));
+    ConvOpt o2;
+    o2.bias = m.bias(ln);
+    o2.act = ACT_LRELU;
+    float* z = conv_x_new(c, wl, col, lout->N, C * K * K, lout, taps_1d(1), o2);
+    float* pooled = c.f32((size_t)lay->B * wl->M);
+    RUN(c, as_mean_pool_f32(z, lout->N, lout->d_off, lay->B, wl->M, 0, pooled, wl->M, c.s));
+    const HostT* lw = m.host(linear + ".weight");
+    if (!lw) return;
+    const float *lww = m.vec(linear + ".weight"), *lwb = m.vec(linear + ".bias");
+    RUN(c, as_linear_rows_f32(pooled, wl->M, lww, lwb, lay->B, lw->dim(0), lw->dim(1), y, ldy, c.s));
+}
+
+// F0_block / energy_block + Linear (models.py:402-411,414-415)
+void tower1d(Ctx& c, const std::string& p, const float* X, int ldx, const Lay* lay, const std::string& linear, float* y, int ldy)
+{
+    const as_model& m = c.m;
+    const GemmW* w0 = m.conv(p + ".0");
+    if (!w0 || !lay) { c.fail(AS_EINVAL); return; }
+    ConvOpt o;
+    o.bias = m.bias(p + ".0");
+    Act x;
+    x.p = conv_x_new(c, w0, X, ldx, 1, lay, taps_1d(3), o);
+    x.C = w0->M; x.ld = lay->N; x.lay = lay;
+    for (int i = 1; i <= 4; ++i) {
+        x = resblk_down(c, p + "." + std::to_string(i), x, false, true);
+        if (!x.lay) return;
+    }
+    float* pooled = c.f32((size_t)lay->B * x.C);
+    RUN(c, as_mean_pool_f32(x.p, x.ld, x.lay->d_off, lay->B, x.C, 1, pooled, x.C, c.s));
+    const HostT* lw = m.host(linear + ".weight");
+    if (!lw) return;
+    const float *lww = m.vec(linear + ".weight"), *lwb = m.vec(linear + ".bias");
+    RUN(c, as_linear_rows_f32(pooled, x.C, lww, lwb, lay->B, lw->dim(0), lw->dim(1), y, ldy, c.s));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// modules
+// ------------------------------------------------------------------------------------------------------------------
+struct StyleIn {                  // the T-1 crop of the reference features and the towers' images (models.py:459-471)
+    float* crop = nullptr;        // [12 + n_mels][N1]: rows 0 n, 1 f0, 2..11 ema, 12.. mel
+    const Lay *l1 = nullptr, *lm = nullptr, *le = nullptr;
+    float *mel_img = nullptr, *ema_img = nullptr;
+};
+
+StyleIn style_inputs(Ctx& c, const float* feat12, int ldf, const float* mel, int ldm, const Lay* ref)
+{
+    StyleIn s;
+    const int n_mels = c.m.cfg.n_mels, R = 12 + n_mels;
+    std::vector<int> w(ref->w);
+    for (int& v : w) v = v > 0 ? v - 1 : 0;                               // start = randint(0, 1) = 0, length T - 1
+    s.l1 = c.lay(w);
+    s.lm = c.lay(w, n_mels);
+    s.le = c.lay(w, 10);
+    if (!s.l1 || !s.lm || !s.le) return s;
+    const int N1 = std::max(s.l1->N, 1);
+    s.crop = c.f32((size_t)R * N1);
+    RUN(c, as_crop_f32(feat12, ldf, ref->d_off, 0, s.crop, s.l1->N, s.l1->d_off, ref->B, 12, s.l1->max_cols(), c.s));
+    RUN(c, as_crop_f32(mel, ldm, ref->d_off, 0, s.crop ? s.crop + (size_t)12 * s.l1->N : nullptr, s.l1->N, s.l1->d_off, ref->B, n_mels,
+                       s.l1->max_cols(), c.s));
+    s.mel_img = c.f32((size_t)std::max(s.lm->N, 1));
+    s.ema_img = c.f32((size_t)std::max(s.le->N, 1));
+    RUN(c, as_rows_to_images_f32(s.crop + (size_t)12 * s.l1->N, s.l1->N, s.l1->d_off, 0, n_mels, s.mel_img, s.lm->d_off, ref->B, s.l1->max_cols(), c.s));
+    RUN(c, as_rows_to_images_f32(s.crop + (size_t)2 * s.l1->N, s.l1->N, s.l1->d_off, 0, 10, s.ema_img, s.le->d_off, ref->B, s.l1->max_cols(), c.s));
+    return s;
+}
+
+// one of the four towers of StyleEncoder.style_extractor (models.py:417-424) -> its slice of Style [B][2 * style_dim]
+void style_tower(Ctx& c, int which, const StyleIn& s, float* style)
+{
+    const std::string p = "style_encoder";
+    const int sd = c.m.cfg.style_dim, lds = 2 * sd;
+    if (which == 0) tower2d(c, p + ".Mel_block", s.mel_img, s.lm, {true, true, true, true}, 6, 1, p + ".Mellinear", style, lds);
+    else if (which == 1) tower2d(c, p + ".EMA_block", s.ema_img, s.le, {false, false, true}, 5, 2, p + ".EMAlinear", style ? style + sd : nullptr, lds);
+    else if (which == 2) tower1d(c, p + ".F0_block", s.crop ? s.crop + (size_t)s.l1->N : nullptr, s.l1->N, s.l1, p + ".F0linear",
+                                 style ? style + sd + sd / 2 : nullptr, lds);
+    else tower1d(c, p + ".energy_block", s.crop, s.l1->N, s.l1, p + ".Energylinear", style ? style + sd + sd / 2 + sd / 4 : nullptr, lds);
+}
+
+// DurationPredictor (models.py:540-566) in three pieces
+void duration_style(Ctx& c, const float* ema_ext, int lde, const Lay* ref, float* ds /* [B][style_dim / 4] */)
+{
+    // dur_block + dur_linear on the FULL-length TV track (models.py:543-546)
+    const std::string p = "durationPredictor";
+    const Lay* limg = c.lay(ref->w, 10);
+    if (!limg) return;
+    float* img = c.f32((size_t)std::max(limg->N, 1));
+    RUN(c, as_rows_to_images_f32(ema_ext, lde, ref->d_off, 0, 10, img, limg->d_off, ref->B, ref->max_cols(), c.s));
+    tower2d(c, p + ".dur_block", img, limg, {false, false, true}, 5, 2, p + ".dur_linear", ds, c.m.cfg.style_dim / 4);
+}
+
+float* duration_tail(Ctx& c, float* d, const float* ds, const Lay* tok)          // 3 x AdainResBlk1d -> BiLSTM -> duration_proj -> [1][N]
+{
+    const std::string p = "durationPredictor";
+    const int C = c.m.cfg.hidden_dim, S = c.m.cfg.style_dim / 4;
+    std::vector<std::string> blocks;
+    for (int i = 0; i < 3; ++i) blocks.push_back(p + ".duration." + std::to_string(i));
+    const std::vector<GB> gbs = adain_fc(c, blocks, ds, S, tok->B);
+    Act x;
+    x.p = d; x.C = C; x.ld = tok->N; x.lay = tok;
+    for (int i = 0; i < 3; ++i) x = adain_resblk1d(c, blocks[i], x, gbs[2 * i], gbs[2 * i + 1], nullptr, 0, false);
+    const std::vector<Act> h = bilstm_many(c, {p + ".LSTM"}, {x});
+    const std::string key = "DP:" + p;
+    const GemmW* w;
+    {
+        auto it = c.m.gemm.find(key);
+        const HostT* lw = c.m.host(p + ".duration_proj.linear_layer.weight");
+        if (!lw) return nullptr;
+        w = it != c.m.gemm.end() ? &it->second : (c.m.frozen ? nullptr : c.m.gemm_from(key, lw->v.data(), 1, 1, lw->dim(1), 1));
+        if (!w) { c.fail(AS_EINVAL); return nullptr; }
+    }
+    ConvOpt o;
+    o.bias = c.m.vec(p + ".duration_proj.linear_layer.bias");
+    return conv_x_new(c, w, h[0].p, h[0].ld, h[0].C, tok, taps_1d(1), o);
+}
+
+// ArtsPredictor.forward (models.py:596-621): a [C][N] on `lay` -> F0, N [1][ldp], EMA [10][ldp] on the x2 layout
+void arts_predictor(Ctx& c, const float* a_en, int lda, const Lay* lay, const float* style, float* F0, float* Nn, float* EMA, int ldp)
+{
+    const as_model& m = c.m;
+    const std::string p = "artsPredictor";
+    const int C = m.cfg.hidden_dim, sd = m.cfg.style_dim, lds = 2 * sd, B = lay->B;
+    const char* br[3] = {"F0", "N", "EMA"};
+    const int s_off[3] = {sd + sd / 2, sd + sd / 2 + sd / 4, sd};          // style slices (models.py:597-599): F0 384:448, N 448:512, TV 256:384
+    std::vector<std::string> first = {p + ".shared"};
+    for (int i = 0; i < 3; ++i) first.push_back(p + "." + br[i] + ".0");
+    const std::vector<GB> g0 = adain_fc(c, first, style, lds, B);
+    std::vector<GB> g12[3];
+    for (int i = 0; i < 3; ++i)
+        g12[i] = adain_fc(c, {p + "." + br[i] + ".1", p + "." + br[i] + ".2"}, style ? style + s_off[i] : nullptr, lds, B);
+    Act a;
+    a.p = const_cast<float*>(a_en); a.C = C; a.ld = lda; a.lay = lay;
+    a = adain_resblk1d(c, p + ".shared", a, g0[0], g0[1], nullptr, 0, false);
+    std::vector<Act> feats(3);
+    std::vector<std::string> lstm_names;
+    {
+        Fork f(c, 3, 0);                                                    // the F0 / N / EMA branches
+        for (int i = 0; i < 3; ++i) {
+            f.branch(i);
+            const std::string b = p + "." + br[i];
+            Act x = adain_resblk1d(c, b + ".0", a, g0[2 + 2 * i], g0[3 + 2 * i], nullptr, 0, true);
+            if (!x.lay) { f.join(); return; }
+            x = adain_resblk1d(c, b + ".1", x, g12[i][0], g12[i][1], nullptr, 0, false);
+            x = adain_resblk1d(c, b + ".2", x, g12[i][2], g12[i][3], nullptr, 0, false);
+            feats[i] = x;
+            lstm_names.push_back(b + "_LSTM");
+        }
+        f.join();
+    }
+    const std::vector<Act> hs = bilstm_many(c, lstm_names, feats);          // the three recurrences share one launch
+    float* outs[3] = {F0, Nn, EMA};
+    for (int i = 0; i < 3; ++i) {
+        ConvOpt o;
+        o.bias = m.bias(p + "." + br[i] + "_proj");
+        conv_x(c, m.conv(p + "." + br[i] + "_proj"), hs[i].p, hs[i].ld, hs[i].C, hs[i].lay, taps_1d(1), outs[i], ldp, o);
+    }
+}
+
+struct DecGB {
+    std::vector<GB> a, b;             // encode + decode.0..2 (style); decode.3..5 (mel_style = style[:, :style_dim])
+};
+// gamma / beta of every AdaIN of the decoder: depends on the style vector only, so it can run beside the predictors
+DecGB decoder_adain(Ctx& c, const float* style, int B)
+{
+    const std::string p = "decoder";
+    DecGB g;
+    const int lds = 2 * c.m.cfg.style_dim;
+    g.a = adain_fc(c, {p + ".encode", p + ".decode.0", p + ".decode.1", p + ".decode.2"}, style, lds, B);
+    g.b = adain_fc(c, {p + ".decode.3", p + ".decode.4", p + ".decode.5"}, style, lds, B);
+    return g;
+}
+
+void copy_rows(Ctx& c, float* dst, int ldd, const float* src, int lds, int rows, int cols)
+{
+    if (c.go() && rows > 0 && cols > 0 &&
+        hipMemcpy2DAsync(dst, (size_t)ldd * 4, src, (size_t)lds * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToDevice, c.s) != hipSuccess)
+        c.fail((int)hipErrorUnknown);
+}
+
+// Decoder.forward (models.py:497-517).  x0 [C + 128][N2]: rows 0..C-1 already hold the up-sampled text encoding (models.py:500);
+// F0 / N [1][ldp], EMA [10][ldp]; mel [n_mels][ldo].
+void decoder(Ctx& c, float* x0, const Lay* lay2, const float* F0, const float* Nn, const float* EMA, int ldp, const DecGB& g, float* mel, int ldo)
+{
+    const as_model& m = c.m;
+    const std::string p = "decoder";
+    const int C = m.cfg.hidden_dim, N2 = lay2->N, Nn2 = std::max(N2, 1), bott = 2 * C, cat = bott + 64 + 128;
+    const Taps k1 = taps_1d(1);
+    auto small = [&](const char* name, const float* X, int K, float* Y) {
+        ConvOpt o;
+        o.bias = m.bias(p + name);
+        conv_x(c, m.conv(p + name), X, ldp, K, lay2, k1, Y, N2, o);
+    };
+    float* side = x0 ? x0 + (size_t)C * N2 : nullptr;
+    small(".F0_conv", F0, 1, side);
+    small(".N_conv", Nn, 1, side ? side + (size_t)32 * N2 : nullptr);
+    small(".EMA_conv", EMA, 10, side ? side + (size_t)64 * N2 : nullptr);
+    float* cat_a = c.f32((size_t)cat * Nn2);
+    float* cat_b = c.f32((size_t)cat * Nn2);
+    Act x;
+    x.p = x0; x.C = C + 128; x.ld = N2; x.lay = lay2;
+    adain_resblk1d(c, p + ".encode", x, g.a[0], g.a[1], cat_a, N2, false);
+    {
+        ConvOpt o;
+        o.bias = m.bias(p + ".asr_res.0");
+        conv_x(c, m.conv(p + ".asr_res.0"), x0, N2, C, lay2, k1, cat_a ? cat_a + (size_t)bott * N2 : nullptr, N2, o);
+    }
+    if (c.go()) {
+        copy_rows(c, cat_a + (size_t)(bott + 64) * N2, N2, side, N2, 128, N2);
+        copy_rows(c, cat_b + (size_t)bott * N2, N2, cat_a + (size_t)bott * N2, N2, 64 + 128, N2);
+    }
+    Act xa, xb;
+    xa.p = cat_a; xa.C = cat; xa.ld = N2; xa.lay = lay2;
+    xb = xa;
+    xb.p = cat_b;
+    adain_resblk1d(c, p + ".decode.0", xa, g.a[2], g.a[3], cat_b, N2, false);
+    adain_resblk1d(c, p + ".decode.1", xb, g.a[4], g.a[5], cat_a, N2, false);
+    Act y = adain_resblk1d(c, p + ".decode.2", xa, g.a[6], g.a[7], nullptr, 0, false);
+    for (int i = 3; i <= 5; ++i) y = adain_resblk1d(c, p + ".decode." + std::to_string(i), y, g.b[2 * (i - 3)], g.b[2 * (i - 3) + 1], nullptr, 0, false);
+    ConvOpt o;
+    o.bias = m.bias(p + ".to_out.0");
+    conv_x(c, m.conv(p + ".to_out.0"), y.p, y.ld, y.C, lay2, k1, mel, ldo, o);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ArtsSpeech.forward(step="test"), models.py:356-371
+// ------------------------------------------------------------------------------------------------------------------
+struct PhaseA {                   // what the first half leaves in workspace A for the second
+    float *feat12 = nullptr, *style = nullptr, *a_en = nullptr, *t_en = nullptr, *duration = nullptr;
+    int ld_en = 0;
+    int32_t *dur_i = nullptr, *frame_off = nullptr;
+    const Lay *tok = nullptr, *ref = nullptr;
+};
+
+bool batch_ok(const as_batch* b, bool tok, bool ref, bool frames)
+{
+    return b && b->B > 0 && (!tok || b->tok_lens) && (!ref || b->ref_lens) && (!frames || b->frames);
+}
+std::vector<int> vec_of(const int32_t* p, int n) { return std::vector<int>(p, p + n); }
+
+PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
+{
+    const as_model& m = c.m;
+    PhaseA A;
+    const int C = m.cfg.hidden_dim, B = batch->B, n_mels = m.cfg.n_mels, sd2 = 2 * m.cfg.style_dim;
+    A.tok = c.lay(vec_of(batch->tok_lens, B));
+    A.ref = c.lay(vec_of(batch->ref_lens, B));
+    if (!A.tok || !A.ref) return A;
+    const int Nt = std::max(A.tok->N, 1), Nr = std::max(A.ref->N, 1);
+    A.feat12 = c.f32((size_t)12 * Nr);
+    A.style = c.f32((size_t)B * sd2);
+    A.duration = nullptr;
+    A.dur_i = c.i32(Nt);
+    A.frame_off = c.i32(B + 1);
+    float* ds = c.f32((size_t)B * (m.cfg.style_dim / 4));
+    const float* stats = m.vec("__stats24");
+    RUN(c, as_ref_features_f32(io->mel, io->ld_mel, n_mels, io->f0_raw, io->ema_raw, io->ld_ema, A.ref->N, stats, A.feat12, A.ref->N, c.s));
+    const StyleIn si = style_inputs(c, A.feat12, A.ref->N, io->mel, io->ld_mel, A.ref);
+    if (!si.l1) return A;
+    // The articulatory + text encoders (twins: one double-width encoder), the mel tower, the duration predictor and the three
+    // small towers are mutually independent (models.py:358-360) and individually too small to fill 256 CUs: four concurrent
+    // branches (measured in round 1: 3 branches 9.35 ms, these 4 8.89 ms, 5 branches 9.76 ms per step).
+    Fork f(c, 4, 0);
+    f.branch(0);
+    int second = 0;
+    float* enc = rel_encoder_pair(c, "arts_encoder", "text_encoder", io->tokens, A.tok, 4, &second, &A.ld_en);
+    A.a_en = enc;
+    A.t_en = enc ? enc + second : nullptr;
+    f.branch(1);
+    style_tower(c, 0, si, A.style);
+    f.branch(2);
+    duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
+    {
+        float* d = rel_encoder(c, "durationPredictor.text_encoder", io->tokens, A.tok, 2);
+        A.duration = duration_tail(c, d, ds, A.tok);
+    }
+    f.branch(3);
+    for (int t = 1; t <= 3; ++t) style_tower(c, t, si, A.style);
+    f.join();
+    // round half even -> clamp(min = 1) (or the forced durations), per-utterance frame offsets (models.py:361-366)
+    RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, A.dur_i, A.frame_off, nullptr, 0, c.s));
+    (void)C;
+    return A;
+}
+
+void copy_out(Ctx& c, void* dst, const void* src, size_t bytes)
+{
+    if (dst && c.go() && bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c.s) != hipSuccess) c.fail((int)hipErrorUnknown);
+}
+
+void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_io* io)
+{
+    const as_model& m = c.m;
+    const int C = m.cfg.hidden_dim, B = batch->B, n_mels = m.cfg.n_mels;
+    const Lay* lay1 = c.lay(vec_of(batch->frames, B));
+    if (!lay1) return;
+    const Lay* lay2 = c.scaled(lay1, 2);
+    if (!lay2) return;
+    const int N1 = lay1->N, N2 = lay2->N;
+    if (io->ld_out < N2 || (io->F0 && io->ld_pred < N2)) { c.fail(AS_ENOSPC); return; }
+    int32_t* tof = c.i32((size_t)std::max(N1, 1));
+    int32_t* dur_i = c.i32((size_t)std::max(A.tok->N, 1));
+    int32_t* frame_off = c.i32(B + 1);
+    RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, dur_i, frame_off, tof, N1, c.s));
+    float* a_ex = c.f32((size_t)C * std::max(N1, 1));
+    float* F0 = c.f32((size_t)std::max(N2, 1));
+    float* Nn = c.f32((size_t)std::max(N2, 1));
+    float* EMA = c.f32((size_t)10 * std::max(N2, 1));
+    float* x0 = c.f32((size_t)(C + 128) * std::max(N2, 1));
+    DecGB g;
+    {
+        // the decoder's style-only work (its AdaIN fc layers: ~40 MB of weights) runs beside the predictors
+        Fork f(c, 1, 4);
+        f.branch(0);
+        g = decoder_adain(c, A.style, B);
+        f.back();
+        // T_en @ pred_aln_trg is a column gather (models.py:367-368)
+        RUN(c, as_expand_f32(A.a_en, A.ld_en, C, tof, N1, 1, a_ex, N1, c.s));
+        arts_predictor(c, a_ex, N1, lay1, A.style, F0, Nn, EMA, N2);
+        f.join();
+    }
+    RUN(c, as_expand_f32(A.t_en, A.ld_en, C, tof, N1, 2, x0, N2, c.s));      // text encoding at the mel rate: nearest x2 (models.py:500)
+    decoder(c, x0, lay2, F0, Nn, EMA, N2, g, io->mel_out, io->ld_out);
+    if (c.go()) {
+        if (io->F0) copy_rows(c, io->F0, io->ld_pred, F0, N2, 1, N2);
+        if (io->N) copy_rows(c, io->N, io->ld_pred, Nn, N2, 1, N2);
+        if (io->EMA) copy_rows(c, io->EMA, io->ld_pred, EMA, N2, 10, N2);
+        copy_out(c, io->dur_i, dur_i, (size_t)A.tok->N * 4);
+        copy_out(c, io->frame_off, frame_off, (size_t)(B + 1) * 4);
+    }
+    (void)n_mels;
+}
+
+void outputs_a(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_io* io)
+{
+    if (!c.go()) return;
+    const int C = c.m.cfg.hidden_dim, Nt = A.tok->N, Nr = A.ref->N;
+    copy_out(c, io->duration, A.duration, (size_t)Nt * 4);
+    copy_out(c, io->style, A.style, (size_t)batch->B * 2 * c.m.cfg.style_dim * 4);
+    if (io->feat12) copy_rows(c, io->feat12, io->ld_feat, A.feat12, Nr, 12, Nr);
+    if (io->t_en) copy_rows(c, io->t_en, io->ld_en, A.t_en, A.ld_en, C, Nt);
+    if (io->a_en) copy_rows(c, io->a_en, io->ld_en, A.a_en, A.ld_en, C, Nt);
+    if (!batch->frames) {
+        copy_out(c, io->dur_i, A.dur_i, (size_t)Nt * 4);
+        copy_out(c, io->frame_off, A.frame_off, (size_t)(batch->B + 1) * 4);
+    }
+}
+
+bool io_ok(const as_forward_io* io, bool need_out)
+{
+    return io && io->tokens && io->mel && io->f0_raw && io->ema_raw && (!need_out || io->mel_out);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+bool read_blob(const void* blob, size_t bytes, std::unordered_map<std::string, HostT>* raw_out)
+{
+    const unsigned char* b = static_cast<const unsigned char*>(blob);
+    size_t o = 0;
+    auto need = [&](size_t n) { return o + n <= bytes; };
+    if (!need(12) || memcmp(b, "ASWBLOB1", 8) != 0) return false;
+    o = 8;
+    uint32_t n;
+    memcpy(&n, b + o, 4);
+    o += 4;
+    struct Ent { std::string name; std::vector<int> dims; uint64_t off; };
+    std::vector<Ent> ents(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint16_t nl;
+        if (!need(2)) return false;
+        memcpy(&nl, b + o, 2);
+        o += 2;
+        if (!need((size_t)nl + 1)) return false;
+        ents[i].name.assign(reinterpret_cast<const char*>(b + o), nl);
+        o += nl;
+        const int nd = b[o++];
+        if (!need((size_t)nd * 4 + 8)) return false;
+        for (int d = 0; d < nd; ++d) {
+            uint32_t v;
+            memcpy(&v, b + o, 4);
+            o += 4;
+            ents[i].dims.push_back((int)v);
+        }
+        memcpy(&ents[i].off, b + o, 8);
+        o += 8;
+    }
+    uint64_t data_bytes;
+    if (!need(8)) return false;
+    memcpy(&data_bytes, b + o, 8);
+    o += 8;
+    if (!need(data_bytes)) return false;
+    for (auto& e : ents) {
+        size_t numel = 1;
+        for (int d : e.dims) numel *= (size_t)d;
+        if (e.off + numel * 4 > data_bytes) return false;
+        HostT t;
+        t.dims = e.dims;
+        t.v.resize(numel);
+        memcpy(t.v.data(), b + o + e.off, numel * 4);
+        (*raw_out)[e.name] = std::move(t);
+    }
+    return true;
+}
+
+bool ends_with(const std::string& s, const char* suf)
+{
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// weight_norm (torch old-style, dim 0): w = v * g / ||v|| over all dims but 0; spectral_norm in eval: w = W / (u . (W2d v))
+// (artspeech_amd/weights.py is the Python statement of the same)
+bool fold(const std::unordered_map<std::string, HostT>& in, std::unordered_map<std::string, HostT>* out)
+{
+    for (const auto& kv : in) {
+        std::string k = kv.first;
+        if (k.compare(0, 7, "module.") == 0) k = k.substr(7);
+        if (k.compare(0, 30, "style_encoder.pitch_extractor.") == 0 || k.compare(0, 28, "style_encoder.ema_extractor.") == 0) continue;
+        auto get = [&](const std::string& name) -> const HostT* {
+            auto it = in.find(name);
+            if (it == in.end()) it = in.find("module." + name);
+            return it == in.end() ? nullptr : &it->second;
+        };
+        if (ends_with(k, ".weight_g")) {
+            const std::string p = k.substr(0, k.size() - 9);
+            const HostT* v = get(p + ".weight_v");
+            if (!v || v->dims.empty() || kv.second.numel() != (size_t)v->dims[0]) return false;
+            HostT w;
+            w.dims = v->dims;
+            w.v.resize(v->numel());
+            const size_t rows = v->dims[0], per = v->numel() / rows;
+            for (size_t r = 0; r < rows; ++r) {
+                double s = 0;
+                for (size_t i = 0; i < per; ++i) s += (double)v->v[r * per + i] * v->v[r * per + i];
+                const float scale = kv.second.v[r] / (float)sqrt(s);
+                for (size_t i = 0; i < per; ++i) w.v[r * per + i] = v->v[r * per + i] * scale;
+            }
+            (*out)[p + ".weight"] = std::move(w);
+        } else if (ends_with(k, ".weight_orig")) {
+            const std::string p = k.substr(0, k.size() - 12);
+            const HostT *u = get(p + ".weight_u"), *vv = get(p + ".weight_v");
+            const HostT& W = kv.second;
+            if (!u || !vv || W.dims.empty() || u->numel() != (size_t)W.dims[0] || vv->numel() * W.dims[0] != W.numel()) return false;
+            const size_t rows = W.dims[0], per = W.numel() / rows;
+            double sigma = 0;
+            for (size_t r = 0; r < rows; ++r) {
+                double s = 0;
+                for (size_t i = 0; i < per; ++i) s += (double)W.v[r * per + i] * vv->v[i];
+                sigma += (double)u->v[r] * (double)(float)s;
+            }
+            HostT w;
+            w.dims = W.dims;
+            w.v.resize(W.numel());
+            const float sg = (float)sigma;
+            for (size_t i = 0; i < W.numel(); ++i) w.v[i] = W.v[i] / sg;
+            (*out)[p + ".weight"] = std::move(w);
+        } else if (ends_with(k, ".weight_v") || ends_with(k, ".weight_u")) {
+            continue;
+        } else {
+            (*out)[k] = kv.second;
+        }
+    }
+    return true;
+}
+
+size_t count_module(const as_model* m, as_plan* p, int module, const as_batch* batch, bool prepare);
+
+}  // namespace
+
+extern "C" int as_model_create(const void* blob_host, size_t blob_bytes, const as_model_cfg* cfg, as_model** out)
+{
+    if (!blob_host || !cfg || !out || cfg->hidden_dim <= 0 || cfg->hidden_dim % 16 || cfg->dim_in <= 0 || cfg->style_dim <= 0 || cfg->style_dim % 4 ||
+        cfg->n_mels <= 0)
+        return AS_EINVAL;
+    std::unordered_map<std::string, HostT> blob;
+    if (!read_blob(blob_host, blob_bytes, &blob)) return AS_EINVAL;
+    std::unique_ptr<as_model> m(new as_model());
+    m->cfg = *cfg;
+    if (!fold(blob, &m->raw)) return AS_EINVAL;
+    blob.clear();
+    AS_CHECK(hipGetDevice(&m->device));
+    {
+        HostT st;
+        st.dims = {24};
+        st.v.assign(cfg->stats, cfg->stats + 24);
+        m->raw["__stats24"] = st;
+    }
+    // prepare pass: walk the whole launch sequence once on a minimal geometry; every weight it touches is built and uploaded
+    as_plan* plan = nullptr;
+    int rc = as_plan_create(m.get(), &plan);
+    if (rc != AS_OK) { m->pool.release(); return rc; }
+    const int32_t tl[1] = {8}, rl[1] = {96}, fr[1] = {12};
+    as_batch b = {1, tl, rl, fr};
+    for (int mod : {AS_MOD_FORWARD_A, AS_MOD_FORWARD_B}) count_module(m.get(), plan, mod, &b, true);
+    as_plan_destroy(plan);
+    if (m->err) { rc = m->err; m->pool.release(); return rc; }
+    m->frozen = true;
+    AS_CHECK(hipDeviceSynchronize());
+    *out = m.release();
+    return AS_OK;
+}
+
+extern "C" int as_model_destroy(as_model* m)
+{
+    if (!m) return AS_EINVAL;
+    m->pool.release();
+    delete m;
+    return AS_OK;
+}
+
+extern "C" int as_plan_create(const as_model* m, as_plan** out)
+{
+    if (!m || !out) return AS_EINVAL;
+    as_plan* p = new as_plan();
+    p->model = m;
+    *out = p;
+    return AS_OK;
+}
+
+extern "C" int as_plan_destroy(as_plan* p)
+{
+    if (!p) return AS_EINVAL;
+    for (hipStream_t s : p->side) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    p->pool.release();
+    delete p;
+    return AS_OK;
+}
+
+extern "C" int as_plan_set_serial(as_plan* p, int on)
+{
+    if (!p) return AS_EINVAL;
+    p->serial = on != 0;
+    return AS_OK;
+}
+
+namespace {
+
+const as_forward_io* dummy_io()
+{
+    static as_forward_io io;
+    static bool init = false;
+    if (!init) {
+        memset(&io, 0, sizeof(io));
+        io.tokens = reinterpret_cast<const int32_t*>(16);
+        io.mel = io.f0_raw = io.ema_raw = reinterpret_cast<const float*>(16);
+        io.mel_out = reinterpret_cast<float*>(16);
+        io.ld_mel = io.ld_ema = io.ld_out = io.ld_pred = 1 << 30;
+        init = true;
+    }
+    return &io;
+}
+
+// the sequence of one module with nothing behind it: workspace bytes (and, for as_model_create, the weights it touches)
+size_t count_module(const as_model* m, as_plan* p, int module, const as_batch* batch, bool prepare)
+{
+    Ctx c(*m, *p, nullptr, nullptr, 0, false, true);
+    (void)prepare;
+    const as_forward_io* io = dummy_io();
+    const int B = batch->B, C = m->cfg.hidden_dim;
+    switch (module) {
+    case AS_MOD_FORWARD_A:
+        if (!batch_ok(batch, true, true, false)) return 0;
+        forward_a(c, batch, io);
+        break;
+    case AS_MOD_FORWARD_B: {
+        if (!batch_ok(batch, true, true, true)) return 0;
+        Ctx ca(*m, *p, nullptr, nullptr, 0, false, true);
+        const PhaseA A = forward_a(ca, batch, io);
+        if (ca.rc || !A.tok) return 0;
+        forward_b(c, A, batch, io);
+        break;
+    }
+    case AS_MOD_ENCODER: {
+        if (!batch_ok(batch, true, false, false)) return 0;
+        const Lay* lay = c.lay(vec_of(batch->tok_lens, B));
+        int second = 0, ld = 0;
+        if (lay) rel_encoder_pair(c, "arts_encoder", "text_encoder", io->tokens, lay, 4, &second, &ld);
+        if (lay) rel_encoder(c, "durationPredictor.text_encoder", io->tokens, lay, 2);
+        break;
+    }
+    case AS_MOD_STYLE: {
+        if (!batch_ok(batch, false, true, false)) return 0;
+        const Lay* ref = c.lay(vec_of(batch->ref_lens, B));
+        if (!ref) return 0;
+        const StyleIn si = style_inputs(c, nullptr, ref->N, nullptr, ref->N, ref);
+        if (si.l1) for (int t = 0; t < 4; ++t) style_tower(c, t, si, nullptr);
+        break;
+    }
+    case AS_MOD_DURATION: {
+        if (!batch_ok(batch, true, true, false)) return 0;
+        const Lay *tok = c.lay(vec_of(batch->tok_lens, B)), *ref = c.lay(vec_of(batch->ref_lens, B));
+        if (!tok || !ref) return 0;
+        float* ds = c.f32((size_t)B * (m->cfg.style_dim / 4));
+        duration_style(c, nullptr, ref->N, ref, ds);
+        duration_tail(c, rel_encoder(c, "durationPredictor.text_encoder", io->tokens, tok, 2), ds, tok);
+        break;
+    }
+    case AS_MOD_ARTS: {
+        if (!batch_ok(batch, false, false, true)) return 0;
+        const Lay* lay = c.lay(vec_of(batch->frames, B));
+        if (!lay) return 0;
+        arts_predictor(c, nullptr, lay->N, lay, nullptr, nullptr, nullptr, nullptr, 2 * lay->N);
+        break;
+    }
+    case AS_MOD_DECODER: {
+        if (!batch_ok(batch, false, false, true)) return 0;
+        const Lay* lay = c.lay(vec_of(batch->frames, B));
+        if (!lay) return 0;
+        const Lay* lay2 = c.scaled(lay, 2);
+        c.i32((size_t)std::max(lay->N, 1));
+        float* x0 = c.f32((size_t)(C + 128) * std::max(lay2->N, 1));
+        const DecGB g = decoder_adain(c, nullptr, B);
+        decoder(c, x0, lay2, nullptr, nullptr, nullptr, lay2->N, g, nullptr, lay2->N);
+        break;
+    }
+    default: return 0;
+    }
+    return c.rc ? 0 : c.off + 256;
+}
+
+struct Call {                     // common prologue of the run entry points
+    Ctx c;
+    Call(const as_model* m, as_plan* p, void* ws, size_t bytes, as_stream_t stream, bool launch = true)
+        : c(*m, *p, static_cast<hipStream_t>(stream), ws, bytes, launch, false)
+    {
+        if (launch) p->next_event = 0;
+        if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) c.fail(AS_EINVAL);
+    }
+    int done() const { return c.rc ? c.rc : c.m.err; }
+};
+
+}  // namespace
+
+extern "C" size_t as_module_workspace_bytes(const as_model* m, as_plan* p, int module, const as_batch* batch)
+{
+    if (!m || !p || !batch) return 0;
+    return count_module(m, p, module, batch, false);
+}
+
+extern "C" int as_encoder_forward(const as_model* m, as_plan* p, int which, const as_batch* batch, const int32_t* tokens, float* out, int ldo,
+                                  void* ws, size_t ws_bytes, as_stream_t stream)
+{
+    if (!m || !p || !batch_ok(batch, true, false, false) || !tokens || !out || which < 0 || which > 2) return AS_EINVAL;
+    Call k(m, p, ws, ws_bytes, stream);
+    Ctx& c = k.c;
+    const Lay* lay = c.lay(vec_of(batch->tok_lens, batch->B));
+    if (!lay || ldo < lay->N) return AS_EINVAL;
+    // the text and articulatory encoders exist as ONE stacked weight set (they always run together in the path): a single one
+    // is asked for by running the pair and returning its half
+    if (which == 2) {
+        float* y = rel_encoder(c, "durationPredictor.text_encoder", tokens, lay, 2);
+        copy_rows(c, out, ldo, y, lay->N, m->cfg.hidden_dim, lay->N);
+    } else {
+        int second = 0, ld = 0;
+        float* y = rel_encoder_pair(c, "arts_encoder", "text_encoder", tokens, lay, 4, &second, &ld);
+        copy_rows(c, out, ldo, y ? y + (which == 0 ? second : 0) : nullptr, ld, m->cfg.hidden_dim, lay->N);
+    }
+    return k.done();
+}
+
+extern "C" int as_style_forward(const as_model* m, as_plan* p, const as_batch* batch, const float* mel, int ldm, const float* f0_raw,
+                                const float* ema_raw, int lde, float* feat12, int ldf, float* style, void* ws, size_t ws_bytes, as_stream_t stream)
+{
+    if (!m || !p || !batch_ok(batch, false, true, false) || !mel || !f0_raw || !ema_raw || !feat12 || !style) return AS_EINVAL;
+    Call k(m, p, ws, ws_bytes, stream);
+    Ctx& c = k.c;
+    const Lay* ref = c.lay(vec_of(batch->ref_lens, batch->B));
+    if (!ref || ldm < ref->N || lde < ref->N || ldf < ref->N) return AS_EINVAL;
+    const float* stats = m->vec("__stats24");
+    RUN(c, as_ref_features_f32(mel, ldm, m->cfg.n_mels, f0_raw, ema_raw, lde, ref->N, stats, feat12, ldf, c.s));
+    const StyleIn si = style_inputs(c, feat12, ldf, mel, ldm, ref);
+    if (si.l1) for (int t = 0; t < 4; ++t) style_tower(c, t, si, style);
+    return k.done();
+}
+
+extern "C" int as_duration_forward(const as_model* m, as_plan* p, const as_batch* batch, const int32_t* tokens, const float* ema_ext, int lde,
+                                   float* duration, void* ws, size_t ws_bytes, as_stream_t stream)
+{
+    if (!m || !p || !batch_ok(batch, true, true, false) || !tokens || !ema_ext || !duration) return AS_EINVAL;
+    Call k(m, p, ws, ws_bytes, stream);
+    Ctx& c = k.c;
+    const Lay *tok = c.lay(vec_of(batch->tok_lens, batch->B)), *ref = c.lay(vec_of(batch->ref_lens, batch->B));
+    if (!tok || !ref || lde < ref->N) return AS_EINVAL;
+    float* ds = c.f32((size_t)batch->B * (m->cfg.style_dim / 4));
+    duration_style(c, ema_ext, lde, ref, ds);
+    float* d = duration_tail(c, rel_encoder(c, "durationPredictor.text_encoder", tokens, tok, 2), ds, tok);
+    copy_out(c, duration, d, (size_t)tok->N * 4);
+    return k.done();
+}
+
+extern "C" int as_arts_forward(const as_model* m, as_plan* p, const as_batch* batch, const float* a_ens, int lda, const float* style, float* F0,
+                               float* N, float* EMA, int ldp, void* ws, size_t ws_bytes, as_stream_t stream)
+{
+    if (!m || !p || !batch_ok(batch, false, false, true) || !a_ens || !style || !F0 || !N || !EMA) return AS_EINVAL;
+    Call k(m, p, ws, ws_bytes, stream);
+    Ctx& c = k.c;
+    const Lay* lay = c.lay(vec_of(batch->frames, batch->B));
+    if (!lay || lda < lay->N || ldp < 2 * lay->N) return AS_EINVAL;
+    arts_predictor(c, a_ens, lda, lay, style, F0, N, EMA, ldp);
+    return k.done();
+}
+
+extern "C" int as_decoder_forward(const as_model* m, as_plan* p, const as_batch* batch, const float* asr, int lda, const float* style,
+                                  const float* F0, const float* N, const float* EMA, int ldp, float* mel, int ldo, void* ws, size_t ws_bytes,
+                                  as_stream_t stream)
+{
+    if (!m || !p || !batch_ok(batch, false, false, true) || !asr || !style || !F0 || !N || !EMA || !mel) return AS_EINVAL;
+    Call k(m, p, ws, ws_bytes, stream);
+    Ctx& c = k.c;
+    const Lay* lay = c.lay(vec_of(batch->frames, batch->B));
+    if (!lay) return AS_EINVAL;
+    const Lay* lay2 = c.scaled(lay, 2);
+    if (!lay2 || lda < lay->N || ldp < lay2->N || ldo < lay2->N) return AS_EINVAL;
+    // nearest x2 of the text encoding (models.py:500) = a column gather with every frame as its own token
+    int32_t* ident = c.i32((size_t)std::max(lay->N, 1));
+    if (c.go() && lay->N > 0) {
+        std::vector<int32_t> h(lay->N);
+        for (int i = 0; i < lay->N; ++i) h[i] = i;
+        if (hipMemcpyAsync(ident, h.data(), (size_t)lay->N * 4, hipMemcpyHostToDevice, c.s) != hipSuccess || hipStreamSynchronize(c.s) != hipSuccess)
+            c.fail((int)hipErrorUnknown);
+    }
+    const int C = m->cfg.hidden_dim;
+    float* x0 = c.f32((size_t)(C + 128) * std::max(lay2->N, 1));
+    RUN(c, as_expand_f32(asr, lda, C, ident, lay->N, 2, x0, lay2->N, c.s));
+    const DecGB g = decoder_adain(c, style, batch->B);
+    decoder(c, x0, lay2, F0, N, EMA, ldp, g, mel, ldo);
+    return k.done();
+}
+
+extern "C" int as_forward_test_begin(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
+                                     as_stream_t stream)
+{
+    if (!m || !p || !batch_ok(batch, true, true, false) || !io_ok(io, false)) return AS_EINVAL;
+    Call k(m, p, ws_a, ws_a_bytes, stream);
+    const PhaseA A = forward_a(k.c, batch, io);
+    if (A.tok && A.ref) outputs_a(k.c, A, batch, io);
+    return k.done();
+}
+
+extern "C" int as_forward_test_finish(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
+                                      void* ws_b, size_t ws_b_bytes, as_stream_t stream)
+{
+    if (!m || !p || !batch_ok(batch, true, true, true) || !io_ok(io, true)) return AS_EINVAL;
+    // recover where the first half left its results: the same allocation sequence, nothing launched
+    Call ka(m, p, ws_a, ws_a_bytes, stream, false);
+    const PhaseA A = forward_a(ka.c, batch, io);
+    if (ka.done() || !A.tok || !A.ref) return ka.done() ? ka.done() : AS_EINVAL;
+    Call kb(m, p, ws_b, ws_b_bytes, stream);
+    forward_b(kb.c, A, batch, io);
+    return kb.done();
+}
+
+extern "C" int as_forward_test(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
+                               void* ws_b, size_t ws_b_bytes, int32_t* frames_host_out, as_stream_t stream)
+{
+    if (!m || !p || !batch_ok(batch, true, true, false) || !io_ok(io, true)) return AS_EINVAL;
+    Call ka(m, p, ws_a, ws_a_bytes, stream);
+    const PhaseA A = forward_a(ka.c, batch, io);
+    if (ka.done() || !A.tok || !A.ref) return ka.done() ? ka.done() : AS_EINVAL;
+    as_batch b2 = *batch;
+    if (!batch->frames) {                                                   // the one device -> host read of the path
+        std::vector<int32_t> off(batch->B + 1);
+        AS_CHECK(hipMemcpyAsync(off.data(), A.frame_off, off.size() * 4, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+        AS_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        p->frames_host.resize(batch->B);
+        for (int i = 0; i < batch->B; ++i) p->frames_host[i] = off[i + 1] - off[i];
+        b2.frames = p->frames_host.data();
+    }
+    if (frames_host_out) memcpy(frames_host_out, b2.frames, (size_t)batch->B * 4);
+    outputs_a(ka.c, A, &b2, io);
+    if (ka.done()) return ka.done();
+    Ctx cb(*m, *p, static_cast<hipStream_t>(stream), ws_b, ws_b_bytes, true, false);
+    if ((reinterpret_cast<uintptr_t>(ws_b) & 255) != 0) return AS_EINVAL;
+    forward_b(cb, A, &b2, io);
+    return cb.rc ? cb.rc : m->err;
+}

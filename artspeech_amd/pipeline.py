@@ -139,7 +139,7 @@ class ArtSpeech:
             feats = (f0, ema)
         mel, aux = self.model.ArtsSpeech([text, input_lengths, mels, mel_input_length, None, None, None], None, None,
                                          step="test", features=feats, forced_durations=forced_durations, return_aux=True)   # test.py:113
-        self._last_frames = list(aux["lay2"].widths_host)
+        self._last_frames = list(aux["frames2"])
         return mel
 
     def synthesis(self, text, ref_wav, save_path):

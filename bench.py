@@ -59,10 +59,9 @@ def make_inputs(dev):
     host = dict(tokens=toks, mel=mels, f0=f0s, ema=emas, forced=forced)
     if dev is None:
         return host, None
-    from artspeech_amd.ops import layout
     g = dict(
         tok=torch.from_numpy(np.concatenate(toks)).to(dev, torch.int32),
-        tok_lay=layout([N_TOK] * B, dev), ref_lay=layout([T_REF] * B, dev),
+        tok_lens=[N_TOK] * B, ref_lens=[T_REF] * B,
         mel=torch.from_numpy(np.concatenate(mels, 1)).to(dev).contiguous(),
         f0=torch.from_numpy(np.concatenate(f0s, 1).astype(np.float32)).to(dev).contiguous(),
         ema=torch.from_numpy(np.concatenate(emas, 1).astype(np.float32)).to(dev).contiguous(),
@@ -129,13 +128,13 @@ def main():
     net = model.ArtsSpeech
     host, g = make_inputs(dev)
     if args.no_concurrency:
-        models.CONCURRENT = False
+        net.rt.set_serial(True)
 
-    def step():
-        return net.forward_packed(g["tok"], g["tok_lay"], g["mel"], g["f0"], g["ema"], g["ref_lay"], forced=g["forced"],
-                                  frames_hint=g["frames"])
+    def step(out=None):
+        return net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
+                                  frames_hint=g["frames"], out=out)
 
-    out = step()                                            # also uploads weights / builds layouts
+    out = step()                                            # also uploads the geometry tables (one blocking upload per new geometry)
     torch.cuda.synchronize()
     mel_first = out["mel"].clone()
 
@@ -146,10 +145,10 @@ def main():
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            step()
+            gout = step()
             torch.cuda.synchronize()
             with torch.cuda.graph(graph, stream=s):
-                gout = step()
+                step(out=gout)
         torch.cuda.current_stream().wait_stream(s)
         run = graph.replay
     else:
@@ -184,7 +183,7 @@ def main():
     #  its own and not that of whatever shared the chip with it)
     L = _lib.lib()
     prof_steps = 3
-    models.CONCURRENT = False
+    net.rt.set_serial(True)
     step()
     torch.cuda.synchronize()
     L.as_prof_enable(1)
@@ -195,7 +194,7 @@ def main():
     cnt = (ctypes.c_int32 * n)()
     _lib.check(L.as_prof_collect(ms, fl, by, cnt, n), "as_prof_collect")
     L.as_prof_enable(0)
-    models.CONCURRENT = not args.no_concurrency
+    net.rt.set_serial(args.no_concurrency)
     kern = {CLASSES[i]: dict(ms_per_step=ms[i] / prof_steps, launches_per_step=cnt[i] // prof_steps,
                              gflop_per_step=fl[i] / prof_steps / 1e9) for i in range(n) if cnt[i]}
     gemm_ms = ms[0] / max(cnt[0], 1)

@@ -282,6 +282,118 @@ int as_interleave_phases_f32(const float* z, int ldz, const float* bias, int C, 
 /* y = (a + b + c) / 3 over [C][N]                                              vocoder.py:104-110 */
 int as_mean3_f32(const float* a, const float* b, const float* c, int ld, int C, int N, float* y, int ldy, as_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Module-level entry points: the acoustic model behind an opaque handle.  A C / C++ host runs
+ * the whole path of models.py:356-371 -- ArtsSpeech.forward(step="test") -- or one sub-module at a time through these; the
+ * Python mirror of the reference's classes (artspeech_amd/models.py) is a thin caller of the same functions.
+ *
+ * as_model  = the weights: immutable after as_model_create, shareable between host threads, one per GPU.
+ *             Exception to the conventions above: as_model_create ALLOCATES device memory (the prepared weights,
+ *             ~1.3 GB for the shipped configuration) on the current HIP device and synchronises; as_model_destroy frees it.
+ * as_plan   = per-caller mutable state: the small device tables of the batch geometries it has seen (utterance offsets,
+ *             column descriptors), side HIP streams and events for the independent branches.  Not thread-safe: one per
+ *             host thread / stream.  The first call with a new geometry uploads its tables and synchronises the stream
+ *             (do not capture that call into a hipGraph); later calls with the same geometry only enqueue kernels.
+ * All activations are "packed frames" (above): every utterance of the batch back to back along the column axis, no padding.
+ * Workspaces are caller-owned device memory (256-byte aligned); as_module_workspace_bytes says how much a call needs.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct as_model as_model;
+typedef struct as_plan as_plan;
+#define AS_ENOSPC (-2)      /* an output buffer or workspace is too small */
+
+/* models.py:680-683 build_model(args): the Munch fields the inference path reads (config.yml model_params), plus the
+ * normalisation statistics of Data/stats.json that StyleEncoder.forward applies (models.py:447-449; utils.py:86-92). */
+typedef struct as_model_cfg {
+    int32_t hidden_dim;    /* 512: channels of the encoders / predictors / decoder */
+    int32_t dim_in;        /* 64: first width of the style towers */
+    int32_t style_dim;     /* 256 (the Style vector has 2 * style_dim entries; its slices are hard-coded, models.py:499,597-599) */
+    int32_t n_mels;        /* 80 */
+    int32_t n_token;       /* 178 */
+    int32_t reserved;
+    float stats[24];       /* energy_mean, energy_std, pitch_mean, pitch_std, EMA_mean[10], EMA_std[10] */
+} as_model_cfg;
+
+/* blob_host: the checkpoint's ArtsSpeech state_dict in the reference's own key layout (weight_norm g / v, spectral_norm
+ * orig / u / v) serialised as
+ *     "ASWBLOB1" | u32 n | n x { u16 name_len | name | u8 ndim | u32 dims[ndim] | u64 data_offset } | u64 data_bytes | fp32 data
+ * (little endian; data_offset counts from the start of the data section; artspeech_amd/blob.py writes it from a
+ * state_dict).  Folds weight_norm / spectral_norm (models.py:685-701 does it implicitly on every forward), lays every
+ * weight out for the kernels and uploads it. */
+int as_model_create(const void* blob_host, size_t blob_bytes, const as_model_cfg* cfg, as_model** out);
+int as_model_destroy(as_model* m);
+int as_plan_create(const as_model* m, as_plan** out);
+int as_plan_destroy(as_plan* p);
+/* on = 1: the independent branches of a forward run back to back on the calling stream instead of on side streams
+ * (per-kernel timing: a kernel's event-bracketed duration is then its own) */
+int as_plan_set_serial(as_plan* p, int on);
+
+/* geometry of one batch: HOST arrays */
+typedef struct as_batch {
+    int32_t B;
+    const int32_t* tok_lens;   /* [B] tokens per utterance (text modules) */
+    const int32_t* ref_lens;   /* [B] reference mel frames per utterance (style modules) */
+    const int32_t* frames;     /* [B] half-rate frames per utterance = sum of its integer durations (predictors / decoder);
+                                  as_forward_test: NULL = not known yet, read back from the device (one stream synchronisation) */
+} as_batch;
+
+enum { AS_MOD_FORWARD_A = 0, AS_MOD_FORWARD_B = 1, AS_MOD_ENCODER = 2, AS_MOD_STYLE = 3, AS_MOD_DURATION = 4, AS_MOD_ARTS = 5,
+       AS_MOD_DECODER = 6 };
+/* workspace bytes of one module call for this geometry (AS_MOD_FORWARD_A / _B: the two workspaces of as_forward_test) */
+size_t as_module_workspace_bytes(const as_model* m, as_plan* p, int module, const as_batch* batch);
+
+/* RelTransformerEncoder.forward (RelTransformerEnc.py:371-380).  which: 0 text_encoder, 1 arts_encoder, 2 the duration
+ * predictor's text_encoder.  tokens int32 [sum tok_lens]; out fp32 [hidden_dim][ldo >= sum tok_lens] (the reference returns
+ * its transpose, padded per utterance). */
+int as_encoder_forward(const as_model* m, as_plan* p, int which, const as_batch* batch, const int32_t* tokens, float* out, int ldo,
+                       void* ws, size_t ws_bytes, as_stream_t stream);
+/* StyleEncoder.forward (models.py:426-472) behind the two frozen extractors: mel [n_mels][ldm], f0_raw [sum ref_lens],
+ * ema_raw [10][lde] (models.py:432-433 outputs) -> feat12 [12][ldf] (row 0 energy n_ext, 1 f0_ext, 2..11 ema_ext, normalised),
+ * style [B][2 * style_dim]. */
+int as_style_forward(const as_model* m, as_plan* p, const as_batch* batch, const float* mel, int ldm, const float* f0_raw,
+                     const float* ema_raw, int lde, float* feat12, int ldf, float* style, void* ws, size_t ws_bytes, as_stream_t stream);
+/* DurationPredictor.forward (models.py:540-566): tokens, ema_ext [10][lde] (rows 2..11 of feat12) -> duration fp32 [sum tok_lens] */
+int as_duration_forward(const as_model* m, as_plan* p, const as_batch* batch, const int32_t* tokens, const float* ema_ext, int lde,
+                        float* duration, void* ws, size_t ws_bytes, as_stream_t stream);
+/* ArtsPredictor.forward (models.py:596-621): a_ens [hidden_dim][lda >= sum frames], style [B][2 * style_dim] ->
+ * F0, N [1][ldp], EMA [10][ldp], ldp >= 2 * sum frames */
+int as_arts_forward(const as_model* m, as_plan* p, const as_batch* batch, const float* a_ens, int lda, const float* style, float* F0,
+                    float* N, float* EMA, int ldp, void* ws, size_t ws_bytes, as_stream_t stream);
+/* Decoder.forward (models.py:497-517): asr [hidden_dim][lda >= sum frames] (half rate; the x2 nearest up-sampling of
+ * models.py:500 happens inside), style, F0 / N [1][ldp], EMA [10][ldp] -> mel [n_mels][ldo >= 2 * sum frames] */
+int as_decoder_forward(const as_model* m, as_plan* p, const as_batch* batch, const float* asr, int lda, const float* style,
+                       const float* F0, const float* N, const float* EMA, int ldp, float* mel, int ldo, void* ws, size_t ws_bytes,
+                       as_stream_t stream);
+
+/* ArtsSpeech.forward(step="test") (models.py:356-371), batched: every utterance gets exactly its batch-1 result.
+ * Two halves sharing workspace A: _begin runs everything up to the integer durations (encoders, style towers, duration
+ * predictor; results stay in ws_a), _finish the alignment expansion, the articulatory predictors and the decoder (needs
+ * batch->frames).  as_forward_test = both; with batch->frames == NULL it synchronises the stream once in between to read the
+ * frame counts (returns AS_ENOSPC if ld_out or ws_b turn out too small; frames_host_out, if given, then says what is needed). */
+typedef struct as_forward_io {
+    /* inputs (device) */
+    const int32_t* tokens;               /* [sum tok_lens] */
+    const float* mel; int32_t ld_mel;    /* [n_mels][ld_mel >= sum ref_lens] normalised log-mel of the reference utterances */
+    const float* f0_raw;                 /* [sum ref_lens]      pitch extractor output (models.py:432) */
+    const float* ema_raw; int32_t ld_ema;/* [10][ld_ema]        EMA extractor output (models.py:433) */
+    const int32_t* forced_dur;           /* optional [sum tok_lens]: integer durations replacing the predictor's (benchmarks) */
+    /* output (device) */
+    float* mel_out; int32_t ld_out;      /* [n_mels][ld_out >= 2 * sum frames] */
+    /* optional outputs (device; NULL = not wanted) */
+    float* duration;                     /* [sum tok_lens] fp32 durations before rounding */
+    int32_t* dur_i;                      /* [sum tok_lens] integer durations (round half even, clamp >= 1) */
+    int32_t* frame_off;                  /* [B + 1] half-rate frame offsets */
+    float* style;                        /* [B][2 * style_dim] */
+    float* feat12; int32_t ld_feat;      /* [12][ld_feat >= sum ref_lens] */
+    float* t_en; float* a_en; int32_t ld_en;          /* [hidden_dim][ld_en >= sum tok_lens] */
+    float* F0; float* N; float* EMA; int32_t ld_pred; /* [1] / [1] / [10] x [ld_pred >= 2 * sum frames] */
+} as_forward_io;
+int as_forward_test_begin(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
+                          as_stream_t stream);
+int as_forward_test_finish(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
+                           void* ws_b, size_t ws_b_bytes, as_stream_t stream);
+int as_forward_test(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
+                    void* ws_b, size_t ws_b_bytes, int32_t* frames_host_out, as_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,18 +192,80 @@ def test_pipeline_surface(cuda, golden_dir):
         tts.synthesis("hello", "ref.wav", "out.wav")
 
 
-def test_paired_encoders_equal_separate(cuda):
-    """rel_encoder_pair (text + articulatory encoders as one double-width launch sequence, per-column parameter sets) against the two
-    encoders run one after the other, on a ragged batch whose column count needs the 128-column filler."""
-    from artspeech_amd import models, synth
-    from artspeech_amd.weights import fold_state_dict
-    W = models.Weights(fold_state_dict(synth.synth_state_dict(64, 8, seed=3407)), cuda)
-    lens = [40, 17, 5, 33]
-    lay = models.layout(lens, cuda)
-    tok = torch.from_numpy(np.concatenate([synth.synth_tokens(n, 3 + i) for i, n in enumerate(lens)])).to(device=cuda, dtype=torch.int32)
-    a1 = models.rel_encoder(W, "arts_encoder", tok, lay, 4)
-    t1 = models.rel_encoder(W, "text_encoder", tok, lay, 4)
-    a2, t2 = models.rel_encoder_pair(W, "arts_encoder", "text_encoder", tok, lay, 4)
-    assert a2.shape == a1[:, : lay.N].shape and float((a2 - a1[:, : lay.N]).abs().max()) <= 2e-5
-    assert float((t2 - t1[:, : lay.N]).abs().max()) <= 2e-5
-    assert float((a1[:, : lay.N] - t1[:, : lay.N]).abs().max()) > 1e-3          # (the two encoders do differ)
+def test_encoders_ragged_batch(cuda, golden_dir):
+    """The text and articulatory encoders run inside the library as ONE double-width encoder (stacked weight sets, per-column
+    parameter choice).  On a ragged batch whose column count needs the 128-column filler, each half must equal the reference's own
+    encoder outputs for every utterance (tests/golden: t_en / a_en of the reference's forward), and the two must differ."""
+    files = sorted(glob.glob(os.path.join(golden_dir, "net_tiny_*.npz")))
+    gs = [np.load(f) for f in files]
+    net = get_model(64, 8, int(gs[0]["weight_seed"]), cuda)
+    lens = [len(g["tokens"]) for g in gs]
+    assert sum(lens) % 128 != 0
+    x = torch.zeros(len(gs), max(lens), dtype=torch.long)
+    for b, g in enumerate(gs):
+        x[b, : lens[b]] = torch.from_numpy(g["tokens"])
+    t = net.text_encoder(x, torch.tensor(lens))
+    a = net.arts_encoder(x, torch.tensor(lens))
+    for b, g in enumerate(gs):
+        assert float(np.abs(t[b, : lens[b]].t().cpu().numpy() - g["ref/t_en"]).max()) <= AUX_TOL
+        assert float(np.abs(a[b, : lens[b]].t().cpu().numpy() - g["ref/a_en"]).max()) <= AUX_TOL
+    assert float((a - t).abs().max()) > 1e-3
+
+
+def test_c_abi_forward_on_full_goldens(cuda, golden_dir):
+    """as_forward_test driven through ctypes alone (no Python orchestration): model from the blob, plan, workspaces, one call;
+    durations identical to the reference's, mel within 1e-4 of the reference's own output (tests/golden/net_full_*.npz)."""
+    import ctypes
+    from artspeech_amd import _lib
+    from artspeech_amd.blob import state_dict_to_blob
+    L = _lib.lib()
+    files = sorted(glob.glob(os.path.join(golden_dir, "net_full_*.npz")))
+    g0 = np.load(files[0])
+    sd = synth.synth_state_dict(int(g0["hidden_dim"]), int(g0["dim_in"]), seed=int(g0["weight_seed"]))
+    blob = state_dict_to_blob(sd)
+    cfg = _lib.ModelCfg()
+    cfg.hidden_dim, cfg.dim_in, cfg.style_dim, cfg.n_mels, cfg.n_token = int(g0["hidden_dim"]), int(g0["dim_in"]), 256, 80, 178
+    for i, v in enumerate(models.stats_floats(load_distribution(DEFAULT_STATS))):
+        cfg.stats[i] = v
+    model, plan = ctypes.c_void_p(), ctypes.c_void_p()
+    torch.cuda.set_device(cuda)
+    assert L.as_model_create(blob, len(blob), ctypes.byref(cfg), ctypes.byref(model)) == 0
+    assert L.as_plan_create(model, ctypes.byref(plan)) == 0
+    try:
+        for f in files:
+            g = np.load(f)
+            tokens = g["tokens"].astype(np.int32)
+            mel, f0_raw, ema_raw = raw_features(int(g["t_ref"]), int(g["seed"]))
+            n, t = len(tokens), mel.shape[1]
+            tl, rl = (ctypes.c_int32 * 1)(n), (ctypes.c_int32 * 1)(t)
+            I32P = ctypes.POINTER(ctypes.c_int32)
+            b = _lib.Batch(1, ctypes.cast(tl, I32P), ctypes.cast(rl, I32P), None)
+            d_tok, d_mel = torch.from_numpy(tokens).to(cuda), torch.from_numpy(mel).to(cuda).contiguous()
+            d_f0, d_ema = torch.from_numpy(f0_raw).to(cuda).contiguous(), torch.from_numpy(ema_raw).to(cuda).contiguous()
+            cap = 2 * int(g["ref/pred_dur"].sum()) + 64
+            out = torch.zeros(80, cap, device=cuda)
+            dur_i = torch.zeros(n, dtype=torch.int32, device=cuda)
+            io = _lib.ForwardIO()
+            io.tokens, io.mel, io.ld_mel, io.f0_raw, io.ema_raw, io.ld_ema = d_tok.data_ptr(), d_mel.data_ptr(), t, d_f0.data_ptr(), d_ema.data_ptr(), t
+            io.mel_out, io.ld_out, io.dur_i = out.data_ptr(), cap, dur_i.data_ptr()
+            na = L.as_module_workspace_bytes(model, plan, _lib.AS_MOD_FORWARD_A, ctypes.byref(b))
+            assert na > 0
+            ws_a = torch.empty(na, dtype=torch.uint8, device=cuda)
+            # frames unknown: workspace B sized for the capacity we allow
+            fr = (ctypes.c_int32 * 1)(cap // 2)
+            b_cap = _lib.Batch(1, ctypes.cast(tl, I32P), ctypes.cast(rl, I32P), ctypes.cast(fr, I32P))
+            nb = L.as_module_workspace_bytes(model, plan, _lib.AS_MOD_FORWARD_B, ctypes.byref(b_cap))
+            ws_b = torch.empty(nb, dtype=torch.uint8, device=cuda)
+            frames = (ctypes.c_int32 * 1)(0)
+            rc = L.as_forward_test(model, plan, ctypes.byref(b), ctypes.byref(io), ws_a.data_ptr(), na, ws_b.data_ptr(), nb, frames,
+                                   torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+            assert frames[0] == int(g["ref/pred_dur"].sum())
+            assert np.array_equal(dur_i.cpu().numpy(), g["ref/pred_dur"].astype(np.int32))
+            d = float(np.abs(out[:, : 2 * frames[0]].cpu().numpy() - g["ref/mel"]).max())
+            print(os.path.basename(f), "C ABI mel max-abs", d)
+            assert d <= MEL_TOL, (f, d)
+    finally:
+        L.as_plan_destroy(plan)
+        L.as_model_destroy(model)
