@@ -82,6 +82,12 @@ _SIGNATURES.update({
 })
 
 
+class AdainArgs(ctypes.Structure):
+    _fields_ = [("x", c_p), ("ldx", ctypes.c_int32), ("C", ctypes.c_int32), ("gb", c_p), ("gb_off", c_p), ("ldgb", ctypes.c_int32),
+                ("gb_sc", ctypes.c_int32), ("col_off", c_p), ("src_off", c_p), ("U", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("lrelu", ctypes.c_int32), ("yh", c_p), ("pool_w", c_p), ("pool_b", c_p), ("x_up", c_p), ("ld_up", ctypes.c_int32)]
+
+
 class ModelCfg(ctypes.Structure):
     _fields_ = [("hidden_dim", ctypes.c_int32), ("dim_in", ctypes.c_int32), ("style_dim", ctypes.c_int32), ("n_mels", ctypes.c_int32),
                 ("n_token", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stats", ctypes.c_float * 24)]
@@ -102,6 +108,9 @@ class ForwardIO(ctypes.Structure):
 AS_MOD_FORWARD_A, AS_MOD_FORWARD_B, AS_MOD_ENCODER, AS_MOD_STYLE, AS_MOD_DURATION, AS_MOD_ARTS, AS_MOD_DECODER = range(7)
 _pB, _pIO = ctypes.POINTER(Batch), ctypes.POINTER(ForwardIO)
 _SIGNATURES.update({
+    "as_adain_image_f32": (c_i, [ctypes.POINTER(AdainArgs), c_p]),
+    "as_rows_image_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "as_project_cols_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "as_model_create": (c_i, [c_p, c_sz, ctypes.POINTER(ModelCfg), ctypes.POINTER(c_p)]),
     "as_model_destroy": (c_i, [c_p]),
     "as_plan_create": (c_i, [c_p, ctypes.POINTER(c_p)]),

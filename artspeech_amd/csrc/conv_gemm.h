@@ -85,7 +85,7 @@ static __device__ __forceinline__ float epi_act(float x, float slope)
 // half of each of the tile's four 8-row groups.  v_permlane32_swap hands lane (col, lk = 0) the other half of groups 0 and 2
 // and lane (col, lk = 1) that of groups 1 and 3, so every lane stores whole 16-byte rows: 8 swaps, 4 stores per tile.
 static __device__ __forceinline__ void yh_store_tile(const ConvGemmArgs& a, __amdgpu_buffer_rsrc_t rsH, const float (&v)[16], int row0,
-                                                     int col, int lk)
+                                                     int col, int lk, int n_end)
 {
     const unsigned NXy = (unsigned)a.N + 1u;
     const int groups = 2 * as_kbx(a.M);
@@ -109,7 +109,7 @@ static __device__ __forceinline__ void yh_store_tile(const ConvGemmArgs& a, __am
         u32x4_t h, l;
         split2(t, h, l);
         const int g = (row0 >> 3) + 2 * pr + lk;                        // 8-row group: k-block g / 2, k-half g % 2
-        const bool ok = col < a.N && g < groups;
+        const bool ok = col < n_end && g < groups;
         const unsigned off = ok ? ((unsigned)((g >> 1) * 4 + (g & 1)) * NXy + (unsigned)col) * 16u : OOBH;
         __builtin_amdgcn_raw_buffer_store_b128(h, rsH, off, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(l, rsH, off + 2u * NXy * 16u, 0, 0);
@@ -129,10 +129,9 @@ static __device__ __forceinline__ void yh_store_tile(const ConvGemmArgs& a, __am
 // get an out-of-range offset -- no exec-mask branches, no 64-bit address arithmetic per element.
 template <int TM, int TN, bool DIV, int ACT, bool TR>
 static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int rbase, int cbase,
-                                                      int l31, int lk)
+                                                      int l31, int lk, int grp, int n_end)
 {
-    // (cbase is 64-aligned inside a tile that starts at a multiple of 64 and group_cols is a multiple of 128: a wave's columns are all in one group)
-    const int grp = a.n_groups > 1 ? cbase / a.group_cols : 0;
+    // grp: the weight set of this tile's columns; n_end: one past the tile's last valid column (the end of its group, or N)
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.bias ? a.bias + (size_t)grp * a.M : nullptr), 0, a.bias ? a.M * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
@@ -160,7 +159,7 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
         for (int jn = 0; jn < TN; ++jn) {
             const int col = cbase + jn * 32 + l31;
             const int row0 = rbase + i * 32;
-            const unsigned r_off = col < a.N ? (unsigned)(row0 * a.ldr + col) * 4u : OOBH;
+            const unsigned r_off = col < n_end ? (unsigned)(row0 * a.ldr + col) * 4u : OOBH;
             float v[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = 0.f;
@@ -177,7 +176,7 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
             }
             if (TR) {                                        // time-major output for the LSTM: Y[col][row], 4 rows = 16 bytes
                 const bool quad = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 && row0 + 28 <= a.M;
-                const unsigned off = col < a.N ? (unsigned)(col * a.ldy + row0) * 4u : OOBH;
+                const unsigned off = col < n_end ? (unsigned)(col * a.ldy + row0) * 4u : OOBH;
                 if (quad) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -194,13 +193,13 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
                 }
             } else {
                 if (a.Y) {
-                    const unsigned off = col < a.N ? (unsigned)(row0 * a.ldy + col) * 4u : OOBH;
+                    const unsigned off = col < n_end ? (unsigned)(row0 * a.ldy + col) * 4u : OOBH;
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rsY,
                                                               off + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.ldy * 4), 0, 0);
                 }
-                if (a.Yh) yh_store_tile(a, rsH, v, row0 - 4 * lk, col, lk);
+                if (a.Yh) yh_store_tile(a, rsH, v, row0 - 4 * lk, col, lk, n_end);
             }
         }
     }
@@ -208,14 +207,14 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
 
 template <int TM, int TN>
 static __device__ __forceinline__ void slab_store(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], __amdgpu_buffer_rsrc_t rs,
-                                                  int rbase, int cbase, int l31)
+                                                  int rbase, int cbase, int l31, int n_end)
 {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
             const int col = cbase + jn * 32 + l31;
-            const unsigned v0 = col < a.N ? (unsigned)((rbase + i * 32) * a.N + col) * 4u : OOBH;
+            const unsigned v0 = col < n_end ? (unsigned)((rbase + i * 32) * a.N + col) * 4u : OOBH;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 // through a VGPR: storing element e of an accumulator tuple directly, hipcc 7.2 emits the tuple's
@@ -230,19 +229,19 @@ static __device__ __forceinline__ void slab_store(const ConvGemmArgs& a, const f
 
 template <int TM, int TN>
 static __device__ __forceinline__ void epilogue_dispatch(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int rbase, int cbase,
-                                                         int l31, int lk)
+                                                         int l31, int lk, int grp, int n_end)
 {
     // one lean copy per (divide, activation, transposed) combination the path uses
-    if (a.transpose_out) epilogue_tiles<TM, TN, false, 0, true>(a, acc, rbase, cbase, l31, lk);
-    else if (a.div_sqrt2 && a.act == 0) epilogue_tiles<TM, TN, true, 0, false>(a, acc, rbase, cbase, l31, lk);
-    else if (a.div_sqrt2 && a.act == 2) epilogue_tiles<TM, TN, true, 2, false>(a, acc, rbase, cbase, l31, lk);
-    else if (a.div_sqrt2) epilogue_tiles<TM, TN, true, 1, false>(a, acc, rbase, cbase, l31, lk);
-    else if (a.act == 0) epilogue_tiles<TM, TN, false, 0, false>(a, acc, rbase, cbase, l31, lk);
-    else if (a.act == 1) epilogue_tiles<TM, TN, false, 1, false>(a, acc, rbase, cbase, l31, lk);
-    else if (a.act == 3) epilogue_tiles<TM, TN, false, 3, false>(a, acc, rbase, cbase, l31, lk);
-    else if (a.act == 4) epilogue_tiles<TM, TN, false, 4, false>(a, acc, rbase, cbase, l31, lk);
-    else if (a.act == 5) epilogue_tiles<TM, TN, false, 5, false>(a, acc, rbase, cbase, l31, lk);
-    else epilogue_tiles<TM, TN, false, 2, false>(a, acc, rbase, cbase, l31, lk);
+    if (a.transpose_out) epilogue_tiles<TM, TN, false, 0, true>(a, acc, rbase, cbase, l31, lk, grp, n_end);
+    else if (a.div_sqrt2 && a.act == 0) epilogue_tiles<TM, TN, true, 0, false>(a, acc, rbase, cbase, l31, lk, grp, n_end);
+    else if (a.div_sqrt2 && a.act == 2) epilogue_tiles<TM, TN, true, 2, false>(a, acc, rbase, cbase, l31, lk, grp, n_end);
+    else if (a.div_sqrt2) epilogue_tiles<TM, TN, true, 1, false>(a, acc, rbase, cbase, l31, lk, grp, n_end);
+    else if (a.act == 0) epilogue_tiles<TM, TN, false, 0, false>(a, acc, rbase, cbase, l31, lk, grp, n_end);
+    else if (a.act == 1) epilogue_tiles<TM, TN, false, 1, false>(a, acc, rbase, cbase, l31, lk, grp, n_end);
+    else if (a.act == 3) epilogue_tiles<TM, TN, false, 3, false>(a, acc, rbase, cbase, l31, lk, grp, n_end);
+    else if (a.act == 4) epilogue_tiles<TM, TN, false, 4, false>(a, acc, rbase, cbase, l31, lk, grp, n_end);
+    else if (a.act == 5) epilogue_tiles<TM, TN, false, 5, false>(a, acc, rbase, cbase, l31, lk, grp, n_end);
+    else epilogue_tiles<TM, TN, false, 2, false>(a, acc, rbase, cbase, l31, lk, grp, n_end);
 }
 
 // S > 1 (split-K): this slice's raw partial sums go to its slab; splitk_reduce_kernel sums the slabs in a fixed order
@@ -251,17 +250,17 @@ static __device__ __forceinline__ void epilogue_dispatch(const ConvGemmArgs& a, 
 // `active` = this wave holds a result (false for the waves of a K group that already folded theirs into group 0).
 template <int TM, int TN>
 static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
-                                                int wn, int l31, int lk, int S, bool active = true)
+                                                int wn, int l31, int lk, int S, bool active, int grp, int n_end)
 {
     if (!active) return;
     const int rbase = m0 + wm * 32 * TM + 4 * lk;          // this lane's first row; element e adds i*32 + (e&3) + 8*(e>>2)
     const int cbase = n0 + wn * 32 * TN;
     if (S == 1) {
-        epilogue_dispatch<TM, TN>(a, acc, rbase, cbase, l31, lk);
+        epilogue_dispatch<TM, TN>(a, acc, rbase, cbase, l31, lk, grp, n_end);
         return;
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<float*>(a.ws) + (size_t)blockIdx.y * a.M * a.N, 0, (int)((unsigned)a.M * a.N * 4u), 0x00020000);
-    slab_store<TM, TN>(a, acc, rs, rbase, cbase, l31);
+    slab_store<TM, TN>(a, acc, rs, rbase, cbase, l31, n_end);
 }
 #endif

@@ -286,7 +286,7 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if ((!a.Wh && !(a.W && a.K == 1)) || (!a.X && !a.Xh) || (!a.Y && !a.Yh) || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS)
         return AS_EINVAL;
     if (a.Kp < a.K || a.Kp % 16 || a.Kp - a.K >= 16) return AS_EINVAL;
-    if (a.n_groups > 1 && (a.group_cols <= 0 || a.group_cols % 128 || (long)a.group_cols * a.n_groups < a.N)) return AS_EINVAL;
+    if (a.n_groups > 1 && (a.group_cols <= 0 || (long)a.group_cols * a.n_groups < a.N)) return AS_EINVAL;
     if ((a.X && a.ldx < a.N) || (a.Y && a.ldy < (a.transpose_out ? a.M : a.N)) || (a.res && (a.ldr < a.N || a.transpose_out)) ||
         (a.Yh && a.transpose_out))
         return AS_EINVAL;

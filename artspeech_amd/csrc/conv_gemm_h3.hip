@@ -105,10 +105,18 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     const int l31 = lane & 31, lk = lane >> 5;
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tile = logical_tile();
-    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+    const int m0 = (tile % tiles_m) * BM;
+    // column tiles: per weight set when the launch is grouped (a group's columns are [grp * group_cols, (grp + 1) * group_cols);
+    // its last tile is cut at the group's end, so group_cols needs no alignment)
+    int n0 = (tile / tiles_m) * BN, grp = 0, n_end = a.N;
+    if (a.n_groups > 1) {
+        const int tpg = (a.group_cols + BN - 1) / BN, tn = tile / tiles_m;
+        grp = tn / tpg;
+        n0 = grp * a.group_cols + (tn - grp * tpg) * BN;
+        n_end = min(a.N, (grp + 1) * a.group_cols);
+    }
     const int KB = a.Kp >> 4, KBx = (KB + 3) & ~3;
     const int NX = a.N + 1;                                              // columns of the activation image (the last one is zero)
-    const int grp = a.n_groups > 1 ? n0 / a.group_cols : 0;
 
     const unsigned w_bytes = (unsigned)a.T * KBx * 4u * a.M * 16u;       // one weight set
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
@@ -135,7 +143,7 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     const int j = n0 + tid % BN;                                         // the column this thread stages (same for every chunk)
     unsigned tapmask = 0;                                                // taps that are valid for column j
     int Wj = 0;
-    if (j < a.N) {
+    if (j < n_end) {
         if (a.meta) {
             const unsigned long long md = a.meta[j];
             const int h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff);
@@ -337,7 +345,7 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
                             for (int c = 0; c < 4; ++c) acc[i][jn][4 * e4 + c] += v[c];
                         }
     }
-    epilogue<2, 2>(a, acc, m0, n0, wm, wn, l31, lk, S, wk == 0);
+    epilogue<2, 2>(a, acc, m0, n0, wm, wn, l31, lk, S, wk == 0, grp, n_end);
 }
 
 template <int WM, int WN, int WK, int KT, int NS, int NP>
@@ -352,7 +360,8 @@ static int launch_h3(const ConvGemmArgs& a, int S, hipStream_t stream)
     }
     H3Taps tp;
     if (h3_pack_taps(a, &tp) != AS_OK) return AS_EINVAL;
-    const dim3 grid(as_cdiv(a.M, C::BM) * as_cdiv(a.N, C::BN), S);
+    const int tiles_n = a.n_groups > 1 ? a.n_groups * as_cdiv(a.group_cols, C::BN) : as_cdiv(a.N, C::BN);
+    const dim3 grid(as_cdiv(a.M, C::BM) * tiles_n, S);
     hipLaunchKernelGGL((conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP>), grid, dim3(C::NT), C::LDS, stream, a, tp);
     AS_CHECK_LAUNCH();
     return AS_OK;
@@ -513,24 +522,30 @@ static __device__ __forceinline__ float h3_wave_sum(float v)
     return v;
 }
 
+// AsAdainArgs addressing (include/artspeech_hip.h): gamma(u, c) = gb[gb_off[u] + c * gb_sc] (gb_off NULL: u * ldgb), beta at channel
+// C + c; utterance u reads its input at columns src_off[u].. (NULL: col_off[u]) and writes at col_off[u].. -- at 2 col_off[u]
+// with the fused depthwise ConvTranspose1d(k3, s2, p1, op1) x2 up-sampler (models.py:172,195): out[2i] = a[i] w1 + b,
+// out[2i+1] = a[i] w2 + a[i+1] w0 + b, and x_up (fp32) gets the nearest x2 copy of x (the block's shortcut, models.py:184).
 __global__ void __launch_bounds__(256)
-adain_split_kernel(const float* __restrict__ x, int ldx, int C, const float* __restrict__ gb, int ldgb,
-                   const int* __restrict__ col_off, int N, int act, u32x4_t* __restrict__ xs)
+adain_image_kernel(const AsAdainArgs a)
 {
     __shared__ float st[8][4];                                          // mean, rstd, 1 + gamma, beta
-    const int g = blockIdx.x, b = blockIdx.y;
-    const int c0 = g * 8;
+    const int g = blockIdx.x, u = blockIdx.y;
+    const int c0 = g * 8, C = a.C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t NX = (size_t)N + 1;
+    const size_t NX = (size_t)a.N + 1;
+    u32x4_t* xs = reinterpret_cast<u32x4_t*>(a.yh);
     const size_t plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;         // part h of this (k-block, k-half); l at + 2 NX
-    if (b == 0 && threadIdx.x < 2) xs[plane + (size_t)threadIdx.x * 2 * NX + N] = u32x4_t{0u, 0u, 0u, 0u};   // the zero column
-    const int o0 = col_off[b], L = col_off[b + 1] - o0;
+    if (u == 0 && threadIdx.x < 2) xs[plane + (size_t)threadIdx.x * 2 * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};   // the zero column
+    const int o0 = a.col_off[u], L = a.col_off[u + 1] - o0;
     if (L <= 0) return;
+    const int s0 = a.src_off ? a.src_off[u] : o0;
+    const size_t gbase = a.gb_off ? (size_t)a.gb_off[u] : (size_t)u * a.ldgb;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = c0 + wave * 2 + q;
         if (c < C) {                                                    // wave-uniform
-            const float* xr = x + (size_t)c * ldx + o0;
+            const float* xr = a.x + (size_t)c * a.ldx + s0;
             float s = 0.f;
             for (int i = lane; i < L; i += 64) s += xr[i];
             const float mean = h3_wave_sum(s) / (float)L;
@@ -540,41 +555,126 @@ adain_split_kernel(const float* __restrict__ x, int ldx, int C, const float* __r
             if (lane == 0) {
                 st[wave * 2 + q][0] = mean;
                 st[wave * 2 + q][1] = 1.0f / sqrtf(var + 1e-5f);
-                st[wave * 2 + q][2] = 1.0f + gb[(size_t)b * ldgb + c];
-                st[wave * 2 + q][3] = gb[(size_t)b * ldgb + C + c];
+                st[wave * 2 + q][2] = 1.0f + a.gb[gbase + (size_t)c * a.gb_sc];
+                st[wave * 2 + q][3] = a.gb[gbase + (size_t)(C + c) * a.gb_sc];
             }
         }
     }
     __syncthreads();
+    if (!a.pool_w) {
+        for (int i = threadIdx.x; i < L; i += 256) {
+            float t[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float o = 0.f;
+                if (c0 + r < C) {
+                    o = st[r][2] * ((a.x[(size_t)(c0 + r) * a.ldx + s0 + i] - st[r][0]) * st[r][1]) + st[r][3];
+                    if (a.lrelu) o = o > 0.f ? o : 0.2f * o;
+                }
+                t[r] = o;
+            }
+            u32x4_t h, l;
+            split2(t, h, l);
+            const size_t at = plane + o0 + i;
+            xs[at] = h;
+            xs[at + 2 * NX] = l;
+        }
+        return;
+    }
+    float w0[8], w1[8], w2[8], pb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const bool ok = c0 + r < C;
+        w0[r] = ok ? a.pool_w[(c0 + r) * 3 + 0] : 0.f;
+        w1[r] = ok ? a.pool_w[(c0 + r) * 3 + 1] : 0.f;
+        w2[r] = ok ? a.pool_w[(c0 + r) * 3 + 2] : 0.f;
+        pb[r] = ok ? a.pool_b[c0 + r] : 0.f;
+    }
     for (int i = threadIdx.x; i < L; i += 256) {
-        float t[8];
+        float e0[8], e1[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            float o = 0.f;
+            float o0v = 0.f, o1v = 0.f;
             if (c0 + r < C) {
-                o = st[r][2] * ((x[(size_t)(c0 + r) * ldx + o0 + i] - st[r][0]) * st[r][1]) + st[r][3];
-                if (act) o = o > 0.f ? o : 0.2f * o;
+                const float* xr = a.x + (size_t)(c0 + r) * a.ldx + s0;
+                const float xi = xr[i];
+                float a0 = st[r][2] * ((xi - st[r][0]) * st[r][1]) + st[r][3];
+                if (a.lrelu) a0 = a0 > 0.f ? a0 : 0.2f * a0;
+                float a1 = 0.f;
+                if (i + 1 < L) {
+                    a1 = st[r][2] * ((xr[i + 1] - st[r][0]) * st[r][1]) + st[r][3];
+                    if (a.lrelu) a1 = a1 > 0.f ? a1 : 0.2f * a1;
+                }
+                o0v = a0 * w1[r] + pb[r];
+                o1v = (a0 * w2[r] + a1 * w0[r]) + pb[r];
+                if (a.x_up) {
+                    float* ur = a.x_up + (size_t)(c0 + r) * a.ld_up + 2 * o0 + 2 * i;
+                    ur[0] = xi;
+                    ur[1] = xi;
+                }
             }
-            t[r] = o;
+            e0[r] = o0v;
+            e1[r] = o1v;
         }
         u32x4_t h, l;
-        split2(t, h, l);
-        const size_t at = plane + o0 + i;
+        split2(e0, h, l);
+        const size_t at = plane + 2 * (size_t)o0 + 2 * i;
         xs[at] = h;
         xs[at + 2 * NX] = l;
+        split2(e1, h, l);
+        xs[at + 1] = h;
+        xs[at + 1 + 2 * NX] = l;
     }
+}
+
+extern "C" int as_adain_image_f32(const AsAdainArgs* args_host, as_stream_t stream)
+{
+    if (!args_host) return AS_EINVAL;
+    const AsAdainArgs& a = *args_host;
+    if (!a.x || !a.gb || !a.col_off || !a.yh || a.C <= 0 || a.U <= 0 || a.N < 0 || a.gb_sc <= 0 || (!a.gb_off && a.ldgb <= 0)) return AS_EINVAL;
+    if ((a.pool_w == nullptr) != (a.pool_b == nullptr) || (a.x_up && !a.pool_w)) return AS_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a.yh) & 15) != 0) return AS_EINVAL;
+    if (a.N == 0) return AS_OK;
+    AsProfScope prof__(AS_CLS_ADAIN, 0, 8.0 * a.C * (double)a.N, (hipStream_t)stream);
+    hipLaunchKernelGGL(adain_image_kernel, dim3(2 * as_kbx(a.C), a.U), dim3(256), 0, (hipStream_t)stream, a);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
 }
 
 extern "C" int as_adain_split_f32(const float* x, int ldx, int C, const float* gamma_beta, int ldgb, const int32_t* col_off, int B,
                                   int N, int lrelu, uint16_t* xs, as_stream_t stream)
 {
     if (!x || !gamma_beta || !col_off || !xs || C <= 0 || B <= 0 || N < 0 || ldgb < 2 * C) return AS_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(xs) & 15) != 0) return AS_EINVAL;
-    if (N == 0) return AS_OK;
-    const int KBx = as_kbx(C);
-    AsProfScope prof__(AS_CLS_ADAIN, 0, 8.0 * C * (double)N, (hipStream_t)stream);
-    hipLaunchKernelGGL(adain_split_kernel, dim3(2 * KBx, B), dim3(256), 0, (hipStream_t)stream, x, ldx, C, gamma_beta, ldgb, col_off, N,
-                       lrelu, reinterpret_cast<u32x4_t*>(xs));
+    AsAdainArgs a = {};
+    a.x = x; a.ldx = ldx; a.C = C; a.gb = gamma_beta; a.ldgb = ldgb; a.gb_sc = 1; a.col_off = col_off; a.U = B; a.N = N; a.lrelu = lrelu; a.yh = xs;
+    return as_adain_image_f32(&a, stream);
+}
+
+// x [B][ldx] fp32 (one K-vector per utterance: the style vectors) -> the split operand image of its transpose [K][B]: the
+// AdaIN fc layers of the whole model then run as ONE conv GEMM with the utterances as columns (models.py:237)
+__global__ void __launch_bounds__(256)
+rows_image_kernel(const float* __restrict__ x, int ldx, int K, int B, u32x4_t* __restrict__ xh)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int groups = 2 * as_kbx(K);
+    if (i >= groups * (B + 1)) return;
+    const int g = i / (B + 1), b = i % (B + 1);
+    float t[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] = (b < B && g * 8 + r < K) ? x[(size_t)b * ldx + g * 8 + r] : 0.f;
+    u32x4_t h, l;
+    split2(t, h, l);
+    const size_t at = ((size_t)(g >> 1) * 4 + (g & 1)) * (B + 1) + b;
+    xh[at] = h;
+    xh[at + 2 * (size_t)(B + 1)] = l;
+}
+
+extern "C" int as_rows_image_f32(const float* x, int ldx, int K, int B, uint16_t* xh, as_stream_t stream)
+{
+    if (!x || !xh || K <= 0 || B <= 0 || ldx < K || (reinterpret_cast<uintptr_t>(xh) & 15) != 0) return AS_EINVAL;
+    AsProfScope prof__(AS_CLS_OTHER, 0, 8.0 * K * (double)B, (hipStream_t)stream);
+    hipLaunchKernelGGL(rows_image_kernel, dim3(as_cdiv((long)2 * as_kbx(K) * (B + 1), 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, K, B,
+                       reinterpret_cast<u32x4_t*>(xh));
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

@@ -296,6 +296,47 @@ extern "C" int as_linear_rows_f32(const float* x, int ldx, const float* w, const
 }
 
 // ---------------------------------------------------------------------------------------------------
+// A handful of output rows over many columns: Y[m][j] = bias[m] + sum_k W[m][k] X[k][j], M <= 16 (duration_proj, the
+// F0 / energy / TV projections, models.py:565,619-621).  One column per thread: every X row is read once, coalesced;
+// the weights are wave-uniform (scalar loads).
+// ---------------------------------------------------------------------------------------------------
+template <int MM>
+__global__ void __launch_bounds__(256)
+project_cols_kernel(const float* __restrict__ x, int ldx, int K, int N, const float* __restrict__ w, const float* __restrict__ bias, int M,
+                    float* __restrict__ y, int ldy)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float v = x[(size_t)k * ldx + j];
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+            if (m < M) acc[m] += w[m * K + k] * v;
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+        if (m < M) y[(size_t)m * ldy + j] = acc[m] + (bias ? bias[m] : 0.f);
+}
+
+extern "C" int as_project_cols_f32(const float* x, int ldx, int K, int N, const float* w, const float* bias, int M, float* y, int ldy,
+                                   as_stream_t stream)
+{
+    if (!x || !w || !y || K <= 0 || N < 0 || M <= 0 || M > 16 || ldx < N || ldy < N) return AS_EINVAL;
+    if (N == 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 2.0 * M * K * (double)N, 4.0 * (K + M) * (double)N, (hipStream_t)stream);
+    const dim3 grid(as_cdiv(N, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 1) hipLaunchKernelGGL(project_cols_kernel<1>, grid, block, 0, s, x, ldx, K, N, w, bias, M, y, ldy);
+    else if (M <= 4) hipLaunchKernelGGL(project_cols_kernel<4>, grid, block, 0, s, x, ldx, K, N, w, bias, M, y, ldy);
+    else hipLaunchKernelGGL(project_cols_kernel<16>, grid, block, 0, s, x, ldx, K, N, w, bias, M, y, ldy);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K2: durations -> integer alignment -> gather          models.py:361-368
 // ---------------------------------------------------------------------------------------------------
 // round-half-even, clamp(min=1) (torch.round + clamp, models.py:361); frame offsets per utterance;

@@ -80,12 +80,6 @@ struct Vec {
     float* p = nullptr;
     size_t n = 0;
 };
-struct FcCat {                  // the AdaIN fc layers of several blocks sharing a style vector, rows concatenated
-    float* w = nullptr;         // [Mtot][S]
-    float* b = nullptr;         // [Mtot]
-    int Mtot = 0, S = 0;
-    std::vector<int> off;       // row offset of (block i, norm1 / norm2): off[2 i], off[2 i + 1]
-};
 struct LstmW {
     const GemmW* wih = nullptr; // [8H][I] both directions
     float* bias = nullptr;      // [8H] b_ih + b_hh
@@ -101,7 +95,6 @@ struct as_model {
     std::unordered_map<std::string, HostT> raw;             // folded fp32 host tensors, reference names with plain ".weight"
     mutable std::unordered_map<std::string, GemmW> gemm;    // filled while !frozen (as_model_create), read-only afterwards
     mutable std::unordered_map<std::string, Vec> vecs;
-    mutable std::unordered_map<std::string, FcCat> fcs;
     mutable std::unordered_map<std::string, LstmW> lstms;
     mutable DevPool pool{(size_t)256 << 20};
     mutable bool frozen = false;
@@ -138,36 +131,45 @@ struct as_model {
         }
         return &(gemm[key] = g);
     }
-    // conv weight `name` ([Cout][Cin][k...]), optionally stacked with a second layer of the same shape (grouped launch)
-    const GemmW* conv(const std::string& name, const std::string& name2 = std::string()) const
+    // conv weights `names` ([Cout][Cin][k...] each, same shape) stacked as the weight sets of one grouped launch
+    const GemmW* conv_stack(const std::vector<std::string>& names) const
     {
-        const std::string key = name2.empty() ? name : name + "|" + name2;
+        std::string key = names[0];
+        for (size_t i = 1; i < names.size(); ++i) key += "|" + names[i];
         auto it = gemm.find(key);
         if (it != gemm.end()) return &it->second;
-        if (frozen) { if (!err) err = AS_EINVAL; return nullptr; }
-        const HostT* a = host(name + ".weight");
-        const HostT* b = name2.empty() ? nullptr : host(name2 + ".weight");
-        if (!a || (!name2.empty() && (!b || b->dims != a->dims))) { if (!err) err = AS_EINVAL; return nullptr; }
+        if (frozen) { if (!err) { err = AS_EINVAL; fprintf(stderr, "artspeech_hip: '%s' was not prepared by as_model_create\n", key.c_str()); } return nullptr; }
+        const HostT* a = host(names[0] + ".weight");
+        if (!a) return nullptr;
         const int Cout = a->dim(0), Cin = a->dim(1), T = (int)(a->numel() / ((size_t)Cout * Cin));
-        if (!b) return gemm_from(key, a->v.data(), 1, Cout, Cin, T);
+        if (names.size() == 1) return gemm_from(key, a->v.data(), 1, Cout, Cin, T);
         std::vector<float> w(a->v);
-        w.insert(w.end(), b->v.begin(), b->v.end());
-        return gemm_from(key, w.data(), 2, Cout, Cin, T);
+        for (size_t i = 1; i < names.size(); ++i) {
+            const HostT* b = host(names[i] + ".weight");
+            if (!b || b->dims != a->dims) { if (!err) err = AS_EINVAL; return nullptr; }
+            w.insert(w.end(), b->v.begin(), b->v.end());
+        }
+        return gemm_from(key, w.data(), (int)names.size(), Cout, Cin, T);
     }
-    // a raw tensor (bias, gamma, table ...) on the device; name2: a second one of the same size stacked behind it
-    const float* vec(const std::string& name, const std::string& name2 = std::string()) const
+    const GemmW* conv(const std::string& name, const std::string& name2 = std::string()) const
     {
-        const std::string key = name2.empty() ? name : name + "|" + name2;
+        return name2.empty() ? conv_stack({name}) : conv_stack({name, name2});
+    }
+    // raw tensors (bias, gamma, table ...) on the device, stacked one behind the other
+    const float* vec_stack(const std::vector<std::string>& names) const
+    {
+        std::string key = names[0];
+        for (size_t i = 1; i < names.size(); ++i) key += "|" + names[i];
         auto it = vecs.find(key);
         if (it != vecs.end()) return it->second.p;
         if (frozen) { if (!err) { err = AS_EINVAL; fprintf(stderr, "artspeech_hip: '%s' was not prepared by as_model_create\n", key.c_str()); } return nullptr; }
-        const HostT* a = host(name);
-        if (!a) return nullptr;
-        std::vector<float> v(a->v);
-        if (!name2.empty()) {
-            const HostT* b = host(name2);
-            if (!b || b->numel() != a->numel()) { if (!err) err = AS_EINVAL; return nullptr; }
-            v.insert(v.end(), b->v.begin(), b->v.end());
+        std::vector<float> v;
+        size_t n0 = 0;
+        for (size_t i = 0; i < names.size(); ++i) {
+            const HostT* a = host(names[i]);
+            if (!a || (i && a->numel() != n0)) { if (!err) err = AS_EINVAL; return nullptr; }
+            n0 = a->numel();
+            v.insert(v.end(), a->v.begin(), a->v.end());
         }
         Vec d;
         d.n = v.size();
@@ -175,10 +177,21 @@ struct as_model {
         vecs[key] = d;
         return d.p;
     }
+    const float* vec(const std::string& name, const std::string& name2 = std::string()) const
+    {
+        return name2.empty() ? vec_stack({name}) : vec_stack({name, name2});
+    }
     const float* bias(const std::string& name, const std::string& name2 = std::string()) const
     {
         if (!has(name + ".bias")) return nullptr;
         return vec(name + ".bias", name2.empty() ? name2 : name2 + ".bias");
+    }
+    const float* bias_stack(const std::vector<std::string>& names) const
+    {
+        if (!has(names[0] + ".bias")) return nullptr;
+        std::vector<std::string> n(names);
+        for (auto& x : n) x += ".bias";
+        return vec_stack(n);
     }
     // q / k / v projections of one attention layer as one [3C] GEMM (RelTransformerEnc.py:128-133)
     const GemmW* qkv(const std::string& p, const std::string& p2, const float** bias_out) const
@@ -239,29 +252,102 @@ struct as_model {
         L.whh_t = upload(t.data(), t.size());
         return &(lstms[p] = L);
     }
-    // fc layers of the AdaIN1d norms of `blocks` (all fed by the same style vector): one GEMV over the concatenated rows
-    const FcCat* fccat(const std::vector<std::string>& blocks) const
+    // input projections of several LSTMs of the same shape as the weight sets of one grouped launch
+    const GemmW* lstm_wih_stack(const std::vector<std::string>& names, const float** bias_out) const
     {
-        std::string key;
-        for (const auto& b : blocks) key += b + "|";
-        auto it = fcs.find(key);
-        if (it != fcs.end()) return &it->second;
-        if (frozen) { if (!err) err = AS_EINVAL; return nullptr; }
-        FcCat f;
-        std::vector<float> w, b;
-        for (const auto& blk : blocks)
-            for (const char* n : {".norm1", ".norm2"}) {
-                const HostT *wt = host(blk + n + ".fc.weight"), *bt = host(blk + n + ".fc.bias");
-                if (!wt || !bt) return nullptr;
-                f.S = wt->dim(1);
-                f.off.push_back(f.Mtot);
-                f.Mtot += wt->dim(0);
-                w.insert(w.end(), wt->v.begin(), wt->v.end());
-                b.insert(b.end(), bt->v.begin(), bt->v.end());
+        std::string key = "LSTMS:";
+        for (const auto& n : names) key += n + "|";
+        auto it = gemm.find(key);
+        if (it == gemm.end()) {
+            if (frozen) { if (!err) err = AS_EINVAL; return nullptr; }
+            std::vector<float> w, b;
+            int H = 0, I = 0;
+            for (const auto& p : names) {
+                const HostT *wi = host(p + ".weight_ih_l0"), *wir = host(p + ".weight_ih_l0_reverse"), *bi = host(p + ".bias_ih_l0"),
+                            *bh = host(p + ".bias_hh_l0"), *bir = host(p + ".bias_ih_l0_reverse"), *bhr = host(p + ".bias_hh_l0_reverse");
+                if (!wi || !wir || !bi || !bh || !bir || !bhr) return nullptr;
+                H = wi->dim(0) / 4;
+                I = wi->dim(1);
+                w.insert(w.end(), wi->v.begin(), wi->v.end());
+                w.insert(w.end(), wir->v.begin(), wir->v.end());
+                for (int i = 0; i < 4 * H; ++i) b.push_back(bi->v[i] + bh->v[i]);
+                for (int i = 0; i < 4 * H; ++i) b.push_back(bir->v[i] + bhr->v[i]);
             }
-        f.w = upload(w.data(), w.size());
-        f.b = upload(b.data(), b.size());
-        return &(fcs[key] = f);
+            if (!gemm_from(key, w.data(), (int)names.size(), 8 * H, I, 1)) return nullptr;
+            Vec d;
+            d.n = b.size();
+            d.p = upload(b.data(), b.size());
+            vecs[key] = d;
+            it = gemm.find(key);
+        }
+        *bias_out = vecs[key].p;
+        return &it->second;
+    }
+    // Every AdaIN1d fc layer fed by one style vector as ONE weight matrix [Mtot][K] (models.py:237: h = fc(s); gamma, beta =
+    // chunk(h)): `norms` = (layer name, first style entry it reads, entries it reads) -- a layer that reads a slice of the style
+    // (models.py:499,597-599) gets zero columns elsewhere.  row0[name] = its first output row (gamma rows, then beta rows).
+    struct FcAll {
+        const GemmW* w = nullptr;
+        const float* bias = nullptr;
+        std::unordered_map<std::string, int> row0;
+        int Mtot = 0, K = 0;
+    };
+    mutable std::unordered_map<std::string, FcAll> fcalls;
+    struct NormSpec { std::string name; int off, S; };
+    const FcAll* fc_all(const std::string& key, const std::vector<NormSpec>& norms, int K) const
+    {
+        auto it = fcalls.find(key);
+        if (it != fcalls.end()) return &it->second;
+        if (frozen) { if (!err) err = AS_EINVAL; return nullptr; }
+        FcAll f;
+        f.K = K;
+        std::vector<float> w, b;
+        for (const auto& n : norms) {
+            const HostT *wt = host(n.name + ".fc.weight"), *bt = host(n.name + ".fc.bias");
+            if (!wt || !bt || wt->dim(1) != n.S || n.off + n.S > K) { if (!err) err = AS_EINVAL; return nullptr; }
+            const int M = wt->dim(0);
+            f.row0[n.name] = f.Mtot;
+            f.Mtot += M;
+            const size_t base = w.size();
+            w.resize(base + (size_t)M * K, 0.f);
+            for (int m = 0; m < M; ++m)
+                for (int k = 0; k < n.S; ++k) w[base + (size_t)m * K + n.off + k] = wt->v[(size_t)m * n.S + k];
+            b.insert(b.end(), bt->v.begin(), bt->v.end());
+        }
+        f.w = gemm_from("FCALL:" + key, w.data(), 1, f.Mtot, K, 1);
+        f.bias = upload(b.data(), b.size());
+        if (!f.w || !f.bias) return nullptr;
+        return &(fcalls[key] = f);
+    }
+    // decoder.F0_conv (1 -> 32), N_conv (1 -> 32), EMA_conv (10 -> 64) (models.py:480-482, 1x1, weight-norm) as ONE block-diagonal
+    // 1x1 conv from the stacked [F0; N; EMA] rows (12) to the 128 channels the decoder concatenates (models.py:503-505)
+    const GemmW* fne(const float** bias_out) const
+    {
+        const std::string key = "FNE:decoder";
+        auto it = gemm.find(key);
+        if (it == gemm.end()) {
+            if (frozen) { if (!err) err = AS_EINVAL; return nullptr; }
+            const HostT *f = host("decoder.F0_conv.weight"), *n = host("decoder.N_conv.weight"), *e = host("decoder.EMA_conv.weight");
+            const HostT *fb = host("decoder.F0_conv.bias"), *nb = host("decoder.N_conv.bias"), *eb = host("decoder.EMA_conv.bias");
+            if (!f || !n || !e || !fb || !nb || !eb) return nullptr;
+            const int mf = f->dim(0), mn = n->dim(0), me = e->dim(0), ke = e->dim(1), K = 2 + ke, M = mf + mn + me;
+            std::vector<float> w((size_t)M * K, 0.f), b;
+            for (int m = 0; m < mf; ++m) w[(size_t)m * K + 0] = f->v[m];
+            for (int m = 0; m < mn; ++m) w[(size_t)(mf + m) * K + 1] = n->v[m];
+            for (int m = 0; m < me; ++m)
+                for (int k = 0; k < ke; ++k) w[(size_t)(mf + mn + m) * K + 2 + k] = e->v[(size_t)m * ke + k];
+            b.insert(b.end(), fb->v.begin(), fb->v.end());
+            b.insert(b.end(), nb->v.begin(), nb->v.end());
+            b.insert(b.end(), eb->v.begin(), eb->v.end());
+            if (!gemm_from(key, w.data(), 1, M, K, 1)) return nullptr;
+            Vec d;
+            d.n = b.size();
+            d.p = upload(b.data(), b.size());
+            vecs[key] = d;
+            it = gemm.find(key);
+        }
+        *bias_out = vecs[key].p;
+        return &it->second;
     }
 };
 
@@ -275,6 +361,7 @@ struct Lay {
     std::vector<int> w, off;
     int32_t *d_w = nullptr, *d_off = nullptr;
     uint64_t* d_meta = nullptr;
+    std::map<std::string, int32_t*> tabs;      // further per-utterance device tables of launches on this layout
     int max_cols() const { return H * max_w; }
 };
 
@@ -391,6 +478,19 @@ struct Ctx {
             if (r != AS_OK || hipStreamSynchronize(s) != hipSuccess) { fail(r ? r : (int)hipErrorUnknown); return nullptr; }
         }
         return M->d_meta;
+    }
+    // a per-utterance int32 table that belongs to layout L (built and uploaded on first real use, like L's own tables)
+    template <typename F>
+    const int32_t* itable(const Lay* L, const std::string& key, F&& build)
+    {
+        if (!L || count || !launch) return nullptr;
+        Lay* M = const_cast<Lay*>(L);
+        auto it = M->tabs.find(key);
+        if (it != M->tabs.end()) return it->second;
+        const std::vector<int32_t> h = build();
+        int32_t* d = static_cast<int32_t*>(p.pool.alloc(h.size() * sizeof(int32_t)));
+        if (!d || hipMemcpy(d, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { fail((int)hipErrorOutOfMemory); return nullptr; }
+        return M->tabs[key] = d;
     }
     const Lay* scaled(const Lay* L, int k)
     {
@@ -553,107 +653,149 @@ float* conv_h_new(Ctx& c, const GemmW* w, const uint16_t* xh, int K, const Lay* 
 // ------------------------------------------------------------------------------------------------------------------
 // building blocks (the launch sequences of the reference's modules)
 // ------------------------------------------------------------------------------------------------------------------
-struct GB {                      // gamma / beta rows of one AdaIN1d: [B][ld], gamma first
-    const float* p = nullptr;
-    int ld = 0;
+// gamma / beta of one AdaIN1d launch: AsAdainArgs addressing into the output of the fc GEMM ([rows][ldB], utterances as columns)
+struct Norm {
+    const float* gb = nullptr;
+    const int32_t* gb_off = nullptr;   // per-utterance offsets (grouped launches); NULL: utterance u at gb + u
+    int gb_sc = 0;                     // stride between channels = ldB
 };
 
-// all AdaIN fc layers of `blocks` (sharing the style vector `style` [B][lds], S entries used) in one launch
-std::vector<GB> adain_fc(Ctx& c, const std::vector<std::string>& blocks, const float* style, int lds, int B)
+// Every AdaIN fc layer fed by `style` [B][lds] in one GEMM: gbT [Mtot][B] = W style^T + b (models.py:237).
+// Returns the output; row0 of a layer through FcAll::row0.
+struct FcOut {
+    const as_model::FcAll* f = nullptr;
+    float* gbT = nullptr;
+    int B = 0;
+    Norm norm(const std::string& name, int group_stride_rows = 0, const int32_t* gb_off = nullptr) const
+    {
+        Norm n;
+        auto it = f ? f->row0.find(name) : decltype(f->row0.begin())();
+        if (!f || it == f->row0.end()) return n;
+        n.gb = gbT ? gbT + (size_t)it->second * B : nullptr;
+        n.gb_off = gb_off;
+        n.gb_sc = B;
+        (void)group_stride_rows;
+        return n;
+    }
+};
+
+FcOut adain_fc_all(Ctx& c, const std::string& key, const std::vector<as_model::NormSpec>& norms, const float* style, int lds, int K, int B)
 {
-    std::vector<GB> out(2 * blocks.size());
-    const FcCat* f = c.m.fccat(blocks);
-    if (!f) { c.fail(AS_EINVAL); return out; }
-    float* gb = c.f32((size_t)B * f->Mtot);
-    RUN(c, as_linear_rows_f32(style, lds, f->w, f->b, B, f->Mtot, f->S, gb, f->Mtot, c.s));
-    for (size_t i = 0; i < out.size(); ++i) { out[i].p = gb ? gb + f->off[i] : nullptr; out[i].ld = f->Mtot; }
-    return out;
+    FcOut o;
+    o.B = B;
+    o.f = c.m.fc_all(key, norms, K);
+    if (!o.f) { c.fail(AS_EINVAL); return o; }
+    uint16_t* sh = c.image(K, B);
+    RUN(c, as_rows_image_f32(style, lds, K, B, sh, c.s));
+    const Lay* lb = c.lay(std::vector<int>(B, 1));
+    if (!lb) return o;
+    o.gbT = c.f32((size_t)o.f->Mtot * B);
+    ConvOpt q;
+    q.bias = o.f->bias;
+    conv_h(c, o.f->w, sh, K, lb, taps_1d(1), o.gbT, B, q);
+    return o;
 }
 
-struct Act {                     // fp32 activation [C][ld] on a layout
+void adain_image(Ctx& c, const float* x, int ldx, int C, const Norm& n, const Lay* lay, const int32_t* src_off, int N_out, uint16_t* yh,
+                 const float* pool_w = nullptr, const float* pool_b = nullptr, float* x_up = nullptr, int ld_up = 0)
+{
+    if (!lay) { c.fail(AS_EINVAL); return; }
+    if (!c.go() || N_out == 0) return;
+    AsAdainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = ldx; a.C = C;
+    a.gb = n.gb; a.gb_off = n.gb_off; a.ldgb = 1; a.gb_sc = n.gb_sc;
+    a.col_off = lay->d_off; a.src_off = src_off; a.U = lay->B; a.N = N_out; a.lrelu = 1; a.yh = yh;
+    a.pool_w = pool_w; a.pool_b = pool_b; a.x_up = x_up; a.ld_up = ld_up;
+    RUN(c, as_adain_image_f32(&a, c.s));
+}
+
+struct Act {                     // fp32 activation [C][ld] on a layout (+ optionally its raw operand image)
     float* p = nullptr;
     int C = 0, ld = 0;
     const Lay* lay = nullptr;
+    const uint16_t* h = nullptr;
 };
 
-// AdainResBlk1d.forward (models.py:189-202).  X [din][N] -> [dout][N or 2N]; out: where to put it (row stride ldo), or null.
-Act adain_resblk1d(Ctx& c, const std::string& p, const Act& X, GB gb1, GB gb2, float* out, int ldo, bool upsample)
+// AdainResBlk1d.forward (models.py:189-202), G blocks of the same shape side by side along the column axis when names.size() > 1
+// (the F0 / energy / TV branches, models.py:606-618: weight set g serves the columns [g * group_cols, (g + 1) * group_cols)).
+struct BlkOpt {
+    std::vector<std::string> names;    // block prefixes (one per group)
+    int group_cols = 0;                // columns per group of X's layout (ignored for one group)
+    Norm n1, n2;
+    bool upsample = false;
+    const int32_t* src_off = nullptr;  // (upsample, grouped) where each utterance of the OUTPUT layout reads X
+    const Lay* lay_out = nullptr;      // (upsample) the pre-doubling layout the outputs are laid out on (default X.lay)
+    float* out = nullptr;              // destination (row stride ldo), or null: from the workspace
+    int ldo = 0;
+    bool want_yh = false;              // also write the output as an operand image
+    uint16_t* yh = nullptr;            // (where; null with want_yh: from the workspace)
+    float* sc_tmp = nullptr;           // learned-shortcut result when `out` aliases rows of X (decoder: in-place on the concat buffer)
+};
+
+Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
 {
     const as_model& m = c.m;
-    const Lay* lay = X.lay;
-    const int din = X.C, B = lay->B;
-    const GemmW *w1 = m.conv(p + ".conv1"), *w2 = m.conv(p + ".conv2");
-    const bool has_sc = m.has(p + ".conv1x1.weight");
     Act Y;
-    if (!w1 || !w2) { c.fail(AS_EINVAL); return Y; }
-    const int dout = w1->M;
-    const Lay* lay2 = upsample ? c.scaled(lay, 2) : lay;
+    const int G = (int)o.names.size();
+    auto sfx = [&](const char* s) { std::vector<std::string> v(o.names); for (auto& n : v) n += s; return v; };
+    const GemmW *w1 = m.conv_stack(sfx(".conv1")), *w2 = m.conv_stack(sfx(".conv2"));
+    const bool has_sc = m.has(o.names[0] + ".conv1x1.weight");
+    if (!w1 || !w2 || !X.lay) { c.fail(AS_EINVAL); return Y; }
+    const int din = X.C, dout = w1->M;
+    const Lay* lay_in = o.upsample && o.lay_out ? o.lay_out : X.lay;     // utterances of the block's (pre-doubling) output layout
+    const Lay* lay2 = o.upsample ? c.scaled(lay_in, 2) : lay_in;
     if (!lay2) return Y;
-    const int N2 = std::max(lay2->N, 1);
-    if (!out) { out = c.f32((size_t)dout * N2); ldo = lay2->N; }
+    const int N2 = lay2->N, Nn2 = std::max(N2, 1);
+    const int gc2 = G > 1 ? (o.upsample ? 2 * o.group_cols : o.group_cols) : 0;
+    float* out = o.out;
+    int ldo = o.ldo;
+    if (!out) { out = c.f32((size_t)dout * Nn2); ldo = N2; }
     const Taps k3 = taps_1d(3), k1 = taps_1d(1);
+    // norm1 -> LeakyReLU (-> depthwise ConvTranspose1d x2, models.py:172,195) exists only as conv1's operand image
+    uint16_t* xs = c.image(din, N2);
     const float* sc = X.p;
     int ldsc = X.ld;
-    float* h1;
-    if (upsample) {
-        // norm1 -> LeakyReLU -> depthwise ConvTranspose1d x2 (models.py:172,195), shortcut = nearest x2 (models.py:184,261-270)
-        float* h = c.f32((size_t)din * N2);
-        float* up = c.f32((size_t)din * N2);
-        const float *pw = m.vec(p + ".pool.weight"), *pb = m.vec(p + ".pool.bias");      // (looked up outside RUN: the prepare pass builds them)
-        RUN(c, as_adain_f32(X.p, X.ld, din, gb1.p, gb1.ld, lay->d_off, B, h, lay2->N, 1, pw, pb, up, lay2->N, c.s));
-        ConvOpt o;
-        o.bias = m.bias(p + ".conv1");
-        h1 = conv_x_new(c, w1, h, lay2->N, din, lay2, k3, o);
+    if (o.upsample) {
+        float* up = c.f32((size_t)din * Nn2);                           // shortcut = nearest x2 (models.py:184,261-270)
+        const float *pw = m.vec_stack(sfx(".pool.weight")), *pb = m.vec_stack(sfx(".pool.bias"));
+        if (G > 1) { c.fail(AS_EINVAL); return Y; }                      // (grouped up-sampling blocks go through adain_image per group: see arts_predictor)
+        adain_image(c, X.p, X.ld, din, o.n1, lay_in, o.src_off, N2, xs, pw, pb, up, N2);
         sc = up;
-        ldsc = lay2->N;
+        ldsc = N2;
     } else {
-        uint16_t* xs = c.image(din, lay->N);
-        RUN(c, as_adain_split_f32(X.p, X.ld, din, gb1.p, gb1.ld, lay->d_off, B, lay->N, 1, xs, c.s));
-        ConvOpt o;
-        o.bias = m.bias(p + ".conv1");
-        h1 = conv_h_new(c, w1, xs, din, lay2, k3, o);
+        adain_image(c, X.p, X.ld, din, o.n1, lay_in, nullptr, N2, xs);
     }
+    ConvOpt q1;
+    q1.bias = m.bias_stack(sfx(".conv1"));
+    q1.group_cols = gc2;
+    float* h1 = conv_h_new(c, w1, xs, din, lay2, k3, q1);
     if (has_sc) {                                                       // learned shortcut (models.py:185-186), no bias
-        ConvOpt o;
-        conv_x(c, m.conv(p + ".conv1x1"), sc, ldsc, din, lay2, k1, out, ldo, o);
-        sc = out;
-        ldsc = ldo;
+        ConvOpt q;
+        q.group_cols = gc2;
+        float* dst = o.sc_tmp ? o.sc_tmp : out;
+        const int ldd = o.sc_tmp ? N2 : ldo;
+        const GemmW* wsc = m.conv_stack(sfx(".conv1x1"));
+        if (X.h && !o.upsample) conv_h(c, wsc, X.h, din, lay2, k1, dst, ldd, q);
+        else conv_x(c, wsc, sc, ldsc, din, lay2, k1, dst, ldd, q);
+        sc = dst;
+        ldsc = ldd;
     }
-    uint16_t* xs2 = c.image(dout, lay2->N);
-    RUN(c, as_adain_split_f32(h1, lay2->N, dout, gb2.p, gb2.ld, lay2->d_off, B, lay2->N, 1, xs2, c.s));
-    ConvOpt o;
-    o.bias = m.bias(p + ".conv2");
-    o.res = sc;
-    o.ldr = ldsc;
-    o.div_sqrt2 = true;                                                 // (res + sc) / sqrt(2), models.py:201
-    conv_h(c, w2, xs2, dout, lay2, k3, out, ldo, o);
-    Y.p = out; Y.C = dout; Y.ld = ldo; Y.lay = lay2;
+    uint16_t* xs2 = c.image(dout, N2);
+    adain_image(c, h1, N2, dout, o.n2, lay2, nullptr, N2, xs2);
+    ConvOpt q2;
+    q2.bias = m.bias_stack(sfx(".conv2"));
+    q2.res = sc;
+    q2.ldr = ldsc;
+    q2.div_sqrt2 = true;                                                // (res + sc) / sqrt(2), models.py:201
+    q2.group_cols = gc2;
+    if (o.want_yh) {
+        q2.want_yh = true;
+        q2.yh = o.yh ? o.yh : c.image(dout, N2);
+    }
+    conv_h(c, w2, xs2, dout, lay2, k3, out, ldo, q2);
+    Y.p = out; Y.C = dout; Y.ld = ldo; Y.lay = lay2; Y.h = q2.yh;
     return Y;
-}
-
-// nn.LSTM(bidirectional) x n on packed [I][N] inputs over one layout: one hoisted input GEMM each, ONE recurrence launch
-std::vector<Act> bilstm_many(Ctx& c, const std::vector<std::string>& names, const std::vector<Act>& xs)
-{
-    std::vector<Act> out(names.size());
-    if (names.empty() || names.size() > AS_MAX_LSTM_JOBS) { c.fail(AS_EINVAL); return out; }
-    const Lay* lay = xs[0].lay;
-    BiLstmJob jobs[AS_MAX_LSTM_JOBS];
-    int H = 0;
-    for (size_t i = 0; i < names.size(); ++i) {
-        const LstmW* L = c.m.lstm(names[i]);
-        if (!L || !L->wih) { c.fail(AS_EINVAL); return out; }
-        H = L->H;
-        float* gx = c.f32((size_t)std::max(lay->N, 1) * 8 * H);
-        ConvOpt o;
-        o.bias = L->bias;
-        o.transpose_out = true;
-        conv_x(c, L->wih, xs[i].p, xs[i].ld, xs[i].C, lay, taps_1d(1), gx, 8 * H, o);
-        float* y = c.f32((size_t)2 * H * std::max(lay->N, 1));
-        jobs[i].gx_tm = gx; jobs[i].whh_t = L->whh_t; jobs[i].out = y; jobs[i].ldg = 8 * H; jobs[i].ldo = lay->N;
-        out[i].p = y; out[i].C = 2 * H; out[i].ld = lay->N; out[i].lay = lay;
-    }
-    if (lay->N > 0) RUN(c, as_bilstm_f32(jobs, (int)names.size(), lay->d_off, lay->B, H, c.s));
-    return out;
 }
 
 // RelTransformerEncoder.forward (RelTransformerEnc.py:371-380) on packed tokens -> [C][N].
@@ -945,83 +1087,187 @@ void duration_style(Ctx& c, const float* ema_ext, int lde, const Lay* ref, float
 
 float* duration_tail(Ctx& c, float* d, const float* ds, const Lay* tok)          // 3 x AdainResBlk1d -> BiLSTM -> duration_proj -> [1][N]
 {
+    const as_model& m = c.m;
     const std::string p = "durationPredictor";
-    const int C = c.m.cfg.hidden_dim, S = c.m.cfg.style_dim / 4;
-    std::vector<std::string> blocks;
-    for (int i = 0; i < 3; ++i) blocks.push_back(p + ".duration." + std::to_string(i));
-    const std::vector<GB> gbs = adain_fc(c, blocks, ds, S, tok->B);
+    const int C = m.cfg.hidden_dim, S = m.cfg.style_dim / 4;
+    std::vector<as_model::NormSpec> norms;
+    for (int i = 0; i < 3; ++i)
+        for (const char* n : {".norm1", ".norm2"}) norms.push_back({p + ".duration." + std::to_string(i) + n, 0, S});
+    const FcOut fc = adain_fc_all(c, "duration", norms, ds, S, S, tok->B);
     Act x;
     x.p = d; x.C = C; x.ld = tok->N; x.lay = tok;
-    for (int i = 0; i < 3; ++i) x = adain_resblk1d(c, blocks[i], x, gbs[2 * i], gbs[2 * i + 1], nullptr, 0, false);
-    const std::vector<Act> h = bilstm_many(c, {p + ".LSTM"}, {x});
-    const std::string key = "DP:" + p;
-    const GemmW* w;
-    {
-        auto it = c.m.gemm.find(key);
-        const HostT* lw = c.m.host(p + ".duration_proj.linear_layer.weight");
-        if (!lw) return nullptr;
-        w = it != c.m.gemm.end() ? &it->second : (c.m.frozen ? nullptr : c.m.gemm_from(key, lw->v.data(), 1, 1, lw->dim(1), 1));
-        if (!w) { c.fail(AS_EINVAL); return nullptr; }
+    for (int i = 0; i < 3; ++i) {
+        BlkOpt o;
+        o.names = {p + ".duration." + std::to_string(i)};
+        o.n1 = fc.norm(o.names[0] + ".norm1");
+        o.n2 = fc.norm(o.names[0] + ".norm2");
+        o.want_yh = i == 2;                                             // the last block feeds the LSTM's input projection
+        x = adain_resblk1d(c, x, o);
+        if (!x.lay) return nullptr;
     }
-    ConvOpt o;
-    o.bias = c.m.vec(p + ".duration_proj.linear_layer.bias");
-    return conv_x_new(c, w, h[0].p, h[0].ld, h[0].C, tok, taps_1d(1), o);
+    const LstmW* L = m.lstm(p + ".LSTM");
+    if (!L || !L->wih) { c.fail(AS_EINVAL); return nullptr; }
+    const int H = L->H, Nn = std::max(tok->N, 1);
+    float* gx = c.f32((size_t)Nn * 8 * H);
+    ConvOpt q;
+    q.bias = L->bias;
+    q.transpose_out = true;
+    conv_h(c, L->wih, x.h, x.C, tok, taps_1d(1), gx, 8 * H, q);
+    float* h = c.f32((size_t)2 * H * Nn);
+    BiLstmJob job;
+    job.gx_tm = gx; job.whh_t = L->whh_t; job.out = h; job.ldg = 8 * H; job.ldo = tok->N;
+    if (tok->N > 0) RUN(c, as_bilstm_f32(&job, 1, tok->d_off, tok->B, H, c.s));
+    float* y = c.f32(Nn);
+    const float *pw = m.vec(p + ".duration_proj.linear_layer.weight"), *pb = m.vec(p + ".duration_proj.linear_layer.bias");
+    RUN(c, as_project_cols_f32(h, tok->N, 2 * H, tok->N, pw, pb, 1, y, tok->N, c.s));
+    return y;
 }
 
-// ArtsPredictor.forward (models.py:596-621): a [C][N] on `lay` -> F0, N [1][ldp], EMA [10][ldp] on the x2 layout
-void arts_predictor(Ctx& c, const float* a_en, int lda, const Lay* lay, const float* style, float* F0, float* Nn, float* EMA, int ldp)
+// The fc layers of every AdaIN1d that reads the Style vector (artsPredictor + decoder): layer name, first entry, entries read.
+// The three branches' layers of one position are adjacent, so a grouped AdaIN launch addresses group g at + g * 2C rows.
+std::vector<as_model::NormSpec> style_norms(const as_model& m)
+{
+    const int sd = m.cfg.style_dim;
+    std::vector<as_model::NormSpec> v;
+    const char* br[3] = {"F0", "N", "EMA"};
+    const int off[3] = {sd + sd / 2, sd + sd / 2 + sd / 4, sd}, len[3] = {sd / 4, sd / 4, sd / 2};   // models.py:597-599
+    for (const char* n : {".norm1", ".norm2"}) v.push_back({std::string("artsPredictor.shared") + n, 0, 2 * sd});
+    for (int blk = 0; blk < 3; ++blk)
+        for (const char* n : {".norm1", ".norm2"})
+            for (int g = 0; g < 3; ++g)
+                v.push_back({std::string("artsPredictor.") + br[g] + "." + std::to_string(blk) + n, blk == 0 ? 0 : off[g], blk == 0 ? 2 * sd : len[g]});
+    for (const char* n : {".norm1", ".norm2"}) v.push_back({std::string("decoder.encode") + n, 0, 2 * sd});
+    for (int i = 0; i < 6; ++i)
+        for (const char* n : {".norm1", ".norm2"})
+            v.push_back({"decoder.decode." + std::to_string(i) + n, 0, i < 3 ? 2 * sd : sd});          // decode.3..5: Mel_style = Style[:, :style_dim]
+    return v;
+}
+
+// ArtsPredictor.forward (models.py:596-621): a [C][N1] on `lay` -> fne [12][ldp]: row 0 F0, 1 N, 2..11 EMA, on the x2 layout.
+// The F0 / N / EMA branches (three AdainResBlk1d each, identical shapes) run as ONE grouped launch sequence on a layout that holds
+// the batch three times; the three BiLSTMs share one recurrence launch.
+void arts_predictor(Ctx& c, const float* a_en, int lda, const Lay* lay, const FcOut& fc, float* fne, int ldp)
 {
     const as_model& m = c.m;
     const std::string p = "artsPredictor";
-    const int C = m.cfg.hidden_dim, sd = m.cfg.style_dim, lds = 2 * sd, B = lay->B;
+    const int C = m.cfg.hidden_dim, B = lay->B, N1 = lay->N;
     const char* br[3] = {"F0", "N", "EMA"};
-    const int s_off[3] = {sd + sd / 2, sd + sd / 2 + sd / 4, sd};          // style slices (models.py:597-599): F0 384:448, N 448:512, TV 256:384
-    std::vector<std::string> first = {p + ".shared"};
-    for (int i = 0; i < 3; ++i) first.push_back(p + "." + br[i] + ".0");
-    const std::vector<GB> g0 = adain_fc(c, first, style, lds, B);
-    std::vector<GB> g12[3];
-    for (int i = 0; i < 3; ++i)
-        g12[i] = adain_fc(c, {p + "." + br[i] + ".1", p + "." + br[i] + ".2"}, style ? style + s_off[i] : nullptr, lds, B);
     Act a;
     a.p = const_cast<float*>(a_en); a.C = C; a.ld = lda; a.lay = lay;
-    a = adain_resblk1d(c, p + ".shared", a, g0[0], g0[1], nullptr, 0, false);
-    std::vector<Act> feats(3);
-    std::vector<std::string> lstm_names;
     {
-        Fork f(c, 3, 0);                                                    // the F0 / N / EMA branches
-        for (int i = 0; i < 3; ++i) {
-            f.branch(i);
-            const std::string b = p + "." + br[i];
-            Act x = adain_resblk1d(c, b + ".0", a, g0[2 + 2 * i], g0[3 + 2 * i], nullptr, 0, true);
-            if (!x.lay) { f.join(); return; }
-            x = adain_resblk1d(c, b + ".1", x, g12[i][0], g12[i][1], nullptr, 0, false);
-            x = adain_resblk1d(c, b + ".2", x, g12[i][2], g12[i][3], nullptr, 0, false);
-            feats[i] = x;
-            lstm_names.push_back(b + "_LSTM");
+        BlkOpt o;
+        o.names = {p + ".shared"};
+        o.n1 = fc.norm(p + ".shared.norm1");
+        o.n2 = fc.norm(p + ".shared.norm2");
+        a = adain_resblk1d(c, a, o);
+        if (!a.lay) return;
+    }
+    // grouped layouts: the batch three times
+    std::vector<int> w3;
+    for (int g = 0; g < 3; ++g) w3.insert(w3.end(), lay->w.begin(), lay->w.end());
+    const Lay* layG1 = c.lay(w3);
+    const Lay* layG2 = layG1 ? c.scaled(layG1, 2) : nullptr;
+    const Lay* lay2 = c.scaled(lay, 2);
+    if (!layG1 || !layG2 || !lay2) return;
+    const int N2 = lay2->N, NG2 = layG2->N, Nn = std::max(NG2, 1);
+    // per-utterance tables of the grouped launches: where group g's utterance b reads the shared input, and its gamma / beta
+    const int32_t* src_off = c.itable(layG1, "src3", [&]() {
+        std::vector<int32_t> t(3 * B);
+        for (int g = 0; g < 3; ++g)
+            for (int b = 0; b < B; ++b) t[g * B + b] = lay->off[b];
+        return t;
+    });
+    auto gb_table = [&](int rows_per_group) {                           // group g at + g * rows_per_group rows of gbT ([rows][B])
+        return c.itable(layG1, "gb3:" + std::to_string(rows_per_group), [&]() {
+            std::vector<int32_t> t(3 * B);
+            for (int g = 0; g < 3; ++g)
+                for (int b = 0; b < B; ++b) t[g * B + b] = g * rows_per_group * B + b;
+            return t;
+        });
+    };
+    auto gnorm = [&](int blk, const char* n, int Cn) {
+        Norm x = fc.norm(p + "." + br[0] + "." + std::to_string(blk) + n);
+        x.gb_off = gb_table(2 * Cn);
+        return x;
+    };
+    auto names = [&](int blk) { std::vector<std::string> v; for (int g = 0; g < 3; ++g) v.push_back(p + "." + br[g] + "." + std::to_string(blk)); return v; };
+    Act x;
+    {   // block 0 (up-sampling; models.py:579,582,585): AdaIN on the shared input, three parameter sets
+        const std::vector<std::string> nm = names(0);
+        auto sfx = [&](const char* s) { std::vector<std::string> v(nm); for (auto& n : v) n += s; return v; };
+        const GemmW *w1 = m.conv_stack(sfx(".conv1")), *w2 = m.conv_stack(sfx(".conv2"));
+        if (!w1 || !w2) { c.fail(AS_EINVAL); return; }
+        uint16_t* xs = c.image(C, NG2);
+        float* up = c.f32((size_t)C * Nn);
+        // the depthwise ConvTranspose1d weights differ per branch: one launch per group on its third of the grouped layout
+        const Norm n1 = gnorm(0, ".norm1", C);
+        for (int g = 0; g < 3; ++g) {
+            const float *pw = m.vec(nm[g] + ".pool.weight"), *pb = m.vec(nm[g] + ".pool.bias");
+            if (!c.go() || NG2 == 0) continue;
+            AsAdainArgs q;
+            memset(&q, 0, sizeof(q));
+            q.x = a.p; q.ldx = a.ld; q.C = C;
+            q.gb = n1.gb; q.gb_off = n1.gb_off + g * B; q.ldgb = 1; q.gb_sc = n1.gb_sc;
+            q.col_off = layG1->d_off + g * B; q.src_off = src_off + g * B; q.U = B; q.N = NG2; q.lrelu = 1; q.yh = xs;
+            q.pool_w = pw; q.pool_b = pb; q.x_up = up; q.ld_up = NG2;
+            RUN(c, as_adain_image_f32(&q, c.s));
         }
-        f.join();
+        ConvOpt q1;
+        q1.bias = m.bias_stack(sfx(".conv1"));
+        q1.group_cols = 2 * N1;
+        float* h1 = conv_h_new(c, w1, xs, C, layG2, taps_1d(3), q1);
+        uint16_t* xs2 = c.image(w1->M, NG2);
+        adain_image(c, h1, NG2, w1->M, gnorm(0, ".norm2", w1->M), layG2, nullptr, NG2, xs2);
+        ConvOpt q2;
+        q2.bias = m.bias_stack(sfx(".conv2"));
+        q2.res = up;
+        q2.ldr = NG2;
+        q2.div_sqrt2 = true;
+        q2.group_cols = 2 * N1;
+        q2.want_yh = true;                                              // block 1's learned shortcut reads the image
+        q2.yh = c.image(w2->M, NG2);
+        x.p = conv_h_new(c, w2, xs2, w1->M, layG2, taps_1d(3), q2);
+        x.C = w2->M; x.ld = NG2; x.lay = layG2; x.h = q2.yh;
     }
-    const std::vector<Act> hs = bilstm_many(c, lstm_names, feats);          // the three recurrences share one launch
-    float* outs[3] = {F0, Nn, EMA};
-    for (int i = 0; i < 3; ++i) {
-        ConvOpt o;
-        o.bias = m.bias(p + "." + br[i] + "_proj");
-        conv_x(c, m.conv(p + "." + br[i] + "_proj"), hs[i].p, hs[i].ld, hs[i].C, hs[i].lay, taps_1d(1), outs[i], ldp, o);
+    for (int blk = 1; blk <= 2; ++blk) {
+        BlkOpt o;
+        o.names = names(blk);
+        o.group_cols = 2 * N1;
+        const GemmW* w1 = m.conv_stack({o.names[0] + ".conv1", o.names[1] + ".conv1", o.names[2] + ".conv1"});
+        if (!w1) { c.fail(AS_EINVAL); return; }
+        o.n1 = gnorm(blk, ".norm1", x.C);
+        o.n2 = gnorm(blk, ".norm2", w1->M);
+        o.want_yh = true;
+        x = adain_resblk1d(c, x, o);
+        if (!x.lay) return;
     }
-}
-
-struct DecGB {
-    std::vector<GB> a, b;             // encode + decode.0..2 (style); decode.3..5 (mel_style = style[:, :style_dim])
-};
-// gamma / beta of every AdaIN of the decoder: depends on the style vector only, so it can run beside the predictors
-DecGB decoder_adain(Ctx& c, const float* style, int B)
-{
-    const std::string p = "decoder";
-    DecGB g;
-    const int lds = 2 * c.m.cfg.style_dim;
-    g.a = adain_fc(c, {p + ".encode", p + ".decode.0", p + ".decode.1", p + ".decode.2"}, style, lds, B);
-    g.b = adain_fc(c, {p + ".decode.3", p + ".decode.4", p + ".decode.5"}, style, lds, B);
-    return g;
+    // BiLSTMs: one grouped input projection, one recurrence launch for the three (each on its own third of the columns)
+    std::vector<std::string> ln;
+    for (int g = 0; g < 3; ++g) ln.push_back(p + "." + br[g] + "_LSTM");
+    const float* lb = nullptr;
+    const GemmW* wih = m.lstm_wih_stack(ln, &lb);
+    const LstmW* L0 = m.lstm(ln[0]);
+    if (!wih || !L0) { c.fail(AS_EINVAL); return; }
+    const int H = L0->H;
+    float* gx = c.f32((size_t)Nn * 8 * H);
+    ConvOpt q;
+    q.bias = lb;
+    q.transpose_out = true;
+    q.group_cols = 2 * N1;
+    conv_h(c, wih, x.h, x.C, layG2, taps_1d(1), gx, 8 * H, q);
+    float* hs = c.f32((size_t)2 * H * Nn);
+    BiLstmJob jobs[3];
+    for (int g = 0; g < 3; ++g) {
+        const LstmW* L = m.lstm(ln[g]);
+        if (!L) { c.fail(AS_EINVAL); return; }
+        jobs[g].gx_tm = gx + (size_t)g * N2 * 8 * H; jobs[g].whh_t = L->whh_t; jobs[g].out = hs + (size_t)g * N2; jobs[g].ldg = 8 * H; jobs[g].ldo = NG2;
+    }
+    if (N2 > 0) RUN(c, as_bilstm_f32(jobs, 3, lay2->d_off, B, H, c.s));
+    const int rows[3] = {0, 1, 2}, M[3] = {1, 1, 10};
+    for (int g = 0; g < 3; ++g) {
+        const float *pw = m.vec(p + "." + br[g] + "_proj.weight"), *pb = m.vec(p + "." + br[g] + "_proj.bias");
+        RUN(c, as_project_cols_f32(hs + (size_t)g * N2, NG2, 2 * H, N2, pw, pb, M[g], fne + (size_t)rows[g] * ldp, ldp, c.s));
+    }
 }
 
 void copy_rows(Ctx& c, float* dst, int ldd, const float* src, int lds, int rows, int cols)
@@ -1032,47 +1278,79 @@ void copy_rows(Ctx& c, float* dst, int ldd, const float* src, int lds, int rows,
 }
 
 // Decoder.forward (models.py:497-517).  x0 [C + 128][N2]: rows 0..C-1 already hold the up-sampled text encoding (models.py:500);
-// F0 / N [1][ldp], EMA [10][ldp]; mel [n_mels][ldo].
-void decoder(Ctx& c, float* x0, const Lay* lay2, const float* F0, const float* Nn, const float* EMA, int ldp, const DecGB& g, float* mel, int ldo)
+// fne [12][ldp] = F0, N, EMA; mel [n_mels][ldo].
+// One concat buffer: the decode blocks write their result over the rows they were computed from (their learned shortcut goes to
+// a scratch tensor first), so cat([x, asr_res, F0, N, EMA]) (models.py:510) never copies anything; the operand image of the
+// concatenation is the concatenation of the parts' images (k-blocks are the image's outer axis), each written by its producer.
+void decoder(Ctx& c, float* x0, const Lay* lay2, const float* fne, int ldp, const FcOut& fc, float* mel, int ldo)
 {
     const as_model& m = c.m;
     const std::string p = "decoder";
     const int C = m.cfg.hidden_dim, N2 = lay2->N, Nn2 = std::max(N2, 1), bott = 2 * C, cat = bott + 64 + 128;
     const Taps k1 = taps_1d(1);
-    auto small = [&](const char* name, const float* X, int K, float* Y) {
-        ConvOpt o;
-        o.bias = m.bias(p + name);
-        conv_x(c, m.conv(p + name), X, ldp, K, lay2, k1, Y, N2, o);
-    };
-    float* side = x0 ? x0 + (size_t)C * N2 : nullptr;
-    small(".F0_conv", F0, 1, side);
-    small(".N_conv", Nn, 1, side ? side + (size_t)32 * N2 : nullptr);
-    small(".EMA_conv", EMA, 10, side ? side + (size_t)64 * N2 : nullptr);
-    float* cat_a = c.f32((size_t)cat * Nn2);
-    float* cat_b = c.f32((size_t)cat * Nn2);
+    const size_t blk_bytes = (size_t)4 * (N2 + 1) * 16;                 // one k-block of an image over N2 columns
+    auto at_block = [&](uint16_t* img, int kb) { return img ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(img) + (size_t)kb * blk_bytes) : nullptr; };
+    if (C % 64 || (C + 128) % 64) { c.fail(AS_EINVAL); return; }        // parts must start on the image's 4-block granularity
+    uint16_t* x0h = c.image(C + 128, N2);                               // image of x0 = [text encoding | F0 N EMA convs]
+    float* catb = c.f32((size_t)cat * Nn2);                             // [x (2C) | asr_res (64) | F0 N EMA convs (128)]
+    uint16_t* cath = c.image(cat, N2);
+    float* sc_tmp = c.f32((size_t)bott * Nn2);
+    RUN(c, as_split_f16x2_f32(x0, N2, C, N2, 0, 0.f, x0h, c.s));         // text encoding part of x0's image
+    const float* fb = nullptr;
+    const GemmW* wf = m.fne(&fb);
+    if (!wf) { c.fail(AS_EINVAL); return; }
+    {   // F0_conv / N_conv / EMA_conv (models.py:503-505) as one block-diagonal 1x1 conv, once per consumer
+        ConvOpt q;
+        q.bias = fb;
+        q.want_yh = true;
+        q.yh = at_block(x0h, C / 16);
+        conv_x(c, wf, fne, ldp, wf->K, lay2, k1, x0 ? x0 + (size_t)C * N2 : nullptr, N2, q);
+        q.yh = at_block(cath, (bott + 64) / 16);
+        conv_x(c, wf, fne, ldp, wf->K, lay2, k1, catb ? catb + (size_t)(bott + 64) * N2 : nullptr, N2, q);
+    }
     Act x;
-    x.p = x0; x.C = C + 128; x.ld = N2; x.lay = lay2;
-    adain_resblk1d(c, p + ".encode", x, g.a[0], g.a[1], cat_a, N2, false);
+    x.p = x0; x.C = C + 128; x.ld = N2; x.lay = lay2; x.h = x0h;
     {
-        ConvOpt o;
-        o.bias = m.bias(p + ".asr_res.0");
-        conv_x(c, m.conv(p + ".asr_res.0"), x0, N2, C, lay2, k1, cat_a ? cat_a + (size_t)bott * N2 : nullptr, N2, o);
+        BlkOpt o;
+        o.names = {p + ".encode"};
+        o.n1 = fc.norm(p + ".encode.norm1");
+        o.n2 = fc.norm(p + ".encode.norm2");
+        o.out = catb; o.ldo = N2;
+        o.want_yh = true; o.yh = cath;
+        adain_resblk1d(c, x, o);
     }
-    if (c.go()) {
-        copy_rows(c, cat_a + (size_t)(bott + 64) * N2, N2, side, N2, 128, N2);
-        copy_rows(c, cat_b + (size_t)bott * N2, N2, cat_a + (size_t)bott * N2, N2, 64 + 128, N2);
+    {   // asr_res (models.py:507): 1x1 conv of the up-sampled text encoding = the first C channels of x0's image
+        ConvOpt q;
+        q.bias = m.bias(p + ".asr_res.0");
+        q.want_yh = true;
+        q.yh = at_block(cath, bott / 16);
+        conv_h(c, m.conv(p + ".asr_res.0"), x0h, C, lay2, k1, catb ? catb + (size_t)bott * N2 : nullptr, N2, q);
     }
-    Act xa, xb;
-    xa.p = cat_a; xa.C = cat; xa.ld = N2; xa.lay = lay2;
-    xb = xa;
-    xb.p = cat_b;
-    adain_resblk1d(c, p + ".decode.0", xa, g.a[2], g.a[3], cat_b, N2, false);
-    adain_resblk1d(c, p + ".decode.1", xb, g.a[4], g.a[5], cat_a, N2, false);
-    Act y = adain_resblk1d(c, p + ".decode.2", xa, g.a[6], g.a[7], nullptr, 0, false);
-    for (int i = 3; i <= 5; ++i) y = adain_resblk1d(c, p + ".decode." + std::to_string(i), y, g.b[2 * (i - 3)], g.b[2 * (i - 3) + 1], nullptr, 0, false);
-    ConvOpt o;
-    o.bias = m.bias(p + ".to_out.0");
-    conv_x(c, m.conv(p + ".to_out.0"), y.p, y.ld, y.C, lay2, k1, mel, ldo, o);
+    Act xc;
+    xc.p = catb; xc.C = cat; xc.ld = N2; xc.lay = lay2; xc.h = cath;
+    for (int i = 0; i < 2; ++i) {                                       // decode.0, decode.1: 1216 -> 1024, in place on the concat buffer
+        BlkOpt o;
+        o.names = {p + ".decode." + std::to_string(i)};
+        o.n1 = fc.norm(o.names[0] + ".norm1");
+        o.n2 = fc.norm(o.names[0] + ".norm2");
+        o.out = catb; o.ldo = N2;
+        o.want_yh = true; o.yh = cath;
+        o.sc_tmp = sc_tmp;
+        adain_resblk1d(c, xc, o);
+    }
+    Act y;
+    for (int i = 2; i <= 5; ++i) {
+        BlkOpt o;
+        o.names = {p + ".decode." + std::to_string(i)};
+        o.n1 = fc.norm(o.names[0] + ".norm1");
+        o.n2 = fc.norm(o.names[0] + ".norm2");
+        o.want_yh = i == 5;                                             // to_out reads the image
+        y = adain_resblk1d(c, i == 2 ? xc : y, o);
+        if (!y.lay) return;
+    }
+    ConvOpt q;
+    q.bias = m.bias(p + ".to_out.0");
+    conv_h(c, m.conv(p + ".to_out.0"), y.h, y.C, lay2, k1, mel, ldo, q);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1156,28 +1434,19 @@ void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_
     int32_t* frame_off = c.i32(B + 1);
     RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, dur_i, frame_off, tof, N1, c.s));
     float* a_ex = c.f32((size_t)C * std::max(N1, 1));
-    float* F0 = c.f32((size_t)std::max(N2, 1));
-    float* Nn = c.f32((size_t)std::max(N2, 1));
-    float* EMA = c.f32((size_t)10 * std::max(N2, 1));
+    float* fne = c.f32((size_t)12 * std::max(N2, 1));                    // rows: F0, N, EMA[10] (what the three branches predict)
     float* x0 = c.f32((size_t)(C + 128) * std::max(N2, 1));
-    DecGB g;
-    {
-        // the decoder's style-only work (its AdaIN fc layers: ~40 MB of weights) runs beside the predictors
-        Fork f(c, 1, 4);
-        f.branch(0);
-        g = decoder_adain(c, A.style, B);
-        f.back();
-        // T_en @ pred_aln_trg is a column gather (models.py:367-368)
-        RUN(c, as_expand_f32(A.a_en, A.ld_en, C, tof, N1, 1, a_ex, N1, c.s));
-        arts_predictor(c, a_ex, N1, lay1, A.style, F0, Nn, EMA, N2);
-        f.join();
-    }
+    // every AdaIN fc layer of the predictors and the decoder (~75 MB of weights): one GEMM on the style vectors
+    const FcOut fc = adain_fc_all(c, "style", style_norms(m), A.style, 2 * m.cfg.style_dim, 2 * m.cfg.style_dim, B);
+    // T_en @ pred_aln_trg is a column gather (models.py:367-368)
+    RUN(c, as_expand_f32(A.a_en, A.ld_en, C, tof, N1, 1, a_ex, N1, c.s));
+    arts_predictor(c, a_ex, N1, lay1, fc, fne, N2);
     RUN(c, as_expand_f32(A.t_en, A.ld_en, C, tof, N1, 2, x0, N2, c.s));      // text encoding at the mel rate: nearest x2 (models.py:500)
-    decoder(c, x0, lay2, F0, Nn, EMA, N2, g, io->mel_out, io->ld_out);
+    decoder(c, x0, lay2, fne, N2, fc, io->mel_out, io->ld_out);
     if (c.go()) {
-        if (io->F0) copy_rows(c, io->F0, io->ld_pred, F0, N2, 1, N2);
-        if (io->N) copy_rows(c, io->N, io->ld_pred, Nn, N2, 1, N2);
-        if (io->EMA) copy_rows(c, io->EMA, io->ld_pred, EMA, N2, 10, N2);
+        if (io->F0) copy_rows(c, io->F0, io->ld_pred, fne, N2, 1, N2);
+        if (io->N) copy_rows(c, io->N, io->ld_pred, fne + (size_t)N2, N2, 1, N2);
+        if (io->EMA) copy_rows(c, io->EMA, io->ld_pred, fne + (size_t)2 * N2, N2, 10, N2);
         copy_out(c, io->dur_i, dur_i, (size_t)A.tok->N * 4);
         copy_out(c, io->frame_off, frame_off, (size_t)(B + 1) * 4);
     }
@@ -1458,7 +1727,9 @@ size_t count_module(const as_model* m, as_plan* p, int module, const as_batch* b
         if (!batch_ok(batch, false, false, true)) return 0;
         const Lay* lay = c.lay(vec_of(batch->frames, B));
         if (!lay) return 0;
-        arts_predictor(c, nullptr, lay->N, lay, nullptr, nullptr, nullptr, nullptr, 2 * lay->N);
+        const FcOut fc = adain_fc_all(c, "style", style_norms(*m), nullptr, 2 * m->cfg.style_dim, 2 * m->cfg.style_dim, B);
+        float* fne = c.f32((size_t)12 * std::max(2 * lay->N, 1));
+        arts_predictor(c, nullptr, lay->N, lay, fc, fne, 2 * lay->N);
         break;
     }
     case AS_MOD_DECODER: {
@@ -1468,8 +1739,9 @@ size_t count_module(const as_model* m, as_plan* p, int module, const as_batch* b
         const Lay* lay2 = c.scaled(lay, 2);
         c.i32((size_t)std::max(lay->N, 1));
         float* x0 = c.f32((size_t)(C + 128) * std::max(lay2->N, 1));
-        const DecGB g = decoder_adain(c, nullptr, B);
-        decoder(c, x0, lay2, nullptr, nullptr, nullptr, lay2->N, g, nullptr, lay2->N);
+        float* fne = c.f32((size_t)12 * std::max(lay2->N, 1));
+        const FcOut fc = adain_fc_all(c, "style", style_norms(*m), nullptr, 2 * m->cfg.style_dim, 2 * m->cfg.style_dim, B);
+        decoder(c, x0, lay2, fne, lay2->N, fc, nullptr, lay2->N);
         break;
     }
     default: return 0;
@@ -1555,7 +1827,13 @@ extern "C" int as_arts_forward(const as_model* m, as_plan* p, const as_batch* ba
     Ctx& c = k.c;
     const Lay* lay = c.lay(vec_of(batch->frames, batch->B));
     if (!lay || lda < lay->N || ldp < 2 * lay->N) return AS_EINVAL;
-    arts_predictor(c, a_ens, lda, lay, style, F0, N, EMA, ldp);
+    const int N2 = 2 * lay->N, sd2 = 2 * m->cfg.style_dim;
+    const FcOut fc = adain_fc_all(c, "style", style_norms(*m), style, sd2, sd2, batch->B);
+    float* fne = c.f32((size_t)12 * std::max(N2, 1));
+    arts_predictor(c, a_ens, lda, lay, fc, fne, N2);
+    copy_rows(c, F0, ldp, fne, N2, 1, N2);
+    copy_rows(c, N, ldp, fne + (size_t)N2, N2, 1, N2);
+    copy_rows(c, EMA, ldp, fne + (size_t)2 * N2, N2, 10, N2);
     return k.done();
 }
 
@@ -1581,8 +1859,13 @@ extern "C" int as_decoder_forward(const as_model* m, as_plan* p, const as_batch*
     const int C = m->cfg.hidden_dim;
     float* x0 = c.f32((size_t)(C + 128) * std::max(lay2->N, 1));
     RUN(c, as_expand_f32(asr, lda, C, ident, lay->N, 2, x0, lay2->N, c.s));
-    const DecGB g = decoder_adain(c, style, batch->B);
-    decoder(c, x0, lay2, F0, N, EMA, ldp, g, mel, ldo);
+    float* fne = c.f32((size_t)12 * std::max(lay2->N, 1));
+    copy_rows(c, fne, lay2->N, F0, ldp, 1, lay2->N);
+    copy_rows(c, fne + (size_t)lay2->N, lay2->N, N, ldp, 1, lay2->N);
+    copy_rows(c, fne + (size_t)2 * lay2->N, lay2->N, EMA, ldp, 10, lay2->N);
+    const int sd2 = 2 * m->cfg.style_dim;
+    const FcOut fc = adain_fc_all(c, "style", style_norms(*m), style, sd2, sd2, batch->B);
+    decoder(c, x0, lay2, fne, lay2->N, fc, mel, ldo);
     return k.done();
 }
 

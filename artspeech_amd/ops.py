@@ -194,6 +194,35 @@ def adain_split(X, gb, lay, lrelu=True):
     return xs
 
 
+def adain_image(X, lay, gb, gb_sc, N_out, ldgb=1, gb_off=None, src_off=None, pool_w=None, pool_b=None, x_up=None):
+    """as_adain_image_f32: AdaIN1d + LeakyReLU(0.2) (+ the fused x2 up-sampler) of X [C][*] as an operand image over N_out columns;
+    gamma(u, c) = gb[gb_off[u] + c * gb_sc] (gb_off None: u * ldgb), utterance u reads X at src_off[u] (None: its own columns)."""
+    C = X.shape[0]
+    xs = new_image(C, N_out, X.device)
+    a = _lib.AdainArgs()
+    a.x, a.ldx, a.C = _p(X), _ld(X), C
+    a.gb, a.gb_off, a.ldgb, a.gb_sc = _p(gb), _p(gb_off), ldgb, gb_sc
+    a.col_off, a.src_off, a.U, a.N, a.lrelu, a.yh = _p(lay.col_off), _p(src_off), lay.B, N_out, 1, _p(xs)
+    a.pool_w, a.pool_b, a.x_up, a.ld_up = _p(pool_w), _p(pool_b), _p(x_up), (_ld(x_up) if x_up is not None else 0)
+    check(_lib.lib().as_adain_image_f32(ctypes.byref(a), stream()), "as_adain_image_f32")
+    return xs
+
+
+def rows_image(x):
+    """x [B][K] -> the operand image of its transpose [K][B] (as_rows_image_f32)"""
+    B, K = x.shape
+    xh = new_image(K, B, x.device)
+    check(_lib.lib().as_rows_image_f32(_p(x), _ld(x), K, B, _p(xh), stream()), "as_rows_image_f32")
+    return xh
+
+
+def project_cols(X, N, w, bias, Y):
+    """Y[m][j] = bias[m] + sum_k w[m][k] X[k][j], M <= 16 (as_project_cols_f32)"""
+    M, K = w.shape
+    check(_lib.lib().as_project_cols_f32(_p(X), _ld(X), K, N, _p(w), _p(bias), M, _p(Y), _ld(Y), stream()), "as_project_cols_f32")
+    return Y
+
+
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
               use_meta=True, in_slope=0.0, act_slope=0.0, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None):
     """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt: prep_weight(...); X [K][*] fp32 or None with xs= (the split image of

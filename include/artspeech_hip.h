@@ -125,7 +125,7 @@ typedef struct ConvGemmArgs {
     float acc_scale;           /* multiplies the accumulator: 1 / (weight scale of as_prep_weight_f16x2); 0 = 1 */
     /* Grouped launch: G layers of the same shape side by side along the column axis (the text and articulatory encoders,
      * RelTransformerEnc.py; the F0 / energy / TV branches of ArtsPredictor, models.py:606-618): columns
-     * [g * group_cols, (g+1) * group_cols) use weight set g.  n_groups <= 1: off; group_cols a multiple of 128. */
+     * [g * group_cols, (g+1) * group_cols) use weight set g.  n_groups <= 1: off. */
     int32_t n_groups, group_cols;
 } ConvGemmArgs;
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
@@ -175,6 +175,34 @@ int as_adain_f32(const float* x, int ldx, int C, const float* gamma_beta, int ld
  * layout, N = total columns; pass it as ConvGemmArgs.Xh): the fp32 activations are never stored. */
 int as_adain_split_f32(const float* x, int ldx, int C, const float* gamma_beta, int ldgb, const int32_t* col_off, int B, int N,
                        int lrelu, uint16_t* xs, as_stream_t stream);
+/* General form of the above (what the module-level entry points launch): per-utterance addressing of gamma / beta and of the
+ * input columns, so that several layers of the same shape run as ONE launch on a grouped layout (the F0 / energy / TV branches of
+ * ArtsPredictor, models.py:606-618) and read gamma / beta straight from a GEMM's [rows][utterances] output; optional fused
+ * depthwise ConvTranspose1d x2 up-sampler (models.py:172,195) with the nearest-x2 copy of x as second output (models.py:184). */
+typedef struct AsAdainArgs {
+    const float* x;          /* [C][ldx] */
+    int32_t ldx, C;
+    const float* gb;         /* gamma(u, c) = gb[gb_off[u] + c * gb_sc], beta(u, c) = gb[gb_off[u] + (C + c) * gb_sc] */
+    const int32_t* gb_off;   /* [U] float offsets; NULL = u * ldgb */
+    int32_t ldgb, gb_sc;
+    const int32_t* col_off;  /* [U + 1] OUTPUT columns of utterance u (times 2 with the up-sampler) */
+    const int32_t* src_off;  /* [U] first INPUT column of utterance u; NULL = col_off[u] */
+    int32_t U, N;            /* utterances; total output columns of the image (its zero column) */
+    int32_t lrelu;
+    uint16_t* yh;            /* the split image [KBx(C)][4][N+1][8] */
+    const float* pool_w;     /* [C][3] depthwise ConvTranspose1d weights, or NULL = no up-sampling */
+    const float* pool_b;     /* [C] */
+    float* x_up;             /* optional [C][ld_up]: nearest x2 copy of x */
+    int32_t ld_up;
+} AsAdainArgs;
+int as_adain_image_f32(const AsAdainArgs* args_host, as_stream_t stream);
+/* x [B][ldx] (one K-vector per utterance) -> the split image of its transpose [K][B] (columns = utterances): the operand of
+ * the GEMM that evaluates every AdaIN fc layer of the model at once (models.py:237). */
+int as_rows_image_f32(const float* x, int ldx, int K, int B, uint16_t* xh, as_stream_t stream);
+/* Y[m][j] = bias[m] + sum_k W[m][k] X[k][j] for a handful of output rows (M <= 16): the F0 / energy / TV projections behind the
+ * BiLSTMs and duration_proj (models.py:565,619-621) -- bandwidth-bound, one column per thread. */
+int as_project_cols_f32(const float* x, int ldx, int K, int N, const float* w, const float* bias, int M, float* y, int ldy,
+                        as_stream_t stream);
 /* y[b][m] = bias[m] + W[m][:] . x[b][:]       nn.Linear on per-utterance vectors (models.py:237,412-415,538) */
 int as_linear_rows_f32(const float* x, int ldx, const float* w, const float* bias, int B, int M, int K, float* y,
                        int ldy, as_stream_t stream);

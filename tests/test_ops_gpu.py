@@ -121,7 +121,7 @@ def test_epilogue_writes_split_image(cuda, monkeypatch, M, K, lens, tile, ksplit
     assert torch.equal(yh2, want)
 
 
-@pytest.mark.parametrize("G,cin,cout,k,cols", [(2, 64, 128, 3, 256), (3, 96, 80, 1, 128), (3, 512, 512, 3, 6400)])
+@pytest.mark.parametrize("G,cin,cout,k,cols", [(2, 64, 128, 3, 256), (3, 96, 80, 1, 128), (3, 512, 512, 3, 6400), (3, 64, 128, 3, 200), (2, 512, 1024, 9, 52)])
 def test_grouped_launch(cuda, G, cin, cout, k, cols):
     """ConvGemmArgs.n_groups: G layers of the same shape side by side along the column axis equal G separate launches."""
     g = torch.Generator().manual_seed(G * cols)
@@ -136,6 +136,61 @@ def test_grouped_launch(cuda, G, cin, cout, k, cols):
         yi = ops.conv_gemm(ops.prep_weight(ws[i], cuda), X[:, i * cols:(i + 1) * cols].contiguous(), lay1, lay1.new(cout), taps_1d(k),
                            bias=bs[i].to(cuda))
         assert float((y[:, i * cols:(i + 1) * cols] - yi).abs().max()) <= 2e-6 * (1 + 3 * i)
+
+
+def test_adain_image_general_addressing(cuda):
+    """as_adain_image_f32: gamma / beta read from a [rows][utterances] table through per-utterance offsets, three groups of
+    utterances reading ONE shared input (src_off), the fused x2 up-sampler -- against as_adain_f32 + as_split_f16x2_f32 per group."""
+    g = torch.Generator().manual_seed(31)
+    C, lens, G = 48, [17, 64, 30, 1], 3
+    B = len(lens)
+    lay, lay3 = Layout(lens, cuda), Layout(lens * G, cuda)
+    X = (torch.randn(C, lay.N, generator=g) * 2 + 1).to(cuda)
+    gbT = (torch.randn(G * 2 * C, B, generator=g) * 0.3).to(cuda)                  # rows: group g -> gamma[C], beta[C]; columns: utterances
+    pw = [torch.randn(C, 3, generator=g).to(cuda) for _ in range(G)]
+    pb = [torch.randn(C, generator=g).to(cuda) for _ in range(G)]
+    gb_off = torch.tensor([gi * 2 * C * B + b for gi in range(G) for b in range(B)], dtype=torch.int32, device=cuda)
+    src_off = torch.tensor([lay.off_host[b] for _ in range(G) for b in range(B)], dtype=torch.int32, device=cuda)
+    # plain: three groups in one launch on the tripled layout
+    got = ops.adain_image(X, lay3, gbT, B, lay3.N, gb_off=gb_off, src_off=src_off)
+    lay3x2 = lay3.scaled(2)
+    up = torch.zeros(C, lay3x2.N, device=cuda)
+    for gi in range(G):
+        gb_rows = gbT[gi * 2 * C:(gi + 1) * 2 * C].t().contiguous()                # [B][2C] as as_adain_f32 wants it
+        y = ops.adain(X, gb_rows, lay, lay.new(C), True)
+        want = ops.split_act(y, lay)
+        gotp, wantp = image_parts(got, C, lay3.N)[:, :C, gi * lay.N:(gi + 1) * lay.N], image_parts(want, C, lay.N)[:, :C, : lay.N]
+        assert torch.equal(gotp, wantp)
+    # up-sampling variant, one launch per group (the pool weights differ), all into one image
+    xs = ops.new_image(C, lay3x2.N, cuda)
+    a = ops._lib.AdainArgs()
+    for gi in range(G):
+        a.x, a.ldx, a.C, a.gb, a.ldgb, a.gb_sc = X.data_ptr(), lay.N, C, gbT.data_ptr(), 1, B
+        a.gb_off, a.src_off = gb_off.data_ptr() + 4 * gi * B, src_off.data_ptr() + 4 * gi * B
+        a.col_off, a.U, a.N, a.lrelu, a.yh = lay3.col_off.data_ptr() + 4 * gi * B, B, lay3x2.N, 1, xs.data_ptr()
+        a.pool_w, a.pool_b, a.x_up, a.ld_up = pw[gi].data_ptr(), pb[gi].data_ptr(), up.data_ptr(), lay3x2.N
+        ops.check(ops._lib.lib().as_adain_image_f32(ops.ctypes.byref(a), ops.stream()), "as_adain_image_f32")
+    lay2 = lay.scaled(2)
+    for gi in range(G):
+        gb_rows = gbT[gi * 2 * C:(gi + 1) * 2 * C].t().contiguous()
+        yu, xu = lay2.new(C), lay2.new(C)
+        ops.adain(X, gb_rows, lay, yu, True, pw[gi], pb[gi], xu)
+        want = image_parts(ops.split_act(yu, lay2), C, lay2.N)[:, :C, : lay2.N]
+        assert torch.equal(image_parts(xs, C, lay3x2.N)[:, :C, gi * lay2.N:(gi + 1) * lay2.N], want)
+        assert torch.equal(up[:, gi * lay2.N:(gi + 1) * lay2.N], xu)
+    assert not image_parts(xs, C, lay3x2.N)[:, :, lay3x2.N].any()
+
+
+def test_rows_image_and_project_cols(cuda):
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(5, 70, generator=g).to(cuda)
+    parts = image_parts(ops.rows_image(x), 70, 5)
+    h, l = split_ref(x.t().contiguous())
+    assert torch.equal(parts[0, :70, :5], h) and torch.equal(parts[1, :70, :5], l) and not parts[:, 70:].any() and not parts[:, :, 5].any()
+    for M in (1, 3, 10):
+        X, w, b = torch.randn(256, 1000, generator=g).to(cuda), torch.randn(M, 256, generator=g).to(cuda), torch.randn(M, generator=g).to(cuda)
+        y = ops.project_cols(X, 1000, w, b, torch.empty(M, 1000, device=cuda))
+        assert float((y - (w @ X + b[:, None])).abs().max()) <= 2e-4
 
 
 def test_f16_operand_mode(cuda):
