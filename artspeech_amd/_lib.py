@@ -116,6 +116,8 @@ _SIGNATURES.update({
     "as_plan_create": (c_i, [c_p, ctypes.POINTER(c_p)]),
     "as_plan_destroy": (c_i, [c_p]),
     "as_plan_set_serial": (c_i, [c_p, c_i]),
+    "as_plan_set_timing": (c_i, [c_p, c_i]),
+    "as_plan_phase_ms": (c_i, [c_p, ctypes.POINTER(ctypes.c_float), c_i]),
     "as_module_workspace_bytes": (c_sz, [c_p, c_p, c_i, _pB]),
     "as_encoder_forward": (c_i, [c_p, c_p, c_i, _pB, c_p, c_p, c_i, c_p, c_sz, c_p]),
     "as_style_forward": (c_i, [c_p, c_p, _pB, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_sz, c_p]),

@@ -31,3 +31,20 @@ struct AsProfScope {
     AsProfScope(int cls, double flops, double bytes, hipStream_t s, const char* tag = nullptr);
     ~AsProfScope();
 };
+
+#ifdef __HIPCC__
+// AdaIN1d value and the fused depthwise ConvTranspose1d(k3, s2, p1, op1) pair, written with explicit roundings so that every
+// kernel that evaluates them (adain_kernel: fp32 output; adain_image_kernel: operand image) produces the same bits whatever
+// the compiler would contract.
+static __device__ __forceinline__ float as_adain_val(float x, float mean, float rstd, float one_plus_gamma, float beta, int lrelu)
+{
+    const float o = __fmaf_rn(one_plus_gamma, __fmul_rn(__fsub_rn(x, mean), rstd), beta);
+    return (lrelu && o < 0.f) ? __fmul_rn(0.2f, o) : o;
+}
+// out[2i] = a[i] w1 + b ; out[2i+1] = a[i] w2 + a[i+1] w0 + b
+static __device__ __forceinline__ void as_convt_pair(float a0, float a1, float w0, float w1, float w2, float pb, float* o0, float* o1)
+{
+    *o0 = __fmaf_rn(a0, w1, pb);
+    *o1 = __fadd_rn(__fmaf_rn(a1, w0, __fmul_rn(a0, w2)), pb);
+}
+#endif

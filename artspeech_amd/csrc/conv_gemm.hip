@@ -189,29 +189,32 @@ static void tile_dims(int choice, int* bm, int* bn)
     *bn = (choice == 22 || choice == 12) ? 128 : 64;
 }
 
-// Tile choice: a CU runs its L = ceil(tiles / 256) tiles together (they overlap each other's waits); relative speed per tile
-// shape from sweeps on MI355X (scripts/gemm_bench.py).
+// Tile choice, from sweeps on MI355X (scripts/gemm_bench.py, round 2): above one tile per CU the time follows the tile count
+// (several workgroups share a CU and cover each other's waits), below ~160 tiles the idle CUs cost more than a smaller tile's
+// worse operand reuse -- e.g. M512 N1280 K512 T3: 64x64 tiles 16 us, 128x64 20 us; M1536 N2560 K512: 128x128 19 us, 128x64 21 us.
 static int gemm_tile_choice(int M, int N)
 {
     const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 22, 21, 12, 11
     if (env && atoi(env) > 0) return atoi(env);
     const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);   // a 128-row tile is not half empty
-    static const int choices[3] = {22, 21, 12};
-    static const double eff[3] = {1.0, 0.95, 0.85};
-    int best = 12;
+    static const int choices[4] = {22, 21, 12, 11};
+    static const double eff[4] = {1.0, 0.95, 0.9, 0.8};
+    int best = 11;
     double best_cost = 1e30;
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 4; ++c) {
         int bm, bn;
         tile_dims(choices[c], &bm, &bn);
         if (bm == 128 && !tall) continue;
-        const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
-        const long L = (tiles + 255) / 256;
-        const double cost = (double)L * bm * bn / eff[c] * (L >= 2 ? 0.85 : 1.0);
-        if (cost < best_cost) { best_cost = cost; best = choices[c]; }
+        const double tiles = (double)as_cdiv(M, bm) * as_cdiv(N, bn);
+        const double cost = (tiles > 256.0 ? tiles / 256.0 : 1.0) * bm * bn / eff[c] * (tiles < 160.0 ? 160.0 / tiles : 1.0);
+        if (cost < best_cost * 0.97) { best_cost = cost; best = choices[c]; }   // (ties go to the larger tile)
     }
     return best;
 }
 
+// K slices: only where even the smallest tiles leave most CUs idle (the towers' last convs: a few hundred columns, K = 12800).
+// Everywhere else one launch without the reduce pass is as fast or faster (M1024 N2560 K512 T9: 94 us unsplit, 100 + 17 in four
+// slices; M512 N1280 K512 T3: 16 against 31).
 static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
 {
     const char* env = getenv("AS_GEMM_KSPLIT");          // tuning/experiments only
@@ -222,21 +225,12 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
     const int nkt = T * as_cdiv(Kp / 16, wk);             // iterations (k-tile = 16 * WK)
     int s = 1;
     if (env && atoi(env) > 0) s = atoi(env);
-    else {
-        const double gflop = 2e-9 * M * N * (double)Kp * T;
-        if (tiles < 256) {
-            s = as_cdiv(512, tiles);
-            const int cap = (long)M * N >= 262144 ? 4 : 16;
-            if (s > cap) s = cap;
-            // more than half the CUs busy already and a short GEMM: the reduce pass costs more than the slices gain
-            if (tiles >= 128 && gflop < 3.0) s = 1;
-        } else if (tiles < 384 && gflop >= 12.0) {
-            s = 4;
-        }
+    else if (tiles < 64) {
+        s = as_cdiv(192, tiles);
+        if (s > 16) s = 16;
     }
-    // k-tiles a slice keeps: a slice pays a prologue + epilogue and the split a reduce launch; a slice of >= 384 k is best
     const int env_min = getenv("AS_GEMM_MINKT") ? atoi(getenv("AS_GEMM_MINKT")) : 0;   // tuning/experiments only
-    const int min_kt = env_min > 0 ? env_min : 24 / wk;
+    const int min_kt = env_min > 0 ? env_min : 24 / wk;   // a slice keeps >= 384 k
     if (s > nkt / min_kt) s = nkt / min_kt;
     return s < 1 ? 1 : s;
 }

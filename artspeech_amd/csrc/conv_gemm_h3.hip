@@ -526,24 +526,28 @@ static __device__ __forceinline__ float h3_wave_sum(float v)
 // C + c; utterance u reads its input at columns src_off[u].. (NULL: col_off[u]) and writes at col_off[u].. -- at 2 col_off[u]
 // with the fused depthwise ConvTranspose1d(k3, s2, p1, op1) x2 up-sampler (models.py:172,195): out[2i] = a[i] w1 + b,
 // out[2i+1] = a[i] w2 + a[i+1] w0 + b, and x_up (fp32) gets the nearest x2 copy of x (the block's shortcut, models.py:184).
+// Workgroup = (k-block = 16 channels, utterance): a wave computes the statistics of four channels (one pass for the mean, one for
+// the variance, the summation order of adain_kernel), then a thread takes 8 channels of one column, normalises, applies
+// LeakyReLU(0.2), splits and stores the two 16-byte rows (h, l) of its (k-half, column).
+template <bool UP>
 __global__ void __launch_bounds__(256)
 adain_image_kernel(const AsAdainArgs a)
 {
-    __shared__ float st[8][4];                                          // mean, rstd, 1 + gamma, beta
-    const int g = blockIdx.x, u = blockIdx.y;
-    const int c0 = g * 8, C = a.C;
+    __shared__ float st[16][4];                                         // mean, rstd, 1 + gamma, beta
+    const int kb = blockIdx.x, u = blockIdx.y;
+    const int C = a.C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t NX = (size_t)a.N + 1;
     u32x4_t* xs = reinterpret_cast<u32x4_t*>(a.yh);
-    const size_t plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;         // part h of this (k-block, k-half); l at + 2 NX
-    if (u == 0 && threadIdx.x < 2) xs[plane + (size_t)threadIdx.x * 2 * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};   // the zero column
+    const size_t plane0 = (size_t)kb * 4 * NX;                          // plane q = p*2 + kh of this k-block at plane0 + q NX
+    if (u == 0 && threadIdx.x < 4) xs[plane0 + (size_t)threadIdx.x * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};   // the zero column
     const int o0 = a.col_off[u], L = a.col_off[u + 1] - o0;
     if (L <= 0) return;
     const int s0 = a.src_off ? a.src_off[u] : o0;
     const size_t gbase = a.gb_off ? (size_t)a.gb_off[u] : (size_t)u * a.ldgb;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int c = c0 + wave * 2 + q;
+    for (int q = 0; q < 4; ++q) {
+        const int c = kb * 16 + wave * 4 + q;
         if (c < C) {                                                    // wave-uniform
             const float* xr = a.x + (size_t)c * a.ldx + s0;
             float s = 0.f;
@@ -553,23 +557,27 @@ adain_image_kernel(const AsAdainArgs a)
             for (int i = lane; i < L; i += 64) { const float d = xr[i] - mean; v += d * d; }
             const float var = h3_wave_sum(v) / (float)L;
             if (lane == 0) {
-                st[wave * 2 + q][0] = mean;
-                st[wave * 2 + q][1] = 1.0f / sqrtf(var + 1e-5f);
-                st[wave * 2 + q][2] = 1.0f + a.gb[gbase + (size_t)c * a.gb_sc];
-                st[wave * 2 + q][3] = a.gb[gbase + (size_t)(C + c) * a.gb_sc];
+                st[wave * 4 + q][0] = mean;
+                st[wave * 4 + q][1] = 1.0f / sqrtf(var + 1e-5f);
+                st[wave * 4 + q][2] = 1.0f + a.gb[gbase + (size_t)c * a.gb_sc];
+                st[wave * 4 + q][3] = a.gb[gbase + (size_t)(C + c) * a.gb_sc];
             }
         }
     }
     __syncthreads();
-    if (!a.pool_w) {
-        for (int i = threadIdx.x; i < L; i += 256) {
+    // work item = (column i, k-half kh): 2 L items over 256 threads
+    for (int it = threadIdx.x; it < 2 * L; it += 256) {
+        const int kh = it / L, i = it - kh * L;
+        const int c0 = kb * 16 + kh * 8;
+        const size_t plane = plane0 + (size_t)kh * NX;
+        if (!UP) {
             float t[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 float o = 0.f;
                 if (c0 + r < C) {
-                    o = st[r][2] * ((a.x[(size_t)(c0 + r) * a.ldx + s0 + i] - st[r][0]) * st[r][1]) + st[r][3];
-                    if (a.lrelu) o = o > 0.f ? o : 0.2f * o;
+                    const float* sr = st[kh * 8 + r];
+                    o = as_adain_val(a.x[(size_t)(c0 + r) * a.ldx + s0 + i], sr[0], sr[1], sr[2], sr[3], a.lrelu);
                 }
                 t[r] = o;
             }
@@ -578,52 +586,37 @@ adain_image_kernel(const AsAdainArgs a)
             const size_t at = plane + o0 + i;
             xs[at] = h;
             xs[at + 2 * NX] = l;
-        }
-        return;
-    }
-    float w0[8], w1[8], w2[8], pb[8];
+        } else {
+            float e0[8], e1[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const bool ok = c0 + r < C;
-        w0[r] = ok ? a.pool_w[(c0 + r) * 3 + 0] : 0.f;
-        w1[r] = ok ? a.pool_w[(c0 + r) * 3 + 1] : 0.f;
-        w2[r] = ok ? a.pool_w[(c0 + r) * 3 + 2] : 0.f;
-        pb[r] = ok ? a.pool_b[c0 + r] : 0.f;
-    }
-    for (int i = threadIdx.x; i < L; i += 256) {
-        float e0[8], e1[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            float o0v = 0.f, o1v = 0.f;
-            if (c0 + r < C) {
-                const float* xr = a.x + (size_t)(c0 + r) * a.ldx + s0;
-                const float xi = xr[i];
-                float a0 = st[r][2] * ((xi - st[r][0]) * st[r][1]) + st[r][3];
-                if (a.lrelu) a0 = a0 > 0.f ? a0 : 0.2f * a0;
-                float a1 = 0.f;
-                if (i + 1 < L) {
-                    a1 = st[r][2] * ((xr[i + 1] - st[r][0]) * st[r][1]) + st[r][3];
-                    if (a.lrelu) a1 = a1 > 0.f ? a1 : 0.2f * a1;
+            for (int r = 0; r < 8; ++r) {
+                float o0v = 0.f, o1v = 0.f;
+                if (c0 + r < C) {
+                    const float* sr = st[kh * 8 + r];
+                    const float* xr = a.x + (size_t)(c0 + r) * a.ldx + s0;
+                    const float xi = xr[i];
+                    const float a0 = as_adain_val(xi, sr[0], sr[1], sr[2], sr[3], a.lrelu);
+                    const float a1 = i + 1 < L ? as_adain_val(xr[i + 1], sr[0], sr[1], sr[2], sr[3], a.lrelu) : 0.f;
+                    const float w0 = a.pool_w[(c0 + r) * 3 + 0], w1 = a.pool_w[(c0 + r) * 3 + 1], w2 = a.pool_w[(c0 + r) * 3 + 2], pb = a.pool_b[c0 + r];
+                    as_convt_pair(a0, a1, w0, w1, w2, pb, &o0v, &o1v);
+                    if (a.x_up) {
+                        float* ur = a.x_up + (size_t)(c0 + r) * a.ld_up + 2 * o0 + 2 * i;
+                        ur[0] = xi;
+                        ur[1] = xi;
+                    }
                 }
-                o0v = a0 * w1[r] + pb[r];
-                o1v = (a0 * w2[r] + a1 * w0[r]) + pb[r];
-                if (a.x_up) {
-                    float* ur = a.x_up + (size_t)(c0 + r) * a.ld_up + 2 * o0 + 2 * i;
-                    ur[0] = xi;
-                    ur[1] = xi;
-                }
+                e0[r] = o0v;
+                e1[r] = o1v;
             }
-            e0[r] = o0v;
-            e1[r] = o1v;
+            u32x4_t h, l;
+            split2(e0, h, l);
+            const size_t at = plane + 2 * (size_t)o0 + 2 * i;
+            xs[at] = h;
+            xs[at + 2 * NX] = l;
+            split2(e1, h, l);
+            xs[at + 1] = h;
+            xs[at + 1 + 2 * NX] = l;
         }
-        u32x4_t h, l;
-        split2(e0, h, l);
-        const size_t at = plane + 2 * (size_t)o0 + 2 * i;
-        xs[at] = h;
-        xs[at + 2 * NX] = l;
-        split2(e1, h, l);
-        xs[at + 1] = h;
-        xs[at + 1 + 2 * NX] = l;
     }
 }
 
@@ -636,7 +629,8 @@ extern "C" int as_adain_image_f32(const AsAdainArgs* args_host, as_stream_t stre
     if ((reinterpret_cast<uintptr_t>(a.yh) & 15) != 0) return AS_EINVAL;
     if (a.N == 0) return AS_OK;
     AsProfScope prof__(AS_CLS_ADAIN, 0, 8.0 * a.C * (double)a.N, (hipStream_t)stream);
-    hipLaunchKernelGGL(adain_image_kernel, dim3(2 * as_kbx(a.C), a.U), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.pool_w) hipLaunchKernelGGL(adain_image_kernel<true>, dim3(as_kbx(a.C), a.U), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(adain_image_kernel<false>, dim3(as_kbx(a.C), a.U), dim3(256), 0, (hipStream_t)stream, a);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

@@ -192,11 +192,7 @@ adain_kernel(const float* __restrict__ x, int ldx, int C, const float* __restric
     const float be = gb[(size_t)b * ldgb + C + c];
     if (!pool_w) {
         float* yr = y + (size_t)c * ldy + o0;
-        for (int i = lane; i < L; i += 64) {
-            float o = g * ((xr[i] - mean) * rs) + be;
-            if (act) o = lrelu02(o);
-            yr[i] = o;
-        }
+        for (int i = lane; i < L; i += 64) yr[i] = as_adain_val(xr[i], mean, rs, g, be, act);
     } else {
         // depthwise ConvTranspose1d(k3,s2,p1,op1): out[2i] = a[i] w1 + b ; out[2i+1] = a[i] w2 + a[i+1] w0 + b
         const float w0 = pool_w[c * 3 + 0], w1 = pool_w[c * 3 + 1], w2 = pool_w[c * 3 + 2], pb = pool_b[c];
@@ -204,15 +200,12 @@ adain_kernel(const float* __restrict__ x, int ldx, int C, const float* __restric
         float* ur = xup ? xup + (size_t)c * ldup + 2 * o0 : nullptr;
         for (int i = lane; i < L; i += 64) {
             const float xi = xr[i];
-            float a0 = g * ((xi - mean) * rs) + be;
-            if (act) a0 = lrelu02(a0);
-            float a1 = 0.f;
-            if (i + 1 < L) {
-                a1 = g * ((xr[i + 1] - mean) * rs) + be;
-                if (act) a1 = lrelu02(a1);
-            }
-            yr[2 * i] = a0 * w1 + pb;
-            yr[2 * i + 1] = (a0 * w2 + a1 * w0) + pb;
+            const float a0 = as_adain_val(xi, mean, rs, g, be, act);
+            const float a1 = i + 1 < L ? as_adain_val(xr[i + 1], mean, rs, g, be, act) : 0.f;
+            float e0, e1;
+            as_convt_pair(a0, a1, w0, w1, w2, pb, &e0, &e1);
+            yr[2 * i] = e0;
+            yr[2 * i + 1] = e1;
             if (ur) { ur[2 * i] = xi; ur[2 * i + 1] = xi; }
         }
     }
@@ -305,20 +298,41 @@ __global__ void __launch_bounds__(256)
 project_cols_kernel(const float* __restrict__ x, int ldx, int K, int N, const float* __restrict__ w, const float* __restrict__ bias, int M,
                     float* __restrict__ y, int ldy)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
+    // block = 64 columns x 4 k-slices (one wave each: rows k = wave, wave + 4, ...), partial sums meet in LDS
+    __shared__ float part[3][MM][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const bool ok = j < N;
     float acc[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m) acc[m] = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float v = x[(size_t)k * ldx + j];
+    int k = wave;
+    for (; k + 12 < K; k += 16) {                                       // four rows in flight
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ok ? x[(size_t)(k + 4 * u) * ldx + j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                if (m < M) acc[m] += w[m * K + k + 4 * u] * v[u];
+    }
+    for (; k < K; k += 4) {
+        const float v = ok ? x[(size_t)k * ldx + j] : 0.f;
 #pragma unroll
         for (int m = 0; m < MM; ++m)
             if (m < M) acc[m] += w[m * K + k] * v;
     }
+    if (wave > 0) {
 #pragma unroll
-    for (int m = 0; m < MM; ++m)
-        if (m < M) y[(size_t)m * ldy + j] = acc[m] + (bias ? bias[m] : 0.f);
+        for (int m = 0; m < MM; ++m) part[wave - 1][m][lane] = acc[m];
+    }
+    __syncthreads();
+    if (wave == 0 && ok) {
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+            if (m < M) y[(size_t)m * ldy + j] = ((acc[m] + part[0][m][lane]) + (part[1][m][lane] + part[2][m][lane])) + (bias ? bias[m] : 0.f);
+    }
 }
 
 extern "C" int as_project_cols_f32(const float* x, int ldx, int K, int N, const float* w, const float* bias, int M, float* y, int ldy,
@@ -327,7 +341,7 @@ extern "C" int as_project_cols_f32(const float* x, int ldx, int K, int N, const 
     if (!x || !w || !y || K <= 0 || N < 0 || M <= 0 || M > 16 || ldx < N || ldy < N) return AS_EINVAL;
     if (N == 0) return AS_OK;
     AsProfScope prof__(AS_FILE_CLS, 2.0 * M * K * (double)N, 4.0 * (K + M) * (double)N, (hipStream_t)stream);
-    const dim3 grid(as_cdiv(N, 256)), block(256);
+    const dim3 grid(as_cdiv(N, 64)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (M == 1) hipLaunchKernelGGL(project_cols_kernel<1>, grid, block, 0, s, x, ldx, K, N, w, bias, M, y, ldy);
     else if (M <= 4) hipLaunchKernelGGL(project_cols_kernel<4>, grid, block, 0, s, x, ldx, K, N, w, bias, M, y, ldy);

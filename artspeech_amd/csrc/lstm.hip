@@ -350,6 +350,84 @@ bilstm_quad_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B)
     }
 }
 
+// The same with ONE utterance per workgroup: half the multiply-adds and LDS reads per step, twice the workgroups -- used while
+// they all fit the chip at once (the recurrence is latency-bound: a step is as long as one workgroup's dependent chain).
+// The four gates of a unit are accumulated as two packed pairs (v_pk_fma_f32) in two independent chains (even / odd k).
+typedef float lf2 __attribute__((ext_vector_type(2)));
+template <int H>
+__global__ void __launch_bounds__(4 * H)
+bilstm_quad1_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B)
+{
+    constexpr int KQ = H / 4, G = 4 * H;
+    static_assert(KQ % 4 == 0, "quarter of the hidden vector in float4 steps");
+    __shared__ __attribute__((aligned(16))) float hs[2][H];
+    const BiLstmJob job = jobs.j[blockIdx.z];
+    const int dir = blockIdx.y, u = blockIdx.x;
+    const int tid = threadIdx.x, unit = tid >> 2, kq = tid & 3;
+    const int o0 = col_off[u], L = col_off[u + 1] - o0;
+    if (L <= 0) return;
+    for (int i = tid; i < 2 * H; i += G) (&hs[0][0])[i] = 0.f;
+    __syncthreads();
+
+    lf2 wif[KQ], wgo[KQ];                                                // (i, f) and (g, o) rows of this unit, this k quarter
+    const float* wp = job.whh_t + (size_t)dir * H * G + unit;
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) {
+        const float* r = wp + (size_t)(kq * KQ + kk) * G;
+        wif[kk] = lf2{r[0], r[H]};
+        wgo[kk] = lf2{r[2 * H], r[3 * H]};
+    }
+    // lane kq adds the input-projection term of gate kq
+    const float* gxp = job.gx_tm + dir * G + kq * H + unit;
+    auto load_gx = [&](int t) { return (t < L) ? gxp[(size_t)(o0 + (dir ? L - 1 - t : t)) * job.ldg] : 0.f; };
+    constexpr int PF = 4;
+    float gq[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) gq[j] = load_gx(j);
+    float c = 0.f;
+    float* outp = job.out + (size_t)(dir * H + unit) * job.ldo + o0;
+
+    for (int t0 = 0; t0 < L; t0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int t = t0 + j;
+            if (t >= L) break;
+            const float* hc = hs[t & 1] + kq * KQ;
+            float* hn = hs[(t + 1) & 1];
+            const float gx = gq[j];
+            gq[j] = load_gx(t + PF);
+            lf2 aif0 = {kq == 0 ? gx : 0.f, kq == 1 ? gx : 0.f}, ago0 = {kq == 2 ? gx : 0.f, kq == 3 ? gx : 0.f};
+            lf2 aif1 = {0.f, 0.f}, ago1 = {0.f, 0.f};
+#pragma unroll
+            for (int k4 = 0; k4 < KQ; k4 += 4) {
+                const float4 h4 = *reinterpret_cast<const float4*>(hc + k4);
+                aif0 += wif[k4] * lf2{h4.x, h4.x};
+                ago0 += wgo[k4] * lf2{h4.x, h4.x};
+                aif1 += wif[k4 + 1] * lf2{h4.y, h4.y};
+                ago1 += wgo[k4 + 1] * lf2{h4.y, h4.y};
+                aif0 += wif[k4 + 2] * lf2{h4.z, h4.z};
+                ago0 += wgo[k4 + 2] * lf2{h4.z, h4.z};
+                aif1 += wif[k4 + 3] * lf2{h4.w, h4.w};
+                ago1 += wgo[k4 + 3] * lf2{h4.w, h4.w};
+            }
+            float pre[4] = {aif0[0] + aif1[0], aif0[1] + aif1[1], ago0[0] + ago1[0], ago0[1] + ago1[1]};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                pre[g] += __shfl_xor(pre[g], 1);
+                pre[g] += __shfl_xor(pre[g], 2);
+            }
+            if (kq == 0) {
+                const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+                c = fg * c + ig * gg;
+                const float hv = og * tanhf_(c);
+                hn[unit] = hv;
+                outp[dir ? L - 1 - t : t] = hv;
+            }
+            lds_barrier();
+        }
+    }
+}
+
 extern "C" int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32_t* col_off, int B, int H,
                              as_stream_t stream)
 {
@@ -364,6 +442,15 @@ extern "C" int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32
     const size_t smem = sizeof(float) * ((size_t)2 * H * NB + (size_t)4 * H * NB);
     const dim3 grid(as_cdiv(B, NB), 2, n_jobs), block(4 * H);
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
+    // one utterance per workgroup while all the recurrences fit the chip together (AS_LSTM_NB=2 forces the pairs: experiments)
+    const bool single = (H == 64 || H == 128) && (long)n_jobs * 2 * B <= 512 && !getenv("AS_LSTM_NB");
+    if (single) {
+        const dim3 g1(B, 2, n_jobs);
+        if (H == 64) hipLaunchKernelGGL(bilstm_quad1_kernel<64>, g1, block, 0, (hipStream_t)stream, jobs, col_off, B);
+        else hipLaunchKernelGGL(bilstm_quad1_kernel<128>, g1, block, 0, (hipStream_t)stream, jobs, col_off, B);
+        AS_CHECK_LAUNCH();
+        return AS_OK;
+    }
     switch (H) {
     case 16: hipLaunchKernelGGL(bilstm_quad_kernel<16>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B); break;
     case 32: hipLaunchKernelGGL(bilstm_quad_kernel<32>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B); break;

@@ -375,6 +375,14 @@ struct as_plan {
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
     bool serial = false;                  // run the independent branches back to back on the calling stream (profiling)
+    bool timing = false;                  // record phase marks on the calling stream (as_plan_phase_ms)
+    hipEvent_t marks[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void mark(int i, hipStream_t s)
+    {
+        if (!timing) return;
+        if (!marks[i] && hipEventCreate(&marks[i]) != hipSuccess) { marks[i] = nullptr; return; }
+        (void)hipEventRecord(marks[i], s);
+    }
     std::vector<int> frames_host;         // as_forward_test with unknown frame counts reads them here
 
     hipEvent_t event()
@@ -1385,29 +1393,42 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     A.frame_off = c.i32(B + 1);
     float* ds = c.f32((size_t)B * (m.cfg.style_dim / 4));
     const float* stats = m.vec("__stats24");
+    if (c.go()) c.p.mark(0, c.s);
     RUN(c, as_ref_features_f32(io->mel, io->ld_mel, n_mels, io->f0_raw, io->ema_raw, io->ld_ema, A.ref->N, stats, A.feat12, A.ref->N, c.s));
     const StyleIn si = style_inputs(c, A.feat12, A.ref->N, io->mel, io->ld_mel, A.ref);
     if (!si.l1) return A;
+    if (c.go()) c.p.mark(1, c.s);
     // The articulatory + text encoders (twins: one double-width encoder), the mel tower, the duration predictor and the three
     // small towers are mutually independent (models.py:358-360) and individually too small to fill 256 CUs: four concurrent
     // branches (measured in round 1: 3 branches 9.35 ms, these 4 8.89 ms, 5 branches 9.76 ms per step).
+    // (AS_ONLY_BRANCH=k: timing experiments -- only branch k is launched, the others are allocated but skipped; results invalid)
+    const char* only_env = getenv("AS_ONLY_BRANCH");
+    const int only = only_env ? atoi(only_env) : -1;
+    const bool launch0 = c.launch;
+    auto gate = [&](int k) { c.launch = launch0 && (only < 0 || only == k); };
     Fork f(c, 4, 0);
     f.branch(0);
+    gate(0);
     int second = 0;
     float* enc = rel_encoder_pair(c, "arts_encoder", "text_encoder", io->tokens, A.tok, 4, &second, &A.ld_en);
     A.a_en = enc;
     A.t_en = enc ? enc + second : nullptr;
     f.branch(1);
+    gate(1);
     style_tower(c, 0, si, A.style);
     f.branch(2);
+    gate(2);
     duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
     {
         float* d = rel_encoder(c, "durationPredictor.text_encoder", io->tokens, A.tok, 2);
         A.duration = duration_tail(c, d, ds, A.tok);
     }
     f.branch(3);
+    gate(3);
     for (int t = 1; t <= 3; ++t) style_tower(c, t, si, A.style);
+    c.launch = launch0;
     f.join();
+    if (c.go()) c.p.mark(2, c.s);
     // round half even -> clamp(min = 1) (or the forced durations), per-utterance frame offsets (models.py:361-366)
     RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, A.dur_i, A.frame_off, nullptr, 0, c.s));
     (void)C;
@@ -1441,8 +1462,10 @@ void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_
     // T_en @ pred_aln_trg is a column gather (models.py:367-368)
     RUN(c, as_expand_f32(A.a_en, A.ld_en, C, tof, N1, 1, a_ex, N1, c.s));
     arts_predictor(c, a_ex, N1, lay1, fc, fne, N2);
+    if (c.go()) c.p.mark(3, c.s);
     RUN(c, as_expand_f32(A.t_en, A.ld_en, C, tof, N1, 2, x0, N2, c.s));      // text encoding at the mel rate: nearest x2 (models.py:500)
     decoder(c, x0, lay2, fne, N2, fc, io->mel_out, io->ld_out);
+    if (c.go()) c.p.mark(4, c.s);
     if (c.go()) {
         if (io->F0) copy_rows(c, io->F0, io->ld_pred, fne, N2, 1, N2);
         if (io->N) copy_rows(c, io->N, io->ld_pred, fne + (size_t)N2, N2, 1, N2);
@@ -1649,6 +1672,8 @@ extern "C" int as_plan_destroy(as_plan* p)
     if (!p) return AS_EINVAL;
     for (hipStream_t s : p->side) (void)hipStreamDestroy(s);
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->marks)
+        if (e) (void)hipEventDestroy(e);
     p->pool.release();
     delete p;
     return AS_OK;
@@ -1658,6 +1683,25 @@ extern "C" int as_plan_set_serial(as_plan* p, int on)
 {
     if (!p) return AS_EINVAL;
     p->serial = on != 0;
+    return AS_OK;
+}
+
+extern "C" int as_plan_set_timing(as_plan* p, int on)
+{
+    if (!p) return AS_EINVAL;
+    p->timing = on != 0;
+    return AS_OK;
+}
+
+// ms between the phase marks of the last as_forward_test on this plan: [0] reference features + tower inputs, [1] the four
+// concurrent branches (encoders, towers, duration predictor), [2] durations + AdaIN fc GEMM + predictors, [3] decoder
+extern "C" int as_plan_phase_ms(as_plan* p, float* ms, int n)
+{
+    if (!p || !ms || n < 4) return AS_EINVAL;
+    for (int i = 0; i < 5; ++i)
+        if (!p->marks[i]) return AS_EINVAL;
+    AS_CHECK(hipEventSynchronize(p->marks[4]));
+    for (int i = 0; i < 4; ++i) AS_CHECK(hipEventElapsedTime(&ms[i], p->marks[i], p->marks[i + 1]));
     return AS_OK;
 }
 

@@ -73,6 +73,18 @@ class Runtime:
     def set_serial(self, on):
         check(_lib.lib().as_plan_set_serial(self.plan, int(on)), "as_plan_set_serial")
 
+    def phase_ms(self, fn):
+        """run fn() with phase marks on and return the four phase times of its (last) forward in ms"""
+        L = _lib.lib()
+        check(L.as_plan_set_timing(self.plan, 1), "as_plan_set_timing")
+        try:
+            fn()
+            ms = (ctypes.c_float * 4)()
+            check(L.as_plan_phase_ms(self.plan, ms, 4), "as_plan_phase_ms")
+        finally:
+            L.as_plan_set_timing(self.plan, 0)
+        return list(ms)
+
     def batch(self, tok_lens=None, ref_lens=None, frames=None):
         """as_batch for host length lists (the ctypes arrays are kept alive on the returned struct)."""
         n = len(tok_lens if tok_lens is not None else ref_lens if ref_lens is not None else frames)

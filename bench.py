@@ -178,6 +178,9 @@ def main():
     if graph is not None:
         assert torch.equal(gout["mel"], mel_first), "graph replay changed the result"
 
+    # ---- phase times of one eager step with the branches concurrent (HIP events between the phases, on the calling stream)
+    phase = [net.rt.phase_ms(step) for _ in range(3)][-1]
+
     # ---- instrumented pass: per-kernel-class time with HIP events on the launch stream (eager launches)
     # (branches that normally overlap on side streams run back to back here, so a kernel's event-bracketed duration is
     #  its own and not that of whatever shared the chip with it)
@@ -239,6 +242,7 @@ def main():
                      "avg_launch_ms": gemm_ms, "launches_per_step": int(cnt[0] // prof_steps),
                      "algorithmic_gflop_per_step": fl[0] / prof_steps / 1e9},
         "kernel_classes": kern,
+        "phase_ms_eager": dict(zip(["features", "encoders_towers_duration", "predictors", "decoder"], [round(v, 3) for v in phase])),
     }
     if rank == 0 and args.cpu_utts > 0:
         cb, outs = cpu_baseline(host, sd, args.cpu_utts)

@@ -354,6 +354,11 @@ int as_plan_destroy(as_plan* p);
 /* on = 1: the independent branches of a forward run back to back on the calling stream instead of on side streams
  * (per-kernel timing: a kernel's event-bracketed duration is then its own) */
 int as_plan_set_serial(as_plan* p, int on);
+/* on = 1: as_forward_test records phase marks (HIP events) on the calling stream; as_plan_phase_ms then returns the ms of the
+ * last call's phases: [0] reference features + tower inputs, [1] the concurrent branches (encoders, towers, duration predictor),
+ * [2] durations + AdaIN fc + articulatory predictors, [3] decoder.  Blocks until that call has finished. */
+int as_plan_set_timing(as_plan* p, int on);
+int as_plan_phase_ms(as_plan* p, float* ms, int n);
 
 /* geometry of one batch: HOST arrays */
 typedef struct as_batch {

@@ -135,7 +135,7 @@ def test_grouped_launch(cuda, G, cin, cout, k, cols):
     for i in range(G):
         yi = ops.conv_gemm(ops.prep_weight(ws[i], cuda), X[:, i * cols:(i + 1) * cols].contiguous(), lay1, lay1.new(cout), taps_1d(k),
                            bias=bs[i].to(cuda))
-        assert float((y[:, i * cols:(i + 1) * cols] - yi).abs().max()) <= 2e-6 * (1 + 3 * i)
+        assert float((y[:, i * cols:(i + 1) * cols] - yi).abs().max()) <= 1e-5 * (1 + 3 * i)    # (the tile, hence the summation order, may differ)
 
 
 def test_adain_image_general_addressing(cuda):
