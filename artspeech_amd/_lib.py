@@ -74,6 +74,9 @@ _SIGNATURES.update({
     "as_bn_lrelu_maxpool_rows_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
     "as_avgpool_down_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "as_im2col_valid_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "as_dwconv_down_image_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "as_avgpool_down_image_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "as_im2col_valid_image_f32": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "as_mean_pool_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "as_relpos_attention_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
     "as_bilstm_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p]),

@@ -58,33 +58,62 @@ conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
             x[c][t] = ok ? v : 0.f;
         }
     }
-    for (int m = 0; m < a.M; ++m) {
-        float wt[DIRECT_TP];
+    // channels in groups of 8: a group of a column is one 16-byte row per part of the consumer's operand image (a.Yh)
+    u32x4_t* yh = reinterpret_cast<u32x4_t*>(a.Yh);
+    const size_t NX = (size_t)a.N + 1;
+    const int groups = yh ? 2 * as_kbx(a.M) : (a.M + 7) / 8;
+    if (yh && blockIdx.x == 0 && threadIdx.x == 0)
+        for (int g = 0; g < groups; ++g)
+            for (int p = 0; p < 2; ++p) yh[((size_t)(g >> 1) * 4 + (g & 1) + 2 * p) * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};
+    for (int g = 0; g < groups; ++g) {
+        float t8[4][8];
 #pragma unroll
-        for (int q = 0; q < DIRECT_TP / 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&ws[m * DIRECT_TP + 4 * q]);
-            wt[4 * q] = v[0]; wt[4 * q + 1] = v[1]; wt[4 * q + 2] = v[2]; wt[4 * q + 3] = v[3];
+        for (int r = 0; r < 8; ++r) {
+            const int m = g * 8 + r;
+            float y[4] = {0.f, 0.f, 0.f, 0.f};
+            if (m < a.M) {
+                float wt[DIRECT_TP];
+#pragma unroll
+                for (int q = 0; q < DIRECT_TP / 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&ws[m * DIRECT_TP + 4 * q]);
+                    wt[4 * q] = v[0]; wt[4 * q + 1] = v[1]; wt[4 * q + 2] = v[2]; wt[4 * q + 3] = v[3];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) sum += wt[t] * x[c][t];
+                    sum += bs[m];
+                    if (a.act == 1) sum = sum > 0.f ? sum : 0.f;
+                    else if (a.act == 2) sum = sum > 0.f ? sum : a.act_slope * sum;
+                    else if (a.act == 3) sum = tanhf(sum);
+                    else if (a.act == 4) sum = fabsf(sum);
+                    else if (a.act == 5) sum = sum / (1.0f + expf(-sum));
+                    y[c] = sum;
+                }
+                if (a.Y) {
+                    float* yr = a.Y + (size_t)m * a.ldy + j0;
+                    if (VEC) *reinterpret_cast<f32x4*>(yr) = f32x4{y[0], y[1], y[2], y[3]};
+                    else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (j0 + c < a.N) yr[c] = y[c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t8[c][r] = (a.yh_lrelu && y[c] < 0.f) ? a.in_slope * y[c] : y[c];
         }
-        float y[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float sum = 0.f;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) sum += wt[t] * x[c][t];
-            sum += bs[m];
-            if (a.act == 1) sum = sum > 0.f ? sum : 0.f;
-            else if (a.act == 2) sum = sum > 0.f ? sum : a.act_slope * sum;
-            else if (a.act == 3) sum = tanhf(sum);
-            else if (a.act == 4) sum = fabsf(sum);
-            else if (a.act == 5) sum = sum / (1.0f + expf(-sum));
-            y[c] = sum;
-        }
-        float* yr = a.Y + (size_t)m * a.ldy + j0;
-        if (VEC) *reinterpret_cast<f32x4*>(yr) = f32x4{y[0], y[1], y[2], y[3]};
-        else {
+        if (yh) {
+            const size_t plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX + j0;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (j0 + c < a.N) yr[c] = y[c];
+                if (j0 + c < a.N) {
+                    u32x4_t h, l;
+                    split2(t8[c], h, l);
+                    yh[plane + c] = h;
+                    yh[plane + c + 2 * NX] = l;
+                }
         }
     }
 }
@@ -198,7 +227,7 @@ static int gemm_tile_choice(int M, int N)
     if (env && atoi(env) > 0) return atoi(env);
     const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);   // a 128-row tile is not half empty
     static const int choices[4] = {22, 21, 12, 11};
-    static const double eff[4] = {1.0, 0.95, 0.9, 0.8};
+    static const double eff[4] = {1.0, 0.95, 0.9, 0.55};     // (64x64: twice the staged bytes per flop, one workgroup per CU)
     int best = 11;
     double best_cost = 1e30;
     for (int c = 0; c < 4; ++c) {
@@ -253,7 +282,7 @@ static GemmPlan gemm_plan(const ConvGemmArgs& a)
 
 static bool direct_cin1(const ConvGemmArgs& a)
 {
-    return a.K == 1 && a.W && a.X && !a.Yh && !a.res && !a.div_sqrt2 && !a.transpose_out && a.M <= DIRECT_MAX_M && a.n_groups <= 1 &&
+    return a.K == 1 && a.W && a.X && (!a.Yh || a.T <= 9) && !a.res && !a.div_sqrt2 && !a.transpose_out && a.M <= DIRECT_MAX_M && a.n_groups <= 1 &&
            !getenv("AS_GEMM_NO_DIRECT");
 }
 
@@ -296,7 +325,7 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
         snprintf(tag, sizeof(tag), "M%d N%d K1 T%d direct", a.M, a.N, a.T);
         AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.T, 4.0 * ((double)a.T * a.M + a.N + (double)a.M * a.N), stream, tag);
         if (a.T <= 9) {
-            const bool vec = (a.N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0;
+            const bool vec = a.Y && (a.N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0;
             if (vec) hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<true>, dim3(as_cdiv(a.N, 1024)), dim3(256), 0, stream, a);
             else hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<false>, dim3(as_cdiv(a.N, 1024)), dim3(256), 0, stream, a);
         } else {

@@ -3,6 +3,7 @@
 // col_off int32 [B+1] gives each utterance's column range).
 #include "common.h"
 #include "artspeech_hip.h"
+#include "conv_gemm.h"
 #define AS_FILE_CLS AS_CLS_OTHER
 
 static __device__ __forceinline__ float wave_sum(float v)
@@ -557,34 +558,70 @@ extern "C" int as_bn_lrelu_maxpool_rows_f32(const float* x, int ldx, const int32
 // LearnedDownSample (models.py:27-31): depthwise conv, 'half' = 3x3 s2 p1, 'channelpreserve' = 1x3 s(1,2) p(0,1);
 // ResBlk1d.pool (models.py:116) is the H = 1 case of 'channelpreserve'.  Optional LeakyReLU on the result
 // (the activation that follows it at models.py:94 / :148).
-__global__ void dwconv_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off,
-                                   const int* __restrict__ in_w, int Hin, float* __restrict__ y, int ldy,
-                                   const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout,
-                                   const float* __restrict__ w, const float* __restrict__ bias, int kh, int sh, int ph,
-                                   int act)
+// A workgroup takes 8 consecutive channels of one utterance, a thread one output position of all eight: the values leave as
+// fp32 rows (y) and / or as one 16-byte row per part of the consumer conv's operand image (yh: the output of
+// models.py:27-31,116 feeds nothing but the block's second conv).
+__global__ void __launch_bounds__(256)
+dwconv_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off, const int* __restrict__ in_w, int Hin,
+                   float* __restrict__ y, int ldy, const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout,
+                   const float* __restrict__ w, const float* __restrict__ bias, int kh, int sh, int ph, int act, int C,
+                   u32x4_t* __restrict__ yh, int Nout)
 {
-    const int b = blockIdx.y, c = blockIdx.z;
+    const int b = blockIdx.y, g = blockIdx.z, c0 = g * 8;
     const int Wi = in_w[b], Wo = out_w[b];
-    const float* xr = x + (size_t)c * ldx + in_off[b];
-    float* yr = y + (size_t)c * ldy + out_off[b];
-    const float* wc = w + (size_t)c * kh * 3;
-    const float bb = bias[c];
+    const size_t NX = (size_t)Nout + 1, plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;
+    if (yh && b == 0 && blockIdx.x == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + Nout] = u32x4_t{0u, 0u, 0u, 0u};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
         const int ho = i / Wo, wo = i - ho * Wo;
-        float s = 0.f;
-        for (int a = 0; a < kh; ++a) {
-            const int hi = ho * sh - ph + a;
-            if (hi < 0 || hi >= Hin) continue;
-            for (int d = 0; d < 3; ++d) {
-                const int wi = wo * 2 - 1 + d;
-                if (wi < 0 || wi >= Wi) continue;
-                s += xr[(size_t)hi * Wi + wi] * wc[a * 3 + d];
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c = c0 + r;
+            float s = 0.f;
+            if (c < C) {
+                const float* xr = x + (size_t)c * ldx + in_off[b];
+                const float* wc = w + (size_t)c * kh * 3;
+                for (int a = 0; a < kh; ++a) {
+                    const int hi = ho * sh - ph + a;
+                    if (hi < 0 || hi >= Hin) continue;
+                    for (int d = 0; d < 3; ++d) {
+                        const int wi = wo * 2 - 1 + d;
+                        if (wi < 0 || wi >= Wi) continue;
+                        s += xr[(size_t)hi * Wi + wi] * wc[a * 3 + d];
+                    }
+                }
+                s += bias[c];
+                if (act) s = lrelu02(s);
+                if (y) y[(size_t)c * ldy + out_off[b] + i] = s;
             }
+            t[r] = s;
         }
-        s += bb;
-        if (act) s = lrelu02(s);
-        yr[i] = s;
+        if (yh) {
+            u32x4_t h, l;
+            split2(t, h, l);
+            const size_t at = plane + out_off[b] + i;
+            yh[at] = h;
+            yh[at + 2 * NX] = l;
+        }
     }
+}
+
+static int dwconv_launch(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy, const int32_t* out_off,
+                         const int32_t* out_w, int Hout, const float* w, const float* bias, int kh, int B, int C, int max_out, int lrelu,
+                         uint16_t* yh, int Nout, hipStream_t stream)
+{
+    if (!x || (!y && !yh) || !in_off || !in_w || !out_off || !out_w || !w || !bias || (kh != 1 && kh != 3) || B < 0 || C <= 0) return AS_EINVAL;
+    if (yh && ((reinterpret_cast<uintptr_t>(yh) & 15) != 0 || Nout < 0)) return AS_EINVAL;
+    if (B == 0 || max_out <= 0) return AS_OK;
+    const int sh = kh == 3 ? 2 : 1, ph = kh == 3 ? 1 : 0;
+    int gx = as_cdiv(max_out, 256);
+    gx = gx > 32 ? 32 : gx;
+    const int groups = yh ? 2 * as_kbx(C) : as_cdiv(C, 8);
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, stream);
+    hipLaunchKernelGGL(dwconv_down_kernel, dim3(gx, B, groups), dim3(256), 0, stream, x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout, w,
+                       bias, kh, sh, ph, lrelu, C, reinterpret_cast<u32x4_t*>(yh), Nout);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
 }
 
 extern "C" int as_dwconv_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin,
@@ -592,57 +629,93 @@ extern "C" int as_dwconv_down_f32(const float* x, int ldx, const int32_t* in_off
                                   const float* w, const float* bias, int kh, int B, int C, int max_out, int lrelu,
                                   as_stream_t stream)
 {
-    if (!x || !y || !in_off || !in_w || !out_off || !out_w || !w || !bias || (kh != 1 && kh != 3) || B < 0 || C <= 0) return AS_EINVAL;
-    if (B == 0 || max_out <= 0) return AS_OK;
-    const int sh = kh == 3 ? 2 : 1, ph = kh == 3 ? 1 : 0;
-    int gx = as_cdiv(max_out, 256);
-    gx = gx > 32 ? 32 : gx;
-    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(dwconv_down_kernel, dim3(gx, B, C), dim3(256), 0, (hipStream_t)stream, x, ldx, in_off, in_w, Hin,
-                       y, ldy, out_off, out_w, Hout, w, bias, kh, sh, ph, lrelu);
-    AS_CHECK_LAUNCH();
-    return AS_OK;
+    return dwconv_launch(x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout, w, bias, kh, B, C, max_out, lrelu, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int as_dwconv_down_image_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, const int32_t* out_off,
+                                        const int32_t* out_w, int Hout, const float* w, const float* bias, int kh, int B, int C, int max_out,
+                                        int lrelu, uint16_t* yh, int n_out, as_stream_t stream)
+{
+    if (!yh) return AS_EINVAL;
+    return dwconv_launch(x, ldx, in_off, in_w, Hin, nullptr, 0, out_off, out_w, Hout, w, bias, kh, B, C, max_out, lrelu, yh, n_out, (hipStream_t)stream);
 }
 
 // DownSample (models.py:43-57) / ResBlk1d.downsample (:127-130): replicate the last column when W is odd,
 // then average pool (ph x 2); optionally  y = (pool(x) + res) / sqrt(2)  (the block's output, models.py:99-100).
-__global__ void avgpool_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off,
-                                    const int* __restrict__ in_w, int Hin, float* __restrict__ y, int ldy,
-                                    const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout, int ph,
-                                    const float* __restrict__ res, int ldr)
+__global__ void __launch_bounds__(256)
+avgpool_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off, const int* __restrict__ in_w, int Hin,
+                    float* __restrict__ y, int ldy, const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout, int ph,
+                    const float* __restrict__ res, int ldr, int C, u32x4_t* __restrict__ yh, int Nout, int yh_lrelu)
 {
-    const int b = blockIdx.y, c = blockIdx.z;
+    // 8 consecutive channels per workgroup, one output position of all eight per thread (as dwconv_down_kernel)
+    const int b = blockIdx.y, g = blockIdx.z, c0 = g * 8;
     const int Wi = in_w[b], Wo = out_w[b];
-    const float* xr = x + (size_t)c * ldx + in_off[b];
-    float* yr = y + (size_t)c * ldy + out_off[b];
+    const size_t NX = (size_t)Nout + 1, plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;
+    if (yh && b == 0 && blockIdx.x == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + Nout] = u32x4_t{0u, 0u, 0u, 0u};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
         const int ho = i / Wo, wo = i - ho * Wo;
-        float s = 0.f;
-        for (int a = 0; a < ph; ++a) {
-            const int hi = ho * ph + a;
-            const int w0 = 2 * wo, w1 = (2 * wo + 1 < Wi) ? 2 * wo + 1 : Wi - 1;
-            s += xr[(size_t)hi * Wi + w0];
-            s += xr[(size_t)hi * Wi + w1];
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c = c0 + r;
+            float s = 0.f;
+            if (c < C) {
+                const float* xr = x + (size_t)c * ldx + in_off[b];
+                for (int a = 0; a < ph; ++a) {
+                    const int hi = ho * ph + a;
+                    const int w0 = 2 * wo, w1 = (2 * wo + 1 < Wi) ? 2 * wo + 1 : Wi - 1;
+                    s += xr[(size_t)hi * Wi + w0];
+                    s += xr[(size_t)hi * Wi + w1];
+                }
+                s = s / (float)(2 * ph);
+                if (res) s = (s + res[(size_t)c * ldr + out_off[b] + i]) / 1.41421356237309504880f;
+                if (y) y[(size_t)c * ldy + out_off[b] + i] = s;
+                if (yh_lrelu) s = lrelu02(s);
+            }
+            t[r] = s;
         }
-        s = s / (float)(2 * ph);
-        if (res) s = (s + res[(size_t)c * ldr + out_off[b] + i]) / 1.41421356237309504880f;
-        yr[i] = s;
+        if (yh) {
+            u32x4_t h, l;
+            split2(t, h, l);
+            const size_t at = plane + out_off[b] + i;
+            yh[at] = h;
+            yh[at + 2 * NX] = l;
+        }
     }
+}
+
+static int avgpool_launch(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy, const int32_t* out_off,
+                          const int32_t* out_w, int Hout, int pool_h, const float* res, int ldr, int B, int C, int max_out, uint16_t* yh, int Nout,
+                          int yh_lrelu, hipStream_t stream)
+{
+    if (!x || (!y && !yh) || !in_off || !in_w || !out_off || !out_w || (pool_h != 1 && pool_h != 2) || B < 0 || C <= 0) return AS_EINVAL;
+    if (yh && ((reinterpret_cast<uintptr_t>(yh) & 15) != 0 || Nout < 0)) return AS_EINVAL;
+    if (B == 0 || max_out <= 0) return AS_OK;
+    int gx = as_cdiv(max_out, 256);
+    gx = gx > 32 ? 32 : gx;
+    const int groups = yh ? 2 * as_kbx(C) : as_cdiv(C, 8);
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, stream);
+    hipLaunchKernelGGL(avgpool_down_kernel, dim3(gx, B, groups), dim3(256), 0, stream, x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout,
+                       pool_h, res, ldr, C, reinterpret_cast<u32x4_t*>(yh), Nout, yh_lrelu);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
 }
 
 extern "C" int as_avgpool_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin,
                                    float* y, int ldy, const int32_t* out_off, const int32_t* out_w, int Hout,
                                    int pool_h, const float* res, int ldr, int B, int C, int max_out, as_stream_t stream)
 {
-    if (!x || !y || !in_off || !in_w || !out_off || !out_w || (pool_h != 1 && pool_h != 2) || B < 0 || C <= 0) return AS_EINVAL;
-    if (B == 0 || max_out <= 0) return AS_OK;
-    int gx = as_cdiv(max_out, 256);
-    gx = gx > 32 ? 32 : gx;
-    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(avgpool_down_kernel, dim3(gx, B, C), dim3(256), 0, (hipStream_t)stream, x, ldx, in_off, in_w, Hin,
-                       y, ldy, out_off, out_w, Hout, pool_h, res, ldr);
-    AS_CHECK_LAUNCH();
-    return AS_OK;
+    if (!y) return AS_EINVAL;
+    return avgpool_launch(x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout, pool_h, res, ldr, B, C, max_out, nullptr, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int as_avgpool_down_image_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy,
+                                         const int32_t* out_off, const int32_t* out_w, int Hout, int pool_h, const float* res, int ldr, int B,
+                                         int C, int max_out, uint16_t* yh, int n_out, int yh_lrelu, as_stream_t stream)
+{
+    if (!yh) return AS_EINVAL;
+    return avgpool_launch(x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout, pool_h, res, ldr, B, C, max_out, yh, n_out, yh_lrelu,
+                          (hipStream_t)stream);
 }
 
 // im2col for the valid KxK convs that close the 2-D towers (models.py:391,399,535), with the LeakyReLU that
@@ -677,6 +750,54 @@ extern "C" int as_im2col_valid_f32(const float* x, int ldx, const int32_t* in_of
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(im2col_valid_kernel, dim3(C * K * K), dim3(256), 0, (hipStream_t)stream, x, ldx, in_off, in_w, Hin, col,
                        ldc, out_off, out_w, Hout, K, stride, lrelu, B);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// The same written directly as the operand image of the conv it feeds (nothing else reads it): a workgroup takes 8 consecutive
+// rows ck of `col`, a thread one packed output column of all eight.
+__global__ void __launch_bounds__(256)
+im2col_valid_image_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off, const int* __restrict__ in_w,
+                          const int* __restrict__ out_off, const int* __restrict__ out_w, int K, int stride, int act, int B, int rows,
+                          u32x4_t* __restrict__ yh)
+{
+    const int g = blockIdx.x;
+    const int total = out_off[B];
+    const size_t NX = (size_t)total + 1, plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;
+    if (threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + total] = u32x4_t{0u, 0u, 0u, 0u};
+    for (int j = threadIdx.x; j < total; j += blockDim.x) {
+        int b = 0;
+        while (b + 1 < B && out_off[b + 1] <= j) ++b;
+        const int i = j - out_off[b], Wo = out_w[b], Wi = in_w[b];
+        const int ho = i / Wo, wo = i - ho * Wo;
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int ck = g * 8 + r;
+            float v = 0.f;
+            if (ck < rows) {
+                const int c = ck / (K * K), a = (ck / K) % K, d = ck % K;
+                v = x[(size_t)c * ldx + in_off[b] + (size_t)(ho * stride + a) * Wi + wo * stride + d];
+                if (act) v = lrelu02(v);
+            }
+            t[r] = v;
+        }
+        u32x4_t h, l;
+        split2(t, h, l);
+        yh[plane + j] = h;
+        yh[plane + j + 2 * NX] = l;
+    }
+}
+
+extern "C" int as_im2col_valid_image_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, const int32_t* out_off,
+                                         const int32_t* out_w, int K, int stride, int lrelu, int B, int C, uint16_t* yh, as_stream_t stream)
+{
+    if (!x || !yh || !in_off || !in_w || !out_off || !out_w || K <= 0 || stride <= 0 || B <= 0 || C <= 0 ||
+        (reinterpret_cast<uintptr_t>(yh) & 15) != 0)
+        return AS_EINVAL;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(im2col_valid_image_kernel, dim3(2 * as_kbx(C * K * K)), dim3(256), 0, (hipStream_t)stream, x, ldx, in_off, in_w, out_off,
+                       out_w, K, stride, lrelu, B, C * K * K, reinterpret_cast<u32x4_t*>(yh));
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

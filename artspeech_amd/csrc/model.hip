@@ -921,8 +921,9 @@ float* rel_encoder_pair(Ctx& c, const std::string& p1, const std::string& p2, co
     return rel_encoder(c, p1, tok2, lay2, n_layers, p2, N + pad, lay->B + (pad ? 1 : 0));
 }
 
-// ResBlk (models.py:79-100) / ResBlk1d(downsample=True) (models.py:127-156)
-Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_d)
+// ResBlk (models.py:79-100) / ResBlk1d(downsample=True) (models.py:127-156).  X.h, if set, is the operand image of
+// LeakyReLU(X) (what conv1 reads); the result carries the same for the next block when want_image.
+Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_d, bool want_image)
 {
     const as_model& m = c.m;
     const Lay* lay = X.lay;
@@ -933,37 +934,66 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
     const Taps taps = one_d ? taps_1d(3) : taps_2d(3, 3);
     ConvOpt o;
     o.bias = m.bias(p + ".conv1");
-    o.in_act = ACT_LRELU;
-    float* r = conv_x_new(c, m.conv(p + ".conv1"), X.p, X.ld, cin, lay, taps, o);
+    float* r;
+    if (X.h) r = conv_h_new(c, m.conv(p + ".conv1"), X.h, cin, lay, taps, o);
+    else {
+        o.in_act = ACT_LRELU;
+        r = conv_x_new(c, m.conv(p + ".conv1"), X.p, X.ld, cin, lay, taps, o);
+    }
+    // LearnedDownSample / pool (models.py:27-31,116) -> LeakyReLU: read by conv2 only, so it exists only as conv2's operand image
     const std::string dname = p + (one_d ? ".pool" : ".downsample_res.conv");
-    float* r2 = c.f32((size_t)cin * N2);
+    uint16_t* r2h = c.image(cin, lay2->N);
     const float *dww = m.vec(dname + ".weight"), *dwb = m.vec(dname + ".bias");
-    RUN(c, as_dwconv_down_f32(r, lay->N, lay->d_off, lay->d_w, lay->H, r2, lay2->N, lay2->d_off, lay2->d_w, lay2->H, dww, dwb, half ? 3 : 1, B, cin,
-                              lay2->max_cols(), 1, c.s));
+    RUN(c, as_dwconv_down_image_f32(r, lay->N, lay->d_off, lay->d_w, lay->H, lay2->d_off, lay2->d_w, lay2->H, dww, dwb, half ? 3 : 1, B, cin,
+                                    lay2->max_cols(), 1, r2h, lay2->N, c.s));
     const GemmW* w2 = m.conv(p + ".conv2");
     if (!w2) { c.fail(AS_EINVAL); return Y; }
     ConvOpt o2;
     o2.bias = m.bias(p + ".conv2");
-    float* r3 = conv_x_new(c, w2, r2, lay2->N, cin, lay2, taps, o2);
+    float* r3 = conv_h_new(c, w2, r2h, cin, lay2, taps, o2);
     float* out;
+    uint16_t* outh = want_image ? c.image(w2->M, lay2->N) : nullptr;
     if (m.has(p + ".conv1x1.weight")) {
         // shortcut = avgpool(conv1x1(x)) (models.py:79-84).  Both are linear and the 1x1 conv has no bias, so it is evaluated as
         // conv1x1(avgpool(x)): a quarter of the columns, and the merge (x + r)/sqrt(2) becomes the GEMM's epilogue.
-        float* xs = c.f32((size_t)cin * N2);
-        RUN(c, as_avgpool_down_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, xs, lay2->N, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, nullptr, 0, B,
-                                   cin, lay2->max_cols(), c.s));
+        uint16_t* xsh = c.image(cin, lay2->N);
+        RUN(c, as_avgpool_down_image_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, nullptr, 0, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, nullptr,
+                                         0, B, cin, lay2->max_cols(), xsh, lay2->N, 0, c.s));
         ConvOpt o3;
         o3.res = r3;
         o3.ldr = lay2->N;
         o3.div_sqrt2 = true;
-        out = conv_x_new(c, m.conv(p + ".conv1x1"), xs, lay2->N, cin, lay2, taps_1d(1), o3);
+        o3.want_yh = want_image;
+        o3.yh = outh;
+        o3.yh_lrelu = true;
+        out = conv_h_new(c, m.conv(p + ".conv1x1"), xsh, cin, lay2, taps_1d(1), o3);
     } else {
         out = c.f32((size_t)w2->M * N2);
-        RUN(c, as_avgpool_down_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, out, lay2->N, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, r3, lay2->N,
-                                   B, cin, lay2->max_cols(), c.s));
+        if (want_image)
+            RUN(c, as_avgpool_down_image_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, out, lay2->N, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, r3,
+                                             lay2->N, B, cin, lay2->max_cols(), outh, lay2->N, 1, c.s));
+        else
+            RUN(c, as_avgpool_down_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, out, lay2->N, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, r3, lay2->N,
+                                       B, cin, lay2->max_cols(), c.s));
     }
-    Y.p = out; Y.C = w2->M; Y.ld = lay2->N; Y.lay = lay2;
+    Y.p = out; Y.C = w2->M; Y.ld = lay2->N; Y.lay = lay2; Y.h = outh;
     return Y;
+}
+
+// first conv of a tower (Cin = 1: the direct kernel): fp32 output for the first block's shortcut + the LeakyReLU image its conv1 reads
+Act tower_stem(Ctx& c, const std::string& name, const float* X, int ldx, const Lay* lay, const Taps& taps)
+{
+    Act x;
+    const GemmW* w0 = c.m.conv(name);
+    if (!w0 || !lay) { c.fail(AS_EINVAL); return x; }
+    ConvOpt o;
+    o.bias = c.m.bias(name);
+    o.want_yh = true;
+    o.yh = c.image(w0->M, lay->N);
+    o.yh_lrelu = true;
+    x.p = conv_x_new(c, w0, X, ldx, 1, lay, taps, o);
+    x.C = w0->M; x.ld = lay->N; x.lay = lay; x.h = o.yh;
+    return x;
 }
 
 // Mel_block / EMA_block / dur_block + their Linear (models.py:385-401,412-413,530-538) -> y [B][ldy] (M entries per row)
@@ -971,15 +1001,11 @@ void tower2d(Ctx& c, const std::string& p, const float* X, const Lay* lay, const
              const std::string& linear, float* y, int ldy)
 {
     const as_model& m = c.m;
-    ConvOpt o;
-    o.bias = m.bias(p + ".0");
-    const GemmW* w0 = m.conv(p + ".0");
-    if (!w0 || !lay) { c.fail(AS_EINVAL); return; }
-    Act x;
-    x.p = conv_x_new(c, w0, X, lay->N, 1, lay, taps_2d(3, 3), o);
-    x.C = w0->M; x.ld = lay->N; x.lay = lay;
+    if (!lay) { c.fail(AS_EINVAL); return; }
+    Act x = tower_stem(c, p + ".0", X, lay->N, lay, taps_2d(3, 3));
+    if (!x.lay) return;
     for (size_t i = 0; i < halves.size(); ++i) {
-        x = resblk_down(c, p + "." + std::to_string(i + 1), x, halves[i], false);
+        x = resblk_down(c, p + "." + std::to_string(i + 1), x, halves[i], false, i + 1 < halves.size());
         if (!x.lay) return;
     }
     const int K = 5, C = x.C;
@@ -1000,13 +1026,13 @@ void tower2d(Ctx& c, const std::string& p, const float* X, const Lay* lay, const
         wl = it != m.gemm.end() ? &it->second : (m.frozen ? nullptr : m.gemm_from(key, wraw->v.data(), 1, wraw->dim(0), C * K * K, 1));
         if (!wl) { c.fail(AS_EINVAL); return; }
     }
-    float* col = c.f32((size_t)C * K * K * lout->N);
-    RUN(c, as_im2col_valid_f32(x.p, x.ld, x.lay->d_off, x.lay->d_w, x.lay->H, col, lout->N, lout->d_off, lout->d_w, lout->H, K, last_stride, 1,
-                               lay->B, C, lout->max_cols(), c.s));
+    // LeakyReLU -> im2col (models.py:390-391,398-399,534-535), written as the last conv's operand image
+    uint16_t* colh = c.image(C * K * K, lout->N);
+    RUN(c, as_im2col_valid_image_f32(x.p, x.ld, x.lay->d_off, x.lay->d_w, lout->d_off, lout->d_w, K, last_stride, 1, lay->B, C, colh, c.s));
     ConvOpt o2;
     o2.bias = m.bias(ln);
     o2.act = ACT_LRELU;
-    float* z = conv_x_new(c, wl, col, lout->N, C * K * K, lout, taps_1d(1), o2);
+    float* z = conv_h_new(c, wl, colh, C * K * K, lout, taps_1d(1), o2);
     float* pooled = c.f32((size_t)lay->B * wl->M);
     RUN(c, as_mean_pool_f32(z, lout->N, lout->d_off, lay->B, wl->M, 0, pooled, wl->M, c.s));
     const HostT* lw = m.host(linear + ".weight");
@@ -1019,15 +1045,11 @@ void tower2d(Ctx& c, const std::string& p, const float* X, const Lay* lay, const
 void tower1d(Ctx& c, const std::string& p, const float* X, int ldx, const Lay* lay, const std::string& linear, float* y, int ldy)
 {
     const as_model& m = c.m;
-    const GemmW* w0 = m.conv(p + ".0");
-    if (!w0 || !lay) { c.fail(AS_EINVAL); return; }
-    ConvOpt o;
-    o.bias = m.bias(p + ".0");
-    Act x;
-    x.p = conv_x_new(c, w0, X, ldx, 1, lay, taps_1d(3), o);
-    x.C = w0->M; x.ld = lay->N; x.lay = lay;
+    if (!lay) { c.fail(AS_EINVAL); return; }
+    Act x = tower_stem(c, p + ".0", X, ldx, lay, taps_1d(3));
+    if (!x.lay) return;
     for (int i = 1; i <= 4; ++i) {
-        x = resblk_down(c, p + "." + std::to_string(i), x, false, true);
+        x = resblk_down(c, p + "." + std::to_string(i), x, false, true, i < 4);
         if (!x.lay) return;
     }
     float* pooled = c.f32((size_t)lay->B * x.C);

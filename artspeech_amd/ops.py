@@ -369,6 +369,32 @@ def avgpool_down(X, lin, Y, lout, pool_h, res=None):
     return Y
 
 
+def dwconv_down_image(X, lin, lout, w, bias, kh, lrelu):
+    """dwconv_down written only as the consumer conv's operand image (as_dwconv_down_image_f32)"""
+    yh = new_image(X.shape[0], lout.N, X.device)
+    check(_lib.lib().as_dwconv_down_image_f32(_p(X), _ld(X), _p(lin.col_off), _p(lin.widths), lin.H, _p(lout.col_off), _p(lout.widths), lout.H,
+                                              _p(w), _p(bias), kh, lin.B, X.shape[0], lout.max_cols, int(lrelu), _p(yh), lout.N, stream()),
+          "as_dwconv_down_image_f32")
+    return yh
+
+
+def avgpool_down_image(X, lin, Y, lout, pool_h, res=None, yh_lrelu=False):
+    """avgpool_down with the result (also) as an operand image; Y may be None (as_avgpool_down_image_f32)"""
+    yh = new_image(X.shape[0], lout.N, X.device)
+    check(_lib.lib().as_avgpool_down_image_f32(_p(X), _ld(X), _p(lin.col_off), _p(lin.widths), lin.H, _p(Y), _ld(Y) if Y is not None else 0,
+                                               _p(lout.col_off), _p(lout.widths), lout.H, pool_h, _p(res), _ld(res) if res is not None else 0,
+                                               lin.B, X.shape[0], lout.max_cols, _p(yh), lout.N, int(yh_lrelu), stream()),
+          "as_avgpool_down_image_f32")
+    return yh
+
+
+def im2col_valid_image(X, lin, lout, K, stride, lrelu):
+    yh = new_image(X.shape[0] * K * K, lout.N, X.device)
+    check(_lib.lib().as_im2col_valid_image_f32(_p(X), _ld(X), _p(lin.col_off), _p(lin.widths), _p(lout.col_off), _p(lout.widths), K, stride,
+                                               int(lrelu), lin.B, X.shape[0], _p(yh), stream()), "as_im2col_valid_image_f32")
+    return yh
+
+
 def im2col_valid(X, lin, col, lout, K, stride, lrelu):
     check(_lib.lib().as_im2col_valid_f32(_p(X), _ld(X), _p(lin.col_off), _p(lin.widths), lin.H, _p(col), _ld(col),
                                          _p(lout.col_off), _p(lout.widths), lout.H, K, stride, int(lrelu), lin.B,

@@ -242,6 +242,17 @@ int as_avgpool_down_f32(const float* x, int ldx, const int32_t* in_off, const in
 int as_im2col_valid_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* col,
                         int ldc, const int32_t* out_off, const int32_t* out_w, int Hout, int K, int stride, int lrelu,
                         int B, int C, int max_out, as_stream_t stream);
+/* The producers above writing the split operand image of the conv that consumes them instead of (or, avgpool: beside) the fp32
+ * tensor: yh [KBx(C)][4][n_out + 1][8] over the n_out packed output columns (as_split_f16x2_f32's layout).  yh_lrelu: the image
+ * holds LeakyReLU(0.2)(y) -- the consumer's input activation (models.py:89,142) -- while y (optional) stays plain. */
+int as_dwconv_down_image_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, const int32_t* out_off,
+                             const int32_t* out_w, int Hout, const float* w, const float* bias, int kh, int B, int C, int max_out,
+                             int lrelu, uint16_t* yh, int n_out, as_stream_t stream);
+int as_avgpool_down_image_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy,
+                              const int32_t* out_off, const int32_t* out_w, int Hout, int pool_h, const float* res, int ldr, int B,
+                              int C, int max_out, uint16_t* yh, int n_out, int yh_lrelu, as_stream_t stream);
+int as_im2col_valid_image_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, const int32_t* out_off,
+                              const int32_t* out_w, int K, int stride, int lrelu, int B, int C, uint16_t* yh, as_stream_t stream);
 int as_mean_pool_f32(const float* x, int ldx, const int32_t* col_off, int B, int C, int lrelu, float* y, int ldy,
                      as_stream_t stream);
 

@@ -409,6 +409,41 @@ def test_down_sampling(cuda, kind):
     assert torch.equal(col, want)
 
 
+@pytest.mark.parametrize("kind", ["half", "channelpreserve"])
+def test_tower_producers_write_images(cuda, kind):
+    """The style towers' non-GEMM producers (depthwise down-sampling conv, average pooling with / without the residual merge, im2col, the
+    Cin = 1 first conv) written as the consumer conv's operand image: bit-identical to the fp32 kernel followed by as_split_f16x2_f32."""
+    g = torch.Generator().manual_seed(13)
+    C, H, widths = 20, 10, [25, 8, 13]
+    xs = [torch.randn(C, H, W, generator=g) for W in widths]
+    kh = 3 if kind == "half" else 1
+    w, b = torch.randn(C, kh * 3, generator=g).to(cuda), torch.randn(C, generator=g).to(cuda)
+    lay = Layout(widths, cuda, H=H)
+    lay2 = lay.halved(kind == "half")
+    X = packed([x.reshape(C, -1) for x in xs]).to(cuda)
+    y = ops.dwconv_down(X, lay, lay2.new(C), lay2, w, b, kh, True)
+    assert torch.equal(ops.dwconv_down_image(X, lay, lay2, w, b, kh, True), ops.split_act(y, lay2))
+    ph = 2 if kind == "half" else 1
+    z = ops.avgpool_down(X, lay, lay2.new(C), lay2, ph)
+    assert torch.equal(ops.avgpool_down_image(X, lay, None, lay2, ph), ops.split_act(z, lay2))
+    res = torch.randn(C, lay2.N, generator=g).to(cuda)
+    z2 = ops.avgpool_down(X, lay, lay2.new(C), lay2, ph, res=res)
+    y2 = lay2.new(C)
+    img = ops.avgpool_down_image(X, lay, y2, lay2, ph, res=res, yh_lrelu=True)
+    assert torch.equal(y2, z2) and torch.equal(img, ops.split_act(z2, lay2, ops.ACT_LRELU, 0.2))
+    lo = lay.valid_conv(5, 2)
+    col = ops.im2col_valid(X, lay, lo.new(C * 25), lo, 5, 2, True)
+    assert torch.equal(ops.im2col_valid_image(X, lay, lo, 5, 2, True), ops.split_act(col, lo))
+    # Cin = 1 direct kernel: fp32 output + LeakyReLU image
+    w1, b1 = torch.randn(64, 1, 3, 3, generator=g) / 3, torch.randn(64, generator=g).to(cuda)
+    wt = ops.prep_weight(w1, cuda)
+    x1 = X[:1].contiguous()
+    y1 = ops.conv_gemm(wt, x1, lay, lay.new(64), ops.taps_2d(3, 3), bias=b1)
+    yh = ops.new_image(64, lay.N, cuda)
+    y1b = ops.conv_gemm(wt, x1, lay, lay.new(64), ops.taps_2d(3, 3), bias=b1, yh=yh, yh_lrelu=True)
+    assert torch.equal(y1, y1b) and torch.equal(yh, ops.split_act(y1, lay, ops.ACT_LRELU, 0.2))
+
+
 @pytest.mark.parametrize("ksplit", ["2", "5", "16"])
 def test_conv_gemm_split_k(cuda, monkeypatch, impl, ksplit):
     """split-K slabs + fixed-order reduce give the same result as the unsplit kernel (to rounding)."""
