@@ -20,6 +20,7 @@ _SIGNATURES = {
     "as_abi_version": (c_i, []),
     "as_prof_enable": (c_i, [c_i]),
     "as_prof_collect": (c_i, [c_p, c_p, c_p, c_p, c_i]),
+    "as_prof_hint": (c_i, [ctypes.c_double, ctypes.c_double]),
     "as_mas_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "as_mas_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "as_softmax_mas_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
@@ -120,6 +121,7 @@ _SIGNATURES.update({
     "as_plan_destroy": (c_i, [c_p]),
     "as_plan_set_serial": (c_i, [c_p, c_i]),
     "as_plan_set_timing": (c_i, [c_p, c_i]),
+    "as_plan_set_operand_mode": (c_i, [c_p, c_i]),
     "as_plan_phase_ms": (c_i, [c_p, ctypes.POINTER(ctypes.c_float), c_i]),
     "as_module_workspace_bytes": (c_sz, [c_p, c_p, c_i, _pB]),
     "as_encoder_forward": (c_i, [c_p, c_p, c_i, _pB, c_p, c_p, c_i, c_p, c_sz, c_p]),

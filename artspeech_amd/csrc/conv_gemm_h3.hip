@@ -27,7 +27,12 @@
 #include "conv_gemm.h"
 #include <type_traits>
 
+// knock-out switches of experiment builds only (scripts/build_exp.sh NAME -DH3_EXP_NOMFMA / _NODMA / _NOFRAG): what bounds the k loop
+#ifdef H3_EXP_NOMFMA
+#define H3_MFMA(A, B, C) (C)
+#else
 #define H3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -89,8 +94,11 @@ struct H3Cfg {
     static constexpr int NFR = 4 * (NP == 1 ? 1 : 2);                    // fragment reads per k-block
 };
 
+#ifndef H3_OCC
+#define H3_OCC 1
+#endif
 template <int WM, int WN, int WK, int KT, int NS, int NP>
-__global__ void __launch_bounds__(64 * WM * WN * WK)
+__global__ void __launch_bounds__(64 * WM * WN * WK, H3_OCC)
 conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
 {
     using C = H3Cfg<WM, WN, WK, KT, NS, NP>;
@@ -170,57 +178,72 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     const int it_lo = (int)((long)nit_all * blockIdx.y / S);
     const int n_it = (int)((long)nit_all * (blockIdx.y + 1) / S) - it_lo;
 
-    // cursor of the next tile to stage; past the end it stays on the last tile (loading it again into a stage nobody
-    // reads is harmless)
-    int c_t = it_lo / it_per_tap, c_kb = (it_lo - c_t * it_per_tap) * KBS;
-    auto advance = [&](int& t, int& kb) {
-        int nkb = kb + KBS, nt = t;
-        if (nkb >= KB) { nkb = 0; nt += 1; }
-        const bool ok = nt < a.T;
-        kb = ok ? nkb : kb;
-        t = ok ? nt : t;
+    // Cursor of the next tile to stage.  Inside a tap an iteration only adds constants to two scalar offsets; the tap's decode
+    // (source column of every thread's rows; weights / activation offsets back to the tap's first k-block) runs when the tap
+    // CHANGES, once per KB / KBS iterations, behind a wave-uniform branch.  (Round 2 PMC: with the decode in every iteration the
+    // loop carried 43 scalar + 23 vector instructions per 12 MFMAs and the waves' issue slots, not the matrix cores, set the pace.)
+    // Past the end the cursor stays on the last tile (loading it again into a stage nobody reads is harmless).
+    int s_t = it_lo / it_per_tap, s_kb = (it_lo - s_t * it_per_tap) * KBS;
+    const int a_step = KBS * 4 * a.M * 16, b_step = KBS * 4 * NX * 16;
+    int a_soff = (s_t * KBx + s_kb) * 4 * a.M * 16, b_soff = s_kb * 4 * NX * 16;
+    unsigned bv[BCH];                                                    // voffset of this thread's activation chunks for the staged tap
+    auto set_tap = [&](int t) {                                          // an invalid tap reads the zero column N
+        const int byte = (int)(h3_tap_word(tp, t) >> ((t & 7) * 8)) & 0xff;
+        const unsigned ok = 0u - ((tapmask >> t) & 1u);                  // all ones / zero: arithmetic select, no exec branch
+        const unsigned src = ((unsigned)((byte >> 4) * tA + (byte & 15) + tC) & ok) | ((unsigned)a.N & ~ok);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) bv[i] = b_plane[i] + src * 16u;
     };
-    unsigned c_col = 0;                                                  // source column * 16 of this thread's rows, staged tap
-    int c_asoff = 0, c_bsoff = 0, c_byte = 0;
-    unsigned long long c_word = 0;
-    auto tap_word = [&]() {
-        c_word = h3_tap_word(tp, c_t);
-        asm volatile("" : "+s"(c_word));                                 // computed HERE (hipcc otherwise sinks it into a branch)
+    set_tap(s_t);
+    auto advance = [&]() {
+        s_kb += KBS;
+        a_soff += a_step;
+        b_soff += b_step;
+        if (s_kb >= KB) {                                                // wave-uniform, once per tap
+            if (s_t + 1 < a.T) {
+                s_t += 1;
+                s_kb = 0;
+                a_soff = s_t * KBx * 4 * a.M * 16;
+                b_soff = 0;
+                set_tap(s_t);
+            } else {
+                s_kb -= KBS;
+                a_soff -= a_step;
+                b_soff -= b_step;
+            }
+        }
     };
-    auto tap_byte = [&]() {
-        c_byte = (int)(c_word >> ((c_t & 7) * 8)) & 0xff;
-        c_asoff = (c_t * KBx + c_kb) * 4 * a.M * 16;
-        c_bsoff = c_kb * 4 * NX * 16;
-        asm volatile("" : "+s"(c_byte), "+s"(c_asoff), "+s"(c_bsoff));
-    };
-    auto tap_col = [&]() {                                               // an invalid tap reads the zero column N
-        const unsigned ok = 0u - ((tapmask >> c_t) & 1u);                // all ones / zero: arithmetic select, no exec branch
-        const unsigned src = ((unsigned)((c_byte >> 4) * tA + (c_byte & 15) + tC) & ok) | ((unsigned)a.N & ~ok);
-        c_col = src * 16u;
-    };
-    (void)c_col;
     auto dma_a = [&](auto i_, int stage) {
-#if __HIP_DEVICE_COMPILE__   // (device pass only: with this builtin in the body hipcc 7.2's HOST pass drops the kernel's launch stub)
+#if __HIP_DEVICE_COMPILE__ && !defined(H3_EXP_NODMA)   // (device pass only: with this builtin in the body hipcc 7.2's HOST pass drops the kernel's launch stub)
         constexpr int i = decltype(i_)::value;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(smem + stage * C::STAGE + wave * 1024 + i * (NT * 16)), 16, a_voff[i],
-                                                 c_asoff, 0, 0);
+                                                 a_soff, 0, 0);
 #endif
     };
     auto dma_b = [&](auto i_, int stage) {
-#if __HIP_DEVICE_COMPILE__
+#if __HIP_DEVICE_COMPILE__ && !defined(H3_EXP_NODMA)
         constexpr int i = decltype(i_)::value;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(smem + stage * C::STAGE + C::A_ST + wave * 1024 + i * (NT * 16)), 16,
-                                                 b_plane[i] + c_col, c_bsoff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(smem + stage * C::STAGE + C::A_ST + wave * 1024 + i * (NT * 16)), 16, bv[i],
+                                                 b_soff, 0, 0);
 #endif
     };
+    (void)bv;
+    (void)a_soff;
+    (void)b_soff;
     // fragments: [set][32-row / 32-column tile][part]
     f16x8 fa[2][2][2], fb[2][2][2];
     const int a_frag = (wk * KT * QP + lk) * BM * 16 + (wm * 64 + l31) * 16;
     const int b_frag = C::A_ST + (wk * KT * QP + lk) * BN * 16 + (wn * 64 + l31) * 16;
     // fragment read q of k-block step s of stage `stage` into register set `set`: q = ab*NFR/2 + p*2 + i
     auto read_frag = [&](auto q_, auto set_, auto s_, int stage) {
+#ifdef H3_EXP_NOFRAG
+        return;
+#endif
         constexpr int q = decltype(q_)::value, set = decltype(set_)::value, s = decltype(s_)::value;
-        constexpr int half = C::NFR / 2, ab = q / half, p = (q % half) / 2, i = q % 2;
+        // in the order the MFMAs first need them: (A h, B l) for h*l, then (A l, B h) for l*h; h*h reuses them
+        constexpr int pair = q / 2, i = q % 2;
+        constexpr int ab = NP == 1 ? pair : (pair == 0 || pair == 2 ? 0 : 1);
+        constexpr int p = NP == 1 ? 0 : (pair == 0 || pair == 3 ? 0 : 1);
         const unsigned char* st = smem + stage * C::STAGE;
         if constexpr (ab == 0) fa[set][i][p] = *reinterpret_cast<const f16x8*>(st + a_frag + (s * QP + p * 2) * BM * 16 + i * 32 * 16);
         else fb[set][i][p] = *reinterpret_cast<const f16x8*>(st + b_frag + (s * QP + p * 2) * BN * 16 + i * 32 * 16);
@@ -241,12 +264,9 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     static_assert(L >= 2, "KT > 1 needs three stages");
     // prologue: tiles 0 .. L-1 staged, fragments of (tile 0, step 0) in set 0
     for (int st = 0; st < L; ++st) {
-        tap_word();
-        tap_byte();
-        tap_col();
         h3_for<0, ACH>([&](auto i_) { dma_a(i_, st); });
         h3_for<0, BCH>([&](auto i_) { dma_b(i_, st); });
-        advance(c_t, c_kb);
+        advance();
     }
     __syncthreads();
     h3_for<0, C::NFR>([&](auto q_) { read_frag(q_, I0{}, I0{}, 0); });
@@ -257,22 +277,31 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     // the other set, and the staging of tile it + L is dealt out behind the MFMAs: a wave issues about one instruction per
     // 4 cycles and an MFMA holds the matrix core for 32.
     constexpr int NMI = KT * C::NMF;                                     // MFMAs per iteration
-    // staging micro-operations of an iteration: tap decode (3), ACH + BCH DMAs, cursor advance
-    constexpr int M_DMA = 3, M_ADV = M_DMA + ACH + BCH, NMS = M_ADV + 1;
+    // staging micro-operations of an iteration: ACH + BCH DMAs, then the cursor advance
+    constexpr int M_ADV = ACH + BCH, NMS = M_ADV + 1;
     constexpr int SLOT0 = 0;
     auto stage_micro = [&](auto m_, auto p_) {
         constexpr int Mi = decltype(m_)::value, P = (decltype(p_)::value + L) % NS;
-        if constexpr (Mi == 0) tap_word();
-        else if constexpr (Mi == 1) tap_byte();
-        else if constexpr (Mi == 2) tap_col();
-        else if constexpr (Mi < M_DMA + ACH) dma_a(std::integral_constant<int, Mi - M_DMA>{}, P);
-        else if constexpr (Mi < M_ADV) dma_b(std::integral_constant<int, Mi - M_DMA - ACH>{}, P);
-        else advance(c_t, c_kb);
+        if constexpr (Mi < ACH) dma_a(std::integral_constant<int, Mi>{}, P);
+        else if constexpr (Mi < M_ADV) dma_b(std::integral_constant<int, Mi - ACH>{}, P);
+        else advance();
     };
-    // slot of staging micro-op m: spread evenly over [SLOT0, NMI)
-    auto slot_of_stage = [](int m) constexpr { return SLOT0 + (m * (NMI - SLOT0)) / NMS; };
+#ifndef H3_PLAN
+#define H3_PLAN 0
+#endif
+    // H3_PLAN (experiment builds): 0 = staging spread over the whole iteration, interleaved with the fragment reads; 1 = fragment
+    // reads first, staging in the second half; 2 = staging first, fragment reads in the second half
+    auto slot_of_stage = [](int m) constexpr {
+        if (KT == 1 && NP == 3 && H3_PLAN == 1) return 6 + (m * 6) / NMS;
+        if (KT == 1 && NP == 3 && H3_PLAN == 2) return (m * 6) / NMS;
+        return SLOT0 + (m * (NMI - SLOT0)) / NMS;
+    };
     // slot of fragment read q of step s (reads of the NEXT step): spread over the first NMF - 2 slots of the step
-    auto slot_of_frag = [](int s, int q) constexpr { return s * C::NMF + (q * (C::NMF - 2)) / C::NFR + (C::NMF > 4 ? 1 : 0); };
+    auto slot_of_frag = [](int s, int q) constexpr {
+        if (KT == 1 && NP == 3 && H3_PLAN == 1) return (q * 6) / C::NFR;
+        if (KT == 1 && NP == 3 && H3_PLAN == 2) return 5 + (q * 6) / C::NFR;
+        return s * C::NMF + (q * (C::NMF - 2)) / C::NFR + (C::NMF > 4 ? 1 : 0);
+    };
     // MFMA n of a step: groups of four, smallest terms first: (A part, B part) = (h,l) (l,h) (h,h); NP = 1: (h,h)
     auto step = [&](auto n_, auto s_, auto p_, auto f_) {
         constexpr int Nn = decltype(n_)::value, Ss = decltype(s_)::value, P = decltype(p_)::value, F = decltype(f_)::value;
@@ -295,6 +324,13 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     // end of an iteration: the tile the NEXT iteration reads fragments from has landed (this wave's share) and everybody
     // is done with the stage the next iteration restages.  Not __syncthreads(): its fence waits for vmcnt(0).
     constexpr int PEND = (L - 2) * (ACH + BCH);                          // LDS-DMAs that may stay in flight across the barrier: tiles it + 3 .. it + L
+#if defined(H3_EXP_NOBAR)
+#define H3_END_OF_ITER asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PEND) : "memory");
+#elif defined(H3_EXP_NOVMWAIT)
+#define H3_END_OF_ITER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+#define H3_END_OF_ITER asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PEND) : "memory");
+#endif
 #define H3_ITER(U)                                                                                                \
     {                                                                                                             \
         h3_for<0, KT>([&](auto s_) {                                                                              \
@@ -303,7 +339,7 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
                      std::integral_constant<int, ((U) * KT + decltype(s_)::value) % 2>{});                        \
             });                                                                                                   \
         });                                                                                                       \
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PEND) : "memory");                       \
+        H3_END_OF_ITER                                                                                            \
     }
     // stage = it % NS, first register set = (it KT) % 2: period lcm(NS, KT odd ? 2 : 1)
     constexpr int PERIOD = (KT % 2 == 0) ? NS : (NS % 2 == 0 ? NS : 2 * NS);
@@ -545,23 +581,63 @@ adain_image_kernel(const AsAdainArgs a)
     if (L <= 0) return;
     const int s0 = a.src_off ? a.src_off[u] : o0;
     const size_t gbase = a.gb_off ? (size_t)a.gb_off[u] : (size_t)u * a.ldgb;
+    // Statistics of the wave's four channels.  Utterances of up to 64 * RV frames: every lane's share of all four rows is loaded
+    // up front (one memory latency for the lot instead of one per row pass: this kernel is latency-bound) and both passes run on
+    // registers; longer ones loop, four rows interleaved.  Summation order as adain_kernel: a lane adds its elements in ascending
+    // order, then the wave's butterfly.
+    constexpr int RV = 8;
+    const float* xr0 = a.x + (size_t)(kb * 16 + wave * 4) * a.ldx + s0;
+    float mean[4], var[4];
+    if (L <= 64 * RV) {
+        float v[4][RV];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < RV; ++j) {
+                const int i = lane + 64 * j;
+                v[q][j] = (kb * 16 + wave * 4 + q < C && i < L) ? xr0[(size_t)q * a.ldx + i] : 0.f;
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int j = 0; j < RV; ++j)
+                if (lane + 64 * j < L) sacc += v[q][j];
+            mean[q] = h3_wave_sum(sacc) / (float)L;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float vacc = 0.f;
+#pragma unroll
+            for (int j = 0; j < RV; ++j)
+                if (lane + 64 * j < L) { const float d = v[q][j] - mean[q]; vacc += d * d; }
+            var[q] = h3_wave_sum(vacc) / (float)L;
+        }
+    } else {
+        float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = lane; i < L; i += 64)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sacc[q] += (kb * 16 + wave * 4 + q < C) ? xr0[(size_t)q * a.ldx + i] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mean[q] = h3_wave_sum(sacc[q]) / (float)L;
+        float vacc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = lane; i < L; i += 64)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float d = ((kb * 16 + wave * 4 + q < C) ? xr0[(size_t)q * a.ldx + i] : 0.f) - mean[q];
+                vacc[q] += d * d;
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) var[q] = h3_wave_sum(vacc[q]) / (float)L;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c = kb * 16 + wave * 4 + q;
-        if (c < C) {                                                    // wave-uniform
-            const float* xr = a.x + (size_t)c * a.ldx + s0;
-            float s = 0.f;
-            for (int i = lane; i < L; i += 64) s += xr[i];
-            const float mean = h3_wave_sum(s) / (float)L;
-            float v = 0.f;
-            for (int i = lane; i < L; i += 64) { const float d = xr[i] - mean; v += d * d; }
-            const float var = h3_wave_sum(v) / (float)L;
-            if (lane == 0) {
-                st[wave * 4 + q][0] = mean;
-                st[wave * 4 + q][1] = 1.0f / sqrtf(var + 1e-5f);
-                st[wave * 4 + q][2] = 1.0f + a.gb[gbase + (size_t)c * a.gb_sc];
-                st[wave * 4 + q][3] = a.gb[gbase + (size_t)(C + c) * a.gb_sc];
-            }
+        if (c < C && lane == 0) {
+            st[wave * 4 + q][0] = mean[q];
+            st[wave * 4 + q][1] = 1.0f / sqrtf(var[q] + 1e-5f);
+            st[wave * 4 + q][2] = 1.0f + a.gb[gbase + (size_t)c * a.gb_sc];
+            st[wave * 4 + q][3] = a.gb[gbase + (size_t)(C + c) * a.gb_sc];
         }
     }
     __syncthreads();

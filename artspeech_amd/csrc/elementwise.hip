@@ -296,11 +296,16 @@ extern "C" int as_linear_rows_f32(const float* x, int ldx, const float* w, const
 // ---------------------------------------------------------------------------------------------------
 template <int MM>
 __global__ void __launch_bounds__(256)
-project_cols_kernel(const float* __restrict__ x, int ldx, int K, int N, const float* __restrict__ w, const float* __restrict__ bias, int M,
+project_cols_kernel(const float* __restrict__ x, int ldx, int K, int N, const float* w, const float* __restrict__ bias, int M,
                     float* __restrict__ y, int ldy)
 {
-    // block = 64 columns x 4 k-slices (one wave each: rows k = wave, wave + 4, ...), partial sums meet in LDS
+    // block = 64 columns x 4 k-slices (one wave each: rows k = wave, wave + 4, ...), partial sums meet in LDS; the weights are
+    // staged in LDS once (read back as broadcasts: every lane of a wave wants the same entry)
     __shared__ float part[3][MM][64];
+    extern __shared__ float wsm[];                                      // [M][K]
+    for (int i = threadIdx.x; i < M * K; i += 256) wsm[i] = w[i];
+    __syncthreads();
+    w = wsm;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
     const bool ok = j < N;
@@ -339,14 +344,15 @@ project_cols_kernel(const float* __restrict__ x, int ldx, int K, int N, const fl
 extern "C" int as_project_cols_f32(const float* x, int ldx, int K, int N, const float* w, const float* bias, int M, float* y, int ldy,
                                    as_stream_t stream)
 {
-    if (!x || !w || !y || K <= 0 || N < 0 || M <= 0 || M > 16 || ldx < N || ldy < N) return AS_EINVAL;
+    if (!x || !w || !y || K <= 0 || N < 0 || M <= 0 || M > 16 || (size_t)M * K * 4 > 48 * 1024 || ldx < N || ldy < N) return AS_EINVAL;
     if (N == 0) return AS_OK;
+    const size_t wsz = (size_t)M * K * sizeof(float);
     AsProfScope prof__(AS_FILE_CLS, 2.0 * M * K * (double)N, 4.0 * (K + M) * (double)N, (hipStream_t)stream);
     const dim3 grid(as_cdiv(N, 64)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (M == 1) hipLaunchKernelGGL(project_cols_kernel<1>, grid, block, 0, s, x, ldx, K, N, w, bias, M, y, ldy);
-    else if (M <= 4) hipLaunchKernelGGL(project_cols_kernel<4>, grid, block, 0, s, x, ldx, K, N, w, bias, M, y, ldy);
-    else hipLaunchKernelGGL(project_cols_kernel<16>, grid, block, 0, s, x, ldx, K, N, w, bias, M, y, ldy);
+    if (M == 1) hipLaunchKernelGGL(project_cols_kernel<1>, grid, block, wsz, s, x, ldx, K, N, w, bias, M, y, ldy);
+    else if (M <= 4) hipLaunchKernelGGL(project_cols_kernel<4>, grid, block, wsz, s, x, ldx, K, N, w, bias, M, y, ldy);
+    else hipLaunchKernelGGL(project_cols_kernel<16>, grid, block, wsz, s, x, ldx, K, N, w, bias, M, y, ldy);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

@@ -376,6 +376,7 @@ struct as_plan {
     size_t next_event = 0;
     bool serial = false;                  // run the independent branches back to back on the calling stream (profiling)
     bool timing = false;                  // record phase marks on the calling stream (as_plan_phase_ms)
+    int n_prod = 3;                       // matrix-core products per fp32 product (as_plan_set_operand_mode)
     hipEvent_t marks[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void mark(int i, hipStream_t s)
     {
@@ -614,6 +615,7 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     a.ldx = X ? ldx : lay->N; a.ldy = ldy; a.ldr = o.ldr;
     a.act = o.act; a.div_sqrt2 = o.div_sqrt2; a.in_act = o.in_act; a.transpose_out = o.transpose_out; a.yh_lrelu = o.yh_lrelu;
     a.acc_scale = 1.0f / w->scale;
+    a.n_prod = c.p.n_prod;
     a.n_groups = w->G; a.group_cols = o.group_cols;
     for (int i = 0; i < taps.n; ++i) { a.dh[i] = taps.dh[i]; a.dw[i] = taps.dw[i]; }
     const bool pointwise = taps.n == 1 && taps.dh[0] == 0 && taps.dw[0] == 0;
@@ -944,6 +946,7 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
     const std::string dname = p + (one_d ? ".pool" : ".downsample_res.conv");
     uint16_t* r2h = c.image(cin, lay2->N);
     const float *dww = m.vec(dname + ".weight"), *dwb = m.vec(dname + ".bias");
+    as_prof_hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
     RUN(c, as_dwconv_down_image_f32(r, lay->N, lay->d_off, lay->d_w, lay->H, lay2->d_off, lay2->d_w, lay2->H, dww, dwb, half ? 3 : 1, B, cin,
                                     lay2->max_cols(), 1, r2h, lay2->N, c.s));
     const GemmW* w2 = m.conv(p + ".conv2");
@@ -957,6 +960,7 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
         // shortcut = avgpool(conv1x1(x)) (models.py:79-84).  Both are linear and the 1x1 conv has no bias, so it is evaluated as
         // conv1x1(avgpool(x)): a quarter of the columns, and the merge (x + r)/sqrt(2) becomes the GEMM's epilogue.
         uint16_t* xsh = c.image(cin, lay2->N);
+        as_prof_hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
         RUN(c, as_avgpool_down_image_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, nullptr, 0, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, nullptr,
                                          0, B, cin, lay2->max_cols(), xsh, lay2->N, 0, c.s));
         ConvOpt o3;
@@ -969,6 +973,7 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
         out = conv_h_new(c, m.conv(p + ".conv1x1"), xsh, cin, lay2, taps_1d(1), o3);
     } else {
         out = c.f32((size_t)w2->M * N2);
+        as_prof_hint(0, 4.0 * cin * ((double)lay->N + (want_image ? 3.0 : 2.0) * lay2->N));
         if (want_image)
             RUN(c, as_avgpool_down_image_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, out, lay2->N, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, r3,
                                              lay2->N, B, cin, lay2->max_cols(), outh, lay2->N, 1, c.s));
@@ -1028,6 +1033,7 @@ void tower2d(Ctx& c, const std::string& p, const float* X, const Lay* lay, const
     }
     // LeakyReLU -> im2col (models.py:390-391,398-399,534-535), written as the last conv's operand image
     uint16_t* colh = c.image(C * K * K, lout->N);
+    as_prof_hint(0, 4.0 * C * ((double)x.lay->N + (double)K * K * lout->N));
     RUN(c, as_im2col_valid_image_f32(x.p, x.ld, x.lay->d_off, x.lay->d_w, lout->d_off, lout->d_w, K, last_stride, 1, lay->B, C, colh, c.s));
     ConvOpt o2;
     o2.bias = m.bias(ln);
@@ -1416,6 +1422,7 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     float* ds = c.f32((size_t)B * (m.cfg.style_dim / 4));
     const float* stats = m.vec("__stats24");
     if (c.go()) c.p.mark(0, c.s);
+    as_prof_hint(0, 4.0 * (n_mels + 11.0 + 12.0) * A.ref->N);
     RUN(c, as_ref_features_f32(io->mel, io->ld_mel, n_mels, io->f0_raw, io->ema_raw, io->ld_ema, A.ref->N, stats, A.feat12, A.ref->N, c.s));
     const StyleIn si = style_inputs(c, A.feat12, A.ref->N, io->mel, io->ld_mel, A.ref);
     if (!si.l1) return A;
@@ -1482,9 +1489,11 @@ void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_
     // every AdaIN fc layer of the predictors and the decoder (~75 MB of weights): one GEMM on the style vectors
     const FcOut fc = adain_fc_all(c, "style", style_norms(m), A.style, 2 * m.cfg.style_dim, 2 * m.cfg.style_dim, B);
     // T_en @ pred_aln_trg is a column gather (models.py:367-368)
+    as_prof_hint(0, 4.0 * C * ((double)A.tok->N + N1));
     RUN(c, as_expand_f32(A.a_en, A.ld_en, C, tof, N1, 1, a_ex, N1, c.s));
     arts_predictor(c, a_ex, N1, lay1, fc, fne, N2);
     if (c.go()) c.p.mark(3, c.s);
+    as_prof_hint(0, 4.0 * C * ((double)A.tok->N + N2));
     RUN(c, as_expand_f32(A.t_en, A.ld_en, C, tof, N1, 2, x0, N2, c.s));      // text encoding at the mel rate: nearest x2 (models.py:500)
     decoder(c, x0, lay2, fne, N2, fc, io->mel_out, io->ld_out);
     if (c.go()) c.p.mark(4, c.s);
@@ -1705,6 +1714,13 @@ extern "C" int as_plan_set_serial(as_plan* p, int on)
 {
     if (!p) return AS_EINVAL;
     p->serial = on != 0;
+    return AS_OK;
+}
+
+extern "C" int as_plan_set_operand_mode(as_plan* p, int n_prod)
+{
+    if (!p || (n_prod != 1 && n_prod != 3)) return AS_EINVAL;
+    p->n_prod = n_prod;
     return AS_OK;
 }
 

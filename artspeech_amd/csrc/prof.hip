@@ -13,6 +13,7 @@
 
 struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; char tag[64]; };
 static bool g_on = false;
+static thread_local double g_hint_flops = 0, g_hint_bytes = 0;      // what the caller knows about the next launch (as_prof_hint)
 static std::vector<ProfRec> g_recs;
 static std::mutex g_mu;
 
@@ -20,7 +21,8 @@ AsProfScope::AsProfScope(int cls, double flops, double bytes, hipStream_t s, con
 {
     if (!g_on) return;
     ProfRec r;
-    r.cls = cls; r.flops = flops; r.bytes = bytes;
+    r.cls = cls; r.flops = flops > 0 ? flops : g_hint_flops; r.bytes = bytes > 0 ? bytes : g_hint_bytes;
+    g_hint_flops = g_hint_bytes = 0;
     r.tag[0] = 0;
     if (tag) { strncpy(r.tag, tag, sizeof(r.tag) - 1); r.tag[sizeof(r.tag) - 1] = 0; }
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -35,6 +37,14 @@ AsProfScope::~AsProfScope()
     if (idx < 0) return;
     std::lock_guard<std::mutex> g(g_mu);
     (void)hipEventRecord(g_recs[idx].b, stream);
+}
+
+// Algorithmic flop / bytes of the NEXT launch on this host thread, for launchers whose arguments do not say (geometry tables live
+// on the device): the module-level entry points know the layouts and tell the profiler.  No effect while profiling is off.
+extern "C" int as_prof_hint(double flops, double bytes)
+{
+    if (g_on) { g_hint_flops = flops; g_hint_bytes = bytes; }
+    return AS_OK;
 }
 
 extern "C" int as_prof_enable(int on)

@@ -73,6 +73,10 @@ class Runtime:
     def set_serial(self, on):
         check(_lib.lib().as_plan_set_serial(self.plan, int(on)), "as_plan_set_serial")
 
+    def set_operand_mode(self, n_prod):
+        """3 = f16x3 (fp32-accurate, default); 1 = plain fp16 operands (BASELINE config C2's 16-bit mode)"""
+        check(_lib.lib().as_plan_set_operand_mode(self.plan, int(n_prod)), "as_plan_set_operand_mode")
+
     def phase_ms(self, fn):
         """run fn() with phase marks on and return the four phase times of its (last) forward in ms"""
         L = _lib.lib()

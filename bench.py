@@ -8,18 +8,27 @@
 One "step" = one pass of the whole hot path -- text encoder + articulatory encoder + style towers +
 duration predictor + integer alignment expansion + F0/energy/TV predictors + AdaIN mel decoder -- over one
 batch of 32 synthetic utterances (config C3 of SURVEY.md section 8: N = 40 tokens, forced integer durations
-summing to M = 100 => 200 mel frames per utterance, T_ref = 200; full-size model, seeded synthetic weights).
-Inputs are resident in HBM before the timed region.  With N > 1 every rank runs the same workload on its own
-GPU (utterance batches shard embarrassingly; no data-path collective) => weak scaling; the only
-torch.distributed use is the barrier and the max-over-ranks of the elapsed time.
+summing to M = 100 => 200 mel frames per utterance, T_ref = 200; full-size model, seeded synthetic weights),
+as ONE call of the library's as_forward_test (csrc/model.hip) captured into a hipGraph and replayed.
+Inputs are resident in HBM before the timed region (the transfer-inclusive rate is reported beside it, "transfers").
+With N > 1 every rank runs its own 32-utterance batch on its own GPU (utterance batches shard embarrassingly; no data-path
+collective) => weak scaling; the only torch.distributed use is the barrier and the max-over-ranks of the elapsed time.
+`--global-batch G` instead builds ONE length-varied batch of G utterances, shards it over the ranks (artspeech_amd.shard) and
+checks the merged result against a single-rank run (BASELINE config C4).
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (the implicit-GEMM conv on the
-matrix cores -- bf16x6 split-operand arithmetic, fp32-accurate, or fp32 MFMAs with AS_GEMM_IMPL=f32 -- timed with
-HIP events on its launch stream in an instrumented pass of the same step) and "cpu_baseline"
-(the oracle's CPU restatement timed on this box's host cores on a bounded sample of the same workload).
+Prints ONE JSON line (rank 0).  Beside the contract's keys:
+  roofline       the dominant kernel, the implicit-GEMM conv on the fp16 matrix cores (f16x3 split-operand arithmetic, fp32-accurate):
+                 algorithmic flop / its HIP-event time on the launch stream (an instrumented pass of the same step, branches back to back)
+  roofline_hbm   the bandwidth-bound group (AdaIN, LayerNorm, pooling / expansion / image writers): algorithmic bytes / event time / 8 TB/s
+  mas            monotonic alignment search (K1) at [32,40,100] and [8,1024,2000]: cells/s, us/column, GB/s, bit-exactness against the
+                 reference-generated golden paths
+  configs        C2 (batch 1, 150 frames: latency; also in the 16-bit-operand mode with its measured error) and C5 (long form)
+  transfers      host->device of tokens / reference features and device->host of the mel, and the step rate including them
+  cpu_baseline   the oracle's CPU restatement timed on this box's host cores on a bounded sample of the same workload
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -32,42 +41,68 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 B, N_TOK, M_HALF, T_REF = 32, 40, 100, 200          # config C3
-FRAMES_PER_UTT = 2 * M_HALF
 FRAME_SEC = 300.0 / 24000.0                          # hop 300 @ 24 kHz (test.py:40)
 WEIGHT_SEED, DATA_SEED = 3407, 1234
-PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 (64 cycles per SIMD)
+PEAK_HBM_TBS = 8.0                                   # MI355X_MICROARCH.md (6.3 achievable)
+PEAK_F32_MFMA_TFLOPS = 157.3                         # v_mfma_f32_32x32x2_f32 (64 cycles per SIMD)
 # f16x3: every fp32 product is three fp16 MFMA products; dense fp16/bf16 peak 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz = 2516.6
 PEAK_F16_MFMA_TFLOPS = 2516.6
-PEAK_H3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0          # fp32-equivalent ceiling of the two-way-split GEMM: 838.9
 PEAK_X6_TFLOPS = PEAK_F16_MFMA_TFLOPS / 6.0          # round 1's arithmetic (bf16x6): 419.4 -- kept for comparison across rounds
 CLASSES = ["conv_gemm", "adain", "layernorm", "attention", "lstm", "mas", "other"]
+HBM_GROUP = ("adain", "layernorm", "other")          # the bandwidth-bound kernels (K2, K6, K7, K11)
 
 
-def make_inputs(dev):
+def source_id():
+    """sha of the kernel sources: ties a committed PMC profile to the build it was taken from"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "artspeech_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def make_inputs(dev, n_utt=B, n_tok=N_TOK, m_half=M_HALF, t_ref=T_REF, vary=False, seed0=DATA_SEED):
+    """n_utt synthetic utterances: tokens, normalised reference features, forced integer durations summing to m_half.
+    vary: lengths spread over [0.6, 1] of the nominal ones (a ragged batch)."""
     from artspeech_amd import synth
     from artspeech_amd.weights import DEFAULT_STATS
-    toks, mels, f0s, emas = [], [], [], []
-    for b in range(B):
-        toks.append(synth.synth_tokens(N_TOK, DATA_SEED + b))
-        mel, f0, ema = synth.synth_ref_features(T_REF, DATA_SEED + b)
+    rng = np.random.default_rng(seed0)
+    toks, mels, f0s, emas, forced, frames, tl, rl = [], [], [], [], [], [], [], []
+    for b in range(n_utt):
+        nt = int(n_tok * rng.uniform(0.6, 1.0)) if vary else n_tok
+        tr = max(int(t_ref * rng.uniform(0.6, 1.0)), 70) if vary else t_ref
+        mh = max(int(m_half * nt / n_tok), nt)
+        toks.append(synth.synth_tokens(nt, seed0 + b))
+        mel, f0, ema = synth.synth_ref_features(tr, seed0 + b)
         mels.append(mel)
-        f0s.append(f0 * np.float32(DEFAULT_STATS["pitch"][3]) + np.float32(DEFAULT_STATS["pitch"][2]))
-        emas.append(ema * np.asarray(DEFAULT_STATS["EMA"][3], np.float32)[:, None] + np.asarray(DEFAULT_STATS["EMA"][2], np.float32)[:, None])
-    forced = np.full(N_TOK, 2, np.int32)
-    forced[::2] = 3                                    # 20*3 + 20*2 = 100 half-rate frames
-    assert forced.sum() == M_HALF
-    host = dict(tokens=toks, mel=mels, f0=f0s, ema=emas, forced=forced)
+        f0s.append((f0 * np.float32(DEFAULT_STATS["pitch"][3]) + np.float32(DEFAULT_STATS["pitch"][2])).astype(np.float32))
+        emas.append((ema * np.asarray(DEFAULT_STATS["EMA"][3], np.float32)[:, None]
+                     + np.asarray(DEFAULT_STATS["EMA"][2], np.float32)[:, None]).astype(np.float32))
+        d = np.full(nt, mh // nt, np.int32)
+        d[: mh - int(d.sum())] += 1                    # integer durations summing to mh, each >= 1
+        forced.append(d)
+        frames.append(int(d.sum()))
+        tl.append(nt)
+        rl.append(tr)
+    host = dict(tokens=toks, mel=mels, f0=f0s, ema=emas, forced=forced, frames=frames, tok_lens=tl, ref_lens=rl)
     if dev is None:
         return host, None
-    g = dict(
-        tok=torch.from_numpy(np.concatenate(toks)).to(dev, torch.int32),
-        tok_lens=[N_TOK] * B, ref_lens=[T_REF] * B,
-        mel=torch.from_numpy(np.concatenate(mels, 1)).to(dev).contiguous(),
-        f0=torch.from_numpy(np.concatenate(f0s, 1).astype(np.float32)).to(dev).contiguous(),
-        ema=torch.from_numpy(np.concatenate(emas, 1).astype(np.float32)).to(dev).contiguous(),
-        forced=torch.from_numpy(np.tile(forced, B)).to(dev, torch.int32),
-        frames=[M_HALF] * B)
-    return host, g
+    return host, pack_inputs(host, list(range(n_utt)), dev)
+
+
+def pack_inputs(host, idx, dev):
+    """the packed-frames device tensors of utterances idx (as_forward_io's inputs)"""
+    cat = lambda key, ax: np.ascontiguousarray(np.concatenate([host[key][i] for i in idx], ax))
+    h = dict(tok=torch.from_numpy(cat("tokens", 0).astype(np.int32)), mel=torch.from_numpy(cat("mel", 1)),
+             f0=torch.from_numpy(cat("f0", 1).reshape(1, -1)), ema=torch.from_numpy(cat("ema", 1)),
+             forced=torch.from_numpy(cat("forced", 0).astype(np.int32)))
+    g = {k: v.to(dev) for k, v in h.items()}
+    g["pinned"] = {k: v.pin_memory() for k, v in h.items()}
+    g["tok_lens"] = [host["tok_lens"][i] for i in idx]
+    g["ref_lens"] = [host["ref_lens"][i] for i in idx]
+    g["frames"] = [host["frames"][i] for i in idx]
+    return g
 
 
 def cpu_baseline(host, sd, n_utt):
@@ -78,30 +113,229 @@ def cpu_baseline(host, sd, n_utt):
     torch.set_num_threads(cores)
     W = fold_state_dict(sd)
     dist = load_distribution(DEFAULT_STATS)
-    args = [(torch.from_numpy(host["tokens"][b % B]), torch.from_numpy(host["mel"][b % B]), torch.from_numpy(host["f0"][b % B].astype(np.float32)),
-             torch.from_numpy(host["ema"][b % B].astype(np.float32))) for b in range(n_utt)]
-    acoustic.forward_test(W, *args[0], dist, forced_dur=host["forced"])          # warm-up
+    nb = len(host["tokens"])
+    args = [(torch.from_numpy(host["tokens"][b % nb]), torch.from_numpy(host["mel"][b % nb]), torch.from_numpy(host["f0"][b % nb]),
+             torch.from_numpy(host["ema"][b % nb]), host["forced"][b % nb]) for b in range(n_utt)]
+    acoustic.forward_test(W, *args[0][:4], dist, forced_dur=args[0][4])          # warm-up
     t0 = time.perf_counter()
     outs = []
     for a in args:                                     # bounded: stop after ~20 s of CPU work
-        outs.append(acoustic.forward_test(W, *a, dist, forced_dur=host["forced"]))
+        outs.append(acoustic.forward_test(W, *a[:4], dist, forced_dur=a[4]))
         if time.perf_counter() - t0 > 20.0:
             break
     dt = time.perf_counter() - t0
-    n_utt = len(outs)
-    return dict(value=n_utt * FRAMES_PER_UTT / dt, unit="mel frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n_utt} utterances of the same C3 workload, one at a time (the reference is batch-1), "
+    frames = sum(2 * host["frames"][b % nb] for b in range(len(outs)))
+    return dict(value=frames / dt, unit="mel frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{len(outs)} utterances of the same C3 workload, one at a time (the reference is batch-1), "
                        f"{dt:.1f} s of CPU work, torch {torch.__version__} fp32"), outs
+
+
+class Runner:
+    """one geometry of the forward, eager or as a replayed hipGraph"""
+
+    def __init__(self, net, g):
+        self.net, self.g, self.out = net, g, None
+
+    def step(self):
+        g = self.g
+        self.out = self.net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
+                                           frames_hint=g["frames"], out=self.out)
+        return self.out
+
+    def capture(self):
+        self.step()                                     # also uploads the geometry tables (one blocking upload per new geometry)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.step()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=s):
+                self.step()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = graph
+        return graph.replay
+
+    def timed(self, run, steps, warmup, barrier=lambda: None):
+        for _ in range(warmup):
+            run()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+
+def profile_classes(net, runner, steps=3):
+    """per-kernel-class time with HIP events on the launch stream, eager launches, the concurrent branches run back to back so that
+    an event-bracketed duration is the kernel's own"""
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    net.rt.set_serial(True)
+    runner.step()
+    torch.cuda.synchronize()
+    L.as_prof_enable(1)
+    for _ in range(steps):
+        runner.step()
+    n = len(CLASSES)
+    ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+    cnt = (ctypes.c_int32 * n)()
+    _lib.check(L.as_prof_collect(ms, fl, by, cnt, n), "as_prof_collect")
+    L.as_prof_enable(0)
+    net.rt.set_serial(False)
+    return {CLASSES[i]: dict(ms_per_step=ms[i] / steps, launches_per_step=cnt[i] // steps, gflop_per_step=fl[i] / steps / 1e9,
+                             gbyte_per_step=by[i] / steps / 1e9) for i in range(n) if cnt[i]}
+
+
+def gemm_roofline(kern, n_prod):
+    k = kern["conv_gemm"]
+    tf = k["gflop_per_step"] / k["ms_per_step"] if k["ms_per_step"] > 0 else 0.0           # GFLOP / ms = TFLOP/s
+    return tf, PEAK_F16_MFMA_TFLOPS / n_prod
+
+
+def bench_mas(dev):
+    """K1 at the two shapes of SURVEY.md D2, timed with HIP events, checked against the paths the REFERENCE's maximum_path1 / 2 produced
+    (tests/golden/mas_*.npz, made by tests/golden/make_golden.py from the reference itself)."""
+    from artspeech_amd import mas, synth
+    gd = os.path.join(ROOT, "tests", "golden")
+    out = {}
+    small = np.load(os.path.join(gd, "mas_small.npz"))
+    large = np.load(os.path.join(gd, "mas_large.npz"))
+    Bl, Txl, Tyl = (int(v) for v in large["shape"])
+    u = synth.hash_tensor(f"mas/{Bl}x{Txl}x{Tyl}", (Bl, Txl, Tyl), int(large["seed"]))
+    cases = {"32x40x100": (small["c3_32x40x100/value"], small["c3_32x40x100/x_lens"], small["c3_32x40x100/y_lens"],
+                           small["c3_32x40x100/rows_v1"], small["c3_32x40x100/rows_v2"]),
+             f"{Bl}x{Txl}x{Tyl}": ((u * u).astype(np.float32), large["x_lens"], large["y_lens"], large["rows_v1"], large["rows_v2"])}
+    for name, (value, xl, yl, r1, r2) in cases.items():
+        v = torch.from_numpy(value).to(dev)
+        xt, yt = torch.from_numpy(xl), torch.from_numpy(yl)
+        exact = True
+        for tie, rows in (("move", r1), ("stay", r2)):
+            got = mas.maximum_path_lens(v, xt, yt, tie=tie, want=("rows",))["rows"].cpu().numpy()
+            exact = exact and bool(np.array_equal(got, rows))
+        run = lambda: mas.maximum_path_lens(v, xt, yt, tie="stay", want=("path", "dur"))
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) / n / 1e3
+        cells = int(xl.astype(np.int64) @ yl.astype(np.int64))             # valid lattice cells
+        nbytes = 4 * cells + 4 * value.size                                 # lattice read + dense 0/1 path written
+        out[name] = dict(us=sec * 1e6, gcells_per_s=cells / sec / 1e9, us_per_column=sec * 1e6 / int(yl.max()),
+                         gb_per_s=nbytes / sec / 1e9, frac_of_hbm_peak=nbytes / sec / 1e12 / PEAK_HBM_TBS, bit_exact_vs_reference=exact)
+    return out
+
+
+def bench_config(net, dev, name, n_utt, n_tok, m_half, t_ref, steps, n_prod_modes=(3,)):
+    """another BASELINE config on the same model: graph-replayed step time, frames/s, its conv-GEMM rate"""
+    host, g = make_inputs(dev, n_utt, n_tok, m_half, t_ref, seed0=DATA_SEED + 1000)
+    res = {}
+    ref_mel = None
+    for n_prod in n_prod_modes:
+        net.rt.set_operand_mode(n_prod)
+        r = Runner(net, g)
+        run = r.capture()
+        el = r.timed(run, steps, 3)
+        mel = r.out["mel"].clone()
+        kern = profile_classes(net, Runner(net, g), steps=2)
+        tf, peak = gemm_roofline(kern, n_prod)
+        frames = 2 * sum(g["frames"])
+        d = dict(ms_per_step=el / steps * 1e3, ms_per_utt=el / steps * 1e3 / n_utt, frames_per_s=frames * steps / el,
+                 x_realtime=frames * steps / el * FRAME_SEC, gemm_tflops=tf, gemm_frac_of_peak=tf / peak,
+                 gemm_gflop_per_step=kern["conv_gemm"]["gflop_per_step"],
+                 attention_ms_per_step=kern.get("attention", {}).get("ms_per_step"), lstm_ms_per_step=kern.get("lstm", {}).get("ms_per_step"))
+        if n_prod == 3:
+            ref_mel = mel
+            res.update(d)
+        else:
+            d["arithmetic"] = "fp16 operands (h parts only, one matrix-core product per fp32 product), fp32 accumulate"
+            d["mel_max_abs_vs_f16x3"] = float((mel - ref_mel).abs().max())
+            res["f16_operand_mode"] = d
+    net.rt.set_operand_mode(3)
+    res["workload"] = f"{name}: batch {n_utt}, {n_tok} tokens -> {2 * m_half} mel frames per utterance, T_ref {t_ref}, forced durations"
+    return res
+
+
+def bench_transfers(runner, run, g, steps):
+    """the boundary hands over host buffers: host->device of tokens / reference features (pinned), the step, device->host of the mel"""
+    pin, dev_t = g["pinned"], {k: g[k] for k in ("tok", "mel", "f0", "ema", "forced")}
+    out_host = torch.empty_like(runner.out["mel"], device="cpu").pin_memory()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def once(record=False):
+        if record:
+            ev[0].record()
+        for k, t in dev_t.items():
+            t.copy_(pin[k], non_blocking=True)
+        if record:
+            ev[1].record()
+        run()
+        if record:
+            ev[2].record()
+        out_host.copy_(runner.out["mel"], non_blocking=True)
+        if record:
+            ev[3].record()
+
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        once()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    once(record=True)
+    torch.cuda.synchronize()
+    nb_in = sum(t.numel() * t.element_size() for t in dev_t.values())
+    nb_out = out_host.numel() * 4
+    return dict(h2d_ms=ev[0].elapsed_time(ev[1]), d2h_ms=ev[2].elapsed_time(ev[3]), h2d_bytes=nb_in, d2h_bytes=nb_out,
+                ms_per_step_including_transfers=dt / steps * 1e3,
+                frames_per_s_including_transfers=out_host.shape[1] * steps / dt, note="pinned host buffers, same stream as the step")
+
+
+def c4_check(net, host, mel_mine, mine, world, rank, dev, dist):
+    """merge the ranks' shards on rank 0 and compare with rank 0 running the whole global batch alone"""
+    from artspeech_amd import shard
+    mels = [m.copy() for m in shard.split_utterances(mel_mine.cpu().numpy(), [2 * host["frames"][i] for i in mine])]
+    if world > 1:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object((mine, mels), gathered, dst=0)
+    else:
+        gathered = [(mine, mels)]
+    if rank != 0:
+        return None
+    merged = shard.merge_shards(gathered, len(host["frames"]))
+    g_all = pack_inputs(host, list(range(len(host["frames"]))), dev)
+    whole = Runner(net, g_all).step()["mel"].cpu().numpy()
+    ref = shard.split_utterances(whole, [2 * f for f in host["frames"]])
+    worst = max(float(np.abs(a - b).max()) for a, b in zip(merged, ref))
+    return dict(utterances=len(ref), shards=world, max_abs_sharded_vs_single_rank=worst,
+                note="not bitwise: the GEMM's tile choice depends on a shard's total column count (bound 5e-5)")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-utts", type=int, default=96, help="utterances in the CPU-baseline sample, capped at ~20 s (0 = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-concurrency", action="store_true", help="run the independent branches back to back (profiling)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the MAS / C2 / C5 / transfer lines (profiling runs)")
+    ap.add_argument("--config", default="C3", choices=["C3", "C5"], help="workload of the timed region (profiling runs; the headline is C3)")
+    ap.add_argument("--global-batch", type=int, default=0, help="C4: ONE ragged batch of this many utterances sharded over the ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,14 +345,15 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist = None
+    if world > 1:                                       # the process group first, before anything touches the GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
 
-    from artspeech_amd import _lib, models, synth
+    from artspeech_amd import models, shard, synth
     from artspeech_amd.weights import DEFAULT_STATS, load_distribution
 
     sd = synth.synth_state_dict(512, 64, seed=WEIGHT_SEED)
@@ -126,129 +361,107 @@ def main():
                                load_distribution(DEFAULT_STATS), dev)
     models.load_checkpoint(model, None, {"net": {"ArtsSpeech": sd}})
     net = model.ArtsSpeech
-    host, g = make_inputs(dev)
     if args.no_concurrency:
         net.rt.set_serial(True)
+    barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
 
-    def step(out=None):
-        return net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
-                                  frames_hint=g["frames"], out=out)
-
-    out = step()                                            # also uploads the geometry tables (one blocking upload per new geometry)
-    torch.cuda.synchronize()
-    mel_first = out["mel"].clone()
-
-    graph = None
-    if not args.no_graph:
-        # the step is a fixed sequence of launches on one stream with no host sync: capture it once
-        graph = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            gout = step()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(graph, stream=s):
-                step(out=gout)
-        torch.cuda.current_stream().wait_stream(s)
-        run = graph.replay
+    c4, mine = None, None
+    if args.global_batch:
+        # C4: one global ragged batch, length-sorted round-robin shards, merged on rank 0 and compared with rank 0 running it all
+        host, _ = make_inputs(None, args.global_batch, vary=True)
+        mine = shard.shard_indices(host["frames"], world, rank)
+        g = pack_inputs(host, mine, dev)
+        frames_total = 2 * sum(host["frames"])
+        workload = f"C4: ONE ragged batch of {args.global_batch} utterances sharded over {world} GPUs (length-sorted round robin)"
+    elif args.config == "C5":
+        host, g = make_inputs(dev, 8, 1024, 1024, 200, seed0=DATA_SEED + 1000)
+        frames_total = world * 2 * sum(host["frames"])
+        workload = "C5: long form, batch 8 per GPU, 1024 tokens -> 2048 mel frames per utterance, T_ref=200 (profiling run)"
     else:
-        gout = None
-        run = step
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        run()
+        host, g = make_inputs(dev)
+        frames_total = world * 2 * sum(host["frames"])
+        workload = ("C3: LibriTTS-like batch=32 per GPU, 40 tokens -> 200 mel frames per utterance, T_ref=200, "
+                    "full predictor+decoder path, forced integer durations, synthetic weights seed 3407")
+    runner = Runner(net, g)
+    mel_first = runner.step()["mel"].clone()
     torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    run = runner.step if args.no_graph else runner.capture()
+    elapsed = runner.timed(run, args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if graph is not None:
-        assert torch.equal(gout["mel"], mel_first), "graph replay changed the result"
+    if not args.no_graph:
+        assert torch.equal(runner.out["mel"], mel_first), "graph replay changed the result"
+    if args.global_batch:
+        c4 = c4_check(net, host, runner.out["mel"], mine, world, rank, dev, dist)
 
     # ---- phase times of one eager step with the branches concurrent (HIP events between the phases, on the calling stream)
-    phase = [net.rt.phase_ms(step) for _ in range(3)][-1]
-
-    # ---- instrumented pass: per-kernel-class time with HIP events on the launch stream (eager launches)
-    # (branches that normally overlap on side streams run back to back here, so a kernel's event-bracketed duration is
-    #  its own and not that of whatever shared the chip with it)
-    L = _lib.lib()
-    prof_steps = 3
-    net.rt.set_serial(True)
-    step()
-    torch.cuda.synchronize()
-    L.as_prof_enable(1)
-    for _ in range(prof_steps):
-        step()
-    n = len(CLASSES)
-    ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
-    cnt = (ctypes.c_int32 * n)()
-    _lib.check(L.as_prof_collect(ms, fl, by, cnt, n), "as_prof_collect")
-    L.as_prof_enable(0)
+    prunner = Runner(net, g)
+    phase = [net.rt.phase_ms(prunner.step) for _ in range(3)][-1]
+    kern = profile_classes(net, Runner(net, g))
     net.rt.set_serial(args.no_concurrency)
-    kern = {CLASSES[i]: dict(ms_per_step=ms[i] / prof_steps, launches_per_step=cnt[i] // prof_steps,
-                             gflop_per_step=fl[i] / prof_steps / 1e9) for i in range(n) if cnt[i]}
-    gemm_ms = ms[0] / max(cnt[0], 1)
-    gemm_tflops = (fl[0] / max(cnt[0], 1)) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    gemm_tflops, gemm_peak = gemm_roofline(kern, 3)
+    k0 = kern["conv_gemm"]
+    hbm_ms = sum(kern[c]["ms_per_step"] for c in HBM_GROUP if c in kern)
+    hbm_gb = sum(kern[c]["gbyte_per_step"] for c in HBM_GROUP if c in kern)
 
-    # HBM traffic of the dominant kernel cannot be read live (PMC needs rocprofv3): it comes from the committed
-    # counter pass of this same command (profiles/latest_pmc_traffic.json, made by scripts/gpu_profile.sh)
-    traffic, traffic_src = None, None
+    # HBM traffic of the dominant kernel cannot be read live (PMC needs rocprofv3): it comes from the committed counter pass of this
+    # same command (profiles/latest_pmc_traffic.json, scripts/gpu_profile.sh), and only when that pass was taken from THIS build
+    traffic, traffic_src = None, "no PMC profile of this build (profiles/latest_pmc_traffic.json was taken from other kernel sources)"
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_traffic.json")))
-        traffic, traffic_src = pj["conv_gemm_hbm_bytes_per_launch"], pj["source"]
+        if pj.get("source_id") == source_id():
+            traffic, traffic_src = pj["conv_gemm_hbm_bytes_per_launch"], pj["source"]
     except Exception:
         pass
 
-    from artspeech_amd import ops as _ops
-    gemm_impl = _ops.GEMM_IMPL
-    n_prod = 1 if gemm_impl == "h1" else 3
-    gemm_kernel = ("conv_gemm_h3_kernel (implicit-GEMM conv, fp16 matrix cores, two-way split operands h + l, %d product%s per fp32 "
-                   "product, fp32 accumulate; both operands pre-split and staged by LDS-DMA)" % (n_prod, "" if n_prod == 1 else "s"))
-    gemm_peak = PEAK_F16_MFMA_TFLOPS / n_prod
-    gemm_peak_basis = f"dense fp16 MFMA 2516.6 TFLOP/s / {n_prod} matrix-core products per fp32 product (achieved = algorithmic fp32 flop)"
-    frames_per_step = B * FRAMES_PER_UTT
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * frames_per_step * args.steps / elapsed
+    value = frames_total * args.steps / elapsed
     line = {
         "metric": "mel frames/sec (whole job; per-GPU = value / n_gpus), acoustic-model inference path, batch 32 x 200-frame utterances",
         "value": value, "unit": "mel frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 operands, f32 accumulate (AS_GEMM_IMPL=h1)" if n_prod == 1 else "f32 (f16x3 split-operand MFMA, fp32 accumulate)",
-        "data": "synthetic",
-        "config": {"workload": "C3: LibriTTS-like batch=32 per GPU, 40 tokens -> 200 mel frames per utterance, T_ref=200, "
-                               "full predictor+decoder path, forced integer durations, synthetic weights seed 3407",
-                   "global_batch": B * world, "frames_per_utt": FRAMES_PER_UTT, "parallelism": f"batch-shard x{world}, no collectives",
-                   "launch": "eager" if graph is None else "hipGraph replay"},
-        "rtf": (elapsed / args.steps) / (frames_per_step * FRAME_SEC),
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
+        "dtype": "f32 (f16x3 split-operand MFMA, fp32 accumulate)", "data": "synthetic",
+        "config": {"workload": workload, "global_batch": args.global_batch or len(g["frames"]) * world, "frames_per_step": frames_total,
+                   "parallelism": f"batch-shard x{world}, no collectives",
+                   "launch": "eager (C ABI as_forward_test)" if args.no_graph else "hipGraph replay of one as_forward_test call"},
+        "rtf": (elapsed / args.steps) / (frames_total * FRAME_SEC),
         "x_realtime_per_gpu": (value / world) * FRAME_SEC,
-        "roofline": {"bound": "mfma", "kernel": gemm_kernel, "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s",
-                     "frac": gemm_tflops / gemm_peak, "peak_basis": gemm_peak_basis,
+        "roofline": {"bound": "mfma",
+                     "kernel": "conv_gemm_h3_kernel (implicit-GEMM conv, fp16 matrix cores, two-way split operands h + l, 3 products per fp32 "
+                               "product, fp32 accumulate; both operands staged by LDS-DMA from producer-written images)",
+                     "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s", "frac": gemm_tflops / gemm_peak,
+                     "peak_basis": "dense fp16 MFMA 2516.6 TFLOP/s / 3 matrix-core products per fp32 product (achieved = algorithmic fp32 flop); "
+                                   "round 1 ran six bf16 products per fp32 product (ceiling 419.4)",
                      "frac_of_fp32_mfma_peak": gemm_tflops / PEAK_F32_MFMA_TFLOPS,
                      "frac_of_round1_bf16x6_ceiling": gemm_tflops / PEAK_X6_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "avg_launch_ms": gemm_ms, "launches_per_step": int(cnt[0] // prof_steps),
-                     "algorithmic_gflop_per_step": fl[0] / prof_steps / 1e9},
+                     "avg_launch_ms": k0["ms_per_step"] / max(k0["launches_per_step"], 1), "launches_per_step": k0["launches_per_step"],
+                     "algorithmic_gflop_per_step": k0["gflop_per_step"]},
+        "roofline_hbm": {"bound": "hbm", "kernels": "AdaIN / LayerNorm operand-image writers, pooling, expansion, im2col, reference features "
+                                                    "(classes adain + layernorm + other of the event profiler)",
+                         "achieved": hbm_gb / hbm_ms if hbm_ms else None, "peak": PEAK_HBM_TBS, "unit": "TB/s",
+                         "frac": hbm_gb / hbm_ms / PEAK_HBM_TBS if hbm_ms else None,
+                         "algorithmic_gbyte_per_step": hbm_gb, "ms_per_step": hbm_ms},
         "kernel_classes": kern,
         "phase_ms_eager": dict(zip(["features", "encoders_towers_duration", "predictors", "decoder"], [round(v, 3) for v in phase])),
     }
-    if rank == 0 and args.cpu_utts > 0:
+    if c4 is not None:
+        line["c4_shard_check"] = c4
+    extras = rank == 0 and not args.no_extras and not args.global_batch and args.config == "C3"
+    if extras:
+        line["transfers"] = bench_transfers(runner, run, g, min(args.steps, 50))
+        line["mas"] = bench_mas(dev)
+        line["configs"] = {
+            "C2": bench_config(net, dev, "C2 (LJSpeech-like latency)", 1, 30, 75, 150, 50, n_prod_modes=(3, 1)),
+            "C5": bench_config(net, dev, "C5 (long form)", 8, 1024, 1024, 200, 10),
+        }
+    if rank == 0 and args.cpu_utts > 0 and not args.global_batch and args.config == "C3":
         cb, outs = cpu_baseline(host, sd, args.cpu_utts)
         line["cpu_baseline"] = cb
-        err = max(float((mel_first[:, b * FRAMES_PER_UTT:(b + 1) * FRAMES_PER_UTT].cpu() - outs[b]["mel"]).abs().max())
-                  for b in range(min(len(outs), B)))
+        fo = np.concatenate([[0], np.cumsum([2 * f for f in g["frames"]])])
+        err = max(float((mel_first[:, fo[b]:fo[b + 1]].cpu() - outs[b]["mel"]).abs().max()) for b in range(min(len(outs), B)))
         line["parity_mel_max_abs_vs_oracle"] = err
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -34,6 +34,9 @@ int as_abi_version(void);
  * kernel time (ms), algorithmic flop, algorithmic bytes and launch count since as_prof_enable(1). */
 int as_prof_enable(int on);
 int as_prof_collect(double* ms, double* flops, double* bytes, int32_t* launches, int n_classes);
+/* algorithmic flop / bytes of the NEXT launch of this host thread, for entry points whose arguments do not determine them
+ * (their geometry tables are device arrays); ignored while profiling is off */
+int as_prof_hint(double flops, double bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * Monotonic alignment search (K1).
@@ -369,6 +372,9 @@ int as_plan_set_serial(as_plan* p, int on);
  * last call's phases: [0] reference features + tower inputs, [1] the concurrent branches (encoders, towers, duration predictor),
  * [2] durations + AdaIN fc + articulatory predictors, [3] decoder.  Blocks until that call has finished. */
 int as_plan_set_timing(as_plan* p, int on);
+/* matrix-core products per fp32 product in this plan's forwards: 3 = f16x3 (fp32-accurate, default); 1 = plain fp16 operands
+ * (the 16-bit-operand mode BASELINE.md names for config C2; its error is reported by bench.py and tests/test_net_gpu.py) */
+int as_plan_set_operand_mode(as_plan* p, int n_prod);
 int as_plan_phase_ms(as_plan* p, float* ms, int n);
 
 /* geometry of one batch: HOST arrays */

@@ -1,9 +1,9 @@
 #!/bin/bash
-# PMC passes on ONE GEMM shape (tuning aid).  usage (on the GPU box): bash scripts/exp/x6_pmc.sh "512,6400,512,3,200" 22
+# PMC passes on ONE GEMM shape (tuning aid).  usage (on the GPU box): bash scripts/exp/h3_pmc.sh "512,6400,512,3,200" 22
 R=${GRAFT_REPO_ROOT:-/root/repo}
-SHAPE=${1:-512,6400,512,3,200}; export TILES=${2:-22}; export IMPLS=x6; export KSPLITS=1
+SHAPE=${1:-1024,6400,1024,3,200}
 cd /tmp && export TMPDIR=/tmp
-OUT=$R/gpurun_out/x6_pmc; rm -rf $OUT; mkdir -p $OUT
+OUT=$R/gpurun_out/h3_pmc; rm -rf $OUT; mkdir -p $OUT
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU SQ_WAVE_CYCLES" \
@@ -17,7 +17,7 @@ import csv, glob, collections
 for f in sorted(glob.glob("$OUT/p*/g_counter_collection.csv")):
     agg = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f)):
-        if "conv_gemm_x6" in r["Kernel_Name"]:
+        if "conv_gemm_h3" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
     print(f.split("/")[-2], {k: round(v / n[k]) for k, v in agg.items()})
 PY

@@ -22,6 +22,14 @@ def test_shard_indices_cover_and_balance():
     with pytest.raises(ValueError):
         shard.shard_indices(lengths, 2, 2)
     assert shard.all_shards([], 2) == [[], []]
+    # packed results back to utterances, and the merge of (indices, results) pairs
+    packed = np.arange(2 * 9).reshape(2, 9)
+    parts = shard.split_utterances(packed, [4, 0, 5])
+    assert [p.shape for p in parts] == [(2, 4), (2, 0), (2, 5)] and np.array_equal(parts[2], packed[:, 4:])
+    assert shard.merge_shards([([2, 0], ["c", "a"]), ([1], ["b"])], 3) == ["a", "b", "c"]
+    with pytest.raises(ValueError):
+        shard.merge_shards([([0], ["a"])], 2)
+    assert shard.sharded_forward(lambda idx: [10 * i for i in idx], [3, 1, 2]) == [0, 10, 20]
 
 
 def _free_port():
@@ -50,6 +58,20 @@ def _worker(rank, world, port, q):
     gathered = shard.gather_objects(local, world)
     merged = shard.merge(shard.all_shards(lengths, world), gathered, n)
     ok = all(np.array_equal(merged[i], omas.maximum_path_c(values[i], np.ones_like(values[i]), False)) for i in range(n))
+    # the product entry point of the C4 path (bench.py --global-batch, pipeline.synthesis_mel(world=...)): same code, the device step
+    # stubbed by a function of the utterance (here: the oracle's MAS; on the GPU: ArtsSpeech.forward_packed on the shard)
+    calls = []
+
+    def step(indices):
+        calls.append(list(indices))
+        return [omas.maximum_path_c(values[i], np.ones_like(values[i]), False) for i in indices]
+
+    merged2 = shard.sharded_forward(step, lengths, world, rank)
+    assert calls == [mine]
+    if rank == 0:
+        ok = ok and all(np.array_equal(merged2[i], merged[i]) for i in range(n))
+    else:
+        ok = ok and merged2 is None
     if rank == 0:
         q.put((ok, float(t.item())))
     dist.destroy_process_group()
