@@ -110,10 +110,33 @@ class ArtSpeech:
         return wav[0] if single else wav
 
     @torch.no_grad()
-    def synthesis_mel(self, phonemes, ref_mel, features=None, forced_durations=None):
+    def synthesis_mel(self, phonemes, ref_mel, features=None, forced_durations=None, world=1, rank=0):
         """phonemes: the string the phonemizer returns (test.py:94-96) or a list of such strings; ref_mel: normalised
         log-mel [80,T] (test.py:43-47) or a list; features: (f0_raw, ema_raw) per utterance when no extractor modules
-        are attached; (None, ema_raw) with a pitch extractor attached (attach_pitch_extractor).  Returns mel [B,80,2*max M] (what test.py:115 hands to the vocoder)."""
+        are attached; (None, ema_raw) with a pitch extractor attached (attach_pitch_extractor).  Returns mel [B,80,2*max M] (what test.py:115 hands to the vocoder).
+        world / rank: BASELINE config C4 -- the batch is one GLOBAL batch, this process (one per GPU, torch.distributed initialised by
+        the caller) synthesises its length-sorted round-robin shard (artspeech_amd.shard: no data-path collective) and rank 0 gets the
+        whole batch back in the caller's order (other ranks: None)."""
+        if world > 1 and not isinstance(phonemes, str):
+            from . import shard
+            lens = [len(p) for p in phonemes]
+
+            def step(idx):
+                if not idx:
+                    return []
+                sub = self.synthesis_mel([phonemes[i] for i in idx], [ref_mel[i] for i in idx],
+                                         features=None if features is None else [features[i] for i in idx],
+                                         forced_durations=None if forced_durations is None else [forced_durations[i] for i in idx])
+                return [sub[k, :, : self._last_frames[k]].cpu() for k in range(len(idx))]
+
+            parts = shard.sharded_forward(step, lens, world, rank)
+            if parts is None:
+                return None
+            self._last_frames = [p.shape[1] for p in parts]
+            out = torch.zeros(len(parts), parts[0].shape[0], max(self._last_frames))
+            for b, p in enumerate(parts):
+                out[b, :, : p.shape[1]] = p
+            return out
         if isinstance(phonemes, str):
             phonemes, ref_mel = [phonemes], [ref_mel]
             if features is not None:
