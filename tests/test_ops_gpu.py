@@ -323,9 +323,16 @@ def test_durations_expand(cuda):
     assert torch.equal(y.cpu(), x.repeat_interleave(want.long(), dim=1).repeat_interleave(2, dim=1))
 
 
-@pytest.mark.parametrize("lens,C", [([40, 33, 7], 64), ([150], 512), ([1, 2, 70, 64, 65], 64), ([40, 33, 7, 64, 1, 63], 512), ([40] * 32, 512)])
-def test_relpos_attention(cuda, lens, C):
+@pytest.mark.parametrize("lens,C,mode", [([40, 33, 7], 64, None), ([150], 512, None), ([1, 2, 70, 64, 65], 64, None),
+                                         ([40, 33, 7, 64, 1, 63], 512, None), ([40] * 32, 512, None), ([150], 512, "valu"),
+                                         ([40, 33, 7, 64, 1, 63], 512, "mfma"), ([1, 2, 70, 64, 65, 128, 129, 127], 512, "mfma"),
+                                         ([700, 257, 3], 512, "mfma")])
+def test_relpos_attention(cuda, lens, C, mode, monkeypatch):
+    """mode None: the dispatch the product uses (matrix cores above 64 tokens with 128-channel heads, the one-workgroup kernel below);
+    "valu" / "mfma" pin the vector-ALU kernels or the matrix-core kernel at every length (AS_ATTN, an experiment switch)"""
     from oracle import acoustic
+    if mode:
+        monkeypatch.setenv("AS_ATTN", mode)
     g = torch.Generator().manual_seed(sum(lens) + C)
     W = {"a.emb_rel_k": torch.randn(1, 9, C // 4, generator=g) * 0.1, "a.emb_rel_v": torch.randn(1, 9, C // 4, generator=g) * 0.1}
     for n in "qkvo":
