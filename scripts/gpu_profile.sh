@@ -1,15 +1,23 @@
 #!/bin/bash
-# rocprofv3 passes of the benchmark step (run on the GPU box through gpurun).  Outputs under gpurun_out/prof_*.
-# Branches are serialised (--no-concurrency) so per-kernel durations are each kernel's own.
+# rocprofv3 passes of the benchmark (run on the GPU box through gpurun; condensed into profiles/ by scripts/make_profiles.py).
+#   prof_trace    the C3 step, eager and with the concurrent branches run back to back: a kernel's duration is its own
+#   prof_graph    the command the driver times (hipGraph replay, branches on side streams), extras (MAS, C2, C5, transfers) included
+#   prof_c5       the long-form configuration
+#   prof_pmc_*    counter passes (kernel trace only, one counter group per run)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out
 mkdir -p $OUT
-ARGS="--steps 10 --warmup 2 --no-graph --no-concurrency --cpu-utts 0"
+ARGS="--steps 10 --warmup 2 --no-graph --no-concurrency --cpu-utts 0 --no-extras"
 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace -o bench --output-format csv -- python3 $R/bench.py $ARGS > $OUT/prof_trace.log 2>&1
-PARGS="--steps 2 --warmup 1 --no-graph --no-concurrency --cpu-utts 0"
+rocprofv3 --kernel-trace --stats -d $OUT/prof_graph -o bench --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-utts 0 > $OUT/prof_graph.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_c5 -o bench --output-format csv -- python3 $R/bench.py --config C5 --no-extras --steps 5 --warmup 2 --no-graph --no-concurrency --cpu-utts 0 > $OUT/prof_c5.log 2>&1
+PARGS="--steps 2 --warmup 1 --no-graph --no-concurrency --cpu-utts 0 --no-extras"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/prof_pmc_sq -o bench --output-format csv -- python3 $R/bench.py $PARGS > $OUT/prof_pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_pmc_fetch -o bench --output-format csv -- python3 $R/bench.py $PARGS > $OUT/prof_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_pmc_write -o bench --output-format csv -- python3 $R/bench.py $PARGS > $OUT/prof_pmc_write.log 2>&1
-ls $OUT/prof_trace $OUT/prof_pmc_sq | head -12
+# the stats CSVs are small; the raw traces are not: keep only what make_profiles.py reads
+for d in prof_trace prof_graph prof_c5; do rm -f $OUT/$d/bench_kernel_trace.csv; done
+ls $OUT/prof_trace $OUT/prof_graph $OUT/prof_c5 $OUT/prof_pmc_sq | head -20
+for f in prof_trace prof_graph prof_c5; do grep '^{' $OUT/$f.log | head -1 | cut -c1-400; done

@@ -1,10 +1,17 @@
 """Condense gpurun_out/prof_* (scripts/gpu_profile.sh) into the small summaries committed under profiles/."""
 import collections, csv, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_id
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 G, P = "gpurun_out", "profiles"
 os.makedirs(P, exist_ok=True)
 shutil.copy(f"{G}/prof_trace/bench_kernel_stats.csv", f"{P}/{tag}_kernel_stats.csv")
-shutil.copy(f"{G}/prof_trace/bench_domain_stats.csv", f"{P}/{tag}_domain_stats.csv")
+shutil.copy(f"{G}/prof_graph/bench_kernel_stats.csv", f"{P}/{tag}_graph_kernel_stats.csv")
+shutil.copy(f"{G}/prof_c5/bench_kernel_stats.csv", f"{P}/{tag}_c5_kernel_stats.csv")
+for name in ("prof_trace", "prof_graph", "prof_c5"):        # the JSON line each profiled command printed
+    for ln in open(f"{G}/{name}.log"):
+        if ln.startswith("{"):
+            open(f"{P}/{tag}_{name[5:]}_bench_line.json", "w").write(ln)
 
 def short(n):
     return n.split('(')[0].replace('void ', '')[:60]
@@ -18,7 +25,7 @@ for r in csv.DictReader(open(f"{G}/prof_pmc_sq/bench_counter_collection.csv")):
 sq = {}
 for k in sorted(dur, key=lambda k: -dur[k])[:14]:
     a = agg[k]; gui = a['GRBM_GUI_ACTIVE']
-    sq[k] = dict(launches=cnt[k], total_us=round(dur[k], 1), clock_GHz=round(gui / 8 / (dur[k] * 1e3), 3) if dur[k] else None,
+    sq[k] = dict(launches=cnt[k], total_us=round(dur[k], 1), gui_cycles_per_ns=round(gui / 8 / (dur[k] * 1e3), 3) if dur[k] else None,
                  mfma_busy_frac=round(a['SQ_VALU_MFMA_BUSY_CYCLES'] / (gui / 8 * 256 * 4), 4) if gui else None,
                  wait_any=round(a['SQ_WAIT_ANY'] / a['SQ_WAVE_CYCLES'], 3), wait_inst_any=round(a['SQ_WAIT_INST_ANY'] / a['SQ_WAVE_CYCLES'], 3),
                  active_inst=round(a['SQ_ACTIVE_INST_ANY'] / a['SQ_WAVE_CYCLES'], 3))
@@ -38,14 +45,14 @@ for k in sorted(f, key=lambda k: -f[k])[:14]:
     fe = f[k] * 1024 / nf[k]; wr = w.get(k, 0) * 1024 / max(nw.get(k, 1), 1)
     tr[k] = dict(launches=nf[k], fetch_bytes_per_launch_raw=round(fe), fetch_bytes_per_launch_x2=round(2 * fe), write_bytes_per_launch=round(wr))
 for k in f:
-    if k.startswith("conv_gemm") or k.startswith("splitk_reduce") or k.startswith("split_bf16x3"):
+    if k.startswith("conv_gemm") or k.startswith("splitk_reduce") or k.startswith("split_f16x2"):
         gem_f += f[k] * 1024; gem_w += w.get(k, 0) * 1024
         if k.startswith("conv_gemm"): gem_n += nf[k]
 json.dump(tr, open(f"{P}/{tag}_pmc_traffic.json", "w"), indent=1)
 # FETCH_SIZE / WRITE_SIZE are KiB; gfx950 reports half of a wide coalesced read stream (MI355X_MICROARCH.md "HBM") -> x2
 latest = dict(conv_gemm_hbm_bytes_per_launch=round((2 * gem_f + gem_w) / max(gem_n, 1)),
               conv_gemm_fetch_bytes_per_launch_x2=round(2 * gem_f / max(gem_n, 1)), conv_gemm_write_bytes_per_launch=round(gem_w / max(gem_n, 1)),
-              launches=gem_n,
+              launches=gem_n, source_id=source_id(),
               source=f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (separate runs), "
                      "conv GEMM + split-K reduce kernels, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream)")
 json.dump(latest, open(f"{P}/latest_pmc_traffic.json", "w"), indent=1)
