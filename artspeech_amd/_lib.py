@@ -51,7 +51,7 @@ _SIGNATURES.update({
     "as_split_f16x2_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "as_prep_weight_f16x2_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "as_prep_weight_f16x2_host": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
-    "as_embed_groups_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
+    "as_embed_groups_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "as_channel_layernorm_groups_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_i, c_p]),
     "as_channel_layernorm_split_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_p]),
     "as_relpos_attention_groups_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, c_p]),

@@ -47,25 +47,28 @@ extern "C" int as_make_meta(const int32_t* widths, const int32_t* col_off, int B
 // Embedding * sqrt(C), transposed to [C][N]   (RelTransformerEnc.py:373-374)
 // ---------------------------------------------------------------------------------------------------
 // (emb2, n_split: columns >= n_split take their rows from a second table -- two encoders run as one double-width launch)
-__global__ void embed_kernel(const int* __restrict__ tok, const float* __restrict__ emb, const float* __restrict__ emb2, int n_split,
-                             int C, int N, int V, float scale, float* __restrict__ y, int ldy)
+// (n_tok < N: the token list is read twice, columns [n_tok, n_split) are filler)
+__global__ void embed_kernel(const int* __restrict__ tok, int n_tok, const float* __restrict__ emb, const float* __restrict__ emb2,
+                             int n_split, int C, int N, int V, float scale, float* __restrict__ y, int ldy)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (j >= N) return;
-    int t = tok[j];
+    const int src = j < n_tok ? j : j - n_split;
+    int t = (src >= 0 && src < n_tok) ? tok[src] : 0;
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
     const float* e = (emb2 && j >= n_split) ? emb2 : emb;
     y[(size_t)c * ldy + j] = e[(size_t)t * C + c] * scale;
 }
 
-extern "C" int as_embed_groups_f32(const int32_t* tokens, const float* emb, const float* emb2, int n_split, int C, int N, int V,
+extern "C" int as_embed_groups_f32(const int32_t* tokens, int n_tok, const float* emb, const float* emb2, int n_split, int C, int N, int V,
                                    float scale, float* y, int ldy, as_stream_t stream)
 {
-    if (!tokens || !emb || !y || C <= 0 || N < 0 || V <= 0 || ldy < N) return AS_EINVAL;
+    if (!tokens || !emb || !y || C <= 0 || N < 0 || V <= 0 || ldy < N || n_tok < 0 || n_tok > N) return AS_EINVAL;
+    if (n_tok < N && (!emb2 || n_split < n_tok || n_split + n_tok > N)) return AS_EINVAL;
     if (N == 0) return AS_OK;
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(embed_kernel, dim3(as_cdiv(N, 64), C), dim3(64), 0, (hipStream_t)stream, tokens, emb, emb2, n_split, C, N, V,
+    hipLaunchKernelGGL(embed_kernel, dim3(as_cdiv(N, 64), C), dim3(64), 0, (hipStream_t)stream, tokens, n_tok, emb, emb2, n_split, C, N, V,
                        scale, y, ldy);
     AS_CHECK_LAUNCH();
     return AS_OK;
@@ -74,7 +77,7 @@ extern "C" int as_embed_groups_f32(const int32_t* tokens, const float* emb, cons
 extern "C" int as_embed_f32(const int32_t* tokens, const float* emb, int C, int N, int V, float scale, float* y,
                             int ldy, as_stream_t stream)
 {
-    return as_embed_groups_f32(tokens, emb, nullptr, 0, C, N, V, scale, y, ldy, stream);
+    return as_embed_groups_f32(tokens, N, emb, nullptr, 0, C, N, V, scale, y, ldy, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

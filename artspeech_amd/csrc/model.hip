@@ -812,7 +812,7 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
 // p2: a SECOND encoder of the same shape whose weights serve the columns >= n_split / utterances >= b_split of `lay`
 // (the text and articulatory encoders are twins on the same tokens): both run as one double-width launch sequence.
 float* rel_encoder(Ctx& c, const std::string& p, const int32_t* tokens, const Lay* lay, int n_layers, const std::string& p2 = std::string(),
-                   int n_split = 0, int b_split = 0)
+                   int n_split = 0, int b_split = 0, int n_tok = -1)
 {
     const as_model& m = c.m;
     const bool pair = !p2.empty();
@@ -825,7 +825,7 @@ float* rel_encoder(Ctx& c, const std::string& p, const int32_t* tokens, const La
     // every weight is looked up OUTSIDE the RUN(...) arguments: the prepare pass (as_model_create) runs this code with
     // launches disabled and must still see each name
     const float *emb1 = m.vec(p + ".emb.weight"), *emb2 = pair ? m.vec(p2 + ".emb.weight") : nullptr;
-    if (N > 0) RUN(c, as_embed_groups_f32(tokens, emb1, emb2, n_split, C, N, V, sqrtf((float)C), x, N, c.s));
+    if (N > 0) RUN(c, as_embed_groups_f32(tokens, n_tok < 0 ? N : n_tok, emb1, emb2, n_split, C, N, V, sqrtf((float)C), x, N, c.s));
     // conv(LayerNorm(xin)): the normalised activations exist only as the conv's operand image
     auto ln_image = [&](const float* xin, const std::string& ln, bool relu) {
         uint16_t* xs = c.image(C, N);
@@ -911,16 +911,9 @@ float* rel_encoder_pair(Ctx& c, const std::string& p1, const std::string& p2, co
     w.insert(w.end(), lay->w.begin(), lay->w.end());
     const Lay* lay2 = c.lay(w);
     if (!lay2) return nullptr;
-    int32_t* tok2 = c.i32((size_t)std::max(lay2->N, 1));
-    if (c.go() && N > 0) {
-        if (hipMemsetAsync(tok2, 0, (size_t)lay2->N * 4, c.s) != hipSuccess ||
-            hipMemcpyAsync(tok2, tokens, (size_t)N * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess ||
-            hipMemcpyAsync(tok2 + N + pad, tokens, (size_t)N * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess)
-            c.fail((int)hipErrorUnknown);
-    }
     *second = N + pad;
     *ld = lay2->N;
-    return rel_encoder(c, p1, tok2, lay2, n_layers, p2, N + pad, lay->B + (pad ? 1 : 0));
+    return rel_encoder(c, p1, tokens, lay2, n_layers, p2, N + pad, lay->B + (pad ? 1 : 0), N);     // the embedding reads the token list twice
 }
 
 // ResBlk (models.py:79-100) / ResBlk1d(downsample=True) (models.py:127-156).  X.h, if set, is the operand image of
@@ -1121,7 +1114,8 @@ void duration_style(Ctx& c, const float* ema_ext, int lde, const Lay* ref, float
     tower2d(c, p + ".dur_block", img, limg, {false, false, true}, 5, 2, p + ".dur_linear", ds, c.m.cfg.style_dim / 4);
 }
 
-float* duration_tail(Ctx& c, float* d, const float* ds, const Lay* tok)          // 3 x AdainResBlk1d -> BiLSTM -> duration_proj -> [1][N]
+// 3 x AdainResBlk1d -> BiLSTM -> duration_proj -> [1][N] (into `dst`, the caller's buffer, when given)
+float* duration_tail(Ctx& c, float* d, const float* ds, const Lay* tok, float* dst = nullptr)
 {
     const as_model& m = c.m;
     const std::string p = "durationPredictor";
@@ -1154,6 +1148,7 @@ float* duration_tail(Ctx& c, float* d, const float* ds, const Lay* tok)         
     job.gx_tm = gx; job.whh_t = L->whh_t; job.out = h; job.ldg = 8 * H; job.ldo = tok->N;
     if (tok->N > 0) RUN(c, as_bilstm_f32(&job, 1, tok->d_off, tok->B, H, c.s));
     float* y = c.f32(Nn);
+    if (dst) y = dst;
     const float *pw = m.vec(p + ".duration_proj.linear_layer.weight"), *pb = m.vec(p + ".duration_proj.linear_layer.bias");
     RUN(c, as_project_cols_f32(h, tok->N, 2 * H, tok->N, pw, pb, 1, y, tok->N, c.s));
     return y;
@@ -1415,10 +1410,16 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     if (!A.tok || !A.ref) return A;
     const int Nt = std::max(A.tok->N, 1), Nr = std::max(A.ref->N, 1);
     A.feat12 = c.f32((size_t)12 * Nr);
+    // results the caller asked for are written where the caller wants them (no copy nodes in the graph)
     A.style = c.f32((size_t)B * sd2);
+    if (io->style) A.style = io->style;
     A.duration = nullptr;
     A.dur_i = c.i32(Nt);
     A.frame_off = c.i32(B + 1);
+    if (!batch->frames) {
+        if (io->dur_i) A.dur_i = io->dur_i;
+        if (io->frame_off) A.frame_off = io->frame_off;
+    }
     float* ds = c.f32((size_t)B * (m.cfg.style_dim / 4));
     const float* stats = m.vec("__stats24");
     if (c.go()) c.p.mark(0, c.s);
@@ -1450,7 +1451,7 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
     {
         float* d = rel_encoder(c, "durationPredictor.text_encoder", io->tokens, A.tok, 2);
-        A.duration = duration_tail(c, d, ds, A.tok);
+        A.duration = duration_tail(c, d, ds, A.tok, io->duration);
     }
     f.branch(3);
     gate(3);
@@ -1462,11 +1463,6 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, A.dur_i, A.frame_off, nullptr, 0, c.s));
     (void)C;
     return A;
-}
-
-void copy_out(Ctx& c, void* dst, const void* src, size_t bytes)
-{
-    if (dst && c.go() && bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c.s) != hipSuccess) c.fail((int)hipErrorUnknown);
 }
 
 void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_io* io)
@@ -1482,6 +1478,8 @@ void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_
     int32_t* tof = c.i32((size_t)std::max(N1, 1));
     int32_t* dur_i = c.i32((size_t)std::max(A.tok->N, 1));
     int32_t* frame_off = c.i32(B + 1);
+    if (io->dur_i) dur_i = io->dur_i;
+    if (io->frame_off) frame_off = io->frame_off;
     RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, dur_i, frame_off, tof, N1, c.s));
     float* a_ex = c.f32((size_t)C * std::max(N1, 1));
     float* fne = c.f32((size_t)12 * std::max(N2, 1));                    // rows: F0, N, EMA[10] (what the three branches predict)
@@ -1501,8 +1499,6 @@ void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_
         if (io->F0) copy_rows(c, io->F0, io->ld_pred, fne, N2, 1, N2);
         if (io->N) copy_rows(c, io->N, io->ld_pred, fne + (size_t)N2, N2, 1, N2);
         if (io->EMA) copy_rows(c, io->EMA, io->ld_pred, fne + (size_t)2 * N2, N2, 10, N2);
-        copy_out(c, io->dur_i, dur_i, (size_t)A.tok->N * 4);
-        copy_out(c, io->frame_off, frame_off, (size_t)(B + 1) * 4);
     }
     (void)n_mels;
 }
@@ -1511,15 +1507,10 @@ void outputs_a(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_
 {
     if (!c.go()) return;
     const int C = c.m.cfg.hidden_dim, Nt = A.tok->N, Nr = A.ref->N;
-    copy_out(c, io->duration, A.duration, (size_t)Nt * 4);
-    copy_out(c, io->style, A.style, (size_t)batch->B * 2 * c.m.cfg.style_dim * 4);
     if (io->feat12) copy_rows(c, io->feat12, io->ld_feat, A.feat12, Nr, 12, Nr);
     if (io->t_en) copy_rows(c, io->t_en, io->ld_en, A.t_en, A.ld_en, C, Nt);
     if (io->a_en) copy_rows(c, io->a_en, io->ld_en, A.a_en, A.ld_en, C, Nt);
-    if (!batch->frames) {
-        copy_out(c, io->dur_i, A.dur_i, (size_t)Nt * 4);
-        copy_out(c, io->frame_off, A.frame_off, (size_t)(batch->B + 1) * 4);
-    }
+    (void)batch;
 }
 
 bool io_ok(const as_forward_io* io, bool need_out)
@@ -1896,8 +1887,7 @@ extern "C" int as_duration_forward(const as_model* m, as_plan* p, const as_batch
     if (!tok || !ref || lde < ref->N) return AS_EINVAL;
     float* ds = c.f32((size_t)batch->B * (m->cfg.style_dim / 4));
     duration_style(c, ema_ext, lde, ref, ds);
-    float* d = duration_tail(c, rel_encoder(c, "durationPredictor.text_encoder", tokens, tok, 2), ds, tok);
-    copy_out(c, duration, d, (size_t)tok->N * 4);
+    duration_tail(c, rel_encoder(c, "durationPredictor.text_encoder", tokens, tok, 2), ds, tok, duration);
     return k.done();
 }
 

@@ -264,12 +264,14 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     return Y if Y is not None else yh
 
 
-def embed(tokens_i32, emb, scale, Y, group2=None):
-    """group2 = (emb2, n_split): token columns >= n_split look their rows up in the second table."""
+def embed(tokens_i32, emb, scale, Y, group2=None, n_cols=None):
+    """group2 = (emb2, n_split): token columns >= n_split look their rows up in the second table.  n_cols > tokens: the token list is
+    read twice (columns [tokens, n_split) are filler, column n_split + j is token j again)."""
     V, C = emb.shape
     emb2, n_split = group2 if group2 is not None else (None, 0)
-    check(_lib.lib().as_embed_groups_f32(_p(tokens_i32), _p(emb), _p(emb2), n_split, C, tokens_i32.numel(), V, scale, _p(Y), _ld(Y),
-                                         stream()), "as_embed_groups_f32")
+    n_tok = tokens_i32.numel()
+    check(_lib.lib().as_embed_groups_f32(_p(tokens_i32), n_tok, _p(emb), _p(emb2), n_split, C, n_tok if n_cols is None else n_cols, V, scale,
+                                         _p(Y), _ld(Y), stream()), "as_embed_groups_f32")
     return Y
 
 

@@ -153,8 +153,10 @@ int as_embed_f32(const int32_t* tokens, const float* emb, int C, int N, int V, f
                  as_stream_t stream);
 /* the *_groups_* variants: columns >= n_split (utterances >= b_split) take the SECOND parameter set -- two encoders of the same
  * shape run as one double-width launch (ConvGemmArgs.n_groups is the GEMM's counterpart); NULL second set = the plain call */
-int as_embed_groups_f32(const int32_t* tokens, const float* emb, const float* emb2, int n_split, int C, int N, int V, float scale,
-                        float* y, int ldy, as_stream_t stream);
+/* as_embed_groups_f32: tokens holds n_tok ids.  n_tok == N: one id per column.  n_tok < N (the same tokens through both tables):
+ * columns [n_tok, n_split) are filler (id 0 of the first table), column n_split + j reads tokens[j] again. */
+int as_embed_groups_f32(const int32_t* tokens, int n_tok, const float* emb, const float* emb2, int n_split, int C, int N, int V,
+                        float scale, float* y, int ldy, as_stream_t stream);
 int as_channel_layernorm_groups_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta, const float* gamma2,
                                     const float* beta2, int n_split, float eps, int relu, float* y, int ldy, as_stream_t stream);
 /* Channel LayerNorm (+ReLU) written as the split operand image of the conv that follows (as_split_f16x2_f32's layout; pass it as
