@@ -477,3 +477,200 @@ extern "C" int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// H = 256 across a CLUSTER of four workgroups (the duration predictor, models.py:526; 1024 sequential steps in the long-form
+// configuration).  A direction's W_hh is 1 MB -- more than a CU's registers and LDS together -- so the single-workgroup kernel above
+// re-streams ~750 KB of it from L2 every step (9.6 us per step, bound by the CU's L2 port).  Here workgroup `member` of a cluster owns
+// 64 hidden units: all four gate rows of those units, 256 KB, register resident for the whole sequence (thread = (unit, k eighth),
+// 128 weight registers as (i,f) / (g,o) pairs for v_pk_fma_f32).  Each step every member publishes its 64 new h values and reads the
+// other 192 through a small exchange buffer in global memory: one 8-byte word per value, {h, tag}, tag = launch epoch and step, written
+// and polled with agent-scope atomics, so a word validates itself (no separate flag, no fence) and a step costs ONE store -> load
+// round trip through L2.  The four members sit on one XCD (linear workgroup ids 8 apart), i.e. behind one L2.
+//   words: slot (t & 1) holds h after step t; a member overwrites slot (t+1) & 1 only after it has seen every member's step-t words,
+//   which they publish after consuming step t-1's -- two slots suffice.
+//   epoch: region[0] of the cluster, read by every member at start, bumped by member 0 at the end: words of earlier launches (the
+//   buffer persists, hipGraph replays repeat the same arguments) never match.
+// Forward progress: members spin, so a cluster needs its four workgroups resident together; the launcher only uses this kernel
+// when the whole grid fits the chip at once, and the poll gives up after ~1 s instead of hanging the device.
+// ---------------------------------------------------------------------------------------------------
+#define CL_P 4
+#define CL_REGION_WORDS 1032                       /* 1 header word + 2 slots x 256 units x 2 utterances, padded to 8 KB + 64 B */
+static __device__ __forceinline__ float dpp_add8(float v)
+{
+    // sum over 8 consecutive lanes: two quad permutes, then the mirror inside each half row
+    int x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));
+    return v;
+}
+
+template <int NBU>
+__global__ void __launch_bounds__(512)
+bilstm_cluster_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B, int n_clusters, unsigned long long* __restrict__ xchg)
+{
+    constexpr int H = 256, G = 4 * H, UW = H / CL_P, KS = 8, KQ = H / KS, SL = KQ * NBU + 4, HB = KS * SL;
+    __shared__ __attribute__((aligned(16))) float hs[2 * HB];
+    const int lin = blockIdx.x;
+    const int cl = (lin & 7) + 8 * ((lin >> 3) / CL_P), member = (lin >> 3) % CL_P;
+    if (cl >= n_clusters) return;
+    const int groups = (B + NBU - 1) / NBU;
+    const int ug = cl % groups, dir = (cl / groups) & 1;
+    const BiLstmJob job = jobs.j[cl / (2 * groups)];
+    const int tid = threadIdx.x, ul = tid >> 3, kq = tid & 7, unit = member * UW + ul;
+    int off[NBU], len[NBU], Lmax = 0;
+#pragma unroll
+    for (int i = 0; i < NBU; ++i) {
+        const int u = ug * NBU + i;
+        off[i] = u < B ? col_off[u] : 0;
+        len[i] = u < B ? col_off[u + 1] - col_off[u] : 0;
+        Lmax = len[i] > Lmax ? len[i] : Lmax;
+    }
+    if (Lmax <= 0) return;                                               // (every member of the cluster agrees)
+    unsigned long long* region = xchg + (size_t)cl * CL_REGION_WORDS;
+    const unsigned epoch = (unsigned)region[0] & 0x7FFFu;
+    const unsigned tagbase = epoch << 17;                                 // tag = epoch : step + 1 (17 bits: the launcher bounds the lengths)
+    unsigned long long* words = region + 1;                              // [2][H][NBU]
+    for (int i = tid; i < 2 * HB; i += 512) hs[i] = 0.f;
+
+    lf2 wif[KQ], wgo[KQ];
+    const float* wp = job.whh_t + (size_t)dir * H * G + unit;
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) {
+        const float* r = wp + (size_t)(kq * KQ + kk) * G;
+        wif[kk] = lf2{r[0], r[H]};
+        wgo[kk] = lf2{r[2 * H], r[3 * H]};
+    }
+    // lane kq carries the input-projection term of gate kq & 3 of utterance kq >> 2
+    const int gu = kq >> 2, gL = gu < NBU ? len[gu < NBU ? gu : 0] : 0, gO = off[gu < NBU ? gu : 0];
+    const float* gxp = job.gx_tm + dir * G + (kq & 3) * H + unit;
+    auto load_gx = [&](int t) { return (t < gL) ? gxp[(size_t)(gO + (dir ? gL - 1 - t : t)) * job.ldg] : 0.f; };
+    constexpr int PF = 4;
+    float gq[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) gq[j] = load_gx(j);
+    float c = 0.f;
+    const int my_u = kq < NBU ? kq : 0, my_L = len[my_u], my_o = off[my_u];
+    float* outp = job.out + (size_t)(dir * H + unit) * job.ldo + my_o;
+    // the word this thread polls: value k = tid / NBU of utterance tid % NBU, stored where the (k / KQ) slice readers expect it
+    const int pk = tid / NBU, pu = tid % NBU, ppos = (pk / KQ) * SL + (pk % KQ) * NBU + pu;
+    __syncthreads();
+
+    for (int t0 = 0; t0 < Lmax; t0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int t = t0 + j;
+            if (t >= Lmax) break;
+            float* hb = hs + (t & 1) * HB;
+            if (t > 0 && tid < H * NBU) {
+                const unsigned long long* w = words + (size_t)((t - 1) & 1) * H * NBU + tid;
+                const unsigned want = tagbase | (unsigned)t;
+                unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int spin = 0; (unsigned)(v >> 32) != want && spin < (1 << 21); ++spin) {
+                    __builtin_amdgcn_s_sleep(1);
+                    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                hb[ppos] = __uint_as_float((unsigned)v);
+            }
+            lds_barrier();
+            const float gx = gq[j];
+            gq[j] = load_gx(t + PF);
+            lf2 aif[NBU], ago[NBU];
+#pragma unroll
+            for (int u = 0; u < NBU; ++u) {
+                aif[u] = lf2{kq == 4 * u ? gx : 0.f, kq == 4 * u + 1 ? gx : 0.f};
+                ago[u] = lf2{kq == 4 * u + 2 ? gx : 0.f, kq == 4 * u + 3 ? gx : 0.f};
+            }
+            const float* hc = hb + kq * SL;
+            if (NBU == 2) {
+#pragma unroll
+                for (int kk = 0; kk < KQ; kk += 2) {
+                    const float4 h4 = *reinterpret_cast<const float4*>(hc + kk * 2);
+                    aif[0] += wif[kk] * lf2{h4.x, h4.x};
+                    ago[0] += wgo[kk] * lf2{h4.x, h4.x};
+                    aif[NBU - 1] += wif[kk] * lf2{h4.y, h4.y};
+                    ago[NBU - 1] += wgo[kk] * lf2{h4.y, h4.y};
+                    aif[0] += wif[kk + 1] * lf2{h4.z, h4.z};
+                    ago[0] += wgo[kk + 1] * lf2{h4.z, h4.z};
+                    aif[NBU - 1] += wif[kk + 1] * lf2{h4.w, h4.w};
+                    ago[NBU - 1] += wgo[kk + 1] * lf2{h4.w, h4.w};
+                }
+            } else {
+                lf2 bif = {0.f, 0.f}, bgo = {0.f, 0.f};                  // a second chain: one utterance has only two accumulators
+#pragma unroll
+                for (int kk = 0; kk < KQ; kk += 4) {
+                    const float4 h4 = *reinterpret_cast<const float4*>(hc + kk);
+                    aif[0] += wif[kk] * lf2{h4.x, h4.x};
+                    ago[0] += wgo[kk] * lf2{h4.x, h4.x};
+                    bif += wif[kk + 1] * lf2{h4.y, h4.y};
+                    bgo += wgo[kk + 1] * lf2{h4.y, h4.y};
+                    aif[0] += wif[kk + 2] * lf2{h4.z, h4.z};
+                    ago[0] += wgo[kk + 2] * lf2{h4.z, h4.z};
+                    bif += wif[kk + 3] * lf2{h4.w, h4.w};
+                    bgo += wgo[kk + 3] * lf2{h4.w, h4.w};
+                }
+                aif[0] += bif;
+                ago[0] += bgo;
+            }
+            float pre[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NBU; ++u) {
+                const float pi = dpp_add8(aif[u][0]), pf = dpp_add8(aif[u][1]), pg = dpp_add8(ago[u][0]), po = dpp_add8(ago[u][1]);
+                if (u == my_u) { pre[0] = pi; pre[1] = pf; pre[2] = pg; pre[3] = po; }
+            }
+            if (kq < NBU) {                                              // lane u of the unit's eight owns utterance u
+                float hv = 0.f;
+                if (t < my_L) {
+                    const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+                    c = fg * c + ig * gg;
+                    hv = og * tanhf_(c);
+                    outp[dir ? my_L - 1 - t : t] = hv;
+                }
+                const unsigned long long word = ((unsigned long long)(tagbase | (unsigned)(t + 1)) << 32) | __float_as_uint(hv);
+                __hip_atomic_store(words + (size_t)(t & 1) * H * NBU + unit * NBU + kq, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (member == 0 && tid == 0) region[0] = epoch + 1;
+}
+
+extern "C" size_t as_bilstm_cluster_bytes(int n_jobs, int B)
+{
+    if (n_jobs <= 0 || B <= 0) return 0;
+    return (size_t)n_jobs * 2 * B * CL_REGION_WORDS * sizeof(unsigned long long);
+}
+
+extern "C" int as_bilstm_cluster_f32(const BiLstmJob* jobs_host, int n_jobs, const int32_t* col_off, int B, int H, int max_len, void* xchg,
+                                     size_t xchg_bytes, as_stream_t stream)
+{
+    if (!jobs_host || n_jobs <= 0 || n_jobs > AS_MAX_LSTM_JOBS || !col_off || B < 0 || H <= 0) return AS_EINVAL;
+    if (B == 0) return AS_OK;
+    // one utterance per cluster while every cluster fits the chip at once, else two; beyond that (or without an exchange buffer, or
+    // another width, or lengths past the tag's step field) the single-workgroup kernels
+    const long c1 = (long)n_jobs * 2 * B, c2 = (long)n_jobs * 2 * ((B + 1) / 2);
+    const int nbu = c1 * CL_P <= 256 ? 1 : (c2 * CL_P <= 256 ? 2 : 0);
+    const char* mode = getenv("AS_LSTM_CLUSTER");                        // experiments: "0" = never, "1" / "2" = utterances per cluster
+    const int use = mode ? atoi(mode) : nbu;
+    if (H != 256 || !xchg || use <= 0 || use > 2 || max_len <= 0 || max_len >= (1 << 17) || (use == 1 ? c1 : c2) * CL_P > 256 ||
+        xchg_bytes < as_bilstm_cluster_bytes(n_jobs, B))
+        return as_bilstm_f32(jobs_host, n_jobs, col_off, B, H, stream);
+    LstmJobs jobs;
+    for (int i = 0; i < AS_MAX_LSTM_JOBS; ++i) jobs.j[i] = jobs_host[i < n_jobs ? i : 0];
+    for (int i = 0; i < n_jobs; ++i)
+        if (!jobs.j[i].gx_tm || !jobs.j[i].whh_t || !jobs.j[i].out || jobs.j[i].ldg < 8 * H) return AS_EINVAL;
+    const int ncl = (int)(use == 1 ? c1 : c2);
+    const dim3 grid(8 * CL_P * as_cdiv(ncl, 8)), block(512);
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
+    if (use == 1)
+        hipLaunchKernelGGL(bilstm_cluster_kernel<1>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B, ncl,
+                           static_cast<unsigned long long*>(xchg));
+    else
+        hipLaunchKernelGGL(bilstm_cluster_kernel<2>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B, ncl,
+                           static_cast<unsigned long long*>(xchg));
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+

@@ -385,6 +385,8 @@ struct as_plan {
         (void)hipEventRecord(marks[i], s);
     }
     std::vector<int> frames_host;         // as_forward_test with unknown frame counts reads them here
+    void* lstm_xchg = nullptr;            // as_bilstm_cluster_f32's exchange buffer (zero-filled once, then the library's)
+    size_t lstm_xchg_bytes = 0;
 
     hipEvent_t event()
     {
@@ -500,6 +502,21 @@ struct Ctx {
         int32_t* d = static_cast<int32_t*>(p.pool.alloc(h.size() * sizeof(int32_t)));
         if (!d || hipMemcpy(d, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { fail((int)hipErrorOutOfMemory); return nullptr; }
         return M->tabs[key] = d;
+    }
+    // the plan's exchange buffer for clustered recurrences (allocated and zero-filled on first real use, like the tables above)
+    void* lstm_xchg(int n_jobs, int B, size_t* bytes)
+    {
+        *bytes = 0;
+        if (count || !launch) return nullptr;
+        const size_t need = as_bilstm_cluster_bytes(n_jobs, B);
+        if (p.lstm_xchg_bytes < need) {
+            void* d = p.pool.alloc(need);
+            if (!d || hipMemset(d, 0, need) != hipSuccess) { fail((int)hipErrorOutOfMemory); return nullptr; }
+            p.lstm_xchg = d;
+            p.lstm_xchg_bytes = need;
+        }
+        *bytes = p.lstm_xchg_bytes;
+        return p.lstm_xchg;
     }
     const Lay* scaled(const Lay* L, int k)
     {
@@ -1146,7 +1163,11 @@ float* duration_tail(Ctx& c, float* d, const float* ds, const Lay* tok, float* d
     float* h = c.f32((size_t)2 * H * Nn);
     BiLstmJob job;
     job.gx_tm = gx; job.whh_t = L->whh_t; job.out = h; job.ldg = 8 * H; job.ldo = tok->N;
-    if (tok->N > 0) RUN(c, as_bilstm_f32(&job, 1, tok->d_off, tok->B, H, c.s));
+    if (tok->N > 0 && c.go()) {
+        size_t xb = 0;
+        void* xchg = c.lstm_xchg(1, tok->B, &xb);
+        RUN(c, as_bilstm_cluster_f32(&job, 1, tok->d_off, tok->B, H, tok->max_w, xchg, xb, c.s));
+    }
     float* y = c.f32(Nn);
     if (dst) y = dst;
     const float *pw = m.vec(p + ".duration_proj.linear_layer.weight"), *pb = m.vec(p + ".duration_proj.linear_layer.bias");

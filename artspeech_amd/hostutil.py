@@ -95,12 +95,12 @@ class Weights:
         return self._cache[key]
 
 
-def bilstm(W, p, X, lay):
+def bilstm(W, p, X, lay, xchg=None):
     """nn.LSTM(bidirectional) on packed [I][N] -> [2H][N]: hoisted input GEMM + recurrence kernel."""
-    return bilstm_many(W, [(p, X)], lay)[0]
+    return bilstm_many(W, [(p, X)], lay, xchg)[0]
 
 
-def bilstm_many(W, items, lay):
+def bilstm_many(W, items, lay, xchg=None):
     """Several independent BiLSTMs of the same size over the same layout (ArtsPredictor's three branches,
     models.py:606-618): one hoisted input GEMM each, ONE recurrence launch for all of them."""
     jobs, H = [], None
@@ -109,7 +109,7 @@ def bilstm_many(W, items, lay):
         gx = torch.empty((max(lay.N, 1), 8 * H), dtype=torch.float32, device=X.device)
         ops.conv_gemm(wih_t, X, lay, gx, [(0, 0)], bias=b, transpose_out=True)
         jobs.append((gx, whh_t, lay.new(2 * H)))
-    return ops.bilstm(jobs, lay, H)
+    return ops.bilstm(jobs, lay, H, xchg)
 
 
 # ------------------------------------------------------------------------------------------------

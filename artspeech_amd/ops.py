@@ -451,11 +451,21 @@ def lstm_step0(gx, H, N, out):
     return out
 
 
-def bilstm(jobs, lay, H):
-    """jobs: list of (gx_tm [N][8H], whh_t [2][H][4H], out [2H][N]) -- independent LSTMs sharing one launch."""
+def bilstm(jobs, lay, H, xchg=None):
+    """jobs: list of (gx_tm [N][8H], whh_t [2][H][4H], out [2H][N]) -- independent LSTMs sharing one launch.
+    xchg: bilstm_exchange_buffer(...) -> H = 256 recurrences run split over clusters of four workgroups."""
     arr = (_lib.BiLstmJob * len(jobs))()
     for i, (gx_tm, whh_t, out) in enumerate(jobs):
         arr[i].gx_tm, arr[i].whh_t, arr[i].out = _p(gx_tm), _p(whh_t), _p(out)
         arr[i].ldg, arr[i].ldo = _ld(gx_tm), _ld(out)
-    check(_lib.lib().as_bilstm_f32(arr, len(jobs), _p(lay.col_off), lay.B, H, stream()), "as_bilstm_f32")
+    if xchg is not None:
+        check(_lib.lib().as_bilstm_cluster_f32(arr, len(jobs), _p(lay.col_off), lay.B, H, lay.max_w, _p(xchg), xchg.numel() * xchg.element_size(),
+                                               stream()), "as_bilstm_cluster_f32")
+    else:
+        check(_lib.lib().as_bilstm_f32(arr, len(jobs), _p(lay.col_off), lay.B, H, stream()), "as_bilstm_f32")
     return [j[2] for j in jobs]
+
+
+def bilstm_exchange_buffer(n_jobs, B, device):
+    """the zero-filled exchange buffer as_bilstm_cluster_f32 wants (allocate once, reuse for every launch)"""
+    return torch.zeros(_lib.lib().as_bilstm_cluster_bytes(n_jobs, B) // 8, dtype=torch.int64, device=device)

@@ -314,6 +314,13 @@ typedef struct BiLstmJob {
     int32_t ldg, ldo;
 } BiLstmJob;
 int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32_t* col_off, int B, int H, as_stream_t stream);
+/* H = 256: the recurrence of an utterance (or a pair) split over a cluster of four workgroups that keep W_hh in registers and exchange h
+ * every step through `xchg` -- a device buffer of as_bilstm_cluster_bytes(n_jobs, B) bytes that the caller zero-fills ONCE and then leaves
+ * to the library (it carries launch epochs; launches that may overlap in time need separate buffers).  max_len = longest utterance.
+ * Falls back to as_bilstm_f32 when the grid would not fit the chip at once, for other H, or with xchg == NULL. */
+size_t as_bilstm_cluster_bytes(int n_jobs, int B);
+int as_bilstm_cluster_f32(const BiLstmJob* jobs_host, int n_jobs, const int32_t* col_off, int B, int H, int max_len, void* xchg,
+                          size_t xchg_bytes, as_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * HiFi-GAN generator glue (Vocoder/vocoder.py:75-125).  Its convolutions run through

@@ -350,6 +350,29 @@ def test_relpos_attention(cuda, lens, C, mode, monkeypatch):
     assert float((out.cpu() - want).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("lens,mode", [([40, 12], None), ([40, 12, 0, 7, 1], "1"), ([40, 12, 0, 7, 1], "2"), ([33] * 32, None), ([300, 280], None),
+                                       ([9] * 40, None)])
+def test_bilstm_cluster(cuda, lens, mode, monkeypatch):
+    """H = 256 split over clusters of four workgroups (as_bilstm_cluster_f32): same results as torch.nn.LSTM per utterance, repeated
+    launches on one exchange buffer (the epochs), one or two utterances per cluster, the fallback when the grid does not fit (40 x 9)"""
+    from artspeech_amd import models
+    if mode:
+        monkeypatch.setenv("AS_LSTM_CLUSTER", mode)
+    H, I = 256, 64
+    g = torch.Generator().manual_seed(len(lens))
+    lstm = torch.nn.LSTM(I, H, 1, batch_first=True, bidirectional=True)
+    raw = {"l." + k: v.detach() for k, v in lstm.state_dict().items()}
+    W = models.Weights(raw, cuda)
+    xchg = ops.bilstm_exchange_buffer(1, len(lens), cuda)
+    lay = Layout(lens, cuda)
+    for rep in range(3):
+        xs = [torch.randn(I, L, generator=g) for L in lens]
+        with torch.no_grad():
+            want = packed([lstm(x.t()[None])[0][0].t() if x.shape[1] else torch.zeros(2 * H, 0) for x in xs])
+        out = models.bilstm(W, "l", packed(xs).to(cuda), lay, xchg)
+        assert float((out.cpu() - want).abs().max()) <= 2e-5, rep
+
+
 @pytest.mark.parametrize("H,I,lens", [(16, 16, [5, 1, 9]), (128, 128, [40, 200, 3, 77, 50, 60, 70, 80, 11]), (256, 512, [40, 12])])
 def test_bilstm(cuda, H, I, lens):
     from artspeech_amd import models
