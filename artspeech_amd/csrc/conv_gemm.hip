@@ -213,29 +213,37 @@ splitk_reduce_kernel(const ConvGemmArgs a, int S)
 
 static void tile_dims(int choice, int* bm, int* bn)
 {
-    // 22 / 21 / 12 / 11: 128x128, 128x64, 64x128, 64x64 (4 waves each)
-    *bm = (choice == 22 || choice == 21) ? 128 : 64;
-    *bn = (choice == 22 || choice == 12) ? 128 : 64;
+    // 42 / 22 / 21 / 12 / 11: 256x128, 128x128, 128x64, 64x128, 64x64 (4 waves each)
+    *bm = choice == 42 ? 256 : (choice == 22 || choice == 21) ? 128 : 64;
+    *bn = (choice == 42 || choice == 22 || choice == 12) ? 128 : 64;
 }
 
 // Tile choice, from sweeps on MI355X (scripts/gemm_bench.py, round 2): above one tile per CU the time follows the tile count
 // (several workgroups share a CU and cover each other's waits), below ~160 tiles the idle CUs cost more than a smaller tile's
 // worse operand reuse -- e.g. M512 N1280 K512 T3: 64x64 tiles 16 us, 128x64 20 us; M1536 N2560 K512: 128x128 19 us, 128x64 21 us.
-static int gemm_tile_choice(int M, int N)
+static int gemm_tile_choice(int M, int N, int n_prod)
 {
-    const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 22, 21, 12, 11
+    const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 42, 22, 21, 12, 11
     if (env && atoi(env) > 0) return atoi(env);
     const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);   // a 128-row tile is not half empty
-    static const int choices[4] = {22, 21, 12, 11};
-    static const double eff[4] = {1.0, 0.95, 0.9, 0.55};     // (64x64: twice the staged bytes per flop, one workgroup per CU)
+    static const int choices[5] = {42, 22, 21, 12, 11};
+    // 256x128 (a wave owns 128 x 64): a third less LDS traffic per matrix-core product, but 364 registers: ONE workgroup per CU, so its
+    // tiles run in whole rounds.  Ten identical launches back to back in a hipGraph: M1024 N6400 K1216 T3 127 us against 152 for 128x128,
+    // M256 N32000 K256 T9 94 against 106, M512 N19200 105 against 96.  Inside the step (other kernels between the GEMMs, operands not in
+    // cache) the same launches take the same time with either tile (C3: 5.08 against 5.10 ms of GEMM per step, C5: 8.78 against 8.70), so
+    // the default stays with the tiles that share a CU; AS_GEMM_TILE=42 / AS_GEMM_USE42=1 select it for experiments.
+    static const double eff[5] = {1.3, 1.0, 0.95, 0.9, 0.55};     // (64x64: twice the staged bytes per flop)
+    static const bool use42 = getenv("AS_GEMM_USE42") != nullptr;
     int best = 11;
     double best_cost = 1e30;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 5; ++c) {
         int bm, bn;
         tile_dims(choices[c], &bm, &bn);
-        if (bm == 128 && !tall) continue;
+        if (bm >= 128 && !tall) continue;
+        if (bm == 256 && (M % 256 != 0 || n_prod != 3 || !use42)) continue;
         const double tiles = (double)as_cdiv(M, bm) * as_cdiv(N, bn);
-        const double cost = (tiles > 256.0 ? tiles / 256.0 : 1.0) * bm * bn / eff[c] * (tiles < 160.0 ? 160.0 / tiles : 1.0);
+        const double rounds = bm == 256 ? ceil(tiles / 256.0) : (tiles > 256.0 ? tiles / 256.0 : 1.0);
+        const double cost = rounds * bm * bn / eff[c] * (tiles < 160.0 ? 160.0 / tiles : 1.0);
         if (cost < best_cost * 0.97) { best_cost = cost; best = choices[c]; }   // (ties go to the larger tile)
     }
     return best;
@@ -250,7 +258,7 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
     int bm, bn;
     tile_dims(choice, &bm, &bn);
     const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
-    const int wk = 4 * 64 * 64 / (bm * bn);               // waves that split K inside the workgroup
+    const int wk = bm * bn >= 4 * 64 * 64 ? 1 : 4 * 64 * 64 / (bm * bn);   // waves that split K inside the workgroup
     const int nkt = T * as_cdiv(Kp / 16, wk);             // iterations (k-tile = 16 * WK)
     int s = 1;
     if (env && atoi(env) > 0) s = atoi(env);
@@ -273,7 +281,7 @@ static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 static GemmPlan gemm_plan(const ConvGemmArgs& a)
 {
     GemmPlan p = {};
-    p.choice = gemm_tile_choice(a.M, a.N);
+    p.choice = gemm_tile_choice(a.M, a.N, a.n_prod ? a.n_prod : 3);
     p.S = gemm_ksplit(a.M, a.N, a.Kp, a.T, p.choice);
     p.slab_bytes = p.S > 1 ? (size_t)p.S * a.M * a.N * sizeof(float) : 0;
     p.xh_bytes = a.Xh ? 0 : as_split_f16x2_bytes(a.K, a.N);

@@ -77,31 +77,32 @@ static __device__ __forceinline__ unsigned long long h3_tap_word(const H3Taps& t
     return (tp.w0 & m0) | (tp.w1 & m1) | (tp.w2 & m2) | (tp.w3 & m3);
 }
 
-template <int WM, int WN, int WK, int KT, int NS, int NP>
+// TM: 32-row MFMA tiles per wave (2: a wave owns 64 x 64; 4: 128 x 64 -- a third less LDS traffic per matrix-core product)
+template <int WM, int WN, int WK, int KT, int NS, int NP, int TM = 2>
 struct H3Cfg {
     static constexpr int QP = NP == 1 ? 2 : 4;                           // planes staged per k-block (h only / h and l)
-    static constexpr int BM = 64 * WM, BN = 64 * WN;
+    static constexpr int BM = 32 * TM * WM, BN = 64 * WN;
     static constexpr int KBS = WK * KT;                                  // k-blocks per stage
     static constexpr int A_BLK = QP * BM * 16, B_BLK = QP * BN * 16;     // bytes per 16-deep k-block
     static constexpr int A_ST = KBS * A_BLK;                             // weight part of a stage
     static constexpr int STAGE = KBS * (A_BLK + B_BLK);
-    static constexpr int RED = (WK - 1) * WM * WN * 64 * 64 * 4;         // cross-wave K reduction scratch
+    static constexpr int RED = (WK - 1) * WM * WN * 32 * TM * 64 * 4;    // cross-wave K reduction scratch
     static constexpr int LDS = NS * STAGE > RED ? NS * STAGE : RED;
     static constexpr int NT = 64 * WM * WN * WK;                         // threads
     static constexpr int ACH = KBS * QP * BM / NT;                       // 16-byte weight chunks per thread per iteration
     static constexpr int BCH = KBS * QP * BN / NT;                       // 16-byte activation chunks per thread per iteration
-    static constexpr int NMF = 4 * NP;                                   // MFMAs per k-block
-    static constexpr int NFR = 4 * (NP == 1 ? 1 : 2);                    // fragment reads per k-block
+    static constexpr int NMF = 2 * TM * NP;                              // MFMAs per k-block
+    static constexpr int NFR = (TM + 2) * (NP == 1 ? 1 : 2);             // fragment reads per k-block
 };
 
 #ifndef H3_OCC
 #define H3_OCC 1
 #endif
-template <int WM, int WN, int WK, int KT, int NS, int NP>
+template <int WM, int WN, int WK, int KT, int NS, int NP, int TM = 2>
 __global__ void __launch_bounds__(64 * WM * WN * WK, H3_OCC)
 conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
 {
-    using C = H3Cfg<WM, WN, WK, KT, NS, NP>;
+    using C = H3Cfg<WM, WN, WK, KT, NS, NP, TM>;
     static_assert(NS == 2 || NS == 3, "stages");
     constexpr int BM = C::BM, BN = C::BN, ACH = C::ACH, BCH = C::BCH, NT = C::NT, QP = C::QP, KBS = C::KBS;
     static_assert(NT == 256 && ACH * NT == KBS * QP * BM && BCH * NT == KBS * QP * BN && ACH >= 1 && BCH >= 1, "tile shape");
@@ -231,8 +232,8 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     (void)a_soff;
     (void)b_soff;
     // fragments: [set][32-row / 32-column tile][part]
-    f16x8 fa[2][2][2], fb[2][2][2];
-    const int a_frag = (wk * KT * QP + lk) * BM * 16 + (wm * 64 + l31) * 16;
+    f16x8 fa[2][TM][2], fb[2][2][2];
+    const int a_frag = (wk * KT * QP + lk) * BM * 16 + (wm * 32 * TM + l31) * 16;
     const int b_frag = C::A_ST + (wk * KT * QP + lk) * BN * 16 + (wn * 64 + l31) * 16;
     // fragment read q of k-block step s of stage `stage` into register set `set`: q = ab*NFR/2 + p*2 + i
     auto read_frag = [&](auto q_, auto set_, auto s_, int stage) {
@@ -241,16 +242,18 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
 #endif
         constexpr int q = decltype(q_)::value, set = decltype(set_)::value, s = decltype(s_)::value;
         // in the order the MFMAs first need them: (A h, B l) for h*l, then (A l, B h) for l*h; h*h reuses them
-        constexpr int pair = q / 2, i = q % 2;
-        constexpr int ab = NP == 1 ? pair : (pair == 0 || pair == 2 ? 0 : 1);
-        constexpr int p = NP == 1 ? 0 : (pair == 0 || pair == 3 ? 0 : 1);
+        // reads: TM x A h, 2 x B l, TM x A l, 2 x B h  (NP = 1: TM x A h, 2 x B h)
+        constexpr int sec = q < TM ? 0 : (q < TM + 2 ? 1 : (q < 2 * TM + 2 ? 2 : 3));
+        constexpr int i = sec == 0 ? q : (sec == 1 ? q - TM : (sec == 2 ? q - TM - 2 : q - 2 * TM - 2));
+        constexpr int ab = sec == 0 || sec == 2 ? 0 : 1;
+        constexpr int p = NP == 1 ? 0 : (sec == 0 || sec == 3 ? 0 : 1);
         const unsigned char* st = smem + stage * C::STAGE;
         if constexpr (ab == 0) fa[set][i][p] = *reinterpret_cast<const f16x8*>(st + a_frag + (s * QP + p * 2) * BM * 16 + i * 32 * 16);
         else fb[set][i][p] = *reinterpret_cast<const f16x8*>(st + b_frag + (s * QP + p * 2) * BN * 16 + i * 32 * 16);
     };
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
@@ -305,7 +308,7 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     // MFMA n of a step: groups of four, smallest terms first: (A part, B part) = (h,l) (l,h) (h,h); NP = 1: (h,h)
     auto step = [&](auto n_, auto s_, auto p_, auto f_) {
         constexpr int Nn = decltype(n_)::value, Ss = decltype(s_)::value, P = decltype(p_)::value, F = decltype(f_)::value;
-        constexpr int grp_ = Nn / 4, i = (Nn % 4) / 2, jn = Nn % 2;
+        constexpr int grp_ = Nn / (2 * TM), i = (Nn % (2 * TM)) / 2, jn = Nn % 2;
         constexpr int PA = NP == 1 ? 0 : (grp_ == 1 ? 1 : 0);
         constexpr int PB = NP == 1 ? 0 : (grp_ == 0 ? 1 : 0);
         acc[i][jn] = H3_MFMA(fa[F][i][PA], fb[F][jn][PB], acc[i][jn]);
@@ -357,13 +360,13 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
         f32x4* red = reinterpret_cast<f32x4*>(smem);
         if (wk > 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) {
                         f32x4 v = {acc[i][jn][4 * e4], acc[i][jn][4 * e4 + 1], acc[i][jn][4 * e4 + 2], acc[i][jn][4 * e4 + 3]};
-                        red[((((wk - 1) * (WM * WN) + wmn) * 4 + i * 2 + jn) * 4 + e4) * 64 + lane] = v;
+                        red[((((wk - 1) * (WM * WN) + wmn) * 2 * TM + i * 2 + jn) * 4 + e4) * 64 + lane] = v;
                     }
         }
         __syncthreads();
@@ -371,26 +374,26 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
 #pragma unroll
             for (int s = 1; s < WK; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                         for (int e4 = 0; e4 < 4; ++e4) {
-                            const f32x4 v = red[((((s - 1) * (WM * WN) + wmn) * 4 + i * 2 + jn) * 4 + e4) * 64 + lane];
+                            const f32x4 v = red[((((s - 1) * (WM * WN) + wmn) * 2 * TM + i * 2 + jn) * 4 + e4) * 64 + lane];
 #pragma unroll
                             for (int c = 0; c < 4; ++c) acc[i][jn][4 * e4 + c] += v[c];
                         }
     }
-    epilogue<2, 2>(a, acc, m0, n0, wm, wn, l31, lk, S, wk == 0, grp, n_end);
+    epilogue<TM, 2>(a, acc, m0, n0, wm, wn, l31, lk, S, wk == 0, grp, n_end);
 }
 
-template <int WM, int WN, int WK, int KT, int NS, int NP>
+template <int WM, int WN, int WK, int KT, int NS, int NP, int TM = 2>
 static int launch_h3(const ConvGemmArgs& a, int S, hipStream_t stream)
 {
-    using C = H3Cfg<WM, WN, WK, KT, NS, NP>;
+    using C = H3Cfg<WM, WN, WK, KT, NS, NP, TM>;
     static bool attr_set = false;
     if (!attr_set) {
-        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP>),
+        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP, TM>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr_set = true;
     }
@@ -398,7 +401,7 @@ static int launch_h3(const ConvGemmArgs& a, int S, hipStream_t stream)
     if (h3_pack_taps(a, &tp) != AS_OK) return AS_EINVAL;
     const int tiles_n = a.n_groups > 1 ? a.n_groups * as_cdiv(a.group_cols, C::BN) : as_cdiv(a.N, C::BN);
     const dim3 grid(as_cdiv(a.M, C::BM) * tiles_n, S);
-    hipLaunchKernelGGL((conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP>), grid, dim3(C::NT), C::LDS, stream, a, tp);
+    hipLaunchKernelGGL((conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP, TM>), grid, dim3(C::NT), C::LDS, stream, a, tp);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
@@ -424,6 +427,9 @@ int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t
 {
     if ((double)as_kbx(a.K) * 4.0 * (a.N + 1.0) * 16.0 >= 2147483648.0) return AS_EINVAL;   // 32-bit offsets in the descriptor
     switch (choice) {
+    case 42:                                                            // 256 x 128, a wave owns 128 x 64
+        if (a.n_prod == 1) return AS_EINVAL;
+        return launch_h3<2, 2, 1, 1, 3, 3, 4>(a, S, stream);
     case 22: return launch_h3_tile<2, 2, 1>(a, S, stream);
     case 21: return launch_h3_tile<2, 1, 2>(a, S, stream);
     case 12: return launch_h3_tile<1, 2, 2>(a, S, stream);

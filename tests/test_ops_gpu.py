@@ -36,7 +36,7 @@ def split_ref(x):
 
 @pytest.mark.parametrize("cin,cout,k,lens", [(64, 128, 3, [50, 13, 1, 200]), (10, 64, 1, [7, 9]), (1, 32, 1, [33]),
                                              (96, 80, 5, [40, 41]), (130, 257, 9, [17, 300, 64]), (512, 1024, 3, [128] * 8)])
-@pytest.mark.parametrize("tile", ["", "11", "21", "22", "12"])
+@pytest.mark.parametrize("tile", ["", "11", "21", "22", "12", "42"])
 def test_conv1d_gemm(cuda, monkeypatch, impl, cin, cout, k, lens, tile):
     if tile:
         monkeypatch.setenv("AS_GEMM_TILE", tile)
@@ -94,7 +94,7 @@ def test_split_activations(cuda, K, lens, lrelu):
     assert torch.equal(y0, y1)
 
 
-@pytest.mark.parametrize("M,K,lens,tile,ksplit", [(128, 64, [50, 13, 1, 200], "22", ""), (80, 96, [40, 41], "21", ""), (257, 130, [17, 300, 64], "", ""),
+@pytest.mark.parametrize("M,K,lens,tile,ksplit", [(128, 64, [50, 13, 1, 200], "22", ""), (300, 64, [50, 13, 1, 200], "42", ""), (256, 48, [129], "42", "2"), (80, 96, [40, 41], "21", ""), (257, 130, [17, 300, 64], "", ""),
                                                   (64, 64, [333], "12", ""), (200, 200, [33, 70], "", "3"), (512, 512, [40] * 32, "", "")])
 @pytest.mark.parametrize("lrelu", [False, True])
 def test_epilogue_writes_split_image(cuda, monkeypatch, M, K, lens, tile, ksplit, lrelu):
