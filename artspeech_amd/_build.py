@@ -14,8 +14,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libartspeech_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# AS_BUILD_FLAGS="-DAS_EXPERIMENTS": also compile the tuning variants (other GEMM pipeline shapes, the 256x128 tile) that the
+# shipped library leaves out; AS_TEST_EXPERIMENTS=1 adds their ids to the test matrix
+EXTRA = os.environ.get("AS_BUILD_FLAGS", "").split()
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall",
-         "-Wno-unused-function", "-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include")]
+         "-Wno-unused-function", "-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include")] + EXTRA
 
 
 def _compile(src):
@@ -29,6 +32,11 @@ def _compile(src):
 
 def build_lib(verbose=True):
     os.makedirs(os.path.join(LIBDIR, "obj"), exist_ok=True)
+    stamp = os.path.join(LIBDIR, "obj", "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(EXTRA):          # other flags: every object is stale
+        for o in glob.glob(os.path.join(LIBDIR, "obj", "*.o")):
+            os.remove(o)
+        open(stamp, "w").write(" ".join(EXTRA))
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         res = list(ex.map(_compile, srcs))

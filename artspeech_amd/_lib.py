@@ -184,6 +184,6 @@ def ptr(t):
 
 
 def stream():
-    """the current HIP stream of the current device.  Tensors of another device are rejected by device_guard (models.py runs
-    every forward under `torch.cuda.device(model device)`), so a launch never mixes a stream of one GPU with memory of another."""
+    """the current HIP stream of the current device.  ops._p rejects tensors of any other device and models.py / mas.py run every
+    call under `torch.cuda.device(model device)`, so a launch never mixes a stream of one GPU with memory of another."""
     return torch.cuda.current_stream().cuda_stream

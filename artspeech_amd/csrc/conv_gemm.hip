@@ -231,9 +231,13 @@ static int gemm_tile_choice(int M, int N, int n_prod)
     // tiles run in whole rounds.  Ten identical launches back to back in a hipGraph: M1024 N6400 K1216 T3 127 us against 152 for 128x128,
     // M256 N32000 K256 T9 94 against 106, M512 N19200 105 against 96.  Inside the step (other kernels between the GEMMs, operands not in
     // cache) the same launches take the same time with either tile (C3: 5.08 against 5.10 ms of GEMM per step, C5: 8.78 against 8.70), so
-    // the default stays with the tiles that share a CU; AS_GEMM_TILE=42 / AS_GEMM_USE42=1 select it for experiments.
+    // the default stays with the tiles that share a CU; -DAS_EXPERIMENTS builds carry it (AS_GEMM_TILE=42 / AS_GEMM_USE42=1).
     static const double eff[5] = {1.3, 1.0, 0.95, 0.9, 0.55};     // (64x64: twice the staged bytes per flop)
+#ifdef AS_EXPERIMENTS
     static const bool use42 = getenv("AS_GEMM_USE42") != nullptr;
+#else
+    constexpr bool use42 = false;
+#endif
     int best = 11;
     double best_cost = 1e30;
     for (int c = 0; c < 5; ++c) {

@@ -414,22 +414,27 @@ static int launch_h3(const ConvGemmArgs& a, int S, hipStream_t stream)
 template <int WM, int WN, int WK>
 static int launch_h3_tile(const ConvGemmArgs& a, int S, hipStream_t stream)
 {
+    if (a.n_prod == 1) return launch_h3<WM, WN, WK, 1, 3, 1>(a, S, stream);
+#ifdef AS_EXPERIMENTS   // (-DAS_EXPERIMENTS builds only: the shipped library carries the one pipeline shape the path launches)
     const char *ekt = getenv("AS_H3_KT"), *ens = getenv("AS_H3_NS");
     const int kt = ekt ? atoi(ekt) : H3_KT, ns = ens ? atoi(ens) : 3;
-    if (a.n_prod == 1) return launch_h3<WM, WN, WK, 1, 3, 1>(a, S, stream);
     if constexpr (H3Cfg<WM, WN, WK, 2, 3, 3>::LDS <= 160 * 1024) {
         if (kt == 2) return launch_h3<WM, WN, WK, 2, 3, 3>(a, S, stream);
     }
-    return ns == 2 ? launch_h3<WM, WN, WK, 1, 2, 3>(a, S, stream) : launch_h3<WM, WN, WK, 1, 3, 3>(a, S, stream);
+    if (ns == 2) return launch_h3<WM, WN, WK, 1, 2, 3>(a, S, stream);
+#endif
+    return launch_h3<WM, WN, WK, 1, 3, 3>(a, S, stream);
 }
 
 int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream)
 {
     if ((double)as_kbx(a.K) * 4.0 * (a.N + 1.0) * 16.0 >= 2147483648.0) return AS_EINVAL;   // 32-bit offsets in the descriptor
     switch (choice) {
+#ifdef AS_EXPERIMENTS
     case 42:                                                            // 256 x 128, a wave owns 128 x 64
         if (a.n_prod == 1) return AS_EINVAL;
         return launch_h3<2, 2, 1, 1, 3, 3, 4>(a, S, stream);
+#endif
     case 22: return launch_h3_tile<2, 2, 1>(a, S, stream);
     case 21: return launch_h3_tile<2, 1, 2>(a, S, stream);
     case 12: return launch_h3_tile<1, 2, 2>(a, S, stream);

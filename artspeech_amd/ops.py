@@ -29,6 +29,10 @@ def _p(t):
         return None
     if not t.is_cuda:
         raise _lib.HipLibraryError("expected a tensor in GPU memory (the HIP path has no CPU fallback)")
+    # launches go to the CURRENT device's current stream (_lib.stream): memory of another GPU would be used from the wrong stream
+    if t.device.index != torch.cuda.current_device():
+        raise _lib.HipLibraryError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                                   "run the call under `with torch.cuda.device(tensor.device)` (models.py / mas.py / pipeline.py do)")
     return t.data_ptr()
 
 

@@ -124,7 +124,8 @@ typedef struct ConvGemmArgs {
     int32_t n_prod;        /* 0 or 3 = f16x3 (fp32-accurate); 1 = h*h only */
     int32_t dh[AS_MAX_TAPS];   /* tap row offsets */
     int32_t dw[AS_MAX_TAPS];   /* tap column offsets */
-    float in_slope, act_slope; /* LeakyReLU slopes of in_act / act; 0 = the path's 0.2 */
+    float in_slope, act_slope; /* LeakyReLU slopes of in_act / act; 0 = the path's 0.2 (a true slope of 0 is ReLU: act = 1; the path
+                                * never rectifies an operand while splitting it, so in_act has no slope-0 form) */
     float acc_scale;           /* multiplies the accumulator: 1 / (weight scale of as_prep_weight_f16x2); 0 = 1 */
     /* Grouped launch: G layers of the same shape side by side along the column axis (the text and articulatory encoders,
      * RelTransformerEnc.py; the F0 / energy / TV branches of ArtsPredictor, models.py:606-618): columns
