@@ -80,6 +80,7 @@ _SIGNATURES.update({
     "as_im2col_valid_image_f32": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "as_mean_pool_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "as_relpos_attention_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
+    "as_relpos_attention_image_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p]),
     "as_bilstm_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p]),
     "as_bilstm_cluster_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "as_bilstm_cluster_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p, ctypes.c_size_t, c_p]),

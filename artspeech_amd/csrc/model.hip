@@ -879,18 +879,29 @@ float* rel_encoder(Ctx& c, const std::string& p, const int32_t* tokens, const La
         ConvOpt o;
         o.bias = bqkv;
         o.group_cols = gc;
+        // 128-channel heads (the shipped model): the q/k/v GEMM also writes its result as an operand image, the attention kernel takes
+        // Q / K fragments straight from it and writes the o-projection's operand image -- no fp32 attention output, no split pass
+        const bool img = C / N_HEADS == 128;
+        if (img) {
+            o.want_yh = true;
+            o.yh = c.image(3 * C, N);
+        }
         float* qkv = conv_h_new(c, wqkv, ln_image(x, e + ".norm_layers_1." + std::to_string(i), false), C, lay, k1, o);
-        float* att = c.f32((size_t)C * Nn);
+        float* att = img ? nullptr : c.f32((size_t)C * Nn);
+        uint16_t* att_h = img ? c.image(C, N) : nullptr;
         const float *ek = m.vec(p + a + ".emb_rel_k"), *ev = m.vec(p + a + ".emb_rel_v");
         const float *ek2 = pair ? m.vec(p2 + a + ".emb_rel_k") : nullptr, *ev2 = pair ? m.vec(p2 + a + ".emb_rel_v") : nullptr;
-        if (N > 0)
+        if (N > 0 && img)
+            RUN(c, as_relpos_attention_image_f32(qkv, N, o.yh, N, C, N_HEADS, WINDOW, ek, ev, ek2, ev2, b_split, lay->d_off, lay->B, lay->max_w,
+                                                 nullptr, 0, att_h, c.s));
+        else if (N > 0)
             RUN(c, as_relpos_attention_groups_f32(qkv, N, C, N_HEADS, WINDOW, ek, ev, ek2, ev2, b_split, lay->d_off, lay->B, lay->max_w, att, N, c.s));
         ConvOpt oo;
         oo.bias = cb(a + ".conv_o");
         oo.res = x;
         oo.ldr = N;
         oo.group_cols = gc;
-        x = conv_x_new(c, cw(a + ".conv_o"), att, N, C, lay, k1, oo);
+        x = img ? conv_h_new(c, cw(a + ".conv_o"), att_h, C, lay, k1, oo) : conv_x_new(c, cw(a + ".conv_o"), att, N, C, lay, k1, oo);
         // FFN (RelTransformerEnc.py:261-269): conv k9 -> ReLU exists only as the 1x1 conv's operand image
         const GemmW* w1 = cw(f + ".conv_1");
         if (!w1) { c.fail(AS_EINVAL); return nullptr; }

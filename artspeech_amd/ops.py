@@ -438,6 +438,16 @@ def relpos_attention(qkv, C, heads, window, ek, ev, lay, out, group2=None):
     return out
 
 
+def relpos_attention_image(qkv, qkv_h, C, heads, window, ek, ev, lay, out=None, out_h=None, group2=None):
+    """the attention fed by the q/k/v GEMM's operand image (qkv_h = conv_gemm(..., yh=...) over the same lay.N columns); writes fp32 `out`
+    and / or `out_h`, the o-projection's operand image"""
+    ek2, ev2, b_split = group2 if group2 is not None else (None, None, 0)
+    check(_lib.lib().as_relpos_attention_image_f32(_p(qkv), _ld(qkv), _p(qkv_h), lay.N, C, heads, window, _p(ek), _p(ev), _p(ek2), _p(ev2), b_split,
+                                                   _p(lay.col_off), lay.B, lay.max_w, _p(out), _ld(out) if out is not None else 0, _p(out_h),
+                                                   stream()), "as_relpos_attention_image_f32")
+    return out if out is not None else out_h
+
+
 def xl_attention(qkv, C, heads, pos, u_bias, v_bias, inv_scale, lay, out):
     check(_lib.lib().as_xl_attention_f32(_p(qkv), _ld(qkv), C, heads, _p(pos), _ld(pos), _p(u_bias), _p(v_bias), inv_scale,
                                          _p(lay.col_off), lay.B, lay.max_w, _p(out), _ld(out), stream()), "as_xl_attention_f32")

@@ -167,6 +167,13 @@ int as_channel_layernorm_split_f32(const float* x, int ldx, int C, int N, const 
 int as_relpos_attention_groups_f32(const float* qkv, int ld, int C, int heads, int window, const float* emb_rel_k,
                                    const float* emb_rel_v, const float* emb_rel_k2, const float* emb_rel_v2, int b_split,
                                    const int32_t* col_off, int B, int max_len, float* out, int ldo, as_stream_t stream);
+/* The same attention fed by the q/k/v projection's operand image (as_conv_gemm_f32 with Y and Yh: qkv fp32 [3C][ld] AND qkv_h, its image
+ * over n_total columns): Q / K fragments come straight from the image, only V is read as fp32.  128-channel heads.  Writes out fp32
+ * [C][ldo] and / or out_h, the operand image of the o-projection (n_total columns). */
+int as_relpos_attention_image_f32(const float* qkv, int ld, const uint16_t* qkv_h, int n_total, int C, int heads, int window,
+                                  const float* emb_rel_k, const float* emb_rel_v, const float* emb_rel_k2, const float* emb_rel_v2,
+                                  int b_split, const int32_t* col_off, int B, int max_len, float* out, int ldo, uint16_t* out_h,
+                                  as_stream_t stream);
 /* channel LayerNorm (eps 1e-4) (+ReLU)       RelTransformerEnc.py:272-290, :322-323 */
 int as_channel_layernorm_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta, float eps,
                              int relu, float* y, int ldy, as_stream_t stream);

@@ -357,6 +357,40 @@ def test_relpos_attention(cuda, lens, C, mode, monkeypatch):
     assert float((out.cpu() - want).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("lens", [[40, 33, 7, 64, 1, 63], [40] * 32, [1, 2, 70, 64, 65, 128, 129, 127], [700, 257, 3], [5]])
+def test_relpos_attention_from_image(cuda, lens):
+    """as_relpos_attention_image_f32: Q / K fragments straight from the q/k/v GEMM's operand image, V from its fp32 result; output as fp32
+    and as the o-projection's operand image (h + l = the fp32 output to 22 bits; the image's zero column written)"""
+    from oracle import acoustic
+    C = 512
+    g = torch.Generator().manual_seed(sum(lens))
+    W = {"a.emb_rel_k": torch.randn(1, 9, C // 4, generator=g) * 0.1, "a.emb_rel_v": torch.randn(1, 9, C // 4, generator=g) * 0.1}
+    for n in "qkvo":
+        W[f"a.conv_{n}.weight"] = torch.randn(C, C, 1, generator=g) / np.sqrt(C)
+        W[f"a.conv_{n}.bias"] = torch.randn(C, generator=g) * 0.1
+    xs = [torch.randn(C, L, generator=g) for L in lens]
+    Wid = dict(W)
+    Wid["a.conv_o.weight"], Wid["a.conv_o.bias"] = torch.eye(C)[:, :, None], torch.zeros(C)
+    want = packed([acoustic.relpos_attention(Wid, "a", x) for x in xs])
+    lay = Layout(lens, cuda)
+    wqkv = ops.prep_weight(torch.cat([W[f"a.conv_{n}.weight"] for n in "qkv"], 0), cuda)
+    bqkv = torch.cat([W[f"a.conv_{n}.bias"] for n in "qkv"], 0).to(cuda)
+    qkv, qkv_h = lay.new(3 * C), ops.new_image(3 * C, lay.N, cuda)
+    ops.conv_gemm(wqkv, packed(xs).to(cuda), lay, qkv, taps_1d(1), bias=bqkv, yh=qkv_h)
+    ek, ev = W["a.emb_rel_k"][0].contiguous().to(cuda), W["a.emb_rel_v"][0].contiguous().to(cuda)
+    out, out_h = lay.new(C), ops.new_image(C, lay.N, cuda)
+    out_h.fill_(0x3c00)                                            # (so that an unwritten zero column would be seen)
+    ops.relpos_attention_image(qkv, qkv_h, C, 4, 4, ek, ev, lay, out=out, out_h=out_h)
+    assert float((out.cpu() - want).abs().max()) <= 2e-5
+    parts = image_parts(out_h.cpu(), C, lay.N)
+    assert float(parts[:, :, lay.N].abs().max()) == 0.0
+    got = (parts[0] + parts[1])[:C, :lay.N]
+    assert float((got - out.cpu()).abs().max()) <= 2.0 ** -21 * float(out.abs().max())
+    only_h = ops.new_image(C, lay.N, cuda)
+    ops.relpos_attention_image(qkv, qkv_h, C, 4, 4, ek, ev, lay, out_h=only_h)
+    assert torch.equal(only_h[: ops.kbx(C) * 4 * (lay.N + 1) * 8].cpu(), out_h[: ops.kbx(C) * 4 * (lay.N + 1) * 8].cpu())
+
+
 @pytest.mark.parametrize("lens,mode", [([40, 12], None), ([40, 12, 0, 7, 1], "1"), ([40, 12, 0, 7, 1], "2"), ([33] * 32, None), ([300, 280], None),
                                        ([9] * 40, None)])
 def test_bilstm_cluster(cuda, lens, mode, monkeypatch):
