@@ -43,9 +43,9 @@ relpos_attention_kernel(const float* __restrict__ qkv, int ld, int C, int heads,
                         const float* __restrict__ emb_k1, const float* __restrict__ emb_v1, const float* __restrict__ emb_k2,
                         const float* __restrict__ emb_v2, int b_split, const int* __restrict__ col_off, float* __restrict__ out, int ldo)
 {
-    const bool second = emb_k2 && (int)blockIdx.z >= b_split;           // utterances >= b_split: the second encoder's tables
-    const float* emb_k = second ? emb_k2 : emb_k1;
-    const float* emb_v = second ? emb_v2 : emb_v1;
+    const int grp = emb_k2 ? (int)blockIdx.z / b_split : 0;             // utterance group g: tables first + g (second - first)
+    const float* emb_k = emb_k1 + (ptrdiff_t)grp * (emb_k2 - emb_k1);
+    const float* emb_v = emb_v1 + (ptrdiff_t)grp * (emb_v2 - emb_v1);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int dk = C / heads;
     const int nrel = 2 * window + 1;
@@ -181,9 +181,9 @@ relpos_attention_small_kernel(const float* __restrict__ qkv, int ld, int C, int 
                               const float* __restrict__ emb_v1, const float* __restrict__ emb_k2, const float* __restrict__ emb_v2,
                               int b_split, const int* __restrict__ col_off, float* __restrict__ out, int ldo)
 {
-    const bool second = emb_k2 && (int)blockIdx.y >= b_split;
-    const float* emb_k = second ? emb_k2 : emb_k1;
-    const float* emb_v = second ? emb_v2 : emb_v1;
+    const int grp = emb_k2 ? (int)blockIdx.y / b_split : 0;
+    const float* emb_k = emb_k1 + (ptrdiff_t)grp * (emb_k2 - emb_k1);
+    const float* emb_v = emb_v1 + (ptrdiff_t)grp * (emb_v2 - emb_v1);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Ks = sm;                              // [DK][SPAD]   (reused for the output transpose)
     float* Vs = Ks + DK * SPAD;                  // [DK][SPAD]
@@ -327,9 +327,9 @@ relpos_attention_mfma_kernel(const float* __restrict__ qkv, int ld, int C, int w
                              int b_split, const int* __restrict__ col_off, float* __restrict__ out, int ldo)
 {
     constexpr int DK = 128, KB = DK / 16, NT = NW * 64, NQ = NW * 32;
-    const bool second = emb_k2 && (int)blockIdx.z >= b_split;
-    const float* emb_k = second ? emb_k2 : emb_k1;
-    const float* emb_v = second ? emb_v2 : emb_v1;
+    const int grp = emb_k2 ? (int)blockIdx.z / b_split : 0;
+    const float* emb_k = emb_k1 + (ptrdiff_t)grp * (emb_k2 - emb_k1);
+    const float* emb_v = emb_v1 + (ptrdiff_t)grp * (emb_v2 - emb_v1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     // Kt[p][kb][g][key 64][8 fp16] (32 KB), Vt[p][c][g][d 128][8 fp16] (32 KB); the query tile is staged through the same bytes first
     u32x4_t* Kt = reinterpret_cast<u32x4_t*>(smraw);
@@ -616,9 +616,9 @@ relpos_attention_image_kernel(const AttnImageArgs a)
 #define ATTN_MARK()
 #endif
     ATTN_MARK();
-    const bool second = a.ek2 && (int)blockIdx.z >= a.b_split;
-    const float* emb_k = second ? a.ek2 : a.ek1;
-    const float* emb_v = second ? a.ev2 : a.ev1;
+    const int grp = a.ek2 ? (int)blockIdx.z / a.b_split : 0;
+    const float* emb_k = a.ek1 + (ptrdiff_t)grp * (a.ek2 - a.ek1);
+    const float* emb_v = a.ev1 + (ptrdiff_t)grp * (a.ev2 - a.ev1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     u32x4_t* Kt = reinterpret_cast<u32x4_t*>(smraw);                    // [2 buffers][p][kb][g][key 64]   (2 x 32 KB)
     u32x4_t* Vt = Kt + 2 * (2 * KB * 2 * FK);                           // [p][c][g][d 128]                (32 KB)
@@ -962,7 +962,7 @@ extern "C" int as_relpos_attention_image_f32(const float* qkv, int ld, const uin
                                              int b_split, const int32_t* col_off, int B, int max_len, float* out, int ldo, uint16_t* out_h,
                                              as_stream_t stream)
 {
-    if ((emb_rel_k2 == nullptr) != (emb_rel_v2 == nullptr)) return AS_EINVAL;
+    if ((emb_rel_k2 == nullptr) != (emb_rel_v2 == nullptr) || (emb_rel_k2 && b_split <= 0)) return AS_EINVAL;
     if (!qkv || !qkv_h || !emb_rel_k || !emb_rel_v || !col_off || (!out && !out_h) || C <= 0 || heads <= 0 || C % heads || n_total < 0 ||
         ld < n_total || (out && ldo < n_total))
         return AS_EINVAL;
@@ -981,7 +981,7 @@ extern "C" int as_relpos_attention_groups_f32(const float* qkv, int ld, int C, i
                                               const float* emb_rel_v, const float* emb_rel_k2, const float* emb_rel_v2, int b_split,
                                               const int32_t* col_off, int B, int max_len, float* out, int ldo, as_stream_t stream)
 {
-    if ((emb_rel_k2 == nullptr) != (emb_rel_v2 == nullptr)) return AS_EINVAL;
+    if ((emb_rel_k2 == nullptr) != (emb_rel_v2 == nullptr) || (emb_rel_k2 && b_split <= 0)) return AS_EINVAL;
     if (!qkv || !emb_rel_k || !emb_rel_v || !col_off || !out || C <= 0 || heads <= 0 || C % heads) return AS_EINVAL;
     const int dk = C / heads;
     if (dk > MAXDK || 2 * window + 1 > MAXREL || window < 0 || B < 0) return AS_EINVAL;

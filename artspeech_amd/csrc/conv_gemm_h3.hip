@@ -779,9 +779,9 @@ channel_ln_split_kernel(const float* __restrict__ x, int ldx, int C, int N, cons
     const int col = threadIdx.x % LNS_COLS, part = threadIdx.x / LNS_COLS;
     const int j = blockIdx.x * LNS_COLS + col;
     const bool ok = j < N;
-    const bool second = gamma2 && j >= n_split;
-    const float* gamma = second ? gamma2 : gamma1;
-    const float* beta = second ? beta2 : beta1;
+    const int grp = gamma2 ? j / n_split : 0;
+    const float* gamma = gamma1 + (ptrdiff_t)grp * (gamma2 - gamma1);
+    const float* beta = beta1 + (ptrdiff_t)grp * (beta2 - beta1);
     const int ngroups = 2 * KBx;                                         // 8-channel groups of the image (zero beyond C)
     float v[LNS_MAXG][8];
     float s = 0.f;
@@ -853,7 +853,7 @@ extern "C" int as_channel_layernorm_split_f32(const float* x, int ldx, int C, in
                                               as_stream_t stream)
 {
     if (!x || !xs || !gamma || !beta || C <= 0 || C > 8 * LNS_PARTS * LNS_MAXG || N <= 0 || ldx < N ||
-        ((gamma2 == nullptr) != (beta2 == nullptr)) || (reinterpret_cast<uintptr_t>(xs) & 15) != 0)
+        ((gamma2 == nullptr) != (beta2 == nullptr)) || (gamma2 && n_split <= 0) || (reinterpret_cast<uintptr_t>(xs) & 15) != 0)
         return AS_EINVAL;
     const int KBx = as_kbx(C);
     AsProfScope prof__(AS_CLS_LN, 8.0 * C * N, 8.0 * C * (double)N, (hipStream_t)stream);

@@ -54,10 +54,11 @@ __global__ void embed_kernel(const int* __restrict__ tok, int n_tok, const float
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (j >= N) return;
-    const int src = j < n_tok ? j : j - n_split;
-    int t = (src >= 0 && src < n_tok) ? tok[src] : 0;
+    const int g = emb2 ? j / n_split : 0;                // column group: table g = emb + g (emb2 - emb), its columns re-read the token list
+    const int src = j - g * n_split;
+    int t = src < n_tok ? tok[src] : 0;
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-    const float* e = (emb2 && j >= n_split) ? emb2 : emb;
+    const float* e = emb + (ptrdiff_t)g * (emb2 - emb);
     y[(size_t)c * ldy + j] = e[(size_t)t * C + c] * scale;
 }
 
@@ -65,7 +66,7 @@ extern "C" int as_embed_groups_f32(const int32_t* tokens, int n_tok, const float
                                    float scale, float* y, int ldy, as_stream_t stream)
 {
     if (!tokens || !emb || !y || C <= 0 || N < 0 || V <= 0 || ldy < N || n_tok < 0 || n_tok > N) return AS_EINVAL;
-    if (n_tok < N && (!emb2 || n_split < n_tok || n_split + n_tok > N)) return AS_EINVAL;
+    if ((emb2 && n_split <= 0) || (n_tok < N && (!emb2 || n_split < n_tok))) return AS_EINVAL;
     if (N == 0) return AS_OK;
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(embed_kernel, dim3(as_cdiv(N, 64), C), dim3(64), 0, (hipStream_t)stream, tokens, n_tok, emb, emb2, n_split, C, N, V,
@@ -97,9 +98,9 @@ channel_ln_kernel(const float* __restrict__ x, int ldx, int C, int N, const floa
     const int col = threadIdx.x % LN_COLS, part = threadIdx.x / LN_COLS;
     const int j = blockIdx.x * LN_COLS + col;
     const bool ok = j < N;
-    const bool second = gamma2 && j >= n_split;          // columns >= n_split: the second encoder's affine parameters
-    const float* gamma = second ? gamma2 : gamma1;
-    const float* beta = second ? beta2 : beta1;
+    const int grp = gamma2 ? j / n_split : 0;            // column group g: affine parameters first + g (second - first)
+    const float* gamma = gamma1 + (ptrdiff_t)grp * (gamma2 - gamma1);
+    const float* beta = beta1 + (ptrdiff_t)grp * (beta2 - beta1);
     float v[LN_MAXV];
     float s = 0.f;
 #pragma unroll
@@ -154,7 +155,9 @@ extern "C" int as_channel_layernorm_groups_f32(const float* x, int ldx, int C, i
                                                const float* gamma2, const float* beta2, int n_split, float eps, int relu, float* y,
                                                int ldy, as_stream_t stream)
 {
-    if (!x || !y || !gamma || !beta || C <= 0 || N < 0 || ldx < N || ldy < N || ((gamma2 == nullptr) != (beta2 == nullptr))) return AS_EINVAL;
+    if (!x || !y || !gamma || !beta || C <= 0 || N < 0 || ldx < N || ldy < N || ((gamma2 == nullptr) != (beta2 == nullptr)) ||
+        (gamma2 && n_split <= 0))
+        return AS_EINVAL;
     if (N == 0) return AS_OK;
     AsProfScope prof__(AS_CLS_LN, 8.0 * C * N, 8.0 * C * N, (hipStream_t)stream);
     hipLaunchKernelGGL(channel_ln_kernel, dim3(as_cdiv(N, LN_COLS)), dim3(1024), 0, (hipStream_t)stream, x, ldx, C, N, gamma,

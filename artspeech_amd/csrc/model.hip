@@ -194,16 +194,16 @@ struct as_model {
         return vec_stack(n);
     }
     // q / k / v projections of one attention layer as one [3C] GEMM (RelTransformerEnc.py:128-133)
-    const GemmW* qkv(const std::string& p, const std::string& p2, const float** bias_out) const
+    const GemmW* qkv(const std::vector<std::string>& ps, const float** bias_out) const
     {
-        const std::string key = "QKV:" + p + "|" + p2;
+        std::string key = "QKV:";
+        for (const std::string& q : ps) key += q + "|";
         auto it = gemm.find(key);
         if (it == gemm.end()) {
             if (frozen) { if (!err) err = AS_EINVAL; return nullptr; }
             std::vector<float> w, b;
             int C = 0, G = 0;
-            for (const std::string& q : {p, p2}) {
-                if (q.empty()) continue;
+            for (const std::string& q : ps) {
                 ++G;
                 for (const char* n : {"q", "k", "v"}) {
                     const HostT* wt = host(q + ".conv_" + n + ".weight");
@@ -825,60 +825,125 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
     return Y;
 }
 
-// RelTransformerEncoder.forward (RelTransformerEnc.py:371-380) on packed tokens -> [C][N].
-// p2: a SECOND encoder of the same shape whose weights serve the columns >= n_split / utterances >= b_split of `lay`
-// (the text and articulatory encoders are twins on the same tokens): both run as one double-width launch sequence.
-float* rel_encoder(Ctx& c, const std::string& p, const int32_t* tokens, const Lay* lay, int n_layers, const std::string& p2 = std::string(),
-                   int n_split = 0, int b_split = 0, int n_tok = -1)
+// RelTransformerEncoder.forward (RelTransformerEnc.py:371-380) for SEVERAL encoders of the same shape on the same tokens
+// (text_encoder, arts_encoder, durationPredictor.text_encoder: models.py:358-359,549) as ONE multi-width launch sequence: the tokens
+// are laid out once per encoder, [utterances | filler up to a multiple of 128 columns | utterances | ...]; encoder g owns columns
+// [g * gc, g * gc + N) and utterances [g * bg, g * bg + B); conv GEMMs pick weight set g per column tile (ConvGemmArgs.n_groups),
+// embedding / LayerNorm / attention take parameter set g of a stack.  Encoders are listed deepest first: when a shallower one has run
+// its last layer its result is finished (its own last LayerNorm) and the launches continue on the remaining, leading groups.
+// Half the launches (a third with three encoders) and fuller tiles: M1024 N3840 is 240 tiles of 128 x 128, one round of the chip.
+struct EncSpec {
+    std::string prefix;
+    int layers;
+};
+struct EncOut {
+    float* y[4] = {nullptr, nullptr, nullptr, nullptr};   // [C][ld[g]] per encoder
+    int ld[4] = {0, 0, 0, 0};
+};
+template <class Done>
+bool rel_encoder_multi(Ctx& c, const std::vector<EncSpec>& enc, const int32_t* tokens, const Lay* lay1, EncOut* out, Done&& done)
 {
     const as_model& m = c.m;
-    const bool pair = !p2.empty();
-    const HostT* emb_h = m.host(p + ".emb.weight");
-    if (!emb_h || !lay) { c.fail(AS_EINVAL); return nullptr; }
-    const int V = emb_h->dim(0), C = emb_h->dim(1), N = lay->N, Nn = std::max(N, 1);
-    auto n2 = [&](const std::string& suffix) { return pair ? p2 + suffix : std::string(); };
-    const int gc = pair ? n_split : 0;
-    float* x = c.f32((size_t)C * Nn);
+    const int G = (int)enc.size();
+    if (G < 1 || G > 4 || !lay1) { c.fail(AS_EINVAL); return false; }
+    for (int g = 1; g < G; ++g)
+        if (enc[g].layers > enc[g - 1].layers) { c.fail(AS_EINVAL); return false; }
+    const HostT* emb_h = m.host(enc[0].prefix + ".emb.weight");
+    if (!emb_h) { c.fail(AS_EINVAL); return false; }
+    const int V = emb_h->dim(0), C = emb_h->dim(1), N1 = lay1->N;
+    const int pad = G > 1 ? (128 - N1 % 128) % 128 : 0, gc = N1 + pad, bg = lay1->B + (pad ? 1 : 0);
+    // layouts of the first k groups, k = G .. 1
+    std::vector<const Lay*> lays(G + 1, nullptr);
+    {
+        std::vector<int> w;
+        for (int k = 1; k <= G; ++k) {
+            if (k > 1 && pad) w.push_back(pad);
+            w.insert(w.end(), lay1->w.begin(), lay1->w.end());
+            lays[k] = c.lay(w);
+            if (!lays[k]) return false;
+        }
+    }
+    const int ld = std::max(lays[G]->N, 1);
+    auto names = [&](const std::string& sfx, int k) {
+        std::vector<std::string> n;
+        for (int g = 0; g < k; ++g) n.push_back(enc[g].prefix + sfx);
+        return n;
+    };
     // every weight is looked up OUTSIDE the RUN(...) arguments: the prepare pass (as_model_create) runs this code with
     // launches disabled and must still see each name
-    const float *emb1 = m.vec(p + ".emb.weight"), *emb2 = pair ? m.vec(p2 + ".emb.weight") : nullptr;
-    if (N > 0) RUN(c, as_embed_groups_f32(tokens, n_tok < 0 ? N : n_tok, emb1, emb2, n_split, C, N, V, sqrtf((float)C), x, N, c.s));
+    auto stack2 = [&](const std::string& sfx, int k, const float** second) {   // parameter stack of the first k encoders; *second = set 1
+        const HostT* h0 = m.host(enc[0].prefix + sfx);
+        const float* s0 = m.vec_stack(names(sfx, k));
+        *second = (k > 1 && s0 && h0) ? s0 + h0->v.size() : nullptr;
+        return s0;
+    };
+    float* x = c.f32((size_t)C * ld);
+    {
+        const float* e2 = nullptr;
+        const float* e1 = stack2(".emb.weight", G, &e2);
+        if (lays[G]->N > 0) RUN(c, as_embed_groups_f32(tokens, N1, e1, e2, gc, C, lays[G]->N, V, sqrtf((float)C), x, ld, c.s));
+    }
     // conv(LayerNorm(xin)): the normalised activations exist only as the conv's operand image
-    auto ln_image = [&](const float* xin, const std::string& ln, bool relu) {
+    auto ln_image = [&](const float* xin, const std::string& ln, bool relu, int k) {
+        const int N = lays[k]->N;
         uint16_t* xs = c.image(C, N);
-        const float *g1 = m.vec(p + ln + ".gamma"), *b1 = m.vec(p + ln + ".beta");
-        const float *g2 = pair ? m.vec(p2 + ln + ".gamma") : nullptr, *b2 = pair ? m.vec(p2 + ln + ".beta") : nullptr;
-        if (N > 0) RUN(c, as_channel_layernorm_split_f32(xin, N, C, N, g1, b1, g2, b2, n_split, 1e-4f, relu, xs, c.s));
+        const float *g2 = nullptr, *b2 = nullptr;
+        const float *g1 = stack2(ln + ".gamma", k, &g2), *b1 = stack2(ln + ".beta", k, &b2);
+        if (N > 0) RUN(c, as_channel_layernorm_split_f32(xin, ld, C, N, g1, b1, g2, b2, gc, 1e-4f, relu, xs, c.s));
         return xs;
     };
-    auto cw = [&](const std::string& name) { return m.conv(p + name, n2(name)); };
-    auto cb = [&](const std::string& name) { return m.bias(p + name, n2(name)); };
-    const Taps k5 = taps_1d(5), k1 = taps_1d(1), k9 = taps_1d(9);
-    float* h;
-    {                                                                          // ConvReluNorm, RelTransformerEnc.py:318-325
+    auto cw = [&](const std::string& name, int k) { return m.conv_stack(names(name, k)); };
+    auto cb = [&](const std::string& name, int k) { return m.bias_stack(names(name, k)); };
+    auto opt = [&](const std::string& bias_of, int k) {
         ConvOpt o;
-        o.bias = cb(".pre.conv_layers.0");
-        o.group_cols = gc;
-        h = conv_x_new(c, cw(".pre.conv_layers.0"), x, N, C, lay, k5, o);
+        o.bias = cb(bias_of, k);
+        o.group_cols = k > 1 ? gc : 0;
+        return o;
+    };
+    const Taps k5 = taps_1d(5), k1 = taps_1d(1), k9 = taps_1d(9);
+    float* h = c.f32((size_t)C * ld);
+    {                                                                          // ConvReluNorm, RelTransformerEnc.py:318-325
+        conv_x(c, cw(".pre.conv_layers.0", G), x, ld, C, lays[G], k5, h, ld, opt(".pre.conv_layers.0", G));
         for (int i = 0; i < 3; ++i) {
-            uint16_t* xs = ln_image(h, ".pre.norm_layers." + std::to_string(i), true);
+            uint16_t* xs = ln_image(h, ".pre.norm_layers." + std::to_string(i), true, G);
             const std::string nxt = i < 2 ? ".pre.conv_layers." + std::to_string(i + 1) : std::string(".pre.proj");
-            ConvOpt q;
-            q.bias = cb(nxt);
-            q.group_cols = gc;
-            if (i == 2) { q.res = x; q.ldr = N; }
-            h = conv_h_new(c, cw(nxt), xs, C, lay, i < 2 ? k5 : k1, q);
+            ConvOpt q = opt(nxt, G);
+            if (i == 2) { q.res = x; q.ldr = ld; }
+            float* hn = c.f32((size_t)C * ld);
+            conv_h(c, cw(nxt, G), xs, C, lays[G], i < 2 ? k5 : k1, hn, ld, q);
+            h = hn;
         }
     }
     x = h;
     const std::string e = ".encoder";
-    for (int i = 0; i < n_layers; ++i) {                                       // Encoder.forward, RelTransformerEnc.py:66-90
+    // one encoder's result: its own last LayerNorm on its columns
+    auto finish = [&](int g0, int g1) {                                        // encoders g0 .. g1 - 1 (they share the remaining depth)
+        const int Nk = (g1 - g0 - 1) * gc + N1;                                // columns from group g0's first to group g1 - 1's last
+        float* y = c.f32((size_t)C * std::max(Nk, 1));
+        std::vector<std::string> ng, nb;
+        for (int g = g0; g < g1; ++g) { ng.push_back(enc[g].prefix + e + ".last_ln.gamma"); nb.push_back(enc[g].prefix + e + ".last_ln.beta"); }
+        const float *lg = m.vec_stack(ng), *lb = m.vec_stack(nb);
+        const float *lg2 = g1 - g0 > 1 && lg ? lg + C : nullptr, *lb2 = g1 - g0 > 1 && lb ? lb + C : nullptr;
+        if (Nk > 0) RUN(c, as_channel_layernorm_groups_f32(x + (size_t)g0 * gc, ld, C, Nk, lg, lb, lg2, lb2, gc, 1e-4f, 0, y, Nk, c.s));
+        for (int g = g0; g < g1; ++g) {
+            out->y[g] = y + (size_t)(g - g0) * gc;
+            out->ld[g] = std::max(Nk, 1);
+        }
+        for (int g = g0; g < g1; ++g) done(g);
+    };
+    int k = G;
+    for (int i = 0; i < enc[0].layers; ++i) {                                  // Encoder.forward, RelTransformerEnc.py:66-90
+        int kn = 0;
+        while (kn < G && enc[kn].layers > i) ++kn;                             // encoders that have a layer i
+        if (kn < k) { finish(kn, k); k = kn; }
+        const Lay* lay = lays[k];
+        const int N = lay->N;
         const std::string a = e + ".attn_layers." + std::to_string(i), f = e + ".ffn_layers." + std::to_string(i);
         const float* bqkv = nullptr;
-        const GemmW* wqkv = m.qkv(p + a, pair ? p2 + a : std::string(), &bqkv);
+        const GemmW* wqkv = m.qkv(names(a, k), &bqkv);
         ConvOpt o;
         o.bias = bqkv;
-        o.group_cols = gc;
+        o.group_cols = k > 1 ? gc : 0;
         // 128-channel heads (the shipped model): the q/k/v GEMM also writes its result as an operand image, the attention kernel takes
         // Q / K fragments straight from it and writes the o-projection's operand image -- no fp32 attention output, no split pass
         const bool img = C / N_HEADS == 128;
@@ -886,63 +951,47 @@ float* rel_encoder(Ctx& c, const std::string& p, const int32_t* tokens, const La
             o.want_yh = true;
             o.yh = c.image(3 * C, N);
         }
-        float* qkv = conv_h_new(c, wqkv, ln_image(x, e + ".norm_layers_1." + std::to_string(i), false), C, lay, k1, o);
-        float* att = img ? nullptr : c.f32((size_t)C * Nn);
+        float* qkv = conv_h_new(c, wqkv, ln_image(x, e + ".norm_layers_1." + std::to_string(i), false, k), C, lay, k1, o);
+        float* att = img ? nullptr : c.f32((size_t)C * std::max(N, 1));
         uint16_t* att_h = img ? c.image(C, N) : nullptr;
-        const float *ek = m.vec(p + a + ".emb_rel_k"), *ev = m.vec(p + a + ".emb_rel_v");
-        const float *ek2 = pair ? m.vec(p2 + a + ".emb_rel_k") : nullptr, *ev2 = pair ? m.vec(p2 + a + ".emb_rel_v") : nullptr;
+        const float *ek2 = nullptr, *ev2 = nullptr;
+        const float *ek = stack2(a + ".emb_rel_k", k, &ek2), *ev = stack2(a + ".emb_rel_v", k, &ev2);
         if (N > 0 && img)
-            RUN(c, as_relpos_attention_image_f32(qkv, N, o.yh, N, C, N_HEADS, WINDOW, ek, ev, ek2, ev2, b_split, lay->d_off, lay->B, lay->max_w,
-                                                 nullptr, 0, att_h, c.s));
+            RUN(c, as_relpos_attention_image_f32(qkv, N, o.yh, N, C, N_HEADS, WINDOW, ek, ev, ek2, ev2, bg, lay->d_off, lay->B, lay->max_w, nullptr,
+                                                 0, att_h, c.s));
         else if (N > 0)
-            RUN(c, as_relpos_attention_groups_f32(qkv, N, C, N_HEADS, WINDOW, ek, ev, ek2, ev2, b_split, lay->d_off, lay->B, lay->max_w, att, N, c.s));
-        ConvOpt oo;
-        oo.bias = cb(a + ".conv_o");
+            RUN(c, as_relpos_attention_groups_f32(qkv, N, C, N_HEADS, WINDOW, ek, ev, ek2, ev2, bg, lay->d_off, lay->B, lay->max_w, att, N, c.s));
+        ConvOpt oo = opt(a + ".conv_o", k);
         oo.res = x;
-        oo.ldr = N;
-        oo.group_cols = gc;
-        x = img ? conv_h_new(c, cw(a + ".conv_o"), att_h, C, lay, k1, oo) : conv_x_new(c, cw(a + ".conv_o"), att, N, C, lay, k1, oo);
+        oo.ldr = ld;
+        float* xo = c.f32((size_t)C * ld);
+        if (img) conv_h(c, cw(a + ".conv_o", k), att_h, C, lay, k1, xo, ld, oo);
+        else conv_x(c, cw(a + ".conv_o", k), att, N, C, lay, k1, xo, ld, oo);
+        // a shallower encoder's columns past the active groups keep their values in the OLD buffer: `finish` ran before this layer
+        x = xo;
         // FFN (RelTransformerEnc.py:261-269): conv k9 -> ReLU exists only as the 1x1 conv's operand image
-        const GemmW* w1 = cw(f + ".conv_1");
-        if (!w1) { c.fail(AS_EINVAL); return nullptr; }
+        const GemmW* w1 = cw(f + ".conv_1", k);
+        if (!w1) { c.fail(AS_EINVAL); return false; }
         uint16_t* yh = c.image(w1->M, N);
-        ConvOpt o1;
-        o1.bias = cb(f + ".conv_1");
+        ConvOpt o1 = opt(f + ".conv_1", k);
         o1.act = ACT_RELU;
-        o1.group_cols = gc;
         o1.want_yh = true;
         o1.yh = yh;
-        conv_h(c, w1, ln_image(x, e + ".norm_layers_2." + std::to_string(i), false), C, lay, k9, nullptr, N, o1);
-        ConvOpt o2;
-        o2.bias = cb(f + ".conv_2");
+        conv_h(c, w1, ln_image(x, e + ".norm_layers_2." + std::to_string(i), false, k), C, lay, k9, nullptr, N, o1);
+        ConvOpt o2 = opt(f + ".conv_2", k);
         o2.res = x;
-        o2.ldr = N;
-        o2.group_cols = gc;
-        x = conv_h_new(c, cw(f + ".conv_2"), yh, w1->M, lay, k1, o2);
+        o2.ldr = ld;
+        float* xf = c.f32((size_t)C * ld);
+        conv_h(c, cw(f + ".conv_2", k), yh, w1->M, lay, k1, xf, ld, o2);
+        x = xf;
     }
-    float* y = c.f32((size_t)C * Nn);
-    const float *lg = m.vec(p + e + ".last_ln.gamma"), *lb = m.vec(p + e + ".last_ln.beta");
-    const float *lg2 = pair ? m.vec(p2 + e + ".last_ln.gamma") : nullptr, *lb2 = pair ? m.vec(p2 + e + ".last_ln.beta") : nullptr;
-    if (N > 0) RUN(c, as_channel_layernorm_groups_f32(x, N, C, N, lg, lb, lg2, lb2, n_split, 1e-4f, 0, y, N, c.s));
-    return y;
+    finish(0, k);
+    return c.rc == 0;
 }
 
-// Two encoders of the same shape on the same tokens (text_encoder / arts_encoder, models.py:358-359) as ONE double-width
-// encoder: the tokens are laid out twice, [utterances | filler up to a multiple of 128 columns | utterances].
-// Returns the double-width result [C][ld]; encoder 1 at column 0, encoder 2 at column *second.
-float* rel_encoder_pair(Ctx& c, const std::string& p1, const std::string& p2, const int32_t* tokens, const Lay* lay, int n_layers, int* second,
-                        int* ld)
-{
-    const int N = lay->N, pad = (128 - N % 128) % 128;
-    std::vector<int> w(lay->w);
-    if (pad) w.push_back(pad);
-    w.insert(w.end(), lay->w.begin(), lay->w.end());
-    const Lay* lay2 = c.lay(w);
-    if (!lay2) return nullptr;
-    *second = N + pad;
-    *ld = lay2->N;
-    return rel_encoder(c, p1, tokens, lay2, n_layers, p2, N + pad, lay->B + (pad ? 1 : 0), N);     // the embedding reads the token list twice
-}
+// the path's three encoders (models.py:358-359,549), deepest first
+std::vector<EncSpec> path_encoders() { return {{"arts_encoder", 4}, {"text_encoder", 4}, {"durationPredictor.text_encoder", 2}}; }
+enum { ENC_ARTS = 0, ENC_TEXT = 1, ENC_DUR = 2 };
 
 // ResBlk (models.py:79-100) / ResBlk1d(downsample=True) (models.py:127-156).  X.h, if set, is the operand image of
 // LeakyReLU(X) (what conv1 reads); the result carries the same for the next block when want_image.
@@ -1468,26 +1517,35 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     const int only = only_env ? atoi(only_env) : -1;
     const bool launch0 = c.launch;
     auto gate = [&](int k) { c.launch = launch0 && (only < 0 || only == k); };
-    Fork f(c, 4, 0);
+    // Side streams: the mel tower and the three small towers.  The calling stream runs the three encoders as one triple-width encoder;
+    // when the duration predictor's (2 layers) is finished its tail forks off to a third side stream while the text / articulatory pair
+    // runs its last two layers.  (Every edge is calling stream <-> side stream: side-to-side edges break hipGraph instantiation.)
+    Fork f(c, 2, 0);
     f.branch(0);
-    gate(0);
-    int second = 0;
-    float* enc = rel_encoder_pair(c, "arts_encoder", "text_encoder", io->tokens, A.tok, 4, &second, &A.ld_en);
-    A.a_en = enc;
-    A.t_en = enc ? enc + second : nullptr;
-    f.branch(1);
     gate(1);
     style_tower(c, 0, si, A.style);
-    f.branch(2);
-    gate(2);
-    duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
-    {
-        float* d = rel_encoder(c, "durationPredictor.text_encoder", io->tokens, A.tok, 2);
-        A.duration = duration_tail(c, d, ds, A.tok, io->duration);
-    }
-    f.branch(3);
+    f.branch(1);
     gate(3);
     for (int t = 1; t <= 3; ++t) style_tower(c, t, si, A.style);
+    f.back();
+    gate(0);
+    EncOut eo;
+    std::unique_ptr<Fork> f2;
+    rel_encoder_multi(c, path_encoders(), io->tokens, A.tok, &eo, [&](int g) {
+        if (g != ENC_DUR) return;
+        const bool l0 = c.launch;
+        f2.reset(new Fork(c, 1, 2));
+        f2->branch(0);
+        gate(2);
+        duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
+        A.duration = duration_tail(c, eo.y[ENC_DUR], ds, A.tok, io->duration);
+        f2->back();
+        c.launch = l0;
+    });
+    A.a_en = eo.y[ENC_ARTS];
+    A.t_en = eo.y[ENC_TEXT];
+    A.ld_en = eo.ld[ENC_ARTS];
+    if (f2) f2->join();
     c.launch = launch0;
     f.join();
     if (c.go()) c.p.mark(2, c.s);
@@ -1806,9 +1864,8 @@ size_t count_module(const as_model* m, as_plan* p, int module, const as_batch* b
     case AS_MOD_ENCODER: {
         if (!batch_ok(batch, true, false, false)) return 0;
         const Lay* lay = c.lay(vec_of(batch->tok_lens, B));
-        int second = 0, ld = 0;
-        if (lay) rel_encoder_pair(c, "arts_encoder", "text_encoder", io->tokens, lay, 4, &second, &ld);
-        if (lay) rel_encoder(c, "durationPredictor.text_encoder", io->tokens, lay, 2);
+        EncOut eo;
+        if (lay) rel_encoder_multi(c, path_encoders(), io->tokens, lay, &eo, [](int) {});
         break;
     }
     case AS_MOD_STYLE: {
@@ -1825,7 +1882,9 @@ size_t count_module(const as_model* m, as_plan* p, int module, const as_batch* b
         if (!tok || !ref) return 0;
         float* ds = c.f32((size_t)B * (m->cfg.style_dim / 4));
         duration_style(c, nullptr, ref->N, ref, ds);
-        duration_tail(c, rel_encoder(c, "durationPredictor.text_encoder", io->tokens, tok, 2), ds, tok);
+        EncOut eo;
+        rel_encoder_multi(c, path_encoders(), io->tokens, tok, &eo, [](int) {});
+        duration_tail(c, eo.y[ENC_DUR], ds, tok);
         break;
     }
     case AS_MOD_ARTS: {
@@ -1881,16 +1940,12 @@ extern "C" int as_encoder_forward(const as_model* m, as_plan* p, int which, cons
     Ctx& c = k.c;
     const Lay* lay = c.lay(vec_of(batch->tok_lens, batch->B));
     if (!lay || ldo < lay->N) return AS_EINVAL;
-    // the text and articulatory encoders exist as ONE stacked weight set (they always run together in the path): a single one
-    // is asked for by running the pair and returning its half
-    if (which == 2) {
-        float* y = rel_encoder(c, "durationPredictor.text_encoder", tokens, lay, 2);
-        copy_rows(c, out, ldo, y, lay->N, m->cfg.hidden_dim, lay->N);
-    } else {
-        int second = 0, ld = 0;
-        float* y = rel_encoder_pair(c, "arts_encoder", "text_encoder", tokens, lay, 4, &second, &ld);
-        copy_rows(c, out, ldo, y ? y + (which == 0 ? second : 0) : nullptr, ld, m->cfg.hidden_dim, lay->N);
-    }
+    // the three encoders exist as ONE stacked weight set (they always run together in the path): a single one is asked for by
+    // running all of them and returning its columns
+    EncOut eo;
+    rel_encoder_multi(c, path_encoders(), tokens, lay, &eo, [](int) {});
+    const int g = which == 0 ? ENC_TEXT : (which == 1 ? ENC_ARTS : ENC_DUR);
+    copy_rows(c, out, ldo, eo.y[g], eo.ld[g], m->cfg.hidden_dim, lay->N);
     return k.done();
 }
 
@@ -1919,7 +1974,9 @@ extern "C" int as_duration_forward(const as_model* m, as_plan* p, const as_batch
     if (!tok || !ref || lde < ref->N) return AS_EINVAL;
     float* ds = c.f32((size_t)batch->B * (m->cfg.style_dim / 4));
     duration_style(c, ema_ext, lde, ref, ds);
-    duration_tail(c, rel_encoder(c, "durationPredictor.text_encoder", tokens, tok, 2), ds, tok, duration);
+    EncOut eo;
+    rel_encoder_multi(c, path_encoders(), tokens, tok, &eo, [](int) {});
+    duration_tail(c, eo.y[ENC_DUR], ds, tok, duration);
     return k.done();
 }
 

@@ -152,10 +152,11 @@ int as_prep_weight_f16x2_host(const float* w_host, int G, int Cout, int Cin, int
 /* emb(x)*sqrt(C), transposed to [C][N]      RelTransformerEnc.py:373-374 */
 int as_embed_f32(const int32_t* tokens, const float* emb, int C, int N, int V, float scale, float* y, int ldy,
                  as_stream_t stream);
-/* the *_groups_* variants: columns >= n_split (utterances >= b_split) take the SECOND parameter set -- two encoders of the same
+/* the *_groups_* variants: column group g = column / n_split (utterance group g = utterance / b_split) takes parameter set
+ * first + g * (second - first): two separately stored sets for two groups, or any number of equally spaced ones (a stack) -- encoders of the same
  * shape run as one double-width launch (ConvGemmArgs.n_groups is the GEMM's counterpart); NULL second set = the plain call */
-/* as_embed_groups_f32: tokens holds n_tok ids.  n_tok == N: one id per column.  n_tok < N (the same tokens through both tables):
- * columns [n_tok, n_split) are filler (id 0 of the first table), column n_split + j reads tokens[j] again. */
+/* as_embed_groups_f32: tokens holds n_tok ids.  n_tok == N: one id per column.  n_tok < N (the same tokens through every table):
+ * column g * n_split + j reads tokens[j]; columns past n_tok inside a group are filler (id 0). */
 int as_embed_groups_f32(const int32_t* tokens, int n_tok, const float* emb, const float* emb2, int n_split, int C, int N, int V,
                         float scale, float* y, int ldy, as_stream_t stream);
 int as_channel_layernorm_groups_f32(const float* x, int ldx, int C, int N, const float* gamma, const float* beta, const float* gamma2,

@@ -259,7 +259,7 @@ def test_layernorm_split_equals_layernorm_then_split(cuda, C, lens, relu):
     X = (torch.randn(C, lay.N, generator=g) * 3 + 1).to(cuda)
     ga, be = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
     ga2, be2 = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
-    n_split = lay.N // 2
+    n_split = (lay.N + 1) // 2                                    # two column groups (group g = column // n_split takes set g)
     grp = (ga2, be2, n_split)
     want = ops.channel_layernorm(X, lay.N, ga, be, lay.new(C), relu=relu, group2=grp)[:, : lay.N]
     xs = ops.channel_layernorm_split(X, lay, ga, be, relu=relu, group2=grp)
