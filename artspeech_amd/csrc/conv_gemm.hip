@@ -10,6 +10,7 @@
 //   nn.Conv1d k in {1,3,5,9}  (RelTransformerEnc.py:110-118,257-258,306-314; models.py:176-181,480-495,592-594)
 //   nn.Conv2d 3x3 / 1x1       (models.py:71-77, 385-399, 530-535)
 //   nn.Linear on [*, C] rows  (the LSTM input projections, hoisted out of the recurrence)
+#include <algorithm>
 #include "common.h"
 #include "conv_gemm.h"
 #include <cstdio>
@@ -62,10 +63,13 @@ conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
     u32x4_t* yh = reinterpret_cast<u32x4_t*>(a.Yh);
     const size_t NX = (size_t)a.N + 1;
     const int groups = yh ? 2 * as_kbx(a.M) : (a.M + 7) / 8;
+    // blockIdx.y takes a share of the channel groups: few columns (the 1-D towers: 7 column blocks) would otherwise leave the chip to
+    // 7 workgroups walking 64 channels each (47 us for 1.6 MB of output)
+    const int gpb = (groups + (int)gridDim.y - 1) / (int)gridDim.y, g_lo = blockIdx.y * gpb, g_hi = min(groups, g_lo + gpb);
     if (yh && blockIdx.x == 0 && threadIdx.x == 0)
-        for (int g = 0; g < groups; ++g)
+        for (int g = g_lo; g < g_hi; ++g)
             for (int p = 0; p < 2; ++p) yh[((size_t)(g >> 1) * 4 + (g & 1) + 2 * p) * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};
-    for (int g = 0; g < groups; ++g) {
+    for (int g = g_lo; g < g_hi; ++g) {
         float t8[4][8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -338,8 +342,10 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
         AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.T, 4.0 * ((double)a.T * a.M + a.N + (double)a.M * a.N), stream, tag);
         if (a.T <= 9) {
             const bool vec = a.Y && (a.N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0;
-            if (vec) hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<true>, dim3(as_cdiv(a.N, 1024)), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<false>, dim3(as_cdiv(a.N, 1024)), dim3(256), 0, stream, a);
+            const int nx = as_cdiv(a.N, 1024), groups = a.Yh ? 2 * as_kbx(a.M) : (a.M + 7) / 8;
+            const int ny = std::max(1, std::min(groups, as_cdiv(1024, nx)));        // >= ~1024 workgroups when the channels allow it
+            if (vec) hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<true>, dim3(nx, ny), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<false>, dim3(nx, ny), dim3(256), 0, stream, a);
         } else {
             hipLaunchKernelGGL(conv_direct_cin1_kernel, dim3(as_cdiv(a.N, 256)), dim3(256), 0, stream, a);
         }

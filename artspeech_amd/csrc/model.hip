@@ -565,6 +565,12 @@ struct Fork {
     }
     void branch(int i) { c.s = on_side ? c.p.stream(first + i) : main; }
     void back() { c.s = main; }            // continue on the calling stream while the branches run; join() later
+    void wait_main(int i)                  // branch i continues only after what the calling stream has enqueued so far
+    {
+        if (!on_side) return;
+        hipEvent_t e = c.p.event();
+        if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(c.p.stream(first + i), e, 0) != hipSuccess) c.fail((int)hipErrorUnknown);
+    }
     void join()
     {
         c.s = main;
@@ -1066,7 +1072,7 @@ Act tower_stem(Ctx& c, const std::string& name, const float* X, int ldx, const L
     o.want_yh = true;
     o.yh = c.image(w0->M, lay->N);
     o.yh_lrelu = true;
-    x.p = conv_x_new(c, w0, X, ldx, 1, lay, taps, o);
+    x.p = conv_x_new(c, w0, X, ldx, w0->K, lay, taps, o);
     x.C = w0->M; x.ld = lay->N; x.lay = lay; x.h = o.yh;
     return x;
 }
@@ -1174,9 +1180,9 @@ void style_tower(Ctx& c, int which, const StyleIn& s, float* style)
     const int sd = c.m.cfg.style_dim, lds = 2 * sd;
     if (which == 0) tower2d(c, p + ".Mel_block", s.mel_img, s.lm, {true, true, true, true}, 6, 1, p + ".Mellinear", style, lds);
     else if (which == 1) tower2d(c, p + ".EMA_block", s.ema_img, s.le, {false, false, true}, 5, 2, p + ".EMAlinear", style ? style + sd : nullptr, lds);
-    else if (which == 2) tower1d(c, p + ".F0_block", s.crop ? s.crop + (size_t)s.l1->N : nullptr, s.l1->N, s.l1, p + ".F0linear",
-                                 style ? style + sd + sd / 2 : nullptr, lds);
-    else tower1d(c, p + ".energy_block", s.crop, s.l1->N, s.l1, p + ".Energylinear", style ? style + sd + sd / 2 + sd / 4 : nullptr, lds);
+    // energy (crop row 0) and F0 (row 1) towers: twins merged at load (merge_twin_towers) into one tower on the two-row input; its Linear
+    // writes the F0 slice and the energy slice of Style, which are adjacent
+    else if (which == 2) tower1d(c, p + ".ENF0_block", s.crop, s.l1->N, s.l1, p + ".ENF0linear", style ? style + sd + sd / 2 : nullptr, lds);
 }
 
 // DurationPredictor (models.py:540-566) in three pieces
@@ -1517,16 +1523,23 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     const int only = only_env ? atoi(only_env) : -1;
     const bool launch0 = c.launch;
     auto gate = [&](int k) { c.launch = launch0 && (only < 0 || only == k); };
-    // Side streams: the mel tower and the three small towers.  The calling stream runs the three encoders as one triple-width encoder;
-    // when the duration predictor's (2 layers) is finished its tail forks off to a third side stream while the text / articulatory pair
-    // runs its last two layers.  (Every edge is calling stream <-> side stream: side-to-side edges break hipGraph instantiation.)
-    Fork f(c, 2, 0);
+    // Side streams: the mel tower; the small towers; the duration predictor's dur_block.  The calling stream runs the three encoders as one
+    // triple-width encoder; when the duration predictor's (2 layers) is finished the third side stream waits for it and runs the
+    // predictor's tail while the text / articulatory pair runs its last two layers.  (Every edge is calling stream <-> side stream:
+    // side-to-side edges break hipGraph instantiation.)
+    const bool early = getenv("AS_DUR_EARLY") != nullptr;               // experiment: dur_block from the start on its own stream (slower in a graph)
+    Fork f(c, early ? 3 : 2, 0);
     f.branch(0);
     gate(1);
     style_tower(c, 0, si, A.style);
     f.branch(1);
     gate(3);
     for (int t = 1; t <= 3; ++t) style_tower(c, t, si, A.style);
+    if (early) {
+        f.branch(2);
+        gate(2);
+        duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
+    }
     f.back();
     gate(0);
     EncOut eo;
@@ -1534,12 +1547,17 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     rel_encoder_multi(c, path_encoders(), io->tokens, A.tok, &eo, [&](int g) {
         if (g != ENC_DUR) return;
         const bool l0 = c.launch;
-        f2.reset(new Fork(c, 1, 2));
-        f2->branch(0);
+        if (early) {
+            f.wait_main(2);                                              // the duration encoder's result
+            f.branch(2);
+        } else {
+            f2.reset(new Fork(c, 1, 2));
+            f2->branch(0);
+        }
         gate(2);
-        duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
+        if (!early) duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
         A.duration = duration_tail(c, eo.y[ENC_DUR], ds, A.tok, io->duration);
-        f2->back();
+        f.back();
         c.launch = l0;
     });
     A.a_en = eo.y[ENC_ARTS];
@@ -1729,6 +1747,70 @@ size_t count_module(const as_model* m, as_plan* p, int module, const as_batch* b
 
 }  // namespace
 
+namespace {
+// Two towers of the same architecture on different input channels (style_encoder.energy_block / F0_block + their Linear layers,
+// models.py:402-411,414-415) as ONE tower of twice the width: every conv weight becomes block diagonal (the off-diagonal zeros multiply
+// exactly to zero), depthwise weights and biases are concatenated.  Half the launches -- these 1-D towers are ~20 kernels of 8-10 us
+// each, all at the fixed cost of a launch -- for twice the (negligible) flop.  Channel order: tower a first.
+bool merge_twin_towers(std::unordered_map<std::string, HostT>* raw, const std::string& a, const std::string& b, const std::string& merged)
+{
+    std::vector<std::pair<std::string, HostT>> add;
+    for (const auto& kv : *raw) {
+        if (kv.first.compare(0, a.size() + 1, a + ".") != 0) continue;
+        const std::string sfx = kv.first.substr(a.size());
+        const auto itb = raw->find(b + sfx);
+        if (itb == raw->end() || itb->second.dims != kv.second.dims) return false;
+        const HostT &ta = kv.second, &tb = itb->second;
+        HostT t;
+        const bool is_w = sfx.size() >= 7 && sfx.compare(sfx.size() - 7, 7, ".weight") == 0;
+        if (!is_w || sfx.find(".pool.") != std::string::npos) {           // bias / depthwise [C][1][k]: concatenate
+            t.dims = ta.dims;
+            t.dims[0] *= 2;
+            t.v = ta.v;
+            t.v.insert(t.v.end(), tb.v.begin(), tb.v.end());
+        } else {                                                          // [Cout][Cin][k]: block diagonal
+            const int co = ta.dim(0), ci = ta.dim(1), k = (int)(ta.numel() / ((size_t)co * ci));
+            t.dims = ta.dims;
+            t.dims[0] = 2 * co;
+            t.dims[1] = 2 * ci;
+            t.v.assign((size_t)4 * co * ci * k, 0.f);
+            for (int m = 0; m < co; ++m)
+                for (int c = 0; c < ci; ++c)
+                    for (int j = 0; j < k; ++j) {
+                        t.v[((size_t)m * 2 * ci + c) * k + j] = ta.v[((size_t)m * ci + c) * k + j];
+                        t.v[((size_t)(co + m) * 2 * ci + ci + c) * k + j] = tb.v[((size_t)m * ci + c) * k + j];
+                    }
+        }
+        add.emplace_back(merged + sfx, std::move(t));
+    }
+    if (add.empty()) return false;
+    for (auto& kv : add) (*raw)[kv.first] = std::move(kv.second);
+    return true;
+}
+// Linear layers of the twins -> one block Linear on [pooled a | pooled b] whose output rows are [rows of lb | rows of la] (the Style
+// vector holds the F0 slice before the energy slice, models.py:423)
+bool merge_twin_linears(std::unordered_map<std::string, HostT>* raw, const std::string& la, const std::string& lb, const std::string& merged)
+{
+    const auto wa = raw->find(la + ".weight"), wb = raw->find(lb + ".weight"), ba = raw->find(la + ".bias"), bb = raw->find(lb + ".bias");
+    if (wa == raw->end() || wb == raw->end() || ba == raw->end() || bb == raw->end() || wa->second.dims != wb->second.dims) return false;
+    const int o = wa->second.dim(0), i = wa->second.dim(1);
+    HostT w, bias;
+    w.dims = {2 * o, 2 * i};
+    w.v.assign((size_t)4 * o * i, 0.f);
+    for (int m = 0; m < o; ++m)
+        for (int c = 0; c < i; ++c) {
+            w.v[(size_t)m * 2 * i + i + c] = wb->second.v[(size_t)m * i + c];          // rows 0 .. o-1: lb on the second half of the input
+            w.v[(size_t)(o + m) * 2 * i + c] = wa->second.v[(size_t)m * i + c];        // rows o .. : la on the first half
+        }
+    bias.dims = {2 * o};
+    bias.v = bb->second.v;
+    bias.v.insert(bias.v.end(), ba->second.v.begin(), ba->second.v.end());
+    (*raw)[merged + ".weight"] = std::move(w);
+    (*raw)[merged + ".bias"] = std::move(bias);
+    return true;
+}
+}  // namespace
+
 extern "C" int as_model_create(const void* blob_host, size_t blob_bytes, const as_model_cfg* cfg, as_model** out)
 {
     if (!blob_host || !cfg || !out || cfg->hidden_dim <= 0 || cfg->hidden_dim % 16 || cfg->dim_in <= 0 || cfg->style_dim <= 0 || cfg->style_dim % 4 ||
@@ -1740,6 +1822,10 @@ extern "C" int as_model_create(const void* blob_host, size_t blob_bytes, const a
     m->cfg = *cfg;
     if (!fold(blob, &m->raw)) return AS_EINVAL;
     blob.clear();
+    // energy tower (input: crop row 0) + F0 tower (row 1) as one double-width tower
+    if (!merge_twin_towers(&m->raw, "style_encoder.energy_block", "style_encoder.F0_block", "style_encoder.ENF0_block") ||
+        !merge_twin_linears(&m->raw, "style_encoder.Energylinear", "style_encoder.F0linear", "style_encoder.ENF0linear"))
+        return AS_EINVAL;
     AS_CHECK(hipGetDevice(&m->device));
     {
         HostT st;

@@ -59,13 +59,24 @@ class Runtime:
             check(L.as_model_create(blob, len(blob), ctypes.byref(cfg), ctypes.byref(self.model)), "as_model_create")
             check(L.as_plan_create(self.model, ctypes.byref(self.plan)), "as_plan_create")
         self._ws = {}
+        self._parent = None
+
+    def fork(self):
+        """A second caller of the SAME weights: its own as_plan (geometry tables, side streams) and workspaces, so that its forwards can
+        be in flight on another stream while this runtime's run (include/artspeech_hip.h: one model per GPU, one plan per stream)."""
+        rt = Runtime.__new__(Runtime)
+        rt.model, rt.plan, rt.device, rt.cfg = self.model, ctypes.c_void_p(), self.device, self.cfg
+        rt._ws, rt._parent = {}, self                                   # (keeps the owner of the model alive)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().as_plan_create(self.model, ctypes.byref(rt.plan)), "as_plan_create")
+        return rt
 
     def __del__(self):
         try:
             L = _lib.lib()
             if self.plan:
                 L.as_plan_destroy(self.plan)
-            if self.model:
+            if self.model and self._parent is None:
                 L.as_model_destroy(self.model)
         except Exception:
             pass
@@ -282,8 +293,19 @@ class ArtsSpeech(_Module):
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
+    def replica(self):
+        """Another ArtsSpeech on the same weights with its own plan and workspaces (Runtime.fork): run it on a second stream to keep two
+        batches in flight."""
+        twin = ArtsSpeech(self.args, "second", self.distribution, self.device)
+        twin.style_encoder = self.style_encoder
+        twin._bind(self.rt.fork())
+        return twin
+
     def load_state_dict(self, sd, strict=False):
-        self.rt = rt = Runtime(sd, dict(self.args), self.distribution, self.device)
+        return self._bind(Runtime(sd, dict(self.args), self.distribution, self.device))
+
+    def _bind(self, rt):
+        self.rt = rt
         self.device = rt.device
         self.text_encoder = RelTransformerEncoder(rt, 0)
         self.arts_encoder = RelTransformerEncoder(rt, 1)
