@@ -351,7 +351,13 @@ def main():
     if world > 1:                                       # the process group first, before anything touches the GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # (AS_BENCH_TEST_ONE_GPU=1, testing only: every rank on GPU 0 with gloo -- exercises this launch path on a 1-GPU box)
+        one_gpu = os.environ.get("AS_BENCH_TEST_ONE_GPU") == "1"
+        if one_gpu:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -409,7 +415,7 @@ def main():
         for r2, _, _ in lanes[1:]:
             assert torch.equal(r2.out["mel"], mel_first), "a second batch in flight changed the result"
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not args.no_graph:
