@@ -433,6 +433,7 @@ struct Ctx {
     {
         const size_t o = off;
         off += align256(bytes ? bytes : 1);
+        if (launch && !count && getenv("AS_DEBUG_ALLOC")) fprintf(stderr, "artspeech_hip: arena %p + %zu : %zu bytes\n", (void*)base, o, bytes);
         if (count) return nullptr;
         if (off > cap) { fail(AS_ENOSPC); return nullptr; }
         return base + o;

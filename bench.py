@@ -396,9 +396,13 @@ def main():
     run = runner.step if args.no_graph else runner.capture()
     elapsed = runner.timed(run, args.steps, args.warmup, barrier)
     single_ms = elapsed / args.steps * 1e3                               # one step at a time: the step's latency
+    if not args.no_graph:
+        torch.cuda.synchronize()
+        assert torch.equal(runner.out["mel"], mel_first), "graph replay changed the result"
     # Consecutive steps are independent batches: with two in flight (a second plan + workspaces on the same weights, its own stream) the
     # tail round of one batch's kernels is filled by the other batch's -- what a server does; the K timed steps alternate between them.
     n_fl = 1 if (args.no_graph or args.global_batch) else max(1, args.in_flight)
+    in_flight_note = None
     if n_fl > 1:
         lanes = [(runner, run, torch.cuda.Stream())]
         for _ in range(n_fl - 1):
@@ -411,15 +415,19 @@ def main():
             it[0] += 1
             with torch.cuda.stream(st):
                 fn()
-        elapsed = runner.timed(run_lanes, args.steps, args.warmup, barrier)
-        for r2, _, _ in lanes[1:]:
-            assert torch.equal(r2.out["mel"], mel_first), "a second batch in flight changed the result"
+        elapsed_fl = runner.timed(run_lanes, args.steps, args.warmup, barrier)
+        # every lane must still produce the bits of the first eager step; if not, the in-flight number is discarded and the line
+        # reports the one-at-a-time run (and says so)
+        lanes_ok = all(torch.equal(r2.out["mel"], mel_first) for r2, _, _ in lanes)
+        if lanes_ok:
+            elapsed = elapsed_fl
+        else:
+            in_flight_note = "results of the batches in flight differed from the one-at-a-time result: in-flight timing discarded"
+            n_fl = 1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if not args.no_graph:
-        assert torch.equal(runner.out["mel"], mel_first), "graph replay changed the result"
     if args.global_batch:
         c4 = c4_check(net, host, runner.out["mel"], mine, world, rank, dev, dist)
 
@@ -455,6 +463,7 @@ def main():
                    "launch": "eager (C ABI as_forward_test)" if args.no_graph else "hipGraph replay of one as_forward_test call",
                    "in_flight": n_fl},
         "ms_per_step_one_in_flight": single_ms,
+        "in_flight_note": in_flight_note,
         "rtf": (elapsed / args.steps) / (frames_total * FRAME_SEC),
         "x_realtime_per_gpu": (value / world) * FRAME_SEC,
         "roofline": {"bound": "mfma",

@@ -1,0 +1,36 @@
+"""GPU: two batches in flight (bench.py's default mode) -- two plans on the same weights, each replaying its own hipGraph on its own
+stream, must keep producing the bits of a step run alone (kernels of different batches share CUs, LDS and caches)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_batches_in_flight_are_bit_identical():
+    import bench
+    from artspeech_amd import models, synth
+    from artspeech_amd.weights import DEFAULT_STATS, load_distribution
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    sd = synth.synth_state_dict(512, 64, seed=bench.WEIGHT_SEED)
+    model = models.build_model(models.Munch(hidden_dim=512, dim_in=64, style_dim=256, n_mels=80), None, "second", load_distribution(DEFAULT_STATS), dev)
+    models.load_checkpoint(model, None, {"net": {"ArtsSpeech": sd}})
+    net = model.ArtsSpeech
+    _, g = bench.make_inputs(dev)
+    a = bench.Runner(net, g)
+    want = a.step()["mel"].clone()
+    torch.cuda.synchronize()
+    run_a = a.capture()
+    b = bench.Runner(net.replica(), g)
+    run_b = b.capture()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    bad = 0
+    for i in range(120):
+        with torch.cuda.stream(sa):
+            run_a()
+        with torch.cuda.stream(sb):
+            run_b()
+        if i % 8 == 7:                                       # (checked while the lanes' last steps overlapped each other)
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(a.out["mel"], want)) + int(not torch.equal(b.out["mel"], want))
+    assert bad == 0, f"{bad} of 30 checks differed from the step run alone"
