@@ -222,21 +222,23 @@ static void tile_dims(int choice, int* bm, int* bn)
     *bn = (choice == 42 || choice == 22 || choice == 12) ? 128 : 64;
 }
 
-// Tile choice, from sweeps on MI355X (scripts/gemm_bench.py, round 2): above one tile per CU the time follows the tile count
-// (several workgroups share a CU and cover each other's waits), below ~160 tiles the idle CUs cost more than a smaller tile's
-// worse operand reuse -- e.g. M512 N1280 K512 T3: 64x64 tiles 16 us, 128x64 20 us; M1536 N2560 K512: 128x128 19 us, 128x64 21 us.
+// Tile choice, fitted to sweeps on MI355X (scripts/gemm_bench.py, round 2).  The time of a launch is the time of its busiest CU:
+// a tile alone on a CU costs t1 (relative to 128x128: 128x64 / 64x128 0.78 -- they split K over wave pairs and stage more per flop --
+// 64x64 0.59), n > 1 tiles sharing a CU cost 0.71 n t1 (two co-resident workgroups cover each other's waits).  Examples the fit
+// reproduces: M512 N6400 K512 T3: 128x128 (200 tiles) 33.5 us, 128x64 (400) 37.1; M512 N3840 K512 T5: 44.8 (120 tiles) against 35.0
+// (240); M512 N1280 K512 T3: 25.6 / 17.8 / 15.2 us for 40 / 80 / 160 tiles.
 static int gemm_tile_choice(int M, int N, int n_prod)
 {
     const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 42, 22, 21, 12, 11
     if (env && atoi(env) > 0) return atoi(env);
     const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);   // a 128-row tile is not half empty
     static const int choices[5] = {42, 22, 21, 12, 11};
-    // 256x128 (a wave owns 128 x 64): a third less LDS traffic per matrix-core product, but 364 registers: ONE workgroup per CU, so its
-    // tiles run in whole rounds.  Ten identical launches back to back in a hipGraph: M1024 N6400 K1216 T3 127 us against 152 for 128x128,
-    // M256 N32000 K256 T9 94 against 106, M512 N19200 105 against 96.  Inside the step (other kernels between the GEMMs, operands not in
-    // cache) the same launches take the same time with either tile (C3: 5.08 against 5.10 ms of GEMM per step, C5: 8.78 against 8.70), so
-    // the default stays with the tiles that share a CU; -DAS_EXPERIMENTS builds carry it (AS_GEMM_TILE=42 / AS_GEMM_USE42=1).
-    static const double eff[5] = {1.3, 1.0, 0.95, 0.9, 0.55};     // (64x64: twice the staged bytes per flop)
+    // 256x128 (a wave owns 128 x 64): a third less LDS traffic per matrix-core product, but 364 registers: ONE workgroup per CU.
+    // Ten identical launches back to back in a hipGraph: M1024 N6400 K1216 T3 127 us against 152 for 128x128, M256 N32000 K256 T9 94
+    // against 106, M512 N19200 105 against 96.  Inside the step the same launches take the same time with either tile (C3: 5.08 against
+    // 5.10 ms of GEMM per step, C5: 8.78 against 8.70), so the default stays with the tiles that share a CU; -DAS_EXPERIMENTS builds
+    // carry it (AS_GEMM_TILE=42 / AS_GEMM_USE42=1).
+    static const double t1[5] = {1.55, 1.0, 0.78, 0.78, 0.59};
 #ifdef AS_EXPERIMENTS
     static const bool use42 = getenv("AS_GEMM_USE42") != nullptr;
 #else
@@ -250,8 +252,8 @@ static int gemm_tile_choice(int M, int N, int n_prod)
         if (bm >= 128 && !tall) continue;
         if (bm == 256 && (M % 256 != 0 || n_prod != 3 || !use42)) continue;
         const double tiles = (double)as_cdiv(M, bm) * as_cdiv(N, bn);
-        const double rounds = bm == 256 ? ceil(tiles / 256.0) : (tiles > 256.0 ? tiles / 256.0 : 1.0);
-        const double cost = rounds * bm * bn / eff[c] * (tiles < 160.0 ? 160.0 / tiles : 1.0);
+        const double n = ceil(tiles / 256.0);
+        const double cost = t1[c] * (bm == 256 ? n : (n > 1.0 ? 0.71 * n : 1.0));
         if (cost < best_cost * 0.97) { best_cost = cost; best = choices[c]; }   // (ties go to the larger tile)
     }
     return best;
