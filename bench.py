@@ -11,6 +11,11 @@ batch of 32 synthetic utterances (config C3 of SURVEY.md section 8: N = 40 token
 summing to M = 100 => 200 mel frames per utterance, T_ref = 200; full-size model, seeded synthetic weights),
 as ONE call of the library's as_forward_test (csrc/model.hip) captured into a hipGraph and replayed.
 Inputs are resident in HBM before the timed region (the transfer-inclusive rate is reported beside it, "transfers").
+Consecutive steps are independent batches: by default TWO are kept in flight per GPU (`--in-flight 2`: a second plan + workspaces on
+the same weights, its own hipGraph and HIP stream; the K timed steps alternate between the lanes), so that one batch's tail rounds and
+latency-bound stretches are filled by the other's kernels.  `value` / `ms_per_step` are K steps / wall time; `ms_per_step_one_in_flight`
+is the same K steps one at a time (a step's latency).  Every lane's result is compared bitwise with the first eager step; if a lane ever
+differed the in-flight timing would be discarded for the one-at-a-time number (`in_flight_note`).
 With N > 1 every rank runs its own 32-utterance batch on its own GPU (utterance batches shard embarrassingly; no data-path
 collective) => weak scaling; the only torch.distributed use is the barrier and the max-over-ranks of the elapsed time.
 `--global-batch G` instead builds ONE length-varied batch of G utterances, shards it over the ranks (artspeech_amd.shard) and

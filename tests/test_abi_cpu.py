@@ -38,6 +38,17 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.as_mas_f32(None, None, None, 1, 4, 4, 0, None, None, None, None, 0, None) == -1
     assert L.as_conv_gemm_f32(None, None) == -1
     assert L.as_bilstm_f32(None, 1, None, 1, 128, None) == -1
+    # entry points added in round 2: the same contract (AS_EINVAL = -1 before anything touches a device)
+    assert L.as_bilstm_cluster_f32(None, 1, None, 1, 256, 40, None, 0, None) == -1
+    assert L.as_bilstm_cluster_bytes(0, 4) == 0 and L.as_bilstm_cluster_bytes(1, 32) > 0
+    assert L.as_relpos_attention_image_f32(None, 0, None, 0, 512, 4, 4, None, None, None, None, 0, None, 1, 40, None, 0, None, None) == -1
+    assert L.as_adain_image_f32(None, None) == -1
+    assert L.as_model_create(None, 0, None, None) == -1
+    assert L.as_plan_create(None, None) == -1
+    assert L.as_forward_test(None, None, None, None, None, 0, None, 0, None, None) == -1
+    assert L.as_module_workspace_bytes(None, None, 0, None) == 0
+    assert L.as_embed_groups_f32(None, 0, None, None, 0, 8, 8, 8, 1.0, None, 8, None) == -1
+    assert L.as_split_f16x2_bytes(0, 10) == 0 and L.as_split_f16x2_bytes(20, 10) == 4 * 4 * 11 * 16      # 20 channels: 2 k-blocks, padded to 4; 4 planes; N + 1 columns of 16 bytes
 
 
 def test_weight_preparation_host_matches_python():
