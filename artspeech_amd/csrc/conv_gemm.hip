@@ -322,6 +322,9 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if (norm.acc_scale == 0.f) norm.acc_scale = 1.0f;
     if (norm.n_prod == 0) norm.n_prod = 3;
     if (norm.n_groups < 1) norm.n_groups = 1;
+    // a 1x1 conv reads every column from itself: no tap can leave the utterance, so the kernels need not fetch the column descriptors
+    // (one dependent global load at the head of every workgroup)
+    if (norm.T == 1 && norm.dh[0] == 0 && norm.dw[0] == 0) norm.meta = nullptr;
     const ConvGemmArgs& a = norm;
     if (a.act < 0 || a.act > 5 || (a.in_act != 0 && a.in_act != 2) || (a.n_prod != 1 && a.n_prod != 3)) return AS_EINVAL;
     if ((!a.Wh && !(a.W && a.K == 1)) || (!a.X && !a.Xh) || (!a.Y && !a.Yh) || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS)
