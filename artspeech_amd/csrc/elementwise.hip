@@ -319,10 +319,21 @@ project_cols_kernel(const float* __restrict__ x, int ldx, int K, int N, const fl
 #pragma unroll
     for (int m = 0; m < MM; ++m) acc[m] = 0.f;
     int k = wave;
+    const float* xc = x + (ok ? j : 0);                                 // (columns past N read column 0 and are not stored)
+    for (; k + 60 < K; k += 64) {                                       // sixteen rows in flight: the kernel is one memory round trip per batch
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = xc[(size_t)(k + 4 * u) * ldx];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                if (m < M) acc[m] += w[m * K + k + 4 * u] * v[u];
+    }
     for (; k + 12 < K; k += 16) {                                       // four rows in flight
         float v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ok ? x[(size_t)(k + 4 * u) * ldx + j] : 0.f;
+        for (int u = 0; u < 4; ++u) v[u] = xc[(size_t)(k + 4 * u) * ldx];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -330,7 +341,7 @@ project_cols_kernel(const float* __restrict__ x, int ldx, int K, int N, const fl
                 if (m < M) acc[m] += w[m * K + k + 4 * u] * v[u];
     }
     for (; k < K; k += 4) {
-        const float v = ok ? x[(size_t)k * ldx + j] : 0.f;
+        const float v = xc[(size_t)k * ldx];
 #pragma unroll
         for (int m = 0; m < MM; ++m)
             if (m < M) acc[m] += w[m * K + k] * v;
