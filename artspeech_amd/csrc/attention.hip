@@ -10,10 +10,13 @@
 //  and the softmax is computed online over 64-key tiles staged in LDS, so
 // nothing of size N^2 ever exists.  q/k/v come from one fused [3C][N] projection GEMM.
 //
-// Workgroup = (utterance, head, 16-query tile), 4 waves x 4 queries.  QK^T: lane = key (K tile rows
-// padded to 65 floats -> conflict-free), softmax statistics by wave shuffles; PV: lane = channel.
-// This round's version runs on the vector ALU in exact fp32; the MFMA version is future work
-// (DESIGN.md "next").
+// Two kernels:
+//   relpos_attention_kernel        exact fp32 on the vector ALU, any head width <= 128, fp32 q/k/v rows (as_relpos_attention_groups_f32:
+//                                  what a configuration with other head widths runs, and the reference the matrix-core kernel is
+//                                  tested against).  Workgroup = (utterance, head, 16-query tile), 4 waves x 4 queries; QK^T: lane = key
+//                                  (K tile rows padded to 65 floats -> conflict-free), softmax statistics by wave shuffles; PV: lane = channel.
+//   relpos_attention_image_kernel  the path (128-channel heads): matrix cores, operands straight from the q/k/v GEMM's operand image
+//                                  (as_relpos_attention_image_f32; described above the kernel).
 #include <cstring>
 #include "common.h"
 #include "artspeech_hip.h"
@@ -165,432 +168,26 @@ relpos_attention_kernel(const float* __restrict__ qkv, int ld, int C, int heads,
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Short utterances (every utterance <= 64 tokens: the text side of the path at 40 tokens per utterance).  The kernel
-// above gives such an utterance three 16-query workgroups that each stage the same K/V tile and walk run-time-bounded
-// loops (79 us per launch on 32 x 40 tokens, 10 launches per step).  Here ONE workgroup owns (utterance, head): Q, K, V
-// are staged once with compile-time trip counts, a wave takes every fourth group of four queries, scores for all keys sit in
-// lanes, probabilities go through LDS to the PV phase (lane = channel).  Same arithmetic order per output as above
-// (dot products accumulate over d ascending, PV over keys ascending then the relative taps ascending).
-// ---------------------------------------------------------------------------------------------------
-#define SN 64
-#define SPAD 65
-template <int DK>
-__global__ void __launch_bounds__(256)
-relpos_attention_small_kernel(const float* __restrict__ qkv, int ld, int C, int window, const float* __restrict__ emb_k1,
-                              const float* __restrict__ emb_v1, const float* __restrict__ emb_k2, const float* __restrict__ emb_v2,
-                              int b_split, const int* __restrict__ col_off, float* __restrict__ out, int ldo)
-{
-    const int grp = emb_k2 ? (int)blockIdx.y / b_split : 0;
-    const float* emb_k = emb_k1 + (ptrdiff_t)grp * (emb_k2 - emb_k1);
-    const float* emb_v = emb_v1 + (ptrdiff_t)grp * (emb_v2 - emb_v1);
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Ks = sm;                              // [DK][SPAD]   (reused for the output transpose)
-    float* Vs = Ks + DK * SPAD;                  // [DK][SPAD]
-    float* Qs = Vs + DK * SPAD;                  // [DK][SPAD]: Qs[d][q]
-    float* Ps = Qs + DK * SPAD;                  // [SN queries][SPAD keys]
-    float* Rk = Ps + SN * SPAD;                  // [SN][MAXREL]
-    float* Ek = Rk + SN * MAXREL;                // [MAXREL][DK]
-    float* Ev = Ek + MAXREL * DK;                // [MAXREL][DK]
-
-    const int b = blockIdx.y, h = blockIdx.x;
-    const int o0 = col_off[b], N = col_off[b + 1] - o0;
-    if (N <= 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nrel = 2 * window + 1;
-    const float scale = sqrtf((float)DK);
-    const float* Qg = qkv + (size_t)(h * DK) * ld + o0;
-    const float* Kg = qkv + (size_t)(C + h * DK) * ld + o0;
-    const float* Vg = qkv + (size_t)(2 * C + h * DK) * ld + o0;
-
-    // stage Q, K, V: thread (column = lane, rows wave + 4 i); all loads of a batch of 16 rows are issued before their stores
-    const bool colok = lane < N;
-#pragma unroll
-    for (int i0 = 0; i0 < DK / 4; i0 += 16) {
-        float q[16], k[16], v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int d = wave + 4 * (i0 + i);
-            q[i] = colok ? Qg[(size_t)d * ld + lane] : 0.f;
-            k[i] = colok ? Kg[(size_t)d * ld + lane] : 0.f;
-            v[i] = colok ? Vg[(size_t)d * ld + lane] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int d = wave + 4 * (i0 + i);
-            Qs[d * SPAD + lane] = q[i];
-            Ks[d * SPAD + lane] = k[i];
-            Vs[d * SPAD + lane] = v[i];
-        }
-    }
-    for (int i = tid; i < nrel * DK; i += 256) { Ek[i] = emb_k[i]; Ev[i] = emb_v[i]; }
-    __syncthreads();
-    // Rk[q][r] = q . Ek[r] / scale: thread (query = lane, taps wave, wave + 4, wave + 8)
-    for (int r = wave; r < nrel; r += 4) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < DK; ++d) s += Qs[d * SPAD + lane] * Ek[r * DK + d];
-        Rk[lane * MAXREL + r] = s / scale;
-    }
-    __syncthreads();
-    // scores + softmax: a wave takes the query groups g = wave, wave + 4, ... of four queries; lane = key
-    const int ngroups = (N + 3) / 4;
-    for (int g = wave; g < ngroups; g += 4) {
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int d = 0; d < DK; ++d) {
-            const float kv = Ks[d * SPAD + lane];
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) s[qq] += Qs[d * SPAD + 4 * g + qq] * kv;
-        }
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const int qi = 4 * g + qq;
-            float sc = s[qq] / scale;
-            const int r = lane - qi + window;
-            if (r >= 0 && r < nrel && qi < SN) sc += Rk[qi * MAXREL + r];
-            if (lane >= N) sc = -INFINITY;
-            const float mx = wmax(sc);
-            const float p = (lane < N) ? expf(sc - mx) : 0.f;
-            const float l = wsum(p);
-            // the general kernel's online softmax with a single key tile: p = exp(sc - max), divided by the sum at the very end
-            Ps[qi * SPAD + lane] = p;
-            if (lane == 0) Ps[qi * SPAD + SN] = l;           // the row's sum rides in its padding slot
-        }
-    }
-    __syncthreads();
-    // PV: lane = channels d0 = lane, d1 = lane + 64
-    float* Os = Ks;                                          // [DK][SPAD]: output transposed for row-contiguous stores
-    const int d0 = lane, d1 = lane + 64;
-    for (int g = wave; g < ngroups; g += 4) {
-        float acc[4][2];
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) { acc[qq][0] = 0.f; acc[qq][1] = 0.f; }
-        for (int j = 0; j < N; ++j) {
-            const float v0 = Vs[d0 * SPAD + j];
-            const float v1 = DK > 64 ? Vs[d1 * SPAD + j] : 0.f;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const float p = Ps[(4 * g + qq) * SPAD + j];
-                acc[qq][0] += p * v0;
-                acc[qq][1] += p * v1;
-            }
-        }
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const int qi = 4 * g + qq;
-            for (int r = 0; r < nrel; ++r) {
-                const int jg = qi + r - window;
-                if (jg < 0 || jg >= N) continue;
-                const float p = Ps[qi * SPAD + jg];
-                acc[qq][0] += p * Ev[r * DK + d0];
-                if (DK > 64) acc[qq][1] += p * Ev[r * DK + d1];
-            }
-        }
-        // (Os aliases Ks, which nobody reads after the barrier above)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const int qi = 4 * g + qq;
-            const float l = Ps[qi * SPAD + SN];
-            Os[d0 * SPAD + qi] = acc[qq][0] / l;
-            if (DK > 64) Os[d1 * SPAD + qi] = acc[qq][1] / l;
-        }
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int i = 0; i < DK / 4; ++i) {
-        const int d = wave + 4 * i;
-        if (lane < N) out[(size_t)(h * DK + d) * ldo + o0 + lane] = Os[d * SPAD + lane];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Long utterances on the matrix cores (C5: 1024 tokens per utterance; the vector-ALU kernel above spends 5.5 ms per launch there).
-// Same arithmetic as the conv GEMMs: every fp32 operand is the sum h + l of two fp16 values (22 bits), a product is
-// h.l + l.h + h.h on v_mfma_f32_32x32x16_f16 with fp32 accumulation.
-//
-//   workgroup = (utterance, head, NW x 32 queries); a wave owns 32 queries for the whole key loop, keys come in tiles of 64.
-//   S^T = K . Q^T   (A = K tile [32 keys][16 d], B = Q^T [16 d][32 queries]): a lane ends up with ONE query (column lane & 31)
-//                   and 16 of the tile's 32 keys -> the online softmax is per-lane arithmetic plus one exchange with lane ^ 32.
-//   O^T += V^T . P^T (A = V^T [32 d][16 keys], B = P^T [16 keys][32 queries]): the S^T accumulator registers ARE the B operand
-//                   (after exp and the h/l split); the contraction visits the keys in the accumulator's row order, so V is
-//                   staged in LDS in exactly that order and nothing is shuffled between the two products.
-// The relative-position terms touch only the +-4 band: a wave adds them (vector ALU, fp32) in the at most three 32-key blocks
-// that intersect its queries' band; Q.Ek is precomputed per query, the band's probabilities pass through a small LDS table.
-// ---------------------------------------------------------------------------------------------------
 #include "conv_gemm.h"
 #define FK 64                                   // keys per tile
-template <int NW>
-__global__ void __launch_bounds__(NW * 64)
-relpos_attention_mfma_kernel(const float* __restrict__ qkv, int ld, int C, int window, const float* __restrict__ emb_k1,
-                             const float* __restrict__ emb_v1, const float* __restrict__ emb_k2, const float* __restrict__ emb_v2,
-                             int b_split, const int* __restrict__ col_off, float* __restrict__ out, int ldo)
-{
-    constexpr int DK = 128, KB = DK / 16, NT = NW * 64, NQ = NW * 32;
-    const int grp = emb_k2 ? (int)blockIdx.z / b_split : 0;
-    const float* emb_k = emb_k1 + (ptrdiff_t)grp * (emb_k2 - emb_k1);
-    const float* emb_v = emb_v1 + (ptrdiff_t)grp * (emb_v2 - emb_v1);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-    // Kt[p][kb][g][key 64][8 fp16] (32 KB), Vt[p][c][g][d 128][8 fp16] (32 KB); the query tile is staged through the same bytes first
-    u32x4_t* Kt = reinterpret_cast<u32x4_t*>(smraw);
-    u32x4_t* Vt = Kt + 2 * KB * 2 * FK;
-    u32x4_t* Qt = Kt;                                                   // [p][kb][g][NQ]
-    constexpr int STAGE = (2 * KB * 2 * FK + 2 * 4 * 2 * DK) > (2 * KB * 2 * NQ) ? (2 * KB * 2 * FK + 2 * 4 * 2 * DK) : (2 * KB * 2 * NQ);
-    float* Ek = reinterpret_cast<float*>(Kt + STAGE);                   // [9][DK]
-    float* Ev = Ek + MAXREL * DK;                                       // [9][DK]
-    float* Rk = Ev + MAXREL * DK;                                       // [NQ][9]   q.Ek[r] * log2(e)/sqrt(dk)
-    float* Pb = Rk + NQ * MAXREL;                                       // [NQ][9]   the band's probabilities of the current block
-
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int o0 = col_off[b], N = col_off[b + 1] - o0;
-    const int q0 = blockIdx.x * NQ;
-    if (q0 >= N) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, lq = lane & 31;
-    const int nrel = 2 * window + 1;
-    const float cs = 1.44269504088896340736f / sqrtf((float)DK);       // scores live in the log2 domain
-    const float* Qg = qkv + (size_t)(h * DK) * ld + o0;
-    const float* Kg = qkv + (size_t)(C + h * DK) * ld + o0;
-    const float* Vg = qkv + (size_t)(2 * C + h * DK) * ld + o0;
-
-    // ---- queries: fp32 -> (h, l) rows of 8 consecutive d, [p][kb][g][query]
-    for (int it = tid; it < NQ * (DK / 8); it += NT) {
-        const int q = it % NQ, dg = it / NQ;
-        const bool ok = q0 + q < N;
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = ok ? Qg[(size_t)(dg * 8 + j) * ld + q0 + q] : 0.f;
-        u32x4_t hh, ll;
-        split2(x, hh, ll);
-        Qt[(0 * KB * 2 + dg) * NQ + q] = hh;
-        Qt[(1 * KB * 2 + dg) * NQ + q] = ll;
-    }
-    for (int i = tid; i < nrel * DK; i += NT) { Ek[i] = emb_k[i]; Ev[i] = emb_v[i]; }
-    __syncthreads();
-    u32x4_t Qh[KB], Ql[KB];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        Qh[kb] = Qt[(0 * KB * 2 + kb * 2 + g) * NQ + wave * 32 + lq];
-        Ql[kb] = Qt[(1 * KB * 2 + kb * 2 + g) * NQ + wave * 32 + lq];
-    }
-    // q . Ek[r] from the split queries (22 bits, like the matrix-core products)
-    for (int it = tid; it < NQ * nrel; it += NT) {
-        const int q = it % NQ, r = it / NQ;
-        float s = 0.f;
-        for (int dg = 0; dg < DK / 8; ++dg) {
-            const f16x8 hv = __builtin_bit_cast(f16x8, Qt[(0 * KB * 2 + dg) * NQ + q]);
-            const f16x8 lv = __builtin_bit_cast(f16x8, Qt[(1 * KB * 2 + dg) * NQ + q]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += ((float)hv[j] + (float)lv[j]) * Ek[r * DK + dg * 8 + j];
-        }
-        Rk[q * MAXREL + r] = s * cs;
-    }
-
-    const int ql = wave * 32 + lq;                                      // this lane's query within the tile
-    const int qi = q0 + ql;
-    const int qw0 = q0 + wave * 32;                                     // the wave's first query
-    float m = -INFINITY, lsum = 0.f;
-    f32x16 acc[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
-
-    // staging registers of one key tile: K as (key = lane, 8 consecutive d), V as (d, 4 consecutive keys)
-    // (NW = 4: the next tile's loads are in flight during a tile's arithmetic; NW = 2 serves utterances of at most 64 tokens, one
-    // tile, and stages it in two halves to stay inside the register file)
-    constexpr int PARTS = NW == 4 ? 1 : 2;
-    constexpr int KI = FK * (DK / 8) / NT / PARTS, VI = DK * (FK / 4) / NT / PARTS;
-    float kr[KI][8], vr[VI][4];
-    auto load_tile = [&](int k0, int part) {
-#pragma unroll
-        for (int it = 0; it < KI; ++it) {
-            const int idx = tid + (it + part * KI) * NT, key = idx % FK, dg = idx / FK;
-            const bool ok = k0 + key < N;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) kr[it][j] = ok ? Kg[(size_t)(dg * 8 + j) * ld + k0 + key] : 0.f;
-        }
-#pragma unroll
-        for (int it = 0; it < VI; ++it) {
-            const int idx = tid + (it + part * VI) * NT, kq = idx % (FK / 4), d = idx / (FK / 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) vr[it][e] = (k0 + kq * 4 + e < N) ? Vg[(size_t)d * ld + k0 + kq * 4 + e] : 0.f;
-        }
-    };
-    auto store_tile = [&](int part) {
-#pragma unroll
-        for (int it = 0; it < KI; ++it) {
-            const int idx = tid + (it + part * KI) * NT, key = idx % FK, dg = idx / FK;
-            u32x4_t hh, ll;
-            split2(kr[it], hh, ll);
-            Kt[(0 * KB * 2 + dg) * FK + key] = hh;
-            Kt[(1 * KB * 2 + dg) * FK + key] = ll;
-        }
-        u32x2_t* V2 = reinterpret_cast<u32x2_t*>(Vt);
-#pragma unroll
-        for (int it = 0; it < VI; ++it) {
-            const int idx = tid + (it + part * VI) * NT, kq = idx % (FK / 4), d = idx / (FK / 4);
-            // tile key 4 kq .. + 3 = block sb, 8-row group ig, lane half gg: contraction block c = 2 sb + ig / 2, slots (ig & 1) 4 ..
-            const int kk = kq * 4, sb = kk >> 5, w32 = kk & 31, ig = w32 >> 3, gg = (w32 & 7) >> 2, c = sb * 2 + (ig >> 1);
-            unsigned h0, l0, h1, l1;
-            split2_pair(vr[it][0], vr[it][1], h0, l0);
-            split2_pair(vr[it][2], vr[it][3], h1, l1);
-            const u32x2_t hh = {h0, h1}, ll = {l0, l1};
-            V2[(((0 * 4 + c) * 2 + gg) * DK + d) * 2 + (ig & 1)] = hh;
-            V2[(((1 * 4 + c) * 2 + gg) * DK + d) * 2 + (ig & 1)] = ll;
-        }
-    };
-
-    if (PARTS == 1) load_tile(0, 0);
-    for (int k0 = 0; k0 < N; k0 += FK) {
-        __syncthreads();                                                // the previous tile (first time: Qt, Rk writes) is done with
-        if (PARTS == 1) {
-            store_tile(0);
-        } else {
-#pragma unroll
-            for (int part = 0; part < PARTS; ++part) {
-                load_tile(k0, part);
-                store_tile(part);
-            }
-        }
-        __syncthreads();
-        if (PARTS == 1 && k0 + FK < N) load_tile(k0 + FK, 0);           // in flight during this tile's arithmetic
-
-        f32x16 S[2];
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) S[sb][e] = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const f16x8 ah = __builtin_bit_cast(f16x8, Kt[(0 * KB * 2 + kb * 2 + g) * FK + sb * 32 + lq]);
-                const f16x8 al = __builtin_bit_cast(f16x8, Kt[(1 * KB * 2 + kb * 2 + g) * FK + sb * 32 + lq]);
-                S[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, Ql[kb]), S[sb], 0, 0, 0);
-                S[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(f16x8, Qh[kb]), S[sb], 0, 0, 0);
-                S[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, Qh[kb]), S[sb], 0, 0, 0);
-            }
-        }
-        // scale, band term, mask; element e of block sb is key k0 + 32 sb + 8 (e >> 2) + 4 g + (e & 3)
-        bool band[2];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            const int kb0 = k0 + sb * 32;
-            band[sb] = kb0 <= qw0 + 31 + window && kb0 + 31 >= qw0 - window;          // wave-uniform
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kb0 + 8 * (e >> 2) + 4 * g + (e & 3);
-                float s = S[sb][e] * cs;
-                if (band[sb]) {
-                    const int r = key - qi + window;
-                    if (r >= 0 && r < nrel) s += Rk[ql * MAXREL + r];
-                }
-                if (key >= N) s = -INFINITY;
-                S[sb][e] = s;
-                mx = fmaxf(mx, s);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mn = fmaxf(m, mx);                                  // finite: key k0 < N is in every tile
-        const float corr = __builtin_amdgcn_exp2f(m - mn);              // 0 on the first tile
-        m = mn;
-        lsum *= corr;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mb][e] *= corr;
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = __builtin_amdgcn_exp2f(S[sb][e] - mn);
-                S[sb][e] = p;
-                lsum += p;
-            }
-        // relative values: out_i += p_ij Ev[j - i + w] on the band
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            if (!band[sb]) continue;
-            const int kb0 = k0 + sb * 32;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int r = kb0 + 8 * (e >> 2) + 4 * g + (e & 3) - qi + window;
-                if (r >= 0 && r < nrel) Pb[ql * MAXREL + r] = S[sb][e];
-            }
-            __builtin_amdgcn_wave_barrier();                            // same wave wrote and reads: LDS operations stay in order
-            for (int r = 0; r < nrel; ++r) {
-                const int key = qi + r - window;
-                const bool in = key >= kb0 && key < kb0 + 32 && key < N;
-                const float p = in ? Pb[ql * MAXREL + r] : 0.f;
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) {
-                        const f32x4 evv = *reinterpret_cast<const f32x4*>(Ev + r * DK + mb * 32 + e4 * 8 + g * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[mb][e4 * 4 + e] += p * evv[e];
-                    }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // O^T += V^T P^T: contraction block c = accumulator elements 8 (c & 1) .. + 7 of block c >> 1
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float pv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pv[j] = S[c >> 1][(c & 1) * 8 + j];
-            u32x4_t ph, pl;
-            split2(pv, ph, pl);
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const f16x8 vh = __builtin_bit_cast(f16x8, Vt[((0 * 4 + c) * 2 + g) * DK + mb * 32 + lq]);
-                const f16x8 vl = __builtin_bit_cast(f16x8, Vt[((1 * 4 + c) * 2 + g) * DK + mb * 32 + lq]);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, __builtin_bit_cast(f16x8, pl), acc[mb], 0, 0, 0);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, __builtin_bit_cast(f16x8, ph), acc[mb], 0, 0, 0);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, __builtin_bit_cast(f16x8, ph), acc[mb], 0, 0, 0);
-            }
-        }
-    }
-    const float ltot = lsum + __shfl_xor(lsum, 32);
-    if (qi < N) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int d = mb * 32 + 8 * (e >> 2) + 4 * g + (e & 3);
-                out[(size_t)(h * DK + d) * ldo + o0 + qi] = acc[mb][e] / ltot;
-            }
-    }
-}
-
-template <int NW>
-static int launch_attention_mfma(const float* qkv, int ld, int C, int heads, int window, const float* ek, const float* ev, const float* ek2,
-                                 const float* ev2, int b_split, const int32_t* col_off, int B, int max_len, float* out, int ldo,
-                                 hipStream_t stream)
-{
-    constexpr int NQ = NW * 32, STAGE = (2 * 8 * 2 * FK + 2 * 4 * 2 * 128) > (2 * 8 * 2 * NQ) ? (2 * 8 * 2 * FK + 2 * 4 * 2 * 128) : (2 * 8 * 2 * NQ);
-    const size_t smem = (size_t)STAGE * 16 + sizeof(float) * (2 * MAXREL * 128 + 2 * NQ * MAXREL);
-    static bool attr = false;
-    if (!attr) {
-        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_mfma_kernel<NW>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    AsProfScope prof__(AS_FILE_CLS, 0, 0, stream);
-    hipLaunchKernelGGL(relpos_attention_mfma_kernel<NW>, dim3(as_cdiv(max_len, NQ), heads, B), dim3(NW * 64), smem, stream, qkv, ld, C,
-                       window, ek, ev, ek2, ev2, b_split, col_off, out, ldo);
-    AS_CHECK_LAUNCH();
-    return AS_OK;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // The same attention fed by the q/k/v GEMM's OPERAND IMAGE (include/artspeech_hip.h: [k-block][plane][column][8 fp16], x = h + l): the image
 // is already in MFMA fragment order, so
 //   Q fragments are 16-byte global loads straight into registers (nothing staged, nothing converted),
 //   K tiles go global -> LDS by LDS-DMA (one 1 KB `buffer_load_dwordx4 ... lds` per plane and k-block, double buffered),
 //   only V (contraction over keys: needs key-contiguous rows) is read from the fp32 result and split while it is staged,
-// and the result can be written as the o-projection's operand image.  The kernels above stage Q, K, V as fp32 rows of one utterance --
-// at 40 tokens that is ~250 dependent 160-byte loads per thread and most of their 38-42 us; this one does 16 + 8 + 16 wide loads.
-// Arithmetic, tile shapes and the band terms are those of relpos_attention_mfma_kernel.
+// and the result can be written as the o-projection's operand image.  (A first matrix-core version staged Q, K, V as fp32 rows of one
+// utterance -- at 40 tokens ~250 dependent 160-byte loads per thread and most of its 38 us; this one does 16 + 8 + 16 wide loads.)
+// Same arithmetic as the conv GEMMs: every fp32 operand is h + l (two fp16 values, 22 bits), a product is h.l + l.h + h.h on
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation.
+//   workgroup = (utterance, head, NW x 32 queries); a wave owns 32 queries for the whole key loop, keys come in tiles of 64.
+//   S^T = K . Q^T   (A = K tile [32 keys][16 d], B = Q^T [16 d][32 queries]): a lane ends up with ONE query (column lane & 31)
+//                   and 16 of the tile's 32 keys -> the online softmax is per-lane arithmetic plus one exchange with lane ^ 32.
+//   O^T += V^T . P^T (A = V^T [32 d][16 keys], B = P^T [16 keys][32 queries]): the S^T accumulator registers ARE the B operand
+//                   (after exp and the h/l split); the contraction visits the keys in the accumulator's row order, so V is
+//                   staged in LDS in exactly that order and nothing is shuffled between the two products.
+//   The two 9-row relative-position tables are matrix-core operands too (built once per workgroup in LDS): q . Ek[r] is one more
+//   "key" block, sum_r p_r Ev[r] one more 16-deep contraction block in the <= 3 key blocks that intersect a wave's band.
 // ---------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void attn_lds_void;
 struct AttnImageArgs {
@@ -986,29 +583,6 @@ extern "C" int as_relpos_attention_groups_f32(const float* qkv, int ld, int C, i
     const int dk = C / heads;
     if (dk > MAXDK || 2 * window + 1 > MAXREL || window < 0 || B < 0) return AS_EINVAL;
     if (B == 0 || max_len <= 0) return AS_OK;
-    const char* mode = getenv("AS_ATTN");                                      // experiments: "valu" = the vector-ALU kernels only, "mfma" = matrix cores at every length
-    const bool force_mfma = mode && !strcmp(mode, "mfma"), no_mfma = mode && !strcmp(mode, "valu");
-    if (dk == 128 && !no_mfma && (max_len > SN || force_mfma)) {
-        if (max_len <= 64)
-            return launch_attention_mfma<2>(qkv, ld, C, heads, window, emb_rel_k, emb_rel_v, emb_rel_k2, emb_rel_v2, b_split, col_off, B,
-                                            max_len, out, ldo, (hipStream_t)stream);
-        return launch_attention_mfma<4>(qkv, ld, C, heads, window, emb_rel_k, emb_rel_v, emb_rel_k2, emb_rel_v2, b_split, col_off, B, max_len,
-                                        out, ldo, (hipStream_t)stream);
-    }
-    if (max_len <= SN && dk == 128 && !getenv("AS_ATTN_GENERAL")) {            // short utterances: one workgroup per (utterance, head)
-        const size_t sm_small = sizeof(float) * ((size_t)3 * 128 * SPAD + SN * SPAD + SN * MAXREL + 2 * MAXREL * 128);
-        static bool attr_small = false;
-        if (!attr_small) {
-            AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_small_kernel<128>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_small = true;
-        }
-        AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
-        hipLaunchKernelGGL(relpos_attention_small_kernel<128>, dim3(heads, B), dim3(256), sm_small, (hipStream_t)stream, qkv, ld, C,
-                           window, emb_rel_k, emb_rel_v, emb_rel_k2, emb_rel_v2, b_split, col_off, out, ldo);
-        AS_CHECK_LAUNCH();
-        return AS_OK;
-    }
     const size_t smem = sizeof(float) * ((size_t)2 * dk * KPAD + QT * dk + 4 * KT * 4 + QT * MAXREL + 2 * MAXREL * dk);
     static bool attr_set = false;                          // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_set) {
