@@ -573,136 +573,172 @@ static __device__ __forceinline__ float h3_wave_sum(float v)
 // C + c; utterance u reads its input at columns src_off[u].. (NULL: col_off[u]) and writes at col_off[u].. -- at 2 col_off[u]
 // with the fused depthwise ConvTranspose1d(k3, s2, p1, op1) x2 up-sampler (models.py:172,195): out[2i] = a[i] w1 + b,
 // out[2i+1] = a[i] w2 + a[i+1] w0 + b, and x_up (fp32) gets the nearest x2 copy of x (the block's shortcut, models.py:184).
-// Workgroup = (k-block = 16 channels, utterance): a wave computes the statistics of four channels (one pass for the mean, one for
-// the variance, the summation order of adain_kernel), then a thread takes 8 channels of one column, normalises, applies
-// LeakyReLU(0.2), splits and stores the two 16-byte rows (h, l) of its (k-half, column).
+//
+// A WAVE owns one 16-byte row group of the image -- 8 consecutive channels (k-block kb, k-half kh) of one utterance -- from the first
+// load to the last store: lane = column (i = lane + 64 j), the 8 x RV values stay in registers through the two statistics passes
+// (summation order of adain_kernel: a lane adds its elements in ascending order, then the wave's butterfly), the normalisation and
+// the split, so the input is read ONCE, nothing goes through LDS and there is no barrier (the round-1 / early round-2 kernel computed
+// the statistics per wave of four channels, parked them in LDS and re-read x from L2 for the second pass: 15-25 us per launch).  The
+// up-sampler's a[i+1] is the next lane's value (lane 63: lane 0 of the next register).  Utterances longer than 64 RV frames take
+// the same mapping with loops over global memory (three passes).  Workgroup = 4 waves = two k-blocks of one utterance.
 template <bool UP>
 __global__ void __launch_bounds__(256)
 adain_image_kernel(const AsAdainArgs a)
 {
-    __shared__ float st[16][4];                                         // mean, rstd, 1 + gamma, beta
-    const int kb = blockIdx.x, u = blockIdx.y;
+    constexpr int RV = 8;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kb = blockIdx.x * 2 + (wave >> 1), kh = wave & 1, u = blockIdx.y;
     const int C = a.C;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (kb >= as_kbx(C)) return;
     const size_t NX = (size_t)a.N + 1;
     u32x4_t* xs = reinterpret_cast<u32x4_t*>(a.yh);
-    const size_t plane0 = (size_t)kb * 4 * NX;                          // plane q = p*2 + kh of this k-block at plane0 + q NX
-    if (u == 0 && threadIdx.x < 4) xs[plane0 + (size_t)threadIdx.x * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};   // the zero column
+    const size_t plane = ((size_t)kb * 4 + kh) * NX;                    // h part; the l part two planes on
+    if (u == 0 && lane == 0) {                                          // the zero column
+        xs[plane + a.N] = u32x4_t{0u, 0u, 0u, 0u};
+        xs[plane + 2 * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};
+    }
     const int o0 = a.col_off[u], L = a.col_off[u + 1] - o0;
     if (L <= 0) return;
     const int s0 = a.src_off ? a.src_off[u] : o0;
     const size_t gbase = a.gb_off ? (size_t)a.gb_off[u] : (size_t)u * a.ldgb;
-    // Statistics of the wave's four channels.  Utterances of up to 64 * RV frames: every lane's share of all four rows is loaded
-    // up front (one memory latency for the lot instead of one per row pass: this kernel is latency-bound) and both passes run on
-    // registers; longer ones loop, four rows interleaved.  Summation order as adain_kernel: a lane adds its elements in ascending
-    // order, then the wave's butterfly.
-    constexpr int RV = 8;
-    const float* xr0 = a.x + (size_t)(kb * 16 + wave * 4) * a.ldx + s0;
-    float mean[4], var[4];
+    const int c0 = kb * 16 + kh * 8;
+    // per-channel constants (wave-uniform addresses); channels >= C (the image's padding rows) come out as zeros
+    float g1[8], bt[8], w0[8], w1[8], w2[8], pb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int c = c0 + r < C ? c0 + r : C - 1;
+        g1[r] = 1.0f + a.gb[gbase + (size_t)c * a.gb_sc];
+        bt[r] = a.gb[gbase + (size_t)(C + c) * a.gb_sc];
+        if (UP) { w0[r] = a.pool_w[c * 3 + 0]; w1[r] = a.pool_w[c * 3 + 1]; w2[r] = a.pool_w[c * 3 + 2]; pb[r] = a.pool_b[c]; }
+    }
+    const float* xr0 = a.x + s0;
+    const size_t at0 = plane + (UP ? 2 * (size_t)o0 : (size_t)o0);
+    float mean[8], rstd[8];
     if (L <= 64 * RV) {
-        float v[4][RV];
+        float v[8][RV];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 8; ++r) {
+            const float* xr = xr0 + (size_t)(c0 + r < C ? c0 + r : C - 1) * a.ldx;
 #pragma unroll
-            for (int j = 0; j < RV; ++j) {
-                const int i = lane + 64 * j;
-                v[q][j] = (kb * 16 + wave * 4 + q < C && i < L) ? xr0[(size_t)q * a.ldx + i] : 0.f;
-            }
+            for (int j = 0; j < RV; ++j) v[r][j] = xr[min(lane + 64 * j, L - 1)];        // loads only; masked below
+        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int r = 0; r < 8; ++r) {
             float sacc = 0.f;
 #pragma unroll
             for (int j = 0; j < RV; ++j)
-                if (lane + 64 * j < L) sacc += v[q][j];
-            mean[q] = h3_wave_sum(sacc) / (float)L;
+                if (lane + 64 * j < L) sacc += v[r][j];
+            mean[r] = h3_wave_sum(sacc) / (float)L;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int r = 0; r < 8; ++r) {
             float vacc = 0.f;
 #pragma unroll
             for (int j = 0; j < RV; ++j)
-                if (lane + 64 * j < L) { const float d = v[q][j] - mean[q]; vacc += d * d; }
-            var[q] = h3_wave_sum(vacc) / (float)L;
+                if (lane + 64 * j < L) { const float d = v[r][j] - mean[r]; vacc += d * d; }
+            rstd[r] = 1.0f / sqrtf(h3_wave_sum(vacc) / (float)L + 1e-5f);
         }
-    } else {
-        float sacc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = lane; i < L; i += 64)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sacc[q] += (kb * 16 + wave * 4 + q < C) ? xr0[(size_t)q * a.ldx + i] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mean[q] = h3_wave_sum(sacc[q]) / (float)L;
-        float vacc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = lane; i < L; i += 64)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float d = ((kb * 16 + wave * 4 + q < C) ? xr0[(size_t)q * a.ldx + i] : 0.f) - mean[q];
-                vacc[q] += d * d;
-            }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) var[q] = h3_wave_sum(vacc[q]) / (float)L;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = kb * 16 + wave * 4 + q;
-        if (c < C && lane == 0) {
-            st[wave * 4 + q][0] = mean[q];
-            st[wave * 4 + q][1] = 1.0f / sqrtf(var[q] + 1e-5f);
-            st[wave * 4 + q][2] = 1.0f + a.gb[gbase + (size_t)c * a.gb_sc];
-            st[wave * 4 + q][3] = a.gb[gbase + (size_t)(C + c) * a.gb_sc];
-        }
-    }
-    __syncthreads();
-    // work item = (column i, k-half kh): 2 L items over 256 threads
-    for (int it = threadIdx.x; it < 2 * L; it += 256) {
-        const int kh = it / L, i = it - kh * L;
-        const int c0 = kb * 16 + kh * 8;
-        const size_t plane = plane0 + (size_t)kh * NX;
-        if (!UP) {
-            float t[8];
+        if (UP && a.x_up) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                float o = 0.f;
-                if (c0 + r < C) {
-                    const float* sr = st[kh * 8 + r];
-                    o = as_adain_val(a.x[(size_t)(c0 + r) * a.ldx + s0 + i], sr[0], sr[1], sr[2], sr[3], a.lrelu);
+                if (c0 + r >= C) continue;
+                float* ur = a.x_up + (size_t)(c0 + r) * a.ld_up + 2 * o0;
+#pragma unroll
+                for (int j = 0; j < RV; ++j) {
+                    const int i = lane + 64 * j;
+                    if (i < L) { ur[2 * i] = v[r][j]; ur[2 * i + 1] = v[r][j]; }
                 }
-                t[r] = o;
             }
-            u32x4_t h, l;
-            split2(t, h, l);
-            const size_t at = plane + o0 + i;
-            xs[at] = h;
-            xs[at + 2 * NX] = l;
+        }
+        // normalise in place; everything outside (channel >= C, column >= L) becomes zero
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < RV; ++j)
+                v[r][j] = (c0 + r < C && lane + 64 * j < L) ? as_adain_val(v[r][j], mean[r], rstd[r], g1[r], bt[r], a.lrelu) : 0.f;
+#pragma unroll
+        for (int j = 0; j < RV; ++j) {
+            const int i = lane + 64 * j;
+            if (64 * j >= L) break;                                      // (wave-uniform)
+            if (!UP) {
+                float t[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) t[r] = v[r][j];
+                u32x4_t h, l;
+                split2(t, h, l);
+                if (i < L) {
+                    xs[at0 + i] = h;
+                    xs[at0 + i + 2 * NX] = l;
+                }
+            } else {
+                float e0[8], e1[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float dn = __shfl_down(v[r][j], 1);
+                    const float wr = j + 1 < RV ? __shfl(v[r][j + 1 < RV ? j + 1 : j], 0) : 0.f;
+                    const float an = i + 1 < L ? (lane == 63 ? wr : dn) : 0.f;
+                    float o0v, o1v;
+                    as_convt_pair(v[r][j], an, w0[r], w1[r], w2[r], pb[r], &o0v, &o1v);
+                    e0[r] = c0 + r < C ? o0v : 0.f;
+                    e1[r] = c0 + r < C ? o1v : 0.f;
+                }
+                u32x4_t h, l, h2, l2;
+                split2(e0, h, l);
+                split2(e1, h2, l2);
+                if (i < L) {
+                    xs[at0 + 2 * i] = h;
+                    xs[at0 + 2 * i + 2 * NX] = l;
+                    xs[at0 + 2 * i + 1] = h2;
+                    xs[at0 + 2 * i + 1 + 2 * NX] = l2;
+                }
+            }
+        }
+        return;
+    }
+    // long utterances: the same mapping, three passes over global memory
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float* xr = xr0 + (size_t)(c0 + r < C ? c0 + r : C - 1) * a.ldx;
+        float sacc = 0.f;
+        for (int i = lane; i < L; i += 64) sacc += xr[i];
+        mean[r] = h3_wave_sum(sacc) / (float)L;
+        float vacc = 0.f;
+        for (int i = lane; i < L; i += 64) { const float d = xr[i] - mean[r]; vacc += d * d; }
+        rstd[r] = 1.0f / sqrtf(h3_wave_sum(vacc) / (float)L + 1e-5f);
+    }
+    for (int i = lane; i < L; i += 64) {
+        float a0[8], a1[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const bool ok = c0 + r < C;
+            const float* xr = xr0 + (size_t)(ok ? c0 + r : C - 1) * a.ldx;
+            const float xi = xr[i], xn = xr[min(i + 1, L - 1)];
+            a0[r] = ok ? as_adain_val(xi, mean[r], rstd[r], g1[r], bt[r], a.lrelu) : 0.f;
+            a1[r] = (ok && i + 1 < L) ? as_adain_val(xn, mean[r], rstd[r], g1[r], bt[r], a.lrelu) : 0.f;
+            if (UP && a.x_up && ok) {
+                float* ur = a.x_up + (size_t)(c0 + r) * a.ld_up + 2 * o0 + 2 * i;
+                ur[0] = xi;
+                ur[1] = xi;
+            }
+        }
+        u32x4_t h, l;
+        if (!UP) {
+            split2(a0, h, l);
+            xs[at0 + i] = h;
+            xs[at0 + i + 2 * NX] = l;
         } else {
             float e0[8], e1[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                float o0v = 0.f, o1v = 0.f;
-                if (c0 + r < C) {
-                    const float* sr = st[kh * 8 + r];
-                    const float* xr = a.x + (size_t)(c0 + r) * a.ldx + s0;
-                    const float xi = xr[i];
-                    const float a0 = as_adain_val(xi, sr[0], sr[1], sr[2], sr[3], a.lrelu);
-                    const float a1 = i + 1 < L ? as_adain_val(xr[i + 1], sr[0], sr[1], sr[2], sr[3], a.lrelu) : 0.f;
-                    const float w0 = a.pool_w[(c0 + r) * 3 + 0], w1 = a.pool_w[(c0 + r) * 3 + 1], w2 = a.pool_w[(c0 + r) * 3 + 2], pb = a.pool_b[c0 + r];
-                    as_convt_pair(a0, a1, w0, w1, w2, pb, &o0v, &o1v);
-                    if (a.x_up) {
-                        float* ur = a.x_up + (size_t)(c0 + r) * a.ld_up + 2 * o0 + 2 * i;
-                        ur[0] = xi;
-                        ur[1] = xi;
-                    }
-                }
-                e0[r] = o0v;
-                e1[r] = o1v;
+                as_convt_pair(a0[r], a1[r], w0[r], w1[r], w2[r], pb[r], &e0[r], &e1[r]);
+                if (c0 + r >= C) { e0[r] = 0.f; e1[r] = 0.f; }
             }
-            u32x4_t h, l;
             split2(e0, h, l);
-            const size_t at = plane + 2 * (size_t)o0 + 2 * i;
-            xs[at] = h;
-            xs[at + 2 * NX] = l;
+            xs[at0 + 2 * i] = h;
+            xs[at0 + 2 * i + 2 * NX] = l;
             split2(e1, h, l);
-            xs[at + 1] = h;
-            xs[at + 1 + 2 * NX] = l;
+            xs[at0 + 2 * i + 1] = h;
+            xs[at0 + 2 * i + 1 + 2 * NX] = l;
         }
     }
 }
@@ -716,8 +752,8 @@ extern "C" int as_adain_image_f32(const AsAdainArgs* args_host, as_stream_t stre
     if ((reinterpret_cast<uintptr_t>(a.yh) & 15) != 0) return AS_EINVAL;
     if (a.N == 0) return AS_OK;
     AsProfScope prof__(AS_CLS_ADAIN, 0, 8.0 * a.C * (double)a.N, (hipStream_t)stream);
-    if (a.pool_w) hipLaunchKernelGGL(adain_image_kernel<true>, dim3(as_kbx(a.C), a.U), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(adain_image_kernel<false>, dim3(as_kbx(a.C), a.U), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.pool_w) hipLaunchKernelGGL(adain_image_kernel<true>, dim3(as_kbx(a.C) / 2, a.U), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(adain_image_kernel<false>, dim3(as_kbx(a.C) / 2, a.U), dim3(256), 0, (hipStream_t)stream, a);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
