@@ -696,49 +696,97 @@ adain_image_kernel(const AsAdainArgs a)
         return;
     }
     // long utterances: the same mapping, three passes over global memory
+    {
+        size_t rowoff[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const float* xr = xr0 + (size_t)(c0 + r < C ? c0 + r : C - 1) * a.ldx;
-        float sacc = 0.f;
-        for (int i = lane; i < L; i += 64) sacc += xr[i];
-        mean[r] = h3_wave_sum(sacc) / (float)L;
-        float vacc = 0.f;
-        for (int i = lane; i < L; i += 64) { const float d = xr[i] - mean[r]; vacc += d * d; }
-        rstd[r] = 1.0f / sqrtf(h3_wave_sum(vacc) / (float)L + 1e-5f);
-    }
-    for (int i = lane; i < L; i += 64) {
-        float a0[8], a1[8];
+        for (int r = 0; r < 8; ++r) rowoff[r] = (size_t)(c0 + r < C ? c0 + r : C - 1) * a.ldx;
+        float acc[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const bool ok = c0 + r < C;
-            const float* xr = xr0 + (size_t)(ok ? c0 + r : C - 1) * a.ldx;
-            const float xi = xr[i], xn = xr[min(i + 1, L - 1)];
-            a0[r] = ok ? as_adain_val(xi, mean[r], rstd[r], g1[r], bt[r], a.lrelu) : 0.f;
-            a1[r] = (ok && i + 1 < L) ? as_adain_val(xn, mean[r], rstd[r], g1[r], bt[r], a.lrelu) : 0.f;
-            if (UP && a.x_up && ok) {
-                float* ur = a.x_up + (size_t)(c0 + r) * a.ld_up + 2 * o0 + 2 * i;
-                ur[0] = xi;
-                ur[1] = xi;
-            }
+        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+        // the eight channels side by side, four columns per trip: 32 loads in flight (a channel's elements still add up in ascending order)
+        int i = lane;
+        for (; i + 192 < L; i += 256) {
+            float t[4][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) t[q][r] = xr0[rowoff[r] + i + 64 * q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[r] += t[q][r];
         }
-        u32x4_t h, l;
-        if (!UP) {
-            split2(a0, h, l);
-            xs[at0 + i] = h;
-            xs[at0 + i + 2 * NX] = l;
-        } else {
-            float e0[8], e1[8];
+        for (; i < L; i += 64)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] += xr0[rowoff[r] + i];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { mean[r] = h3_wave_sum(acc[r]) / (float)L; acc[r] = 0.f; }
+        i = lane;
+        for (; i + 192 < L; i += 256) {
+            float t[4][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) t[q][r] = xr0[rowoff[r] + i + 64 * q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { const float d = t[q][r] - mean[r]; acc[r] += d * d; }
+        }
+        for (; i < L; i += 64)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const float d = xr0[rowoff[r] + i] - mean[r]; acc[r] += d * d; }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rstd[r] = 1.0f / sqrtf(h3_wave_sum(acc[r]) / (float)L + 1e-5f);
+    }
+    // third pass: two columns per trip (i and i + 64), every load before the first use
+    for (int i0 = lane; i0 < L; i0 += 128) {
+        float xi[2][8], xn[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = min(i0 + 64 * q, L - 1);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                as_convt_pair(a0[r], a1[r], w0[r], w1[r], w2[r], pb[r], &e0[r], &e1[r]);
-                if (c0 + r >= C) { e0[r] = 0.f; e1[r] = 0.f; }
+                const float* xr = xr0 + (size_t)(c0 + r < C ? c0 + r : C - 1) * a.ldx;
+                xi[q][r] = xr[i];
+                if (UP) xn[q][r] = xr[min(i + 1, L - 1)];
             }
-            split2(e0, h, l);
-            xs[at0 + 2 * i] = h;
-            xs[at0 + 2 * i + 2 * NX] = l;
-            split2(e1, h, l);
-            xs[at0 + 2 * i + 1] = h;
-            xs[at0 + 2 * i + 1 + 2 * NX] = l;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = i0 + 64 * q;
+            if (i >= L) break;
+            float a0[8], a1[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bool ok = c0 + r < C;
+                a0[r] = ok ? as_adain_val(xi[q][r], mean[r], rstd[r], g1[r], bt[r], a.lrelu) : 0.f;
+                a1[r] = (UP && ok && i + 1 < L) ? as_adain_val(xn[q][r], mean[r], rstd[r], g1[r], bt[r], a.lrelu) : 0.f;
+                if (UP && a.x_up && ok) {
+                    float* ur = a.x_up + (size_t)(c0 + r) * a.ld_up + 2 * o0 + 2 * i;
+                    ur[0] = xi[q][r];
+                    ur[1] = xi[q][r];
+                }
+            }
+            u32x4_t h, l;
+            if (!UP) {
+                split2(a0, h, l);
+                xs[at0 + i] = h;
+                xs[at0 + i + 2 * NX] = l;
+            } else {
+                float e0[8], e1[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    as_convt_pair(a0[r], a1[r], w0[r], w1[r], w2[r], pb[r], &e0[r], &e1[r]);
+                    if (c0 + r >= C) { e0[r] = 0.f; e1[r] = 0.f; }
+                }
+                split2(e0, h, l);
+                xs[at0 + 2 * i] = h;
+                xs[at0 + 2 * i + 2 * NX] = l;
+                split2(e1, h, l);
+                xs[at0 + 2 * i + 1] = h;
+                xs[at0 + 2 * i + 1 + 2 * NX] = l;
+            }
         }
     }
 }

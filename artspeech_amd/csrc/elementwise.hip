@@ -390,6 +390,9 @@ extern "C" int as_project_cols_f32(const float* x, int ldx, int K, int N, const 
 // ---------------------------------------------------------------------------------------------------
 // round-half-even, clamp(min=1) (torch.round + clamp, models.py:361); frame offsets per utterance;
 // tok_of_frame[f] = packed token column that frame f repeats.  Single workgroup (B and N are small).
+// One global exclusive prefix over the packed tokens IS the frame index (utterances are packed back to back in both layouts): thread t
+// owns a contiguous chunk of tokens, chunk sums are scanned in LDS, then every thread writes its tokens' frames.  (One thread per
+// UTTERANCE walking its tokens made the long-form batch -- 8 x 1024 tokens -- a 170 us serial loop.)
 __global__ void __launch_bounds__(1024)
 durations_kernel(const float* __restrict__ dur_f, const int* __restrict__ forced, const int* __restrict__ tok_off,
                  int B, int* __restrict__ dur_i, int* __restrict__ frame_off, int* __restrict__ tok_of_frame,
@@ -397,7 +400,10 @@ durations_kernel(const float* __restrict__ dur_f, const int* __restrict__ forced
 {
     __shared__ int sums[1024];
     const int ntok = tok_off[B];
-    for (int i = threadIdx.x; i < ntok; i += blockDim.x) {
+    const int t = threadIdx.x;
+    const int per = (ntok + 1023) / 1024, lo = min(t * per, ntok), hi = min(lo + per, ntok);
+    int local = 0;
+    for (int i = lo; i < hi; ++i) {
         int d;
         if (forced) d = forced[i];
         else {
@@ -405,26 +411,39 @@ durations_kernel(const float* __restrict__ dur_f, const int* __restrict__ forced
             d = (int)(r < 1.f ? 1.f : r);
         }
         dur_i[i] = d;
+        local += d;
     }
+    sums[t] = local;
     __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        int s = 0;
-        for (int i = tok_off[b]; i < tok_off[b + 1]; ++i) s += dur_i[i];
-        sums[b] = s;
+    for (int off = 1; off < 1024; off <<= 1) {             // inclusive scan of the chunk sums
+        const int v = t >= off ? sums[t - off] : 0;
+        __syncthreads();
+        sums[t] += v;
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int b = 0; b < B; ++b) { frame_off[b] = acc; acc += sums[b]; }
-        frame_off[B] = acc;
+    int f = sums[t] - local;                               // first frame of this thread's first token
+    // frame_off[b] = frame index of utterance b's first token: the thread whose chunk holds that token writes it
+    if (t == 0) frame_off[B] = sums[1023];
+    int b = 0;
+    if (lo < hi || ntok == 0) {
+        // utterances whose first token lies in [lo, hi): B is small, a linear scan per thread is fine
+        for (b = 0; b < B; ++b) {
+            const int first = tok_off[b];
+            if (first >= lo && first < hi) {
+                int fb = f;
+                for (int i = lo; i < first; ++i) fb += dur_i[i];
+                frame_off[b] = fb;
+            }
+        }
     }
-    __syncthreads();
+    if (t == 0)                                            // empty utterances at the very end (first token == ntok)
+        for (b = 0; b < B; ++b)
+            if (tok_off[b] >= ntok) frame_off[b] = sums[1023];
     if (!tok_of_frame) return;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        int f = frame_off[b];
-        for (int i = tok_off[b]; i < tok_off[b + 1]; ++i)
-            for (int r = 0; r < dur_i[i]; ++r, ++f)
-                if (f < max_frames) tok_of_frame[f] = i;
+    for (int i = lo; i < hi; ++i) {
+        const int d = dur_i[i];
+        for (int r = 0; r < d; ++r, ++f)
+            if (f < max_frames) tok_of_frame[f] = i;
     }
 }
 
