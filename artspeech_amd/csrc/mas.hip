@@ -93,7 +93,7 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
 #pragma unroll
                 for (int r = 0; r < R; ++r) prev[r] = (r0 + r == 0) ? cur[0].x : MAS_NEG;
             } else {
-                float up = __shfl_up(prev[R - 1], 1);
+                float up = __shfl_up(prev[R - 1], 1);             // (a DPP wave_shr:1 instead of this ds_bpermute measures the same: 808 us)
                 if (lane == 0) up = (wave == 0) ? MAS_NEG : bnd[((y - 1) & 1) * 16 + wave - 1];
                 float nv[R];
                 unsigned bj = 0u;
@@ -176,7 +176,10 @@ static int mas_geometry(int Tx, int* R, int* W)
         r = atoi(env);
         if (r != 1 && r != 2 && r != 4 && r != 8 && r != 16) return AS_EINVAL;
     } else {
-        while (r < 16 && 64 * r * (r <= 4 ? 16 : 8) < Tx) r <<= 1;
+        // eight waves at most unless the rows do not fit otherwise: [8,1024,2000] 8 waves x 2 rows 0.80 ms, 16 x 1 0.91, 4 x 4 0.86,
+        // 2 x 8 0.95, 1 x 16 1.25 (a variant without the per-column barrier -- skewed waves handing their boundary row over through an
+        // LDS ring -- was 0.1 ms SLOWER at every geometry: the column time is the waves' own dependent chains, not the barrier)
+        while (r < 16 && 64 * r * 8 < Tx) r <<= 1;
     }
     const int w = as_cdiv(Tx > 0 ? Tx : 1, 64 * r);
     if (w > (r <= 4 ? 16 : 8)) return AS_EINVAL;           // Tx <= 8192
