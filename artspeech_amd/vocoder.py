@@ -149,11 +149,19 @@ class Generator:
             x = ops.interleave_phases(z, b, cout, u, lay.N, lay_up.new(cout))
             lay = lay_up
             outs = []
+            # LeakyReLU(x) as an operand image, once for the three residual stacks that start from x; inside a stack every conv hands its
+            # LeakyReLU'd result to the next one as an image (ConvGemmArgs.Yh / yh_lrelu): no fp32 copy of conv1's output, no split passes
+            xh = ops.split_act(x, lay, in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
             for j in range(nk):
-                y = x
-                for (w1, b1, t1, w2, b2, t2) in W[f"rb{i * nk + j}"]:
-                    xt = ops.conv_gemm(w1, y, lay, lay.new(cout), t1, bias=b1, in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
-                    y = ops.conv_gemm(w2, xt, lay, lay.new(cout), t2, bias=b2, res=y, in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
+                y, yh = x, xh
+                blk = W[f"rb{i * nk + j}"]
+                for n, (w1, b1, t1, w2, b2, t2) in enumerate(blk):
+                    xth = ops.new_image(cout, lay.N, x.device)
+                    ops.conv_gemm(w1, None, lay, None, t1, bias=b1, xs=yh, K=cout, yh=xth, yh_lrelu=True, in_slope=LRELU_SLOPE)
+                    last = n + 1 == len(blk)
+                    yh = None if last else ops.new_image(cout, lay.N, x.device)
+                    y = ops.conv_gemm(w2, None, lay, lay.new(cout), t2, bias=b2, res=y, xs=xth, K=cout, yh=yh, yh_lrelu=not last,
+                                      in_slope=LRELU_SLOPE)
                 outs.append(y)
             if nk != 3:
                 raise NotImplementedError("three residual stacks per stage (Vocoder/config.json)")
