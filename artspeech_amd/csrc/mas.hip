@@ -20,6 +20,7 @@
 //
 // Algorithmic bytes: 4*Tx*Ty read per utterance + 4*Tx*Ty path written (memset) +
 // Tx*Ty/8 decision bits written and read.
+#include <cstring>
 #include "common.h"
 #include "artspeech_hip.h"
 
@@ -29,7 +30,15 @@
 #define MAS_NEG (-1e32f)
 typedef unsigned long long u64;
 
-template <int R, bool VEC4, bool TIE_MOVE, int MAXT>
+#ifdef AS_EXPERIMENTS
+__device__ unsigned long long mas_dbg[8];      // shader / wall clocks at the phase boundaries of block 0 (scripts/exp/mas_clock.py)
+#define MAS_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { mas_dbg[2 * (i)] = clock64(); mas_dbg[2 * (i) + 1] = wall_clock64(); } } while (0)
+extern "C" int as_mas_debug(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(mas_dbg), 64); }
+#else
+#define MAS_MARK(i)
+#endif
+
+template <int R, int Q, bool VEC4, bool TIE_MOVE, int MAXT>
 __global__ void __launch_bounds__(MAXT)
 mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const int* __restrict__ t_y,
            int Tx, int Ty, float* __restrict__ path, int* __restrict__ dur, int* __restrict__ rows,
@@ -52,75 +61,97 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
     if (x_len <= 0 || y_len <= 0) return;                  // uniform per block
 
     const float* vb = value + (size_t)b * Tx * Ty;
-    const int nchunk_max = (Ty + 3) >> 2;
-    u64* wsb = ws + (size_t)b * nchunk_max * NT;
+    const int ngroup_max = (Ty + 3) >> 2;                  // a "group" = 4 columns = one decision word per thread
+    u64* wsb = ws + (size_t)b * ngroup_max * NT;
     const int r0 = tid * R;
 
     float prev[R];
-    float4 cur[R], nxt[R];
+    float4 cur[R][Q], nxt[R][Q];
 
-    auto load_chunk = [&](int c, float4 (&dst)[R]) {
+    // a chunk = Q groups = 16 Q bytes of each of the lane's rows.  Q = 8 is one whole 128-byte line per row: the workgroup's rows are
+    // Tx lines 4 Ty bytes apart (128 KB of lines at Tx = 1024, four times the CU's L1), so a line that is fetched 16 bytes at a time
+    // comes up from L2 eight times -- [8,1024,2000] took 0.80 ms that way (0.4 us per column, all of it this traffic), whatever the
+    // geometry of the waves.
+    auto load_chunk = [&](int c, float4 (&dst)[R][Q]) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int x = r0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (x < x_len) {
-                const float* p = vb + (size_t)x * Ty + 4 * c;
-                if (VEC4) {
-                    v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    const int rem = Ty - 4 * c;
-                    v.x = p[0];
-                    if (rem > 1) v.y = p[1];
-                    if (rem > 2) v.z = p[2];
-                    if (rem > 3) v.w = p[3];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int g = c * Q + q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef MAS_KO_LOADS
+                if (false) {
+#else
+                if (x < x_len && 4 * g < Ty) {
+#endif
+                    const float* p = vb + (size_t)x * Ty + 4 * g;
+                    if (VEC4) {
+                        v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        const int rem = Ty - 4 * g;
+                        v.x = p[0];
+                        if (rem > 1) v.y = p[1];
+                        if (rem > 2) v.z = p[2];
+                        if (rem > 3) v.w = p[3];
+                    }
                 }
+                dst[r][q] = v;
             }
-            dst[r] = v;
         }
     };
 
-    const int nchunk = (y_len + 3) >> 2;
+    const int ngroup = (y_len + 3) >> 2;
+    const int nchunk = (ngroup + Q - 1) / Q;
     load_chunk(0, cur);
     for (int c = 0; c < nchunk; ++c) {
         if (c + 1 < nchunk) load_chunk(c + 1, nxt);
-        unsigned bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int y = 4 * c + j;
-            if (y >= y_len) break;
-            if (y == 0) {
+        for (int q = 0; q < Q; ++q) {
+            const int g = c * Q + q;
+            if (g >= ngroup) break;
+            unsigned bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int r = 0; r < R; ++r) prev[r] = (r0 + r == 0) ? cur[0].x : MAS_NEG;
-            } else {
-                float up = __shfl_up(prev[R - 1], 1);             // (a DPP wave_shr:1 instead of this ds_bpermute measures the same: 808 us)
-                if (lane == 0) up = (wave == 0) ? MAS_NEG : bnd[((y - 1) & 1) * 16 + wave - 1];
-                float nv[R];
-                unsigned bj = 0u;
+            for (int j = 0; j < 4; ++j) {
+                const int y = 4 * g + j;
+                if (y >= y_len) break;
+                if (y == 0) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float a = prev[r];
-                    const float cc = (r > 0) ? prev[r - 1] : up;
-                    // v1: direction = where(a > c, 0, -1);  v2/Triton: move iff c > a.  max = where(a > c, a, c).
-                    const bool move = TIE_MOVE ? !(a > cc) : (cc > a);
-                    const float m = move ? cc : a;
-                    bj = (bj << 1) | (move ? 1u : 0u);         // row r ends at bit R-1-r
-                    const float val = (j == 0) ? cur[r].x : (j == 1) ? cur[r].y : (j == 2) ? cur[r].z : cur[r].w;
-                    nv[r] = __fadd_rn(val, m);
+                    for (int r = 0; r < R; ++r) prev[r] = (r0 + r == 0) ? cur[0][0].x : MAS_NEG;
+                } else {
+                    float up = __shfl_up(prev[R - 1], 1);             // (a DPP wave_shr:1 instead of this ds_bpermute measures the same)
+                    if (lane == 0) up = (wave == 0) ? MAS_NEG : bnd[((y - 1) & 1) * 16 + wave - 1];
+                    float nv[R];
+                    unsigned bj = 0u;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float a = prev[r];
+                        const float cc = (r > 0) ? prev[r - 1] : up;
+                        // v1: direction = where(a > c, 0, -1);  v2/Triton: move iff c > a.  max = where(a > c, a, c).
+                        const bool move = TIE_MOVE ? !(a > cc) : (cc > a);
+                        const float m = move ? cc : a;
+                        bj = (bj << 1) | (move ? 1u : 0u);         // row r ends at bit R-1-r
+                        const float val = (j == 0) ? cur[r][q].x : (j == 1) ? cur[r][q].y : (j == 2) ? cur[r][q].z : cur[r][q].w;
+                        nv[r] = __fadd_rn(val, m);
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) prev[r] = nv[r];
+                    bits[j] = bj;
                 }
-#pragma unroll
-                for (int r = 0; r < R; ++r) prev[r] = nv[r];
-                bits[j] = bj;
+                if (W > 1) {
+                    if (lane == 63) bnd[(y & 1) * 16 + wave] = prev[R - 1];
+                    // LDS-only barrier: __syncthreads() would also wait for the prefetched chunk's global loads (vmcnt)
+#ifndef MAS_KO_BARRIER
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+                }
             }
-            if (W > 1) {
-                if (lane == 63) bnd[(y & 1) * 16 + wave] = prev[R - 1];
-                // LDS-only barrier: __syncthreads() would also wait for the prefetched chunk's global loads (vmcnt)
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
+            wsb[(size_t)g * NT + tid] = (u64)(bits[0] | (bits[1] << 16)) | ((u64)(bits[2] | (bits[3] << 16)) << 32);
         }
-        wsb[(size_t)c * NT + tid] = (u64)(bits[0] | (bits[1] << 16)) | ((u64)(bits[2] | (bits[3] << 16)) << 32);
 #pragma unroll
-        for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) cur[r][q] = nxt[r][q];
     }
 
     // ---- backtrack ------------------------------------------------------------------------------
@@ -164,6 +195,348 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
     if (tid == 0 && dur) dur[(size_t)b * Tx + idx] = run;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// The banded variant (rows 16-byte aligned): an utterance's lattice is cut into bands of 64 W rows, one workgroup per band, all
+// bands of an utterance on one XCD.  A workgroup is W DP waves (64 rows each, one row per lane) and a loader wave; every DP wave runs a
+// block or two of columns behind the one above it -- a software pipeline down the rows:
+//   the loader:  LDS-DMA (buffer_load ... lds) of the band's rows, two 32-column blocks in flight, into a four-block ring in LDS; an
+//                instruction fetches 8 rows x 128 bytes (whole lines).  HBM latency never reaches the DP.
+//   a DP wave:   its row of the previous column in a register, the row above through DPP wave_shr:1, no barrier.  A column is ~10
+//                instructions: the compare, v_addc (decision word = 2 word + the compare's lane mask), v_max, v_add, the DPP move, one
+//                ds_write of the new value (lane 63's is the wave's last row) and one ds_read of the row above the wave.
+//   wave -> wave below, same workgroup: the last row's 32 values of a block through LDS, a counter per wave.
+//   band -> band below: through 8-byte {value, tag} words in global memory, written once per launch and polled by the lane that needs
+//                them (no flag, no fence), requested one block early so that the round trip to L2 is off the critical path.
+// Producers have lower workgroup ids than their consumers and never wait for them, so the chain cannot deadlock whatever is resident.
+// One workgroup per utterance did 0.4 us per column on [8,1024,2000] whatever its geometry: 1024 rows x 16 bytes per 4 columns is 64
+// distinct lines per load instruction, and the texture path of ONE CU took as long over them as the DP itself.
+// The backtrack is its own launch (one wave per utterance): the 32 decisions of a block of columns are one word per row; lane l of the
+// wave holds the word of row (current row - l), the walk is v_readlane + bit extract + add in scalar registers, and the next block's
+// words are in flight meanwhile.
+// ----------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void mas_lds_void;
+#define MAS_BLK 32            // columns per block
+#define MAS_RING 4            // blocks in the LDS ring
+#define MAS_AHEAD 2           // blocks of DMA in flight (the ring keeps one more slot than ahead + current: the DP never waits for the
+                              // loader's handshake)
+#define MAS_CHUNK_F 260       // floats per chunk in the ring: 8 rows x 32 columns + 4 of padding
+#define MAS_SLOT_F(R) (8 * (R) * MAS_CHUNK_F)
+
+// v_writelane_b32: lane `lane` (uniform) of `old` := the scalar `val`
+static __device__ __forceinline__ int mas_writelane(int val, int lane, int old)
+{
+    // (two scalar registers in one vector instruction exceed gfx9's constant bus: the lane select goes through m0)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
+                 : "+v"(old)
+                 : "s"(__builtin_amdgcn_readfirstlane(val)), "s"(__builtin_amdgcn_readfirstlane(lane))
+                 : "m0");
+    return old;
+}
+
+// the loader's view of the two progress counters: ds_ instructions the compiler does not see (for its own ds_read / ds_write it drains
+// the wave's LDS-DMAs first -- it cannot tell that they go elsewhere)
+static __device__ __forceinline__ int mas_lds_peek(const int* p)
+{
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)(const __attribute__((address_space(3))) int*)p) : "memory");
+    return v;
+}
+static __device__ __forceinline__ void mas_lds_poke(int* p, int v)
+{
+    asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)p), "v"(v) : "memory");
+}
+template <int N> static __device__ __forceinline__ void mas_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+#define MAS_OUT_RING 8        // blocks of a wave's last row kept for the wave below (it runs at most MAS_RING blocks ahead of it)
+
+// one 32-column block of a DP wave (one row per lane).  FULL: all 32 columns exist and none is column 0 (no per-column tests).
+// in[j] = the row above the wave's first row at column j - 1 of the block (in[0]: the previous block's last column).
+template <bool TIE_MOVE, bool FULL>
+static __device__ __forceinline__ void mas_dp_block(const float* __restrict__ slot, int x_local, int blk, int y_len, int ngroup, bool first_row_here,
+                                                    float& prev, const float* __restrict__ in, unsigned& bits, float* __restrict__ last)
+{
+#if __HIP_DEVICE_COMPILE__
+    const float4* rowp = reinterpret_cast<const float4*>(slot + (x_local >> 3) * MAS_CHUNK_F + (x_local & 7) * 32);
+    const float4* inp = reinterpret_cast<const float4*>(in);
+    float4 cur = rowp[0], nxt = cur, icur = inp[0], inxt = icur;      // (the next group's values are read a group early: LDS latency)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int g = blk * 8 + q;
+        if (!FULL && g >= ngroup) break;
+        if (q < 7) {
+            nxt = rowp[q + 1];
+            inxt = inp[q + 1];
+        }
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+            const int y = 4 * g + j4;
+            if (!FULL && y >= y_len) break;
+            const int j = q * 4 + j4;
+            if (!FULL && y == 0) {
+                prev = first_row_here ? cur.x : MAS_NEG;
+            } else {
+                // the row above is lane - 1's (DPP wave_shr:1); lane 0 keeps `old`: the wave / band above, read from LDS by every lane
+                const float a = prev;
+                const float s_up = (j4 == 0) ? icur.x : (j4 == 1) ? icur.y : (j4 == 2) ? icur.z : icur.w;
+                const float cc = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(s_up), __float_as_int(prev), 0x138, 0xf, 0xf, false));
+                // v1: direction = where(a > c, 0, -1);  v2/Triton: move iff c > a.  max = where(a > c, a, c).
+                const bool move = TIE_MOVE ? !(a > cc) : (cc > a);
+                // bits = 2 bits + move in one instruction (add with the compare's lane mask as carry-in): column j of the block ends at
+                // bit 31 - j.  max(a, c) as v_max_f32 rather than a select on the compare: the same value (for equal operands either
+                // one; the sign of a zero cannot change a later compare), one dependent instruction less.  One fp32 add per cell.
+                unsigned long long carry_out;
+                float m;
+                asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(bits), "=s"(carry_out) : "v"(bits), "s"(__builtin_amdgcn_ballot_w64(move)));
+                asm("v_max_f32_e32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(cc));
+                const float val = (j4 == 0) ? cur.x : (j4 == 1) ? cur.y : (j4 == 2) ? cur.z : cur.w;
+                asm("v_add_f32_e32 %0, %1, %2" : "=v"(prev) : "v"(val), "v"(m));
+            }
+            last[j * 64] = prev;                           // (every lane writes: one ds_write, no lane select; lane 63's is the wave's last row)
+        }
+        cur = nxt;
+        icur = inxt;
+    }
+#endif
+}
+
+template <int W, bool TIE_MOVE>
+__global__ void __launch_bounds__(64 * (W + 1))
+mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const int* __restrict__ t_y, int B, int Tx, int Ty, int P,
+                int nblk_max, u64* __restrict__ xchg, unsigned* __restrict__ masks)
+{
+#if __HIP_DEVICE_COMPILE__
+    // a ring slot = one 32-column block of the band's 64 W rows as 8 W chunks of 8 rows x 128 bytes (one DMA instruction each: lane =
+    // (row of the chunk, 16-byte piece), i.e. whole lines -- with a lane per ROW an instruction touches 64 lines, and the texture path
+    // needs ~4 cycles for each: that, not the DP, was the 0.4 us per column of the one-workgroup kernel).  16 bytes of padding per
+    // chunk spread the DP's reads (lane = row, stride 128 bytes) over the banks.
+    __shared__ __attribute__((aligned(16))) float ring[MAS_RING * MAS_SLOT_F(W)];
+    __shared__ int ctr[1 + 2 * W];                         // [0] blocks loaded, [1 + w] consumed by wave w, [1 + W + w] last rows published by w
+    __shared__ float lastrow[W][MAS_BLK * 64];             // [column of the block][lane]: the lanes' rows (lane 63 = the wave's last)
+    __shared__ float outrow[W][MAS_OUT_RING][MAS_BLK];     // lane 63's of the last blocks, for the wave below
+    __shared__ __attribute__((aligned(16))) float inrow[W][MAS_BLK + 4];   // the row above the wave's first row: [0] column -1 of the block, [1 + j] column j
+    // workgroups n, n+8, n+16, ... share an XCD: utterance b lives on XCD b % 8, its bands in dispatch order
+    const int n = blockIdx.x, k = n >> 3;
+    const int b = (k / P) * 8 + (n & 7), p = k % P;
+    if (b >= B) return;
+    int x_len = t_x[b], y_len = t_y[b];
+    x_len = x_len > Tx ? Tx : x_len;
+    y_len = y_len > Ty ? Ty : y_len;
+    const int band0 = p * 64 * W;
+    if (x_len <= 0 || y_len <= 0 || band0 >= x_len) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 1 + 2 * W) ctr[tid] = 0;
+    if (tid < W * (MAS_BLK + 4)) (&inrow[0][0])[tid] = MAS_NEG;
+    __syncthreads();
+    const int nblk = (y_len + MAS_BLK - 1) / MAS_BLK;
+    const int ngroup = (y_len + 3) >> 2;
+
+    if (wave == W) {
+        // ---- loader: instruction i of a block fetches rows band0 + 8 i .. + 7, lane = (row, 16-byte piece of its 128 bytes) ----
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(value + (size_t)b * Tx * Ty), 0,
+                                                                            (int)((unsigned)Tx * (unsigned)Ty * 4u), 0x00020000);
+        unsigned rowoff[8 * W];
+#pragma unroll
+        for (int i = 0; i < 8 * W; ++i) {
+            const int x = band0 + 8 * i + (lane >> 3);
+            rowoff[i] = x < x_len ? (unsigned)x * (unsigned)Ty * 4u : 0xFFFFFF00u;       // outside the descriptor: reads zero
+        }
+        for (int blk = 0; blk < nblk + MAS_AHEAD; ++blk) {
+            if (blk < nblk) {
+                while (true) {                             // the slot's previous block consumed by every DP wave
+                    int c = mas_lds_peek(&ctr[1]);
+#pragma unroll
+                    for (int w = 1; w < W; ++w) {
+                        const int cw = mas_lds_peek(&ctr[1 + w]);
+                        c = cw < c ? cw : c;
+                    }
+                    if (c >= blk - (MAS_RING - 1)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const int slot = blk % MAS_RING;
+                const unsigned col = (unsigned)(blk * 8 + (lane & 7)) * 16u;
+#pragma unroll
+                for (int i = 0; i < 8 * W; ++i) {
+                    const unsigned voff = (col < (unsigned)Ty * 4u && rowoff[i] != 0xFFFFFF00u) ? rowoff[i] + col : 0xFFFFFF00u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (mas_lds_void*)(ring + slot * MAS_SLOT_F(W) + i * MAS_CHUNK_F), 16, voff, 0, 0, 0);
+                }
+            }
+            if (blk >= MAS_AHEAD) {
+                if (blk < nblk) mas_wait_vmcnt<MAS_AHEAD * 8 * W>();
+                else mas_wait_vmcnt<0>();
+                if (lane == 0) mas_lds_poke(&ctr[0], blk - MAS_AHEAD + 1);
+            }
+        }
+        return;
+    }
+
+    // ---- DP wave `wave`: rows band0 + 64 wave + lane ----
+    const int w = wave, x_local = 64 * w + lane;
+    if (band0 + 64 * w >= x_len) {                         // no rows: never holds the ring back
+        if (lane == 0) __hip_atomic_store(&ctr[1 + w], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    const bool from_wave = w > 0, from_band = w == 0 && p > 0;
+    const bool to_wave = w + 1 < W && band0 + 64 * (w + 1) < x_len;
+    const bool to_band = w + 1 == W && p + 1 < P && band0 + 64 * W < x_len;
+    const int Typ = nblk_max * MAS_BLK;
+    u64* xo = xchg + (size_t)(b * P + p) * Typ;
+    const u64* xi = xchg + (size_t)(b * P + p - 1) * Typ;
+    unsigned* mo = masks + (size_t)(b * P + p) * nblk_max * W * 64;
+    float prev = MAS_NEG, carry = MAS_NEG;
+    auto xcol = [&](int blk) {
+        const int col = blk * MAS_BLK + (lane & 31);
+        return col < y_len ? col : y_len - 1;
+    };
+    u64 vnext = 0;
+    if (from_band) vnext = __hip_atomic_load(xi + xcol(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef AS_EXPERIMENTS
+    long long c_wait = 0, c_poll = 0, c_dp = 0, c_all = clock64();
+#define MAS_T(v) const long long v = clock64()
+#define MAS_ACC(acc, a, b_) acc += (b_) - (a)
+#else
+#define MAS_T(v)
+#define MAS_ACC(acc, a, b_)
+#endif
+    for (int blk = 0; blk < nblk; ++blk) {
+        MAS_T(t0);
+        while (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= blk) __builtin_amdgcn_s_sleep(1);
+        MAS_T(t1);
+        MAS_ACC(c_wait, t0, t1);
+        if (from_wave || from_band) {
+            float v;
+            if (from_wave) {
+                while (__hip_atomic_load(&ctr[1 + W + w - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= blk) __builtin_amdgcn_s_sleep(1);
+                v = outrow[w - 1][blk % MAS_OUT_RING][lane & 31];
+            } else {
+                // the word of this block was requested a block ago (once the band above is two blocks ahead it is there: no round
+                // trip to L2 in the loop); polled only while it is not
+                u64 word = vnext;
+                const u64* wp = xi + xcol(blk);
+                for (int spin = 0; (unsigned)(word >> 32) != 1u && spin < (1 << 22); ++spin) {
+                    __builtin_amdgcn_s_sleep(1);
+                    word = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (blk + 1 < nblk) vnext = __hip_atomic_load(xi + xcol(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = __uint_as_float((unsigned)word);
+            }
+            if (lane < MAS_BLK) inrow[w][1 + lane] = v;
+            if (lane == MAS_BLK) inrow[w][0] = carry;
+            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+        }
+        MAS_T(t2);
+        MAS_ACC(c_poll, t1, t2);
+        const float* slot = ring + (blk % MAS_RING) * MAS_SLOT_F(W);
+        unsigned bits = 0u;
+        const int ncol = (y_len - blk * MAS_BLK) < MAS_BLK ? (y_len - blk * MAS_BLK) : MAS_BLK;
+        if (blk > 0 && ncol == MAS_BLK) {
+            mas_dp_block<TIE_MOVE, true>(slot, x_local, blk, y_len, ngroup, false, prev, inrow[w], bits, &lastrow[w][lane]);
+        } else {
+            mas_dp_block<TIE_MOVE, false>(slot, x_local, blk, y_len, ngroup, band0 + x_local == 0, prev, inrow[w], bits, &lastrow[w][lane]);
+            const int have = blk == 0 ? ncol - 1 : ncol;   // decisions shifted in (column 0 has none)
+            bits = have > 0 ? bits << (MAS_BLK - ncol) : 0u;
+        }
+        MAS_T(t3);
+        MAS_ACC(c_dp, t2, t3);
+        mo[((size_t)blk * W + w) * 64 + lane] = bits;
+        if (to_wave) {
+            if (lane < MAS_BLK) outrow[w][blk % MAS_OUT_RING][lane] = lastrow[w][lane * 64 + 63];
+            if (lane == 0) __hip_atomic_store(&ctr[1 + W + w], blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (to_band && lane < ncol) {
+            __hip_atomic_store(xo + blk * MAS_BLK + lane, ((u64)1u << 32) | __float_as_uint(lastrow[w][lane * 64 + 63]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) __hip_atomic_store(&ctr[1 + w], blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#ifdef AS_EXPERIMENTS
+    if (blockIdx.x == gridDim.x - 8 && tid == 64 * (W - 1)) {   // the last wave of the last band of utterance 0
+        mas_dbg[0] = c_wait; mas_dbg[1] = c_poll; mas_dbg[2] = c_dp; mas_dbg[3] = clock64() - c_all;
+    }
+#endif
+#endif
+}
+
+// The walk.  Lane lambda of the wave holds the 32 decisions (one block of columns) of row base - lambda; a step is v_readlane of the
+// current row's word, a shift and an add, all in scalar registers; the words of the next block are fetched while this one is walked
+// (the row can only have moved up by 32 by then: 64 lanes cover it).
+template <int R>
+__global__ void __launch_bounds__(64)
+mas_backtrack_kernel(const int* __restrict__ t_x, const int* __restrict__ t_y, int Tx, int Ty, int P, int nblk_max,
+                     const unsigned* __restrict__ masks, float* __restrict__ path, int* __restrict__ dur, int* __restrict__ rows)
+{
+#if __HIP_DEVICE_COMPILE__
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int x_len = t_x[b], y_len = t_y[b];
+    x_len = x_len > Tx ? Tx : x_len;
+    y_len = y_len > Ty ? Ty : y_len;
+    if (x_len <= 0 || y_len <= 0) return;
+    int idx = x_len - 1;
+    if (lane == 0) {
+        if (path) path[((size_t)b * Tx + idx) * Ty + (y_len - 1)] = 1.f;
+        if (rows) rows[(size_t)b * Ty + (y_len - 1)] = idx;
+        if (dur) atomicAdd(dur + (size_t)b * Tx + idx, 1);
+    }
+    if (y_len < 2) return;
+    // decisions of rows base - lane in block blk (row 0 never moves, rows above the lattice do not exist: zero).  The load is issued
+    // here and awaited by mas_arrive: the compiler would wait for it at the first v_readlane of the walk it is meant to overlap.
+    auto issue = [&](unsigned& dst, int base, int blk) -> bool {
+        const int row = base - lane;
+        const bool ok = row > 0 && blk >= 0;
+        const int pp = ok ? row / (64 * R) : 0, i = ok ? row - pp * 64 * R : 0;      // R = DP waves per band: wave i / 64, lane i % 64
+        const unsigned* ptr = masks + (((size_t)(b * P + pp) * nblk_max + (ok ? blk : 0)) * R + (i >> 6)) * 64 + (i & 63);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+        return ok;
+    };
+    auto arrive = [&](unsigned& dst, bool ok) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory");
+        dst = ok ? dst : 0u;
+    };
+    int blk = (y_len - 1) >> 5;
+    int base = idx;
+    unsigned W, Wn;
+    const bool ok0 = issue(W, base, blk);
+    arrive(W, ok0);
+    while (blk >= 0) {
+        const bool okn = issue(Wn, idx, blk - 1);          // in flight during the walk
+        const int off = base - idx;                        // lane of the current row in W
+        const int j_top = (blk == (y_len - 1) >> 5) ? ((y_len - 1) & 31) : 31;
+        const int j_low = blk == 0 ? 1 : 0;
+        int d = 0;
+        unsigned T = 0u;                                   // bit k: the step at column j_top - k moved up
+        if (j_top == 31 && j_low == 0) {
+            // a full block: 32 steps unrolled (constant shifts, no loop counter): readlane, bit extract, two adds and an or per column
+#pragma unroll
+            for (int j = 31; j >= 0; --j) {
+                const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)W, __builtin_amdgcn_readfirstlane(off + d));
+                const unsigned bit = (w >> (31 - j)) & 1u;
+                T |= bit << (31 - j);
+                d += (int)bit;
+            }
+        } else {
+            for (int j = j_top; j >= j_low; --j) {
+                const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)W, __builtin_amdgcn_readfirstlane(off + d));
+                const unsigned bit = (w >> (31 - j)) & 1u;
+                T |= bit << (j_top - j);
+                d += (int)bit;
+            }
+        }
+        d = __builtin_amdgcn_readfirstlane(d);
+        arrive(Wn, okn);                                   // (before this block's stores are issued: vmcnt(0) would wait for them too)
+        if (lane >= j_low && lane <= j_top) {
+            const int kk = j_top - lane;
+            const int rr = idx - __popc(T & (0xFFFFFFFFu >> (31 - kk)));
+            const int col = blk * MAS_BLK + lane - 1;      // the row of column y - 1
+            if (path) path[((size_t)b * Tx + rr) * Ty + col] = 1.f;
+            if (rows) rows[(size_t)b * Ty + col] = rr;
+            if (dur) atomicAdd(dur + (size_t)b * Tx + rr, 1);
+        }
+        base = idx;
+        idx -= d;
+        W = Wn;
+        --blk;
+    }
+#endif
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 static int mas_geometry(int Tx, int* R, int* W)
 {
@@ -182,36 +555,68 @@ static int mas_geometry(int Tx, int* R, int* W)
         while (r < 16 && 64 * r * 8 < Tx) r <<= 1;
     }
     const int w = as_cdiv(Tx > 0 ? Tx : 1, 64 * r);
-    if (w > (r <= 4 ? 16 : 8)) return AS_EINVAL;           // Tx <= 8192
+    if (w > (r <= 1 ? 16 : 8)) return AS_EINVAL;           // Tx <= 8192 (the register budget of mas_launch)
     *R = r;
     *W = w;
     return AS_OK;
 }
 
+// banded variant: R DP waves of 64 rows per band (1 up to 64 rows, else 2), P bands, workspace = exchange words + decision words
+struct MasBands {
+    int R, P, nblk;
+    size_t xchg_bytes, mask_bytes;
+};
+static MasBands mas_bands(int B, int Tx, int Ty)
+{
+    MasBands g;
+    g.R = Tx <= 64 ? 1 : 2;
+    g.P = as_cdiv(Tx, 64 * g.R);
+    g.nblk = as_cdiv(Ty, MAS_BLK);
+    g.xchg_bytes = g.P > 1 ? (((size_t)B * g.P * g.nblk * MAS_BLK * sizeof(u64) + 255) & ~(size_t)255) : 0;
+    g.mask_bytes = (size_t)B * g.P * g.nblk * g.R * 64 * sizeof(unsigned);
+    return g;
+}
+static bool mas_banded_ok(const float* value, int Tx, int Ty)
+{
+    const char* env = getenv("AS_MAS_IMPL");               // tuning/experiments only: "one" = the one-workgroup kernel
+    return !(env && !strcmp(env, "one")) && Ty % 4 == 0 && (reinterpret_cast<uintptr_t>(value) & 15) == 0 && (double)Tx * Ty * 4.0 < 2147483648.0;
+}
+
 extern "C" size_t as_mas_workspace_bytes(int B, int Tx, int Ty)
 {
     int R, W;
-    if (B <= 0 || Tx <= 0 || Ty <= 0 || mas_geometry(Tx, &R, &W) != AS_OK) return 0;
-    return (size_t)B * ((Ty + 3) / 4) * 64 * W * sizeof(u64);
+    if (B <= 0 || Tx <= 0 || Ty <= 0) return 0;
+    const MasBands g = mas_bands(B, Tx, Ty);
+    const size_t banded = g.xchg_bytes + g.mask_bytes;
+    // rows that are not 16-byte aligned take the one-workgroup kernel (Tx <= 8192): the caller's buffer serves either
+    const size_t one = mas_geometry(Tx, &R, &W) == AS_OK ? (size_t)B * ((Ty + 3) / 4) * 64 * W * sizeof(u64) : 0;
+    if (one == 0) return 0;
+    return banded > one ? banded : one;
 }
 
 template <int R, bool TIE>
 static void mas_launch(bool vec4, int B, int W, size_t smem, hipStream_t s, const float* value, const int* t_x,
                        const int* t_y, int Tx, int Ty, float* path, int* dur, int* rows, u64* ws, int sc)
 {
-    // W == 1 (the common case, Tx <= 64*R): 64-thread workgroups may use the whole register file, which
-    // the R = 16 prefetch needs; multi-wave geometries go up to 16 waves (128 VGPRs each).
+    // 16-byte pieces of a row in flight per lane (see load_chunk): a whole 128-byte line where the registers allow it.
+    // two chunks of R rows = 8 R Q registers: 128 at most here
+#ifdef MAS_Q_OVERRIDE
+    constexpr int Q = MAS_Q_OVERRIDE;
+#else
+    constexpr int Q = R <= 2 ? 8 : 16 / R;
+#endif
+    // W == 1 (Tx <= 64 R): a 64-thread workgroup may use the whole register file; 16 waves (R = 1) leave 128 VGPRs each, 8 waves 256.
     if (W == 1) {
         if (vec4)
-            hipLaunchKernelGGL((mas_kernel<R, true, TIE, 64>), dim3(B), dim3(64), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
+            hipLaunchKernelGGL((mas_kernel<R, Q, true, TIE, 64>), dim3(B), dim3(64), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
         else
-            hipLaunchKernelGGL((mas_kernel<R, false, TIE, 64>), dim3(B), dim3(64), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
+            hipLaunchKernelGGL((mas_kernel<R, Q, false, TIE, 64>), dim3(B), dim3(64), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
     } else {
-        constexpr int MT = R <= 4 ? 1024 : 512;            // launch bound = register budget: R = 8 / 16 need 256 VGPRs
+        constexpr int MT = R <= 1 ? 1024 : 512;
         if (vec4)
-            hipLaunchKernelGGL((mas_kernel<R, true, TIE, MT>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
+            hipLaunchKernelGGL((mas_kernel<R, Q, true, TIE, MT>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
         else
-            hipLaunchKernelGGL((mas_kernel<R, false, TIE, MT>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
+            hipLaunchKernelGGL((mas_kernel<R, Q, false, TIE, MT>), dim3(B), dim3(64 * W), smem, s, value, t_x, t_y, Tx, Ty, path, dur, rows, ws, sc);
     }
 }
 
@@ -235,13 +640,33 @@ extern "C" int as_mas_f32(const float* value, const int* t_x, const int* t_y, in
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!value || !t_x || !t_y || B < 0 || Tx <= 0 || Ty <= 0 || (tie_mode != 0 && tie_mode != 1)) return AS_EINVAL;
     if (B == 0) return AS_OK;
+    if (path) AS_CHECK(hipMemsetAsync(path, 0, (size_t)B * Tx * Ty * sizeof(float), stream));
+    if (dur) AS_CHECK(hipMemsetAsync(dur, 0, (size_t)B * Tx * sizeof(int), stream));
+    if (rows) AS_CHECK(hipMemsetAsync(rows, 0xFF, (size_t)B * Ty * sizeof(int), stream));
+    if (mas_banded_ok(value, Tx, Ty)) {
+        const MasBands g = mas_bands(B, Tx, Ty);
+        if (!ws || ws_bytes < g.xchg_bytes + g.mask_bytes) return AS_EINVAL;
+        u64* xchg = static_cast<u64*>(ws);
+        unsigned* masks = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(ws) + g.xchg_bytes);
+        if (g.xchg_bytes) AS_CHECK(hipMemsetAsync(xchg, 0, g.xchg_bytes, stream));
+        AsProfScope prof__(AS_CLS_MAS, 2.0 * B * Tx * (double)Ty, 4.0 * B * Tx * (double)Ty * (path ? 2 : 1), stream);
+        const dim3 grid(8 * as_cdiv(B, 8) * g.P);
+        if (g.R == 1) {
+            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<1, true>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks);
+            else hipLaunchKernelGGL((mas_band_kernel<1, false>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks);
+            hipLaunchKernelGGL((mas_backtrack_kernel<1>), dim3(B), dim3(64), 0, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, path, dur, rows);
+        } else {
+            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<2, true>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks);
+            else hipLaunchKernelGGL((mas_band_kernel<2, false>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks);
+            hipLaunchKernelGGL((mas_backtrack_kernel<2>), dim3(B), dim3(64), 0, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, path, dur, rows);
+        }
+        AS_CHECK_LAUNCH();
+        return AS_OK;
+    }
     int R, W;
     if (mas_geometry(Tx, &R, &W) != AS_OK) return AS_EINVAL;
     const size_t need = (size_t)B * ((Ty + 3) / 4) * 64 * W * sizeof(u64);
     if (!ws || ws_bytes < need) return AS_EINVAL;
-    if (path) AS_CHECK(hipMemsetAsync(path, 0, (size_t)B * Tx * Ty * sizeof(float), stream));
-    if (dur) AS_CHECK(hipMemsetAsync(dur, 0, (size_t)B * Tx * sizeof(int), stream));
-    if (rows) AS_CHECK(hipMemsetAsync(rows, 0xFF, (size_t)B * Ty * sizeof(int), stream));
     const int NT = 64 * W;
     int sc = 4096 / NT;                                    // <= 32 KiB of staged decision words
     sc = sc > 16 ? 16 : sc;
