@@ -302,9 +302,20 @@ static __device__ __forceinline__ void mas_dp_block(const float* __restrict__ sl
 template <int W, bool TIE_MOVE>
 __global__ void __launch_bounds__(64 * (W + 1))
 mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const int* __restrict__ t_y, int B, int Tx, int Ty, int P,
-                int nblk_max, u64* __restrict__ xchg, unsigned* __restrict__ masks)
+                int nblk_max, u64* __restrict__ xchg, unsigned* __restrict__ masks, int n_band_wgs, float* __restrict__ path,
+                int* __restrict__ dur, int* __restrict__ rows)
 {
 #if __HIP_DEVICE_COMPILE__
+    if ((int)blockIdx.x >= n_band_wgs) {
+        // the workgroups behind the bands clear the outputs on the CUs the DP leaves idle (the backtrack launch that follows writes the
+        // path's ones, the row indices and the durations): no memset launches in front of the DP
+        const size_t z = blockIdx.x - n_band_wgs, nz = gridDim.x - n_band_wgs, nt = (size_t)64 * (W + 1);
+        const size_t n_path = path ? (size_t)B * Tx * Ty : 0, n_dur = dur ? (size_t)B * Tx : 0, n_rows = rows ? (size_t)B * Ty : 0;
+        for (size_t i = z * nt + threadIdx.x; i < n_path; i += nz * nt) path[i] = 0.f;
+        for (size_t i = z * nt + threadIdx.x; i < n_dur; i += nz * nt) dur[i] = 0;
+        for (size_t i = z * nt + threadIdx.x; i < n_rows; i += nz * nt) rows[i] = -1;
+        return;
+    }
     // a ring slot = one 32-column block of the band's 64 W rows as 8 W chunks of 8 rows x 128 bytes (one DMA instruction each: lane =
     // (row of the chunk, 16-byte piece), i.e. whole lines -- with a lane per ROW an instruction touches 64 lines, and the texture path
     // needs ~4 cycles for each: that, not the DP, was the 0.4 us per column of the one-workgroup kernel).  16 bytes of padding per
@@ -503,14 +514,19 @@ mas_backtrack_kernel(const int* __restrict__ t_x, const int* __restrict__ t_y, i
         int d = 0;
         unsigned T = 0u;                                   // bit k: the step at column j_top - k moved up
         if (j_top == 31 && j_low == 0) {
-            // a full block: 32 steps unrolled (constant shifts, no loop counter): readlane, bit extract, two adds and an or per column
+            // a full block.  M[j] = the lane mask of "row (base - lane) moves up at column j" (a compare per column, all 32 up front):
+            // the walk is then three scalar instructions per column on static registers -- shift M[j] by the current lane, and, add.
+            u64 M[MAS_BLK];
+#pragma unroll
+            for (int j = 0; j < MAS_BLK; ++j) M[j] = __builtin_amdgcn_ballot_w64(((W >> (31 - j)) & 1u) != 0u);
+            int lam = __builtin_amdgcn_readfirstlane(off);
 #pragma unroll
             for (int j = 31; j >= 0; --j) {
-                const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)W, __builtin_amdgcn_readfirstlane(off + d));
-                const unsigned bit = (w >> (31 - j)) & 1u;
+                const unsigned bit = (unsigned)(M[j] >> lam) & 1u;
                 T |= bit << (31 - j);
-                d += (int)bit;
+                lam += (int)bit;
             }
+            d = lam - off;
         } else {
             for (int j = j_top; j >= j_low; --j) {
                 const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)W, __builtin_amdgcn_readfirstlane(off + d));
@@ -561,7 +577,8 @@ static int mas_geometry(int Tx, int* R, int* W)
     return AS_OK;
 }
 
-// banded variant: R DP waves of 64 rows per band (1 up to 64 rows, else 2), P bands, workspace = exchange words + decision words
+// banded variant: R DP waves of 64 rows per band (1 up to 64 rows, else 2; four waves per band were measured: each wave runs a block
+// behind the one above, so the ring must hold W + 3 blocks or the first wave starves -- 0.28 ms against 0.19), P bands, workspace = exchange words + decision words
 struct MasBands {
     int R, P, nblk;
     size_t xchg_bytes, mask_bytes;
@@ -640,9 +657,6 @@ extern "C" int as_mas_f32(const float* value, const int* t_x, const int* t_y, in
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!value || !t_x || !t_y || B < 0 || Tx <= 0 || Ty <= 0 || (tie_mode != 0 && tie_mode != 1)) return AS_EINVAL;
     if (B == 0) return AS_OK;
-    if (path) AS_CHECK(hipMemsetAsync(path, 0, (size_t)B * Tx * Ty * sizeof(float), stream));
-    if (dur) AS_CHECK(hipMemsetAsync(dur, 0, (size_t)B * Tx * sizeof(int), stream));
-    if (rows) AS_CHECK(hipMemsetAsync(rows, 0xFF, (size_t)B * Ty * sizeof(int), stream));
     if (mas_banded_ok(value, Tx, Ty)) {
         const MasBands g = mas_bands(B, Tx, Ty);
         if (!ws || ws_bytes < g.xchg_bytes + g.mask_bytes) return AS_EINVAL;
@@ -650,14 +664,15 @@ extern "C" int as_mas_f32(const float* value, const int* t_x, const int* t_y, in
         unsigned* masks = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(ws) + g.xchg_bytes);
         if (g.xchg_bytes) AS_CHECK(hipMemsetAsync(xchg, 0, g.xchg_bytes, stream));
         AsProfScope prof__(AS_CLS_MAS, 2.0 * B * Tx * (double)Ty, 4.0 * B * Tx * (double)Ty * (path ? 2 : 1), stream);
-        const dim3 grid(8 * as_cdiv(B, 8) * g.P);
+        const int n_band_wgs = 8 * as_cdiv(B, 8) * g.P;
+        const dim3 grid(n_band_wgs + 512);                 // + the workgroups that clear path / dur / rows
         if (g.R == 1) {
-            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<1, true>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks);
-            else hipLaunchKernelGGL((mas_band_kernel<1, false>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks);
+            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<1, true>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows);
+            else hipLaunchKernelGGL((mas_band_kernel<1, false>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows);
             hipLaunchKernelGGL((mas_backtrack_kernel<1>), dim3(B), dim3(64), 0, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, path, dur, rows);
         } else {
-            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<2, true>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks);
-            else hipLaunchKernelGGL((mas_band_kernel<2, false>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks);
+            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<2, true>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows);
+            else hipLaunchKernelGGL((mas_band_kernel<2, false>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows);
             hipLaunchKernelGGL((mas_backtrack_kernel<2>), dim3(B), dim3(64), 0, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, path, dur, rows);
         }
         AS_CHECK_LAUNCH();
@@ -667,6 +682,9 @@ extern "C" int as_mas_f32(const float* value, const int* t_x, const int* t_y, in
     if (mas_geometry(Tx, &R, &W) != AS_OK) return AS_EINVAL;
     const size_t need = (size_t)B * ((Ty + 3) / 4) * 64 * W * sizeof(u64);
     if (!ws || ws_bytes < need) return AS_EINVAL;
+    if (path) AS_CHECK(hipMemsetAsync(path, 0, (size_t)B * Tx * Ty * sizeof(float), stream));
+    if (dur) AS_CHECK(hipMemsetAsync(dur, 0, (size_t)B * Tx * sizeof(int), stream));
+    if (rows) AS_CHECK(hipMemsetAsync(rows, 0xFF, (size_t)B * Ty * sizeof(int), stream));
     const int NT = 64 * W;
     int sc = 4096 / NT;                                    // <= 32 KiB of staged decision words
     sc = sc > 16 ? 16 : sc;

@@ -219,7 +219,7 @@ def bench_mas(dev):
              f"{Bl}x{Txl}x{Tyl}": ((u * u).astype(np.float32), large["x_lens"], large["y_lens"], large["rows_v1"], large["rows_v2"])}
     for name, (value, xl, yl, r1, r2) in cases.items():
         v = torch.from_numpy(value).to(dev)
-        xt, yt = torch.from_numpy(xl), torch.from_numpy(yl)
+        xt, yt = torch.from_numpy(xl).to(dev), torch.from_numpy(yl).to(dev)   # (resident, as the lattice: a host tensor is an H2D copy per call)
         exact = True
         for tie, rows in (("move", r1), ("stay", r2)):
             got = mas.maximum_path_lens(v, xt, yt, tie=tie, want=("rows",))["rows"].cpu().numpy()

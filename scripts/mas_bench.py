@@ -4,7 +4,7 @@ from artspeech_amd import mas, _lib
 dev = torch.device("cuda:0")
 for (B, Tx, Ty) in ((32, 40, 100), (8, 1024, 2000), (32, 128, 500)):
     value = torch.rand(B, Tx, Ty, device=dev)
-    xl = torch.full((B,), Tx); yl = torch.full((B,), Ty)
+    xl = torch.full((B,), Tx, device=dev); yl = torch.full((B,), Ty, device=dev)
     for want in (("dur",), ("path",)):
         for _ in range(3): mas.maximum_path_lens(value, xl, yl, want=want)
         torch.cuda.synchronize(); t0 = time.time()
