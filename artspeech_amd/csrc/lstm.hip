@@ -19,13 +19,21 @@
 
 #define NB 2
 
-// exp via the hardware v_exp_f32 path (~1e-7 abs on the bounded gate outputs; the test bound is 2e-5)
-static __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// exp and reciprocal via the hardware v_exp_f32 / v_rcp_f32 (1 ulp; ~1e-7 abs on the bounded gate outputs, the test bound is 2e-5).
+// Not __frcp_rn: the correctly rounded reciprocal is a ten-instruction division sequence, five of them on every step's critical path.
+static __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 static __device__ __forceinline__ float tanhf_(float x)
 {
     const float e = __expf(-2.0f * fabsf(x));              // in (0, 1]: no overflow
-    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
     return x < 0.f ? -t : t;
+}
+
+// the value of another lane of the quad (DPP quad_perm: 0xB1 = lane ^ 1, 0x4E = lane ^ 2, 0x00 / 0x55 / 0xAA / 0xFF = lane 0 / 1 / 2 / 3)
+template <int CTRL>
+static __device__ __forceinline__ float quad_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
 struct LstmJobs { BiLstmJob j[AS_MAX_LSTM_JOBS]; };
@@ -396,8 +404,7 @@ bilstm_quad1_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B)
             float* hn = hs[(t + 1) & 1];
             const float gx = gq[j];
             gq[j] = load_gx(t + PF);
-            lf2 aif0 = {kq == 0 ? gx : 0.f, kq == 1 ? gx : 0.f}, ago0 = {kq == 2 ? gx : 0.f, kq == 3 ? gx : 0.f};
-            lf2 aif1 = {0.f, 0.f}, ago1 = {0.f, 0.f};
+            lf2 aif0 = {0.f, 0.f}, ago0 = {0.f, 0.f}, aif1 = {0.f, 0.f}, ago1 = {0.f, 0.f};
 #pragma unroll
             for (int k4 = 0; k4 < KQ; k4 += 4) {
                 const float4 h4 = *reinterpret_cast<const float4*>(hc + k4);
@@ -411,15 +418,22 @@ bilstm_quad1_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B)
                 ago1 += wgo[k4 + 3] * lf2{h4.w, h4.w};
             }
             float pre[4] = {aif0[0] + aif1[0], aif0[1] + aif1[1], ago0[0] + ago1[0], ago0[1] + ago1[1]};
+            // the four quarters meet inside the lane quad through DPP (quad_perm, no LDS round trip: __shfl_xor is a ds_bpermute); then lane
+            // kq activates gate kq -- one exp / rcp chain per lane instead of four on one lane of the quad with the other three masked off
+            // (a step is issue-bound: eight waves of ~250 instructions on four SIMDs before this, ~150 after) -- and the activated gates
+            // are handed round the quad again.  tanh(x) = 2 sigmoid(2x) - 1: the same code for all four gates.
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                pre[g] += __shfl_xor(pre[g], 1);
-                pre[g] += __shfl_xor(pre[g], 2);
+                pre[g] += quad_dpp<0xB1>(pre[g]);          // lane ^ 1
+                pre[g] += quad_dpp<0x4E>(pre[g]);          // lane ^ 2
             }
+            const float sc = kq == 2 ? 2.f : 1.f;
+            const float x = (kq == 0 ? pre[0] : kq == 1 ? pre[1] : kq == 2 ? pre[2] : pre[3]) + gx;   // lane kq holds gate kq's input term
+            const float act = fmaf(__builtin_amdgcn_rcpf(1.0f + __expf(-sc * x)), sc, 1.0f - sc);
+            const float ig = quad_dpp<0x00>(act), fg = quad_dpp<0x55>(act), gg = quad_dpp<0xAA>(act), og = quad_dpp<0xFF>(act);
+            c = fg * c + ig * gg;                          // (every lane of the quad keeps the unit's cell state)
+            const float hv = og * fmaf(__builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * c)), 2.0f, -1.0f);
             if (kq == 0) {
-                const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
-                c = fg * c + ig * gg;
-                const float hv = og * tanhf_(c);
                 hn[unit] = hv;
                 outp[dir ? L - 1 - t : t] = hv;
             }
