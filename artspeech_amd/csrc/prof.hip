@@ -74,3 +74,44 @@ extern "C" int as_prof_collect(double* ms, double* flops, double* bytes, int32_t
     if (f) fclose(f);
     return AS_OK;
 }
+
+// What an event pair adds to the kernel it brackets.  An event is a marker in the queue: the time between two of them is the kernel's own
+// duration PLUS the command processor's work around it (~4-5 us per bracket on MI355X), which a kernel trace (rocprofv3) does not count.
+// Measured here so that bench.py can report durations that agree with the trace: brackets of 1, 2, 4 and 8 empty kernels; the intercept of
+// the line through their mean times is the part that belongs to the bracket, not to a kernel.
+__global__ void as_prof_null_kernel() {}
+
+extern "C" int as_prof_bracket_overhead(as_stream_t stream_, double* overhead_ms)
+{
+    if (!overhead_ms) return AS_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int ks[4] = {1, 2, 4, 8}, REP = 48;
+    double mean[4] = {0, 0, 0, 0};
+    std::vector<hipEvent_t> ev(2 * REP);
+    for (auto& e : ev) AS_CHECK(hipEventCreate(&e));
+    for (int c = 0; c < 4; ++c) {
+        for (int warm = 0; warm < 2; ++warm) {
+            for (int r = 0; r < REP; ++r) {
+                AS_CHECK(hipEventRecord(ev[2 * r], stream));
+                for (int k = 0; k < ks[c]; ++k) hipLaunchKernelGGL(as_prof_null_kernel, dim3(1), dim3(64), 0, stream);
+                AS_CHECK(hipEventRecord(ev[2 * r + 1], stream));
+            }
+            AS_CHECK(hipStreamSynchronize(stream));
+        }
+        double sum = 0;
+        for (int r = 0; r < REP; ++r) {
+            float t = 0.f;
+            AS_CHECK(hipEventElapsedTime(&t, ev[2 * r], ev[2 * r + 1]));
+            sum += t;
+        }
+        mean[c] = sum / REP;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    // least squares line mean = o + e k over k = 1, 2, 4, 8
+    double sk = 0, sm = 0, skk = 0, skm = 0;
+    for (int c = 0; c < 4; ++c) { sk += ks[c]; sm += mean[c]; skk += (double)ks[c] * ks[c]; skm += ks[c] * mean[c]; }
+    const double slope = (4 * skm - sk * sm) / (4 * skk - sk * sk);
+    const double o = (sm - slope * sk) / 4;
+    *overhead_ms = o > 0 ? o : 0;
+    return AS_OK;
+}

@@ -37,6 +37,9 @@ int as_prof_collect(double* ms, double* flops, double* bytes, int32_t* launches,
 /* algorithmic flop / bytes of the NEXT launch of this host thread, for entry points whose arguments do not determine them
  * (their geometry tables are device arrays); ignored while profiling is off */
 int as_prof_hint(double flops, double bytes);
+/* what one event bracket adds to the kernel inside it (ms): the command processor's work between the two markers, which a kernel
+ * trace does not count.  Measured with brackets of 1, 2, 4, 8 empty kernels (the intercept); blocks. */
+int as_prof_bracket_overhead(as_stream_t stream, double* overhead_ms);
 
 /* ---------------------------------------------------------------------------------------------
  * Monotonic alignment search (K1).
