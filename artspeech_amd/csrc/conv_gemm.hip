@@ -217,9 +217,9 @@ splitk_reduce_kernel(const ConvGemmArgs a, int S)
 
 static void tile_dims(int choice, int* bm, int* bn)
 {
-    // 42 / 22 / 21 / 12 / 11: 256x128, 128x128, 128x64, 64x128, 64x64 (4 waves each)
-    *bm = choice == 42 ? 256 : (choice == 22 || choice == 21) ? 128 : 64;
-    *bn = (choice == 42 || choice == 22 || choice == 12) ? 128 : 64;
+    // 42 / 22 / 21 / 12 / 11 / 2: 256x128, 128x128, 128x64, 64x128, 64x64, 32x128 (4 waves each)
+    *bm = choice == 42 ? 256 : (choice == 22 || choice == 21) ? 128 : choice == 2 ? 32 : 64;
+    *bn = (choice == 42 || choice == 22 || choice == 12 || choice == 2) ? 128 : 64;
 }
 
 // Tile choice, fitted to sweeps on MI355X (scripts/gemm_bench.py, round 2).  The time of a launch is the time of its busiest CU:
@@ -227,10 +227,11 @@ static void tile_dims(int choice, int* bm, int* bn)
 // 64x64 0.59), n > 1 tiles sharing a CU cost 0.71 n t1 (two co-resident workgroups cover each other's waits).  Examples the fit
 // reproduces: M512 N6400 K512 T3: 128x128 (200 tiles) 33.5 us, 128x64 (400) 37.1; M512 N3840 K512 T5: 44.8 (120 tiles) against 35.0
 // (240); M512 N1280 K512 T3: 25.6 / 17.8 / 15.2 us for 40 / 80 / 160 tiles.
-static int gemm_tile_choice(int M, int N, int n_prod)
+static int gemm_tile_choice(int M, int N, int n_prod, int Kp)
 {
     const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 42, 22, 21, 12, 11
     if (env && atoi(env) > 0) return atoi(env);
+    if (M <= 32 && n_prod == 3) return 2;                              // a 64-row tile would be half empty (HiFi-GAN's last stage: 32 channels, 1.9 M columns)
     const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);   // a 128-row tile is not half empty
     static const int choices[5] = {42, 22, 21, 12, 11};
     // 256x128 (a wave owns 128 x 64): a third less LDS traffic per matrix-core product, but 364 registers: ONE workgroup per CU.
@@ -256,6 +257,10 @@ static int gemm_tile_choice(int M, int N, int n_prod)
         const double cost = t1[c] * (bm == 256 ? n : (n > 1.0 ? 0.71 * n : 1.0));
         if (cost < best_cost * 0.97) { best_cost = cost; best = choices[c]; }   // (ties go to the larger tile)
     }
+    // An image of <= 32 channels may come from the 32-row tile, which leaves the upper half of the image's 64-row block unwritten (clearing
+    // it would be 245 MB per launch at the vocoder's last stage): such a K is never given to the tile whose four waves read all four
+    // k-blocks of the block (64 x 64); every other tile reads two at most, i.e. rows 0..31, which every producer writes.
+    if (Kp <= 32 && best == 11) best = 12;
     return best;
 }
 
@@ -268,7 +273,7 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
     int bm, bn;
     tile_dims(choice, &bm, &bn);
     const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
-    const int wk = bm * bn >= 4 * 64 * 64 ? 1 : 4 * 64 * 64 / (bm * bn);   // waves that split K inside the workgroup
+    const int wk = choice == 2 ? 2 : bm * bn >= 4 * 64 * 64 ? 1 : 4 * 64 * 64 / (bm * bn);   // waves that split K inside the workgroup
     const int nkt = T * as_cdiv(Kp / 16, wk);             // iterations (k-tile = 16 * WK)
     int s = 1;
     if (env && atoi(env) > 0) s = atoi(env);
@@ -291,7 +296,7 @@ static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 static GemmPlan gemm_plan(const ConvGemmArgs& a)
 {
     GemmPlan p = {};
-    p.choice = gemm_tile_choice(a.M, a.N, a.n_prod ? a.n_prod : 3);
+    p.choice = gemm_tile_choice(a.M, a.N, a.n_prod ? a.n_prod : 3, a.Kp);
     p.S = gemm_ksplit(a.M, a.N, a.Kp, a.T, p.choice);
     p.slab_bytes = p.S > 1 ? (size_t)p.S * a.M * a.N * sizeof(float) : 0;
     p.xh_bytes = a.Xh ? 0 : as_split_f16x2_bytes(a.K, a.N);

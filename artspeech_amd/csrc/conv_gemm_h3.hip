@@ -435,6 +435,9 @@ int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t
         if (a.n_prod == 1) return AS_EINVAL;
         return launch_h3<2, 2, 1, 1, 3, 3, 4>(a, S, stream);
 #endif
+    case 2:                                                             // 32 x 128 (a wave owns 32 x 64): the vocoder's 32-channel stage, M <= 32
+        if (a.n_prod == 1) return AS_EINVAL;
+        return launch_h3<1, 2, 2, 1, 3, 3, 1>(a, S, stream);
     case 22: return launch_h3_tile<2, 2, 1>(a, S, stream);
     case 21: return launch_h3_tile<2, 1, 2>(a, S, stream);
     case 12: return launch_h3_tile<1, 2, 2>(a, S, stream);

@@ -128,6 +128,24 @@ def test_epilogue_writes_split_image(cuda, monkeypatch, M, K, lens, tile, ksplit
     assert torch.equal(yh2, want)
 
 
+@pytest.mark.parametrize("M,M2,lens", [(16, 64, [9, 4]), (32, 128, [40]), (8, 64, [100, 3]), (32, 32, [300, 17])])
+def test_small_channel_image_chain(cuda, M, M2, lens):
+    """<= 32 output channels take the 32-row tile, which leaves the upper half of the image's 64-row block unwritten (whatever is
+    there -- here fp16 NaNs): no consumer tile reads it, the chained result equals the one through the fp32 tensor."""
+    g = torch.Generator().manual_seed(M * 7 + M2)
+    lay = Layout(lens, cuda)
+    w1 = ops.prep_weight(torch.randn(M, 48, 3, generator=g) / np.sqrt(3 * 48), cuda)
+    w2 = ops.prep_weight(torch.randn(M2, M, 3, generator=g) / np.sqrt(3 * M), cuda)
+    X = torch.randn(48, lay.N, generator=g).to(cuda)
+    y = ops.conv_gemm(w1, X, lay, lay.new(M), taps_1d(3))
+    yh = ops.new_image(M, lay.N, cuda)
+    yh.fill_(0x7e00)
+    ops.conv_gemm(w1, X, lay, None, taps_1d(3), yh=yh)
+    z0 = ops.conv_gemm(w2, y, lay, lay.new(M2), taps_1d(3))
+    z1 = ops.conv_gemm(w2, None, lay, lay.new(M2), taps_1d(3), xs=yh, K=M)
+    assert bool(torch.isfinite(z1).all()) and torch.equal(z0, z1)
+
+
 @pytest.mark.parametrize("G,cin,cout,k,cols", [(2, 64, 128, 3, 256), (3, 96, 80, 1, 128), (3, 512, 512, 3, 6400), (3, 64, 128, 3, 200), (2, 512, 1024, 9, 52)])
 def test_grouped_launch(cuda, G, cin, cout, k, cols):
     """ConvGemmArgs.n_groups: G layers of the same shape side by side along the column axis equal G separate launches."""
