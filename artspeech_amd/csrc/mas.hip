@@ -3,6 +3,10 @@
 //   S_monotonic_align.py:50-95  (maximum_path2: tie -> stay)
 //   S_monotonic_align_Triton.py:7-71 (Triton kernel, tie -> stay)   utils.py:11-24 (Cython wrapper)
 //
+// Two kernels.  Rows that are 16-byte aligned (Ty % 4 == 0: the usual case) take the BANDED kernel further down (a workgroup per band
+// of 128 rows, DP waves chained down the rows, LDS-DMA loader wave, wave-parallel backtrack: [8,1024,2000] in 0.14 ms).  Everything
+// else takes the round-1 kernel described here (0.80 ms on the same lattice):
+//
 // One workgroup per utterance.  Thread t owns R consecutive lattice rows [t*R, t*R+R); the previous
 // DP column lives in registers, the row above a lane's first row comes from the neighbouring lane
 // (wave shuffle) or, across waves, through a 2-slot LDS mailbox.  Each thread streams ITS rows along
@@ -80,11 +84,7 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
             for (int q = 0; q < Q; ++q) {
                 const int g = c * Q + q;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef MAS_KO_LOADS
-                if (false) {
-#else
                 if (x < x_len && 4 * g < Ty) {
-#endif
                     const float* p = vb + (size_t)x * Ty + 4 * g;
                     if (VEC4) {
                         v = *reinterpret_cast<const float4*>(p);
@@ -141,9 +141,7 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
                 if (W > 1) {
                     if (lane == 63) bnd[(y & 1) * 16 + wave] = prev[R - 1];
                     // LDS-only barrier: __syncthreads() would also wait for the prefetched chunk's global loads (vmcnt)
-#ifndef MAS_KO_BARRIER
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
                 }
             }
             wsb[(size_t)g * NT + tid] = (u64)(bits[0] | (bits[1] << 16)) | ((u64)(bits[2] | (bits[3] << 16)) << 32);
@@ -615,13 +613,8 @@ template <int R, bool TIE>
 static void mas_launch(bool vec4, int B, int W, size_t smem, hipStream_t s, const float* value, const int* t_x,
                        const int* t_y, int Tx, int Ty, float* path, int* dur, int* rows, u64* ws, int sc)
 {
-    // 16-byte pieces of a row in flight per lane (see load_chunk): a whole 128-byte line where the registers allow it.
-    // two chunks of R rows = 8 R Q registers: 128 at most here
-#ifdef MAS_Q_OVERRIDE
-    constexpr int Q = MAS_Q_OVERRIDE;
-#else
-    constexpr int Q = R <= 2 ? 8 : 16 / R;
-#endif
+    // 16-byte pieces of a row in flight per lane (see load_chunk)
+    constexpr int Q = 1;      // (whole 128-byte lines per row, Q = 8, measured SLOWER here: 1.04 against 0.80 ms -- the same 64 lines per instruction)
     // W == 1 (Tx <= 64 R): a 64-thread workgroup may use the whole register file; 16 waves (R = 1) leave 128 VGPRs each, 8 waves 256.
     if (W == 1) {
         if (vec4)

@@ -60,7 +60,9 @@ def test_golden_large(cuda, golden_dir, tie):
 
 
 @pytest.mark.parametrize("shape", [(3, 1, 1), (2, 64, 64), (2, 65, 130), (5, 130, 257), (2, 300, 301),
-                                   (2, 700, 1403), (1, 1500, 1600), (3, 40, 99)])
+                                   (2, 700, 1403), (1, 1500, 1600), (3, 40, 99),
+                                   # rows 16-byte aligned: the banded kernel (1, 2, 3, 6, 8 bands; batches that are not multiples of 8)
+                                   (9, 130, 36), (3, 300, 260), (1, 700, 1000), (10, 129, 64), (2, 1024, 96), (17, 64, 4), (2, 5, 8)])
 @pytest.mark.parametrize("tie", ["move", "stay"])
 def test_random_shapes_vs_oracle(cuda, shape, tie):
     B, Tx, Ty = shape
@@ -73,6 +75,11 @@ def test_random_shapes_vs_oracle(cuda, shape, tie):
     want, wdur = omas.maximum_path_c(value, mask, tie == "move", want_dur=True)
     got = mas.maximum_path(torch.from_numpy(value).to(cuda), torch.from_numpy(mask).to(cuda), tie=tie)
     assert np.array_equal(got.cpu().numpy(), want)
+    out = mas.maximum_path_lens(torch.from_numpy(value).to(cuda), torch.from_numpy(x_lens), torch.from_numpy(y_lens), tie=tie, want=("dur", "rows"))
+    assert np.array_equal(out["dur"].cpu().numpy(), wdur)
+    rows = out["rows"].cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(rows[b, : y_lens[b]], want[b].argmax(0)[: y_lens[b]]) and (rows[b, y_lens[b]:] == -1).all()
 
 
 def test_empty_and_zero_length(cuda):
@@ -91,7 +98,9 @@ def test_cpu_input_fails_loudly():
 
 
 def test_forced_rows_per_lane(cuda, monkeypatch):
-    """Every (rows-per-lane, waves) geometry gives the same answer (multi-wave LDS mailbox path)."""
+    """Every (rows-per-lane, waves) geometry of the one-workgroup kernel (the path of rows that are not 16-byte aligned; forced here)
+    gives the same answer (multi-wave LDS mailbox path)."""
+    monkeypatch.setenv("AS_MAS_IMPL", "one")
     rng = np.random.default_rng(5)
     value = rng.random((2, 200, 420), dtype=np.float32)
     mask = omas.mask_from_lens(value.shape, [200, 150], [420, 333])
