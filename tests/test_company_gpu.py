@@ -43,6 +43,17 @@ def _cases(dev, g):
             return lambda: ops.adain_image(X, lay, gb, 1, lay2.N, ldgb=2 * C, pool_w=pw, pool_b=pb, x_up=xup).clone()
         return lambda: ops.adain_image(X, lay, gb, 1, lay.N, ldgb=2 * C).clone()
 
+    def mas_lattice(B, Tx, Ty):
+        from artspeech_amd import mas
+        v = torch.rand(B, Tx, Ty, generator=g).to(dev)
+        xl = torch.randint(Tx // 2, Tx + 1, (B,), generator=g).to(dev)
+        yl = torch.maximum(xl, torch.randint(Ty // 2, Ty + 1, (B,), generator=g).to(dev))
+
+        def run():                                           # (the banded kernel's workgroups poll each other: other work may hold their CUs)
+            o = mas.maximum_path_lens(v, xl, yl, want=("dur", "rows"))
+            return torch.cat([o["dur"].flatten(), o["rows"].flatten()])
+        return run
+
     def project():
         lay = Layout([200] * 96, dev)
         X, w, b, Y = R(256, lay.N), R(10, 256), R(10), lay.new(10)
@@ -50,7 +61,7 @@ def _cases(dev, g):
 
     return {"attention 40": attention(40, 64), "attention 300": attention(300, 8), "lstm H128": lstm(128, 100, 32, False),
             "lstm H256 clustered": lstm(256, 40, 32, True), "layernorm image": layernorm(), "adain": adain(False), "adain x2": adain(True),
-            "project_cols": project()}
+            "project_cols": project(), "mas 8 bands": mas_lattice(4, 1024, 600), "mas 3 bands": mas_lattice(16, 300, 500)}
 
 
 def test_kernels_keep_their_bits_beside_the_gemm(cuda):
