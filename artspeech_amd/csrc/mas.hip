@@ -517,13 +517,20 @@ mas_backtrack_kernel(const int* __restrict__ t_x, const int* __restrict__ t_y, i
             u64 M[MAS_BLK];
 #pragma unroll
             for (int j = 0; j < MAS_BLK; ++j) M[j] = __builtin_amdgcn_ballot_w64(((W >> (31 - j)) & 1u) != 0u);
-            int lam = __builtin_amdgcn_readfirstlane(off);
+            // three scalar instructions per column: s_bfe_u64 takes the bit of M[j] at the current lane (offset in the low bits of its second
+            // operand, width 1 in bits 16..22 -- the running lane number carries the width field along), s_lshl1_add_u32 shifts it into T,
+            // s_add moves the lane on.  T collects the steps MSB first; reversed afterwards (bit k = the step at column 31 - k).
+            unsigned lamw = (unsigned)__builtin_amdgcn_readfirstlane(off) | (1u << 16);
 #pragma unroll
             for (int j = 31; j >= 0; --j) {
-                const unsigned bit = (unsigned)(M[j] >> lam) & 1u;
-                T |= bit << (31 - j);
-                lam += (int)bit;
+                u64 b;
+                asm("s_bfe_u64 %0, %1, %2" : "=s"(b) : "s"(M[j]), "s"(lamw));
+                const unsigned bit = (unsigned)b;
+                asm("s_lshl1_add_u32 %0, %1, %2" : "=s"(T) : "s"(T), "s"(bit));
+                lamw += bit;
             }
+            T = __builtin_bitreverse32(T);
+            const int lam = (int)(lamw & 0xFFFFu);
             d = lam - off;
         } else {
             for (int j = j_top; j >= j_low; --j) {
