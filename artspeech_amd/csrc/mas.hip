@@ -466,7 +466,9 @@ mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, co
 
 // The walk.  Lane lambda of the wave holds the 32 decisions (one block of columns) of row base - lambda; a step is v_readlane of the
 // current row's word, a shift and an add, all in scalar registers; the words of the next block are fetched while this one is walked
-// (the row can only have moved up by 32 by then: 64 lanes cover it).
+// (the row can only have moved up by 32 by then: 64 lanes cover it).  A block costs ~250 instructions of ONE wave (64 to make the
+// masks, ~100 of walk, the stores): that, ~0.6 us, is the launch's time -- fetching eight blocks of words at once into LDS (one L2 round
+// trip per batch instead of per block) was built and is slower (49 against 40 us).
 template <int R>
 __global__ void __launch_bounds__(64)
 mas_backtrack_kernel(const int* __restrict__ t_x, const int* __restrict__ t_y, int Tx, int Ty, int P, int nblk_max,
