@@ -58,12 +58,18 @@ HBM_GROUP = ("adain", "layernorm", "other")          # the bandwid
 
 
 def source_id():
-    """sha of the kernel sources: ties a committed PMC profile to the build it was taken from"""
+    """sha of the kernel sources (comments and white space removed: a reworded comment is the same build): ties a committed PMC
+    profile to the build it was taken from"""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "artspeech_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+            src = open(os.path.join(d, f), "r", encoding="utf-8", errors="replace").read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            src = re.sub(r"//[^\n]*", "", src)
+            h.update(f.encode())
+            h.update("".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 
