@@ -37,7 +37,9 @@ typedef unsigned long long u64;
 #ifdef AS_EXPERIMENTS
 __device__ unsigned long long mas_dbg[8];      // shader / wall clocks at the phase boundaries of block 0 (scripts/exp/mas_clock.py)
 #define MAS_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { mas_dbg[2 * (i)] = clock64(); mas_dbg[2 * (i) + 1] = wall_clock64(); } } while (0)
+__device__ unsigned long long mas_dbg2[128];    // wall clock (100 MHz) per (band, wave) of utterance 0: block 0 may start / is done, last block done
 extern "C" int as_mas_debug(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(mas_dbg), 64); }
+extern "C" int as_mas_debug2(unsigned long long* out128) { return (int)hipMemcpyFromSymbol(out128, HIP_SYMBOL(mas_dbg2), 1024); }
 #else
 #define MAS_MARK(i)
 #endif
@@ -247,9 +249,11 @@ template <int N> static __device__ __forceinline__ void mas_wait_vmcnt() { asm v
 
 #define MAS_OUT_RING 8        // blocks of a wave's last row kept for the wave below (it runs at most MAS_RING blocks ahead of it)
 
-// one 32-column block of a DP wave (one row per lane).  FULL: all 32 columns exist and none is column 0 (no per-column tests).
+// one 32-column block of a DP wave (one row per lane).  MODE 0: all 32 columns exist and none is column 0 (no per-column tests);
+// 1: the first block of a lattice of >= 32 columns (column 0 is the only special one -- every wave's start waits for the first block of
+// the wave above, so this block is the pipeline's fill); 2: anything (tests per column).
 // in[j] = the row above the wave's first row at column j - 1 of the block (in[0]: the previous block's last column).
-template <bool TIE_MOVE, bool FULL>
+template <bool TIE_MOVE, int MODE>
 static __device__ __forceinline__ void mas_dp_block(const float* __restrict__ slot, int x_local, int blk, int y_len, int ngroup, bool first_row_here,
                                                     float& prev, const float* __restrict__ in, unsigned& bits, float* __restrict__ last)
 {
@@ -260,7 +264,7 @@ static __device__ __forceinline__ void mas_dp_block(const float* __restrict__ sl
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int g = blk * 8 + q;
-        if (!FULL && g >= ngroup) break;
+        if (MODE == 2 && g >= ngroup) break;
         if (q < 7) {
             nxt = rowp[q + 1];
             inxt = inp[q + 1];
@@ -268,9 +272,9 @@ static __device__ __forceinline__ void mas_dp_block(const float* __restrict__ sl
 #pragma unroll
         for (int j4 = 0; j4 < 4; ++j4) {
             const int y = 4 * g + j4;
-            if (!FULL && y >= y_len) break;
+            if (MODE == 2 && y >= y_len) break;
             const int j = q * 4 + j4;
-            if (!FULL && y == 0) {
+            if ((MODE == 1 && j == 0) || (MODE == 2 && y == 0)) {
                 prev = first_row_here ? cur.x : MAS_NEG;
             } else {
                 // the row above is lane - 1's (DPP wave_shr:1); lane 0 keeps `old`: the wave / band above, read from LDS by every lane
@@ -434,18 +438,27 @@ mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, co
         }
         MAS_T(t2);
         MAS_ACC(c_poll, t1, t2);
+#ifdef AS_EXPERIMENTS
+        if (b == 0 && lane == 0 && blk == 0) mas_dbg2[(p * W + w) * 4 + 0] = wall_clock64();
+#endif
         const float* slot = ring + (blk % MAS_RING) * MAS_SLOT_F(W);
         unsigned bits = 0u;
         const int ncol = (y_len - blk * MAS_BLK) < MAS_BLK ? (y_len - blk * MAS_BLK) : MAS_BLK;
         if (blk > 0 && ncol == MAS_BLK) {
-            mas_dp_block<TIE_MOVE, true>(slot, x_local, blk, y_len, ngroup, false, prev, inrow[w], bits, &lastrow[w][lane]);
+            mas_dp_block<TIE_MOVE, 0>(slot, x_local, blk, y_len, ngroup, false, prev, inrow[w], bits, &lastrow[w][lane]);
+        } else if (blk == 0 && ncol == MAS_BLK) {
+            mas_dp_block<TIE_MOVE, 1>(slot, x_local, blk, y_len, ngroup, band0 + x_local == 0, prev, inrow[w], bits, &lastrow[w][lane]);
         } else {
-            mas_dp_block<TIE_MOVE, false>(slot, x_local, blk, y_len, ngroup, band0 + x_local == 0, prev, inrow[w], bits, &lastrow[w][lane]);
+            mas_dp_block<TIE_MOVE, 2>(slot, x_local, blk, y_len, ngroup, band0 + x_local == 0, prev, inrow[w], bits, &lastrow[w][lane]);
             const int have = blk == 0 ? ncol - 1 : ncol;   // decisions shifted in (column 0 has none)
             bits = have > 0 ? bits << (MAS_BLK - ncol) : 0u;
         }
         MAS_T(t3);
         MAS_ACC(c_dp, t2, t3);
+#ifdef AS_EXPERIMENTS
+        if (b == 0 && lane == 0 && blk == 0) mas_dbg2[(p * W + w) * 4 + 1] = wall_clock64();
+        if (b == 0 && lane == 0 && blk == nblk - 1) mas_dbg2[(p * W + w) * 4 + 2] = wall_clock64();
+#endif
         mo[((size_t)blk * W + w) * 64 + lane] = bits;
         if (to_wave) {
             if (lane < MAS_BLK) outrow[w][blk % MAS_OUT_RING][lane] = lastrow[w][lane * 64 + 63];
