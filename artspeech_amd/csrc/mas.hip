@@ -216,8 +216,8 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
 // ----------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void mas_lds_void;
 #define MAS_BLK 32            // columns per block
-#define MAS_RING 4            // blocks in the LDS ring
-#define MAS_AHEAD 2           // blocks of DMA in flight (the ring keeps one more slot than ahead + current: the DP never waits for the
+#define MAS_RING 6            // blocks in the LDS ring: ahead + the one in use + the lag of the band's second wave (a block) + slack
+#define MAS_AHEAD 3           // blocks of DMA in flight (the ring keeps one more slot than ahead + current: the DP never waits for the
                               // loader's handshake)
 #define MAS_CHUNK_F 260       // floats per chunk in the ring: 8 rows x 32 columns + 4 of padding
 #define MAS_SLOT_F(R) (8 * (R) * MAS_CHUNK_F)
@@ -470,7 +470,7 @@ mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, co
         if (lane == 0) __hip_atomic_store(&ctr[1 + w], blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #ifdef AS_EXPERIMENTS
-    if (blockIdx.x == gridDim.x - 8 && tid == 64 * (W - 1)) {   // the last wave of the last band of utterance 0
+    if (b == 0 && p == 0 && tid == 0) {                      // the first wave of the first band of utterance 0
         mas_dbg[0] = c_wait; mas_dbg[1] = c_poll; mas_dbg[2] = c_dp; mas_dbg[3] = clock64() - c_all;
     }
 #endif
