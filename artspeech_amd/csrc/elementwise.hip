@@ -237,10 +237,12 @@ extern "C" int as_adain_f32(const float* x, int ldx, int C, const float* gamma_b
 // (AdaIN fc models.py:237, style linears models.py:412-415,538, duration_proj models.py:565)
 // one wave per output element, lanes over k.
 // ---------------------------------------------------------------------------------------------------
+template <int KR>
 __global__ void __launch_bounds__(256)
 linear_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
                    int B, int M, int K, float* __restrict__ y, int ldy)
 {
+    static_assert(KR == 1 || KR == 2 || KR == 4 || KR == 8, "quads of the weight row per lane");
     // one wave per output feature m, all B rows: the weight row is read from HBM exactly once (the batched AdaIN
     // projections are 64 MB of weights against 64 KB of styles) and stays in registers; x is cache resident
     const int lane = threadIdx.x & 63;
@@ -248,9 +250,13 @@ linear_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict
     if (m >= M) return;
     const float* wr = w + (size_t)m * K;
     const float bm = bias ? bias[m] : 0.f;
-    constexpr int KR = 8;                                  // K <= 64 * 4 * KR values of the row per lane in registers
+    // KR float4 quads of the weight row per lane (K <= 256 KR) and 32 / KR rows of x per trip: every load of a trip is issued before
+    // its first use and none sits behind a branch (a quad past the row's end re-reads quad 0 against a zero weight), so a trip is ONE
+    // memory round trip.  With one row per trip and the loads inside `if (q < nq)` the 32 rows were 32 round trips; with a fixed KR = 8
+    // and four rows per trip, eight (17.6 us for the towers' 512-wide linears, nearly all of it those eight latencies).
     const bool vec = (K & 3) == 0 && (ldx & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
     if (vec && K <= 256 * KR) {
+        constexpr int RT = 32 / KR;
         const int nq = K >> 2;                             // float4 quads in a row
         float4 wq[KR];
 #pragma unroll
@@ -258,27 +264,22 @@ linear_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict
             const int q = lane + 64 * c;
             wq[c] = q < nq ? reinterpret_cast<const float4*>(wr)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        // four rows per trip, every load issued before the first use and none behind a branch (a quad past the row's end re-reads quad 0
-        // against a zero weight): with one row per trip and the loads inside `if (q < nq)` the 32 rows were 32 memory round trips
-        const int nc = (nq + 63) >> 6;                     // register groups that hold anything (wave-uniform)
-        for (int b0 = 0; b0 < B; b0 += 4) {
-            float4 v[4][KR];
+        for (int b0 = 0; b0 < B; b0 += RT) {
+            float4 v[RT][KR];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < RT; ++r) {
                 const float4* xq = reinterpret_cast<const float4*>(x + (size_t)min(b0 + r, B - 1) * ldx);
 #pragma unroll
-                for (int c = 0; c < KR; ++c)
-                    if (c < nc) {
-                        const int q = lane + 64 * c;
-                        v[r][c] = xq[q < nq ? q : 0];
-                    }
+                for (int c = 0; c < KR; ++c) {
+                    const int q = lane + 64 * c;
+                    v[r][c] = xq[q < nq ? q : 0];
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < RT; ++r) {
                 float s = 0.f;
 #pragma unroll
-                for (int c = 0; c < KR; ++c)
-                    if (c < nc && lane + 64 * c < nq) s += wq[c].x * v[r][c].x + wq[c].y * v[r][c].y + wq[c].z * v[r][c].z + wq[c].w * v[r][c].w;
+                for (int c = 0; c < KR; ++c) s += wq[c].x * v[r][c].x + wq[c].y * v[r][c].y + wq[c].z * v[r][c].z + wq[c].w * v[r][c].w;
                 s = wave_sum(s);
                 if (lane == 0 && b0 + r < B) y[(size_t)(b0 + r) * ldy + m] = s + bm;
             }
@@ -300,8 +301,12 @@ extern "C" int as_linear_rows_f32(const float* x, int ldx, const float* w, const
     if (!x || !w || !y || B < 0 || M <= 0 || K <= 0 || ldx < K || ldy < M) return AS_EINVAL;
     if (B == 0) return AS_OK;
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(linear_rows_kernel, dim3(as_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
-                       bias, B, M, K, y, ldy);
+    const dim3 grid(as_cdiv(M, 4)), block(256);
+    hipStream_t s_ = (hipStream_t)stream;
+    if (K <= 256) hipLaunchKernelGGL(linear_rows_kernel<1>, grid, block, 0, s_, x, ldx, w, bias, B, M, K, y, ldy);
+    else if (K <= 512) hipLaunchKernelGGL(linear_rows_kernel<2>, grid, block, 0, s_, x, ldx, w, bias, B, M, K, y, ldy);
+    else if (K <= 1024) hipLaunchKernelGGL(linear_rows_kernel<4>, grid, block, 0, s_, x, ldx, w, bias, B, M, K, y, ldy);
+    else hipLaunchKernelGGL(linear_rows_kernel<8>, grid, block, 0, s_, x, ldx, w, bias, B, M, K, y, ldy);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

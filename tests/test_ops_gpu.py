@@ -128,6 +128,18 @@ def test_epilogue_writes_split_image(cuda, monkeypatch, M, K, lens, tile, ksplit
     assert torch.equal(yh2, want)
 
 
+@pytest.mark.parametrize("B,M,K", [(1, 7, 64), (5, 256, 256), (32, 256, 512), (33, 19, 516), (32, 64, 1000), (3, 5, 1024), (32, 8, 2048),
+                                   (4, 9, 130), (32, 130, 2052)])
+def test_linear_rows(cuda, B, M, K):
+    """as_linear_rows_f32 (nn.Linear on per-utterance vectors, models.py:237,412-415,538): every register-group count of the kernel,
+    ragged tails, the unaligned fallback -- against float64."""
+    g = torch.Generator().manual_seed(B * 1000 + K)
+    x, w, b = torch.randn(B, K, generator=g), torch.randn(M, K, generator=g) / np.sqrt(K), torch.randn(M, generator=g)
+    y = ops.linear_rows(x.to(cuda), w.to(cuda), b.to(cuda))
+    want = x.double() @ w.double().T + b.double()
+    assert float((y.double().cpu() - want).abs().max()) <= 2e-6 * (1 + float(want.abs().max()))
+
+
 @pytest.mark.parametrize("M,M2,lens", [(16, 64, [9, 4]), (32, 128, [40]), (8, 64, [100, 3]), (32, 32, [300, 17])])
 def test_small_channel_image_chain(cuda, M, M2, lens):
     """<= 32 output channels take the 32-row tile, which leaves the upper half of the image's 64-row block unwritten (whatever is
