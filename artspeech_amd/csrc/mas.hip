@@ -199,7 +199,7 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
 // The banded variant (rows 16-byte aligned): an utterance's lattice is cut into bands of 64 W rows, one workgroup per band, all
 // bands of an utterance on one XCD.  A workgroup is W DP waves (64 rows each, one row per lane) and a loader wave; every DP wave runs a
 // block or two of columns behind the one above it -- a software pipeline down the rows:
-//   the loader:  LDS-DMA (buffer_load ... lds) of the band's rows, two 32-column blocks in flight, into a four-block ring in LDS; an
+//   the loader:  LDS-DMA (buffer_load ... lds) of the band's rows, three 32-column blocks in flight, into a six-block ring in LDS; an
 //                instruction fetches 8 rows x 128 bytes (whole lines).  HBM latency never reaches the DP.
 //   a DP wave:   its row of the previous column in a register, the row above through DPP wave_shr:1, no barrier.  A column is ~10
 //                instructions: the compare, v_addc (decision word = 2 word + the compare's lane mask), v_max, v_add, the DPP move, one
