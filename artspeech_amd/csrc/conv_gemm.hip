@@ -36,12 +36,16 @@ conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
     }
     for (int i = threadIdx.x; i < a.M; i += 256) bs[i] = a.bias ? a.bias[i] : 0.f;
     __syncthreads();
-    const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (j0 >= a.N) return;
+    // a wave owns 256 consecutive columns, a lane the columns lane, lane + 64, lane + 128, lane + 192 of them: every load and every
+    // store of the wave is then one contiguous run (256 bytes of x, 1 KB of an image row).  With four CONSECUTIVE columns per lane a
+    // store instruction wrote 16 bytes every 64 -- 32 lines a quarter full instead of 8 full ones, and the texture path takes ~4 cycles
+    // a line: the mel tower's first conv (130 MB of image) took 86 us.
+    const int j0 = (blockIdx.x * 256 + (threadIdx.x & ~63)) * 4 + (threadIdx.x & 63);
+    if ((blockIdx.x * 256 + (threadIdx.x & ~63)) * 4 >= a.N) return;   // (the whole wave)
     float x[4][9];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int j = j0 + c;
+        const int j = j0 + 64 * c;
         int h = 0, w = 0, H = 1, Wj = 0x7fffffff;
         if (a.meta && j < a.N) {
             const unsigned long long md = a.meta[j];
@@ -97,12 +101,9 @@ conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
                 }
                 if (a.Y) {
                     float* yr = a.Y + (size_t)m * a.ldy + j0;
-                    if (VEC) *reinterpret_cast<f32x4*>(yr) = f32x4{y[0], y[1], y[2], y[3]};
-                    else {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (j0 + c < a.N) yr[c] = y[c];
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        if (j0 + 64 * c < a.N) yr[64 * c] = y[c];
                 }
             }
 #pragma unroll
@@ -112,11 +113,11 @@ conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
             const size_t plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX + j0;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (j0 + c < a.N) {
+                if (j0 + 64 * c < a.N) {
                     u32x4_t h, l;
                     split2(t8[c], h, l);
-                    yh[plane + c] = h;
-                    yh[plane + c + 2 * NX] = l;
+                    yh[plane + 64 * c] = h;
+                    yh[plane + 64 * c + 2 * NX] = l;
                 }
         }
     }
