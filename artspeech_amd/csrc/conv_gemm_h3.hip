@@ -449,43 +449,40 @@ int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t
 // ----------------------------------------------------------------------------------------------------------------
 // X fp32 [K][ldx] -> Xh[(K/16 up to a multiple of 4)][p*2 + kh][N + 1][8] fp16, x = h + l; optional LeakyReLU first;
 // column N and rows >= K are zero.
-// A thread owns 4 consecutive columns x 8 consecutive k: eight 16-byte loads (range-checked buffer loads: the last
-// quad of a row may reach past N, and past the allocation on the last row), eight 16-byte stores.
+// A thread owns 8 consecutive k of 4 columns -- lane, lane + 64, lane + 128, lane + 192 of its wave's 256: every load is 256
+// contiguous bytes of a row and every store 1 KB of an image row (with four CONSECUTIVE columns per lane a store put 16 bytes every 64:
+// 32 quarter-filled lines per instruction).  Range-checked buffer loads: offsets of rows >= K fall outside the descriptor (zero).
 __global__ void __launch_bounds__(256)
 split_f16x2_kernel(const float* __restrict__ x, int ldx, int K, int N, int lrelu, float slope, u32x4_t* __restrict__ xh)
 {
-    const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int wcol = (blockIdx.x * 256 + (threadIdx.x & ~63)) * 4;      // the wave's first column
+    const int col = wcol + (threadIdx.x & 63);
     const int g = blockIdx.y;                                           // 8-row group: kb = g / 2, kh = g % 2
-    if (col > N) return;
+    if (wcol > N) return;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(((unsigned)(K - 1) * ldx + N) * 4u), 0x00020000);
-    const bool al = ((reinterpret_cast<uintptr_t>(x) | ((uintptr_t)ldx * 4)) & 15) == 0;   // 16-byte loads need aligned rows
-    f32x4 v[8];
+    float v[8][4];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int k = g * 8 + r;
-        const unsigned off = k < K ? (unsigned)(k * ldx + col) * 4u : OOB;
-        if (al) v[r] = buf_load4(rs, off, 0);
-        else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[r][c] = buf_load1(rs, k < K ? off + 4u * c : OOB, 0);
-        }
+        for (int c = 0; c < 4; ++c) v[r][c] = buf_load1(rs, (k < K && col + 64 * c < N) ? (unsigned)(k * ldx + col + 64 * c) * 4u : OOB, 0);
     }
     const size_t NX = (size_t)N + 1;
     const size_t base = ((size_t)(g >> 1) * 4 + (g & 1)) * NX + col;    // plane p*2 + kh of k-block kb
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        if (col + c > N) break;
+        if (col + 64 * c > N) break;                                    // (column N itself is written: the zero column)
         float t[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            float e = col + c < N ? v[r][c] : 0.f;                      // column N: the zero column
+            float e = v[r][c];                                          // zero past N and past K
             if (lrelu) e = e > 0.f ? e : slope * e;
             t[r] = e;
         }
         u32x4_t h, l;
         split2(t, h, l);
-        xh[base + c] = h;
-        xh[base + c + 2 * NX] = l;
+        xh[base + 64 * c] = h;
+        xh[base + 64 * c + 2 * NX] = l;
     }
 }
 
