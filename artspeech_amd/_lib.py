@@ -18,6 +18,9 @@ c_f = ctypes.c_float
 
 _SIGNATURES = {
     "as_abi_version": (c_i, []),
+    "as_device_status": (c_i, [c_i]),
+    "as_device_status_raise_for_test": (c_i, [c_i, c_p]),
+    "as_set_range_probe": (c_i, [c_i]),
     "as_prof_enable": (c_i, [c_i]),
     "as_prof_collect": (c_i, [c_p, c_p, c_p, c_p, c_i]),
     "as_prof_hint": (c_i, [ctypes.c_double, ctypes.c_double]),
@@ -41,7 +44,7 @@ class ConvGemmArgs(ctypes.Structure):
                 ("transpose_out", ctypes.c_int32), ("yh_lrelu", ctypes.c_int32), ("n_prod", ctypes.c_int32),
                 ("dh", ctypes.c_int32 * AS_MAX_TAPS), ("dw", ctypes.c_int32 * AS_MAX_TAPS),
                 ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float), ("acc_scale", ctypes.c_float),
-                ("n_groups", ctypes.c_int32), ("group_cols", ctypes.c_int32)]
+                ("n_groups", ctypes.c_int32), ("group_cols", ctypes.c_int32), ("status", ctypes.c_void_p)]
 
 
 _SIGNATURES.update({
@@ -127,6 +130,9 @@ _SIGNATURES.update({
     "as_plan_set_timing": (c_i, [c_p, c_i]),
     "as_plan_set_operand_mode": (c_i, [c_p, c_i]),
     "as_plan_phase_ms": (c_i, [c_p, ctypes.POINTER(ctypes.c_float), c_i]),
+    "as_plan_set_layout_cap": (c_i, [c_p, c_i]),
+    "as_plan_layout_flushes": (c_i, [c_p]),
+    "as_bilstm_cluster_test_hooks": (c_i, [c_i, c_i]),
     "as_module_workspace_bytes": (c_sz, [c_p, c_p, c_i, _pB]),
     "as_encoder_forward": (c_i, [c_p, c_p, c_i, _pB, c_p, c_p, c_i, c_p, c_sz, c_p]),
     "as_style_forward": (c_i, [c_p, c_p, _pB, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_sz, c_p]),
@@ -168,8 +174,21 @@ def lib():
     return _lib
 
 
+AS_EDEVICE = -3
+STATUS_NAMES = ("clustered LSTM hand-over timed out", "MAS band hand-over timed out", "token id outside [0, n_token)",
+                "non-finite accumulator (an operand beyond fp16's range, or a non-finite input)")
+
+
+def device_status(clear=False):
+    """Names of the device-side failures raised on the current device since the last clear (as_device_status)."""
+    bits = lib().as_device_status(int(clear))
+    return [n for k, n in enumerate(STATUS_NAMES) if bits >> k & 1]
+
+
 def check(rc, what):
     if rc != 0:
+        if rc == AS_EDEVICE:
+            raise HipLibraryError(f"{what} failed: a kernel reported {device_status()} (as_device_status); results since then are invalid")
         kind = "an output buffer or workspace is too small" if rc == -2 else "invalid argument" if rc < 0 else f"hipError_t {rc}"
         raise HipLibraryError(f"{what} failed: {kind}")
 

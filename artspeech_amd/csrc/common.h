@@ -5,6 +5,13 @@
 
 #define AS_OK 0
 #define AS_EINVAL (-1)
+#ifndef AS_EDEVICE
+#define AS_EDEVICE (-3)
+#endif
+
+// device-side status words (status.hip; kinds in include/artspeech_hip.h)
+unsigned* as_status_words_device();     // device address of the current device's words, or NULL
+int as_status_peek();                   // host view: bit k = kind k raised
 
 // Launch-error check: returns the hipError_t (>0) from the calling extern "C" function.
 #define AS_CHECK_LAUNCH()                        \
@@ -33,6 +40,11 @@ struct AsProfScope {
 };
 
 #ifdef __HIPCC__
+// raise status kind `kind` (a kernel's failure path only): one system-scope store into pinned host memory
+static __device__ __forceinline__ void as_status_raise(unsigned* words, int kind)
+{
+    if (words) __hip_atomic_store(words + kind, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // AdaIN1d value and the fused depthwise ConvTranspose1d(k3, s2, p1, op1) pair, written with explicit roundings so that every
 // kernel that evaluates them (adain_kernel: fp32 output; adain_image_kernel: operand image) produces the same bits whatever
 // the compiler would contract.

@@ -141,6 +141,16 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(
         a.Yh, 0, a.Yh ? (int)((unsigned)as_kbx(a.M) * 4u * ((unsigned)a.N + 1u) * 16u) : 0, 0x00020000);
     const float sc = a.acc_scale;
+    if (a.status) {                                        // range probe (as_set_range_probe): a wave-uniform branch, off by default
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bad |= !(fabsf(acc[i][jn][e]) <= 3.0e38f);
+        if (bad) as_status_raise(a.status, AS_STATUS_F16_RANGE);
+    }
     float bv[TM][16];                                      // loads first: Y may alias res, so program order is kept
 #pragma unroll
     for (int i = 0; i < TM; ++i)

@@ -15,6 +15,7 @@
 #include "conv_gemm.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 
 // Cin = 1 (the first conv of every style tower and of the decoder's F0 / energy inputs): 9 MACs per output on a
 // 16-deep matrix-core k-block would be 2 % useful work, and the op is bound by writing Y anyway (M x N x 4 bytes: 130 MB
@@ -212,6 +213,7 @@ splitk_reduce_kernel(const ConvGemmArgs a, int S)
         float x = 0.f;
         if (row < a.M && j < a.N) {
             x = acc8[r];
+            if (a.status && !(fabsf(x) <= 3.0e38f)) as_status_raise(a.status, AS_STATUS_F16_RANGE);
             x *= a.acc_scale;
             if (a.bias) x += bias8[r];
             if (a.res) x += res8[r];
@@ -240,6 +242,14 @@ splitk_reduce_kernel(const ConvGemmArgs a, int S)
         yh[0] = h;
         yh[2 * NX] = l;
     }
+}
+
+// as_set_range_probe: every launch tests its accumulators for inf / NaN (what an operand beyond fp16's range turns into)
+static int g_range_probe = 0;
+extern "C" int as_set_range_probe(int on)
+{
+    g_range_probe = on != 0;
+    return AS_OK;
 }
 
 static void tile_dims(int choice, int* bm, int* bn)
@@ -349,9 +359,9 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!args_host) return AS_EINVAL;
     ConvGemmArgs norm = *args_host;
-    if (norm.in_slope == 0.f) norm.in_slope = 0.2f;
-    if (norm.act_slope == 0.f) norm.act_slope = 0.2f;
+    if (!(fabsf(norm.in_slope) <= 3.0e38f) || !(fabsf(norm.act_slope) <= 3.0e38f)) return AS_EINVAL;   // slopes are used as given
     if (norm.acc_scale == 0.f) norm.acc_scale = 1.0f;
+    norm.status = g_range_probe ? as_status_words_device() : nullptr;
     if (norm.n_prod == 0) norm.n_prod = 3;
     if (norm.n_groups < 1) norm.n_groups = 1;
     // a 1x1 conv reads every column from itself: no tap can leave the utterance, so the kernels need not fetch the column descriptors

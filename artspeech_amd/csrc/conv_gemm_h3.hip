@@ -503,11 +503,11 @@ int as_split_f16x2_launch(const float* x, int ldx, int K, int N, int lrelu, floa
 
 extern "C" int as_split_f16x2_f32(const float* x, int ldx, int K, int N, int in_act, float in_slope, uint16_t* xh, as_stream_t stream)
 {
-    if (!x || !xh || K <= 0 || N < 0 || ldx < N || (in_act != 0 && in_act != 2)) return AS_EINVAL;
+    if (!x || !xh || K <= 0 || N < 0 || ldx < N || (in_act != 0 && in_act != 2) || !(fabsf(in_slope) <= 3.0e38f)) return AS_EINVAL;
     if ((reinterpret_cast<uintptr_t>(xh) & 15) != 0) return AS_EINVAL;
     if (N == 0) return AS_OK;
     AsProfScope prof__(AS_CLS_OTHER, 0, 8.0 * K * (double)N, (hipStream_t)stream);
-    return as_split_f16x2_launch(x, ldx, K, N, in_act == 2, in_slope == 0.f ? 0.2f : in_slope, xh, (hipStream_t)stream);
+    return as_split_f16x2_launch(x, ldx, K, N, in_act == 2, in_slope, xh, (hipStream_t)stream);
 }
 
 // host-side weight preparation (see the header)

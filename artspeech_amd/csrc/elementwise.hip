@@ -49,7 +49,7 @@ extern "C" int as_make_meta(const int32_t* widths, const int32_t* col_off, int B
 // (emb2, n_split: columns >= n_split take their rows from a second table -- two encoders run as one double-width launch)
 // (n_tok < N: the token list is read twice, columns [n_tok, n_split) are filler)
 __global__ void embed_kernel(const int* __restrict__ tok, int n_tok, const float* __restrict__ emb, const float* __restrict__ emb2,
-                             int n_split, int C, int N, int V, float scale, float* __restrict__ y, int ldy)
+                             int n_split, int C, int N, int V, float scale, float* __restrict__ y, int ldy, unsigned* __restrict__ status)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
@@ -57,6 +57,8 @@ __global__ void embed_kernel(const int* __restrict__ tok, int n_tok, const float
     const int g = emb2 ? j / n_split : 0;                // column group: table g = emb + g (emb2 - emb), its columns re-read the token list
     const int src = j - g * n_split;
     int t = src < n_tok ? tok[src] : 0;
+    // nn.Embedding raises on such an id (RelTransformerEnc.py:11-16); a kernel cannot: it reports (as_device_status) and clamps
+    if ((t < 0 || t >= V) && c == 0) as_status_raise(status, AS_STATUS_BAD_TOKEN);
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
     const float* e = emb + (ptrdiff_t)g * (emb2 - emb);
     y[(size_t)c * ldy + j] = e[(size_t)t * C + c] * scale;
@@ -70,7 +72,7 @@ extern "C" int as_embed_groups_f32(const int32_t* tokens, int n_tok, const float
     if (N == 0) return AS_OK;
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(embed_kernel, dim3(as_cdiv(N, 64), C), dim3(64), 0, (hipStream_t)stream, tokens, n_tok, emb, emb2, n_split, C, N, V,
-                       scale, y, ldy);
+                       scale, y, ldy, as_status_words_device());
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

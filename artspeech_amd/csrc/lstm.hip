@@ -505,8 +505,13 @@ extern "C" int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32
 //   which they publish after consuming step t-1's -- two slots suffice.
 //   epoch: region[0] of the cluster, read by every member at start, bumped by member 0 at the end: words of earlier launches (the
 //   buffer persists, hipGraph replays repeat the same arguments) never match.
-// Forward progress: members spin, so a cluster needs its four workgroups resident together; the launcher only uses this kernel
-// when the whole grid fits the chip at once, and the poll gives up after ~1 s instead of hanging the device.
+// Forward progress: members spin, so a cluster needs its four workgroups resident together.  The launcher only uses this kernel
+// when the whole grid fits the chip at once; beside other kernels (the path's side streams, a second plan's graph in flight) it rests
+// on IN-ORDER DISPATCH of a grid's workgroups: a cluster's members have ids inside one window of 32 consecutive ids, so of the
+// workgroups a launch has resident all but the last, partial cluster are complete, finish on their own and free their CUs for the
+// next ids; two launches that share the chip cannot both be left with nothing but partial clusters.  HIP does not promise that
+// order, so every poll is bounded (~1 s) and a poll that gives up RAISES AS_STATUS_LSTM_TIMEOUT (as_device_status): the launch still
+// ends, its output is void, and the module entry points return AS_EDEVICE until the status is cleared.
 // ---------------------------------------------------------------------------------------------------
 #define CL_P 4
 #define CL_REGION_WORDS 1032                       /* 1 header word + 2 slots x 256 units x 2 utterances, padded to 8 KB + 64 B */
@@ -524,7 +529,8 @@ static __device__ __forceinline__ float dpp_add8(float v)
 
 template <int NBU>
 __global__ void __launch_bounds__(512)
-bilstm_cluster_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B, int n_clusters, unsigned long long* __restrict__ xchg)
+bilstm_cluster_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int B, int n_clusters, unsigned long long* __restrict__ xchg,
+                      unsigned* __restrict__ status, int spin_limit, int drop_member)
 {
     constexpr int H = 256, G = 4 * H, UW = H / CL_P, KS = 8, KQ = H / KS, SL = KQ * NBU + 4, HB = KS * SL;
     __shared__ __attribute__((aligned(16))) float hs[2 * HB];
@@ -544,6 +550,7 @@ bilstm_cluster_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int 
         Lmax = len[i] > Lmax ? len[i] : Lmax;
     }
     if (Lmax <= 0) return;                                               // (every member of the cluster agrees)
+    if (member == drop_member) return;                                   // test hook (as_bilstm_cluster_test_hooks): this member never shows up
     unsigned long long* region = xchg + (size_t)cl * CL_REGION_WORDS;
     const unsigned epoch = (unsigned)region[0] & 0x7FFFu;
     const unsigned tagbase = epoch << 17;                                 // tag = epoch : step + 1 (17 bits: the launcher bounds the lengths)
@@ -583,10 +590,14 @@ bilstm_cluster_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int 
                 const unsigned long long* w = words + (size_t)((t - 1) & 1) * H * NBU + tid;
                 const unsigned want = tagbase | (unsigned)t;
                 unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int spin = 0; (unsigned)(v >> 32) != want && spin < (1 << 21); ++spin) {
+                for (int spin = 0; (unsigned)(v >> 32) != want && spin < spin_limit; ++spin) {
                     __builtin_amdgcn_s_sleep(1);
                     v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                // gave up: a peer never published this step (it got no CU, or died).  The word read last is NOT h(t-1): the recurrence
+                // carries on so that the launch ends, and says that its output is void (as_device_status; the module entry points
+                // return AS_EDEVICE from then on)
+                if ((unsigned)(v >> 32) != want) as_status_raise(status, AS_STATUS_LSTM_TIMEOUT);
                 hb[ppos] = __uint_as_float((unsigned)v);
             }
             lds_barrier();
@@ -648,7 +659,35 @@ bilstm_cluster_kernel(const LstmJobs jobs, const int* __restrict__ col_off, int 
             }
         }
     }
-    if (member == 0 && tid == 0) region[0] = epoch + 1;
+    // The epoch is bumped by member 0 once it is done.  With two or more steps it cannot get here before every member has read the
+    // epoch (it consumed their step Lmax - 2 words, which carry it).  With ONE step nothing was polled: wait for the others' step-0
+    // words first -- a member that started late would otherwise read the bumped epoch and leave step-0 words that the NEXT launch's
+    // step-1 poll takes for its own.
+    if (member == 0) {
+        if (Lmax == 1 && tid < H * NBU) {
+            const unsigned long long* w = words + tid;
+            const unsigned want = tagbase | 1u;
+            unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spin = 0; (unsigned)(v >> 32) != want && spin < spin_limit; ++spin) {
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if ((unsigned)(v >> 32) != want) as_status_raise(status, AS_STATUS_LSTM_TIMEOUT);
+        }
+        __syncthreads();
+        if (tid == 0) region[0] = epoch + 1;
+    }
+}
+
+// test hooks (tests/test_status_gpu.py): member `drop_member` of every cluster exits at once (-1 = none) and a poll gives up after
+// `spin_limit` tries (0 = the default, ~1 s), so that the failure path runs in milliseconds
+static int g_cl_drop_member = -1, g_cl_spin_limit = 1 << 21;
+extern "C" int as_bilstm_cluster_test_hooks(int drop_member, int spin_limit)
+{
+    if (drop_member < -1 || drop_member >= CL_P || spin_limit < 0) return AS_EINVAL;
+    g_cl_drop_member = drop_member;
+    g_cl_spin_limit = spin_limit > 0 ? spin_limit : 1 << 21;
+    return AS_OK;
 }
 
 extern "C" size_t as_bilstm_cluster_bytes(int n_jobs, int B)
@@ -677,13 +716,14 @@ extern "C" int as_bilstm_cluster_f32(const BiLstmJob* jobs_host, int n_jobs, con
         if (!jobs.j[i].gx_tm || !jobs.j[i].whh_t || !jobs.j[i].out || jobs.j[i].ldg < 8 * H) return AS_EINVAL;
     const int ncl = (int)(use == 1 ? c1 : c2);
     const dim3 grid(8 * CL_P * as_cdiv(ncl, 8)), block(512);
+    unsigned* status = as_status_words_device();
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     if (use == 1)
         hipLaunchKernelGGL(bilstm_cluster_kernel<1>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B, ncl,
-                           static_cast<unsigned long long*>(xchg));
+                           static_cast<unsigned long long*>(xchg), status, g_cl_spin_limit, g_cl_drop_member);
     else
         hipLaunchKernelGGL(bilstm_cluster_kernel<2>, grid, block, 0, (hipStream_t)stream, jobs, col_off, B, ncl,
-                           static_cast<unsigned long long*>(xchg));
+                           static_cast<unsigned long long*>(xchg), status, g_cl_spin_limit, g_cl_drop_member);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

@@ -305,7 +305,7 @@ template <int W, bool TIE_MOVE>
 __global__ void __launch_bounds__(64 * (W + 1))
 mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const int* __restrict__ t_y, int B, int Tx, int Ty, int P,
                 int nblk_max, u64* __restrict__ xchg, unsigned* __restrict__ masks, int n_band_wgs, float* __restrict__ path,
-                int* __restrict__ dur, int* __restrict__ rows)
+                int* __restrict__ dur, int* __restrict__ rows, unsigned* __restrict__ status)
 {
 #if __HIP_DEVICE_COMPILE__
     if ((int)blockIdx.x >= n_band_wgs) {
@@ -429,6 +429,8 @@ mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, co
                     __builtin_amdgcn_s_sleep(1);
                     word = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                // gave up (the band above never got a CU, or died): what follows is not the alignment -- say so (as_device_status)
+                if ((unsigned)(word >> 32) != 1u) as_status_raise(status, AS_STATUS_MAS_TIMEOUT);
                 if (blk + 1 < nblk) vnext = __hip_atomic_load(xi + xcol(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 v = __uint_as_float((unsigned)word);
             }
@@ -681,13 +683,14 @@ extern "C" int as_mas_f32(const float* value, const int* t_x, const int* t_y, in
         AsProfScope prof__(AS_CLS_MAS, 2.0 * B * Tx * (double)Ty, 4.0 * B * Tx * (double)Ty * (path ? 2 : 1), stream);
         const int n_band_wgs = 8 * as_cdiv(B, 8) * g.P;
         const dim3 grid(n_band_wgs + 512);                 // + the workgroups that clear path / dur / rows
+        unsigned* status = as_status_words_device();
         if (g.R == 1) {
-            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<1, true>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows);
-            else hipLaunchKernelGGL((mas_band_kernel<1, false>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows);
+            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<1, true>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status);
+            else hipLaunchKernelGGL((mas_band_kernel<1, false>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status);
             hipLaunchKernelGGL((mas_backtrack_kernel<1>), dim3(B), dim3(64), 0, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, path, dur, rows);
         } else {
-            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<2, true>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows);
-            else hipLaunchKernelGGL((mas_band_kernel<2, false>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows);
+            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<2, true>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status);
+            else hipLaunchKernelGGL((mas_band_kernel<2, false>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status);
             hipLaunchKernelGGL((mas_backtrack_kernel<2>), dim3(B), dim3(64), 0, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, path, dur, rows);
         }
         AS_CHECK_LAUNCH();

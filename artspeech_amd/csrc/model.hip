@@ -13,11 +13,14 @@
 #include "common.h"
 #include "conv_gemm.h"
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -384,6 +387,25 @@ struct as_plan {
         if (!marks[i] && hipEventCreate(&marks[i]) != hipSuccess) { marks[i] = nullptr; return; }
         (void)hipEventRecord(marks[i], s);
     }
+    // Layout cache.  A key is a whole length vector, so a server that sees ever new ragged batches adds ~10-20 entries per batch.
+    // trim() runs at the START of an entry point, when no `const Lay*` of an earlier call is alive: above the cap it waits for the
+    // device (kernels of earlier calls may still read the tables), drops every layout and rewinds the table pool, so neither the host
+    // map nor device memory grows without bound.  A hipGraph captured from this plan holds table addresses: use a plan of its own
+    // for captured geometries (bench.py does), or watch layout_flushes.
+    size_t lay_cap = 4096;
+    int layout_flushes = 0;
+    int trim()
+    {
+        if (lays.size() <= lay_cap) return AS_OK;
+        const hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) return (int)e;
+        lays.clear();
+        pool.release();
+        lstm_xchg = nullptr;
+        lstm_xchg_bytes = 0;
+        ++layout_flushes;
+        return AS_OK;
+    }
     std::vector<int> frames_host;         // as_forward_test with unknown frame counts reads them here
     void* lstm_xchg = nullptr;            // as_bilstm_cluster_f32's exchange buffer (zero-filled once, then the library's)
     size_t lstm_xchg_bytes = 0;
@@ -463,8 +485,7 @@ struct Ctx {
                 L->max_w = std::max(L->max_w, widths[b]);
             }
             L->N = L->off[L->B];
-            if (p.lays.size() > 4096) p.lays.clear();          // (device tables stay in the pool until the plan dies)
-            p.lays[key] = std::move(u);
+            p.lays[key] = std::move(u);                        // (never evicted inside a call: as_plan::trim runs between calls)
         } else {
             L = it->second.get();
         }
@@ -639,6 +660,7 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     a.ldx = X ? ldx : lay->N; a.ldy = ldy; a.ldr = o.ldr;
     a.act = o.act; a.div_sqrt2 = o.div_sqrt2; a.in_act = o.in_act; a.transpose_out = o.transpose_out; a.yh_lrelu = o.yh_lrelu;
     a.acc_scale = 1.0f / w->scale;
+    a.in_slope = a.act_slope = AS_SLOPE_PATH;                           // LeakyReLU(0.2) everywhere on the path (models.py:163)
     a.n_prod = c.p.n_prod;
     a.n_groups = w->G; a.group_cols = o.group_cols;
     for (int i = 0; i < taps.n; ++i) { a.dh[i] = taps.dh[i]; a.dw[i] = taps.dw[i]; }
@@ -1636,15 +1658,18 @@ namespace {
 
 bool read_blob(const void* blob, size_t bytes, std::unordered_map<std::string, HostT>* raw_out)
 {
+    // Every bound is checked in subtraction form against what is left (o <= bytes always holds): nothing here can wrap for any
+    // header content, and nothing is allocated from a count the file merely claims.
     const unsigned char* b = static_cast<const unsigned char*>(blob);
     size_t o = 0;
-    auto need = [&](size_t n) { return o + n <= bytes; };
+    auto need = [&](size_t n) { return n <= bytes - o; };
     if (!need(12) || memcmp(b, "ASWBLOB1", 8) != 0) return false;
     o = 8;
     uint32_t n;
     memcpy(&n, b + o, 4);
     o += 4;
-    struct Ent { std::string name; std::vector<int> dims; uint64_t off; };
+    if ((size_t)n > (bytes - o) / 11) return false;         // an entry is at least 2 + 0 + 1 + 0 + 8 bytes
+    struct Ent { std::string name; std::vector<int> dims; uint64_t off; size_t numel; };
     std::vector<Ent> ents(n);
     for (uint32_t i = 0; i < n; ++i) {
         uint16_t nl;
@@ -1655,13 +1680,18 @@ bool read_blob(const void* blob, size_t bytes, std::unordered_map<std::string, H
         ents[i].name.assign(reinterpret_cast<const char*>(b + o), nl);
         o += nl;
         const int nd = b[o++];
-        if (!need((size_t)nd * 4 + 8)) return false;
+        if (nd > 8 || !need((size_t)nd * 4 + 8)) return false;
+        size_t numel = 1;
         for (int d = 0; d < nd; ++d) {
             uint32_t v;
             memcpy(&v, b + o, 4);
             o += 4;
+            if (v > (uint32_t)INT32_MAX) return false;
+            if (v != 0 && numel > (SIZE_MAX / 4) / v) return false;   // numel * 4 must not wrap either
+            numel *= v;
             ents[i].dims.push_back((int)v);
         }
+        ents[i].numel = numel;
         memcpy(&ents[i].off, b + o, 8);
         o += 8;
     }
@@ -1669,15 +1699,13 @@ bool read_blob(const void* blob, size_t bytes, std::unordered_map<std::string, H
     if (!need(8)) return false;
     memcpy(&data_bytes, b + o, 8);
     o += 8;
-    if (!need(data_bytes)) return false;
+    if (data_bytes > bytes - o) return false;
     for (auto& e : ents) {
-        size_t numel = 1;
-        for (int d : e.dims) numel *= (size_t)d;
-        if (e.off + numel * 4 > data_bytes) return false;
+        if (e.off > data_bytes || e.numel * 4 > data_bytes - e.off) return false;
         HostT t;
         t.dims = e.dims;
-        t.v.resize(numel);
-        memcpy(t.v.data(), b + o + e.off, numel * 4);
+        t.v.resize(e.numel);
+        if (e.numel) memcpy(t.v.data(), b + o + e.off, e.numel * 4);
         (*raw_out)[e.name] = std::move(t);
     }
     return true;
@@ -1812,14 +1840,16 @@ bool merge_twin_linears(std::unordered_map<std::string, HostT>* raw, const std::
 }
 }  // namespace
 
-extern "C" int as_model_create(const void* blob_host, size_t blob_bytes, const as_model_cfg* cfg, as_model** out)
+static int model_create(const void* blob_host, size_t blob_bytes, const as_model_cfg* cfg, as_model** out)
 {
-    if (!blob_host || !cfg || !out || cfg->hidden_dim <= 0 || cfg->hidden_dim % 16 || cfg->dim_in <= 0 || cfg->style_dim <= 0 || cfg->style_dim % 4 ||
-        cfg->n_mels <= 0)
-        return AS_EINVAL;
     std::unordered_map<std::string, HostT> blob;
     if (!read_blob(blob_host, blob_bytes, &blob)) return AS_EINVAL;
-    std::unique_ptr<as_model> m(new as_model());
+    struct Guard {                                                       // every error return below gives the device memory back
+        std::unique_ptr<as_model> m;
+        ~Guard() { if (m) m->pool.release(); }
+    } g;
+    g.m.reset(new as_model());
+    as_model* m = g.m.get();
     m->cfg = *cfg;
     if (!fold(blob, &m->raw)) return AS_EINVAL;
     blob.clear();
@@ -1836,17 +1866,31 @@ extern "C" int as_model_create(const void* blob_host, size_t blob_bytes, const a
     }
     // prepare pass: walk the whole launch sequence once on a minimal geometry; every weight it touches is built and uploaded
     as_plan* plan = nullptr;
-    int rc = as_plan_create(m.get(), &plan);
-    if (rc != AS_OK) { m->pool.release(); return rc; }
+    int rc = as_plan_create(m, &plan);
+    if (rc != AS_OK) return rc;
     const int32_t tl[1] = {8}, rl[1] = {96}, fr[1] = {12};
     as_batch b = {1, tl, rl, fr};
-    for (int mod : {AS_MOD_FORWARD_A, AS_MOD_FORWARD_B}) count_module(m.get(), plan, mod, &b, true);
+    for (int mod : {AS_MOD_FORWARD_A, AS_MOD_FORWARD_B}) count_module(m, plan, mod, &b, true);
     as_plan_destroy(plan);
-    if (m->err) { rc = m->err; m->pool.release(); return rc; }
+    if (m->err) return m->err;
     m->frozen = true;
     AS_CHECK(hipDeviceSynchronize());
-    *out = m.release();
+    *out = g.m.release();
     return AS_OK;
+}
+
+extern "C" int as_model_create(const void* blob_host, size_t blob_bytes, const as_model_cfg* cfg, as_model** out)
+{
+    if (!blob_host || !cfg || !out || cfg->hidden_dim <= 0 || cfg->hidden_dim % 16 || cfg->dim_in <= 0 || cfg->style_dim <= 0 || cfg->style_dim % 4 ||
+        cfg->n_mels <= 0)
+        return AS_EINVAL;
+    try {                                                                // nothing may unwind through the C boundary
+        return model_create(blob_host, blob_bytes, cfg, out);
+    } catch (const std::bad_alloc&) {
+        return (int)hipErrorOutOfMemory;
+    } catch (...) {
+        return AS_EINVAL;
+    }
 }
 
 extern "C" int as_model_destroy(as_model* m)
@@ -2002,10 +2046,15 @@ size_t count_module(const as_model* m, as_plan* p, int module, const as_batch* b
 
 struct Call {                     // common prologue of the run entry points
     Ctx c;
-    Call(const as_model* m, as_plan* p, void* ws, size_t bytes, as_stream_t stream, bool launch = true)
+    Call(const as_model* m, as_plan* p, void* ws, size_t bytes, as_stream_t stream, bool launch = true, bool first = true)
         : c(*m, *p, static_cast<hipStream_t>(stream), ws, bytes, launch, false)
     {
-        if (launch) p->next_event = 0;
+        if (launch) {
+            p->next_event = 0;
+            const int t = first ? p->trim() : AS_OK;       // (as_forward_test_finish continues _begin's call: it needs _begin's layouts)
+            if (t != AS_OK) c.fail(t);
+            if (as_status_peek()) c.fail(AS_EDEVICE);      // a kernel of earlier work reported a failure: sticky until as_device_status(1)
+        }
         if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) c.fail(AS_EINVAL);
     }
     int done() const { return c.rc ? c.rc : c.m.err; }
@@ -2016,8 +2065,18 @@ struct Call {                     // common prologue of the run entry points
 extern "C" size_t as_module_workspace_bytes(const as_model* m, as_plan* p, int module, const as_batch* batch)
 {
     if (!m || !p || !batch) return 0;
+    // (no trim here: a caller asks for workspace B's size between as_forward_test_begin and _finish, which share layouts)
     return count_module(m, p, module, batch, false);
 }
+
+extern "C" int as_plan_set_layout_cap(as_plan* p, int max_layouts)
+{
+    if (!p || max_layouts < 64) return AS_EINVAL;          // (one forward touches ~20 layouts: the cap must hold a call's own)
+    p->lay_cap = (size_t)max_layouts;
+    return AS_OK;
+}
+
+extern "C" int as_plan_layout_flushes(const as_plan* p) { return p ? p->layout_flushes : AS_EINVAL; }
 
 extern "C" int as_encoder_forward(const as_model* m, as_plan* p, int which, const as_batch* batch, const int32_t* tokens, float* out, int ldo,
                                   void* ws, size_t ws_bytes, as_stream_t stream)
@@ -2135,7 +2194,7 @@ extern "C" int as_forward_test_finish(const as_model* m, as_plan* p, const as_ba
     Call ka(m, p, ws_a, ws_a_bytes, stream, false);
     const PhaseA A = forward_a(ka.c, batch, io);
     if (ka.done() || !A.tok || !A.ref) return ka.done() ? ka.done() : AS_EINVAL;
-    Call kb(m, p, ws_b, ws_b_bytes, stream);
+    Call kb(m, p, ws_b, ws_b_bytes, stream, true, false);
     forward_b(kb.c, A, batch, io);
     return kb.done();
 }
@@ -2152,6 +2211,7 @@ extern "C" int as_forward_test(const as_model* m, as_plan* p, const as_batch* ba
         std::vector<int32_t> off(batch->B + 1);
         AS_CHECK(hipMemcpyAsync(off.data(), A.frame_off, off.size() * 4, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
         AS_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        if (as_status_peek()) return AS_EDEVICE;                            // e.g. the duration predictor's recurrence timed out
         p->frames_host.resize(batch->B);
         for (int i = 0; i < batch->B; ++i) p->frames_host[i] = off[i + 1] - off[i];
         b2.frames = p->frames_host.data();

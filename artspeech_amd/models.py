@@ -40,7 +40,9 @@ def _i32(values):
 
 class Runtime:
     """One loaded model on one GPU: the library's as_model handle, an as_plan (geometry tables, side streams) and the
-    workspaces, which are kept (and only ever grown) so that a captured hipGraph keeps seeing the same addresses."""
+    workspaces.  A workspace is kept and reused while it is large enough; when a call needs more, a larger one REPLACES it and the
+    old tensor stays alive in `_retired` (a hipGraph captured earlier still replays into it: capture after the largest geometry, or
+    call `drop_retired()` once such graphs are gone)."""
 
     def __init__(self, state_dict, args, distribution, device):
         self.model, self.plan = ctypes.c_void_p(), ctypes.c_void_p()
@@ -59,6 +61,7 @@ class Runtime:
             check(L.as_model_create(blob, len(blob), ctypes.byref(cfg), ctypes.byref(self.model)), "as_model_create")
             check(L.as_plan_create(self.model, ctypes.byref(self.plan)), "as_plan_create")
         self._ws = {}
+        self._retired = []
         self._parent = None
 
     def fork(self):
@@ -66,7 +69,7 @@ class Runtime:
         be in flight on another stream while this runtime's run (include/artspeech_hip.h: one model per GPU, one plan per stream)."""
         rt = Runtime.__new__(Runtime)
         rt.model, rt.plan, rt.device, rt.cfg = self.model, ctypes.c_void_p(), self.device, self.cfg
-        rt._ws, rt._parent = {}, self                                   # (keeps the owner of the model alive)
+        rt._ws, rt._retired, rt._parent = {}, [], self                  # (keeps the owner of the model alive)
         with torch.cuda.device(self.device):
             check(_lib.lib().as_plan_create(self.model, ctypes.byref(rt.plan)), "as_plan_create")
         return rt
@@ -121,8 +124,14 @@ class Runtime:
                                        "SURVEY.md A9; every length must be positive)")
         ws = self._ws.get(slot)
         if ws is None or ws.numel() < need:
+            if ws is not None:
+                self._retired.append(ws)                   # captured graphs may still point into it
             ws = self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return ws, ws.numel()
+
+    def drop_retired(self):
+        """free the workspaces that were outgrown (only when no captured hipGraph replays into them any more)"""
+        self._retired.clear()
 
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -361,7 +370,15 @@ class ArtsSpeech(_Module):
             io.f0_raw, io.ema_raw, io.ld_ema = _p(f0_p), _p(ema_p), ema_p.stride(0)
             io.forced_dur = _p(forced)
             res = out if out is not None else {}
-            new = lambda key, shape, dtype=torch.float32: res.setdefault(key, torch.empty(shape, dtype=dtype, device=dev))
+
+            def new(key, shape, dtype=torch.float32):
+                # a tensor of a previous call is reused only if it is exactly what this call needs: predicted durations depend on
+                # the input VALUES, so the frame count (and with it mel / F0 / N / EMA) can change under an unchanged geometry
+                t = res.get(key)
+                if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != dev:
+                    t = res[key] = torch.empty(shape, dtype=dtype, device=dev)
+                return t
+
             io.dur_i, io.frame_off = _p(new("dur_i", (max(Nt, 1),), torch.int32)), _p(new("frame_off", (B + 1,), torch.int32))
             if aux:
                 io.duration = _p(new("duration", (1, max(Nt, 1))))

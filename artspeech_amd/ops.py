@@ -179,7 +179,7 @@ def new_image(K, N, device):
     return torch.empty(max(_lib.lib().as_split_f16x2_bytes(K, N) // 2, 8), dtype=torch.int16, device=device)
 
 
-def split_act(X, lay, in_act=0, in_slope=0.0):
+def split_act(X, lay, in_act=0, in_slope=0.2):
     """X [K][*] fp32 -> the GEMM's split activation image (int16 [KBx][4][N+1][8], LeakyReLU applied first when
     in_act = ACT_LRELU): pass it as conv_gemm(..., xs=) to every conv that reads the same activations."""
     K, N = X.shape[0], lay.N
@@ -228,7 +228,7 @@ def project_cols(X, N, w, bias, Y):
 
 
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
-              use_meta=True, in_slope=0.0, act_slope=0.0, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None):
+              use_meta=True, in_slope=0.2, act_slope=0.2, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None):
     """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt: prep_weight(...); X [K][*] fp32 or None with xs= (the split image of
     X: split_act / adain_split / channel_layernorm_split / another conv's yh=) and K=; Y [M][*] (or [N][*] transposed) or None
     when only yh (the output as the next conv's split image, new_image(M, N)) is wanted.  group_cols: Wt holds Wt.G weight
@@ -255,7 +255,7 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     a.act, a.div_sqrt2, a.in_act, a.transpose_out = act, int(div_sqrt2), in_act, int(transpose_out)
     a.yh_lrelu = int(yh_lrelu)
     a.n_prod = n_prod if n_prod is not None else (1 if GEMM_IMPL == "h1" else 3)
-    a.in_slope, a.act_slope = in_slope, act_slope          # 0 = LeakyReLU(0.2), the acoustic path's slope
+    a.in_slope, a.act_slope = in_slope, act_slope          # used as given (the acoustic path's LeakyReLU slope is 0.2)
     assert len(taps) == T
     for i, (dh, dw) in enumerate(taps):
         a.dh[i], a.dw[i] = dh, dw

@@ -28,6 +28,30 @@ typedef void* as_stream_t; /* hipStream_t */
 /* library/ABI version; bumped on any signature change */
 int as_abi_version(void);
 
+/* Device-side status.  The reference's operators cannot return silently stale results: nn.Embedding raises on an id >= n_token
+ * (RelTransformerEnc.py:11-16), cuDNN's LSTM (models.py:555-561) and the loops of S_monotonic_align.py:5-95 have no
+ * cross-workgroup protocol that could time out.  Kernels of this library that can fail at run time raise a sticky bit instead of
+ * carrying on unnoticed:
+ *   bit AS_STATUS_LSTM_TIMEOUT  a member of a clustered H = 256 recurrence gave up waiting for its peers (as_bilstm_cluster_f32)
+ *   bit AS_STATUS_MAS_TIMEOUT   a band of the alignment search gave up waiting for the band above it (as_mas_f32)
+ *   bit AS_STATUS_BAD_TOKEN     a token id outside [0, n_token) reached the embedding (it was clamped)
+ *   bit AS_STATUS_F16_RANGE     a conv GEMM produced a non-finite accumulator: an operand beyond fp16's range, |x| > 65504, or a
+ *                               non-finite input (debug probe, as_set_range_probe)
+ * as_device_status returns the bits raised on the current HIP device since the last clear (0 = healthy) without synchronising; it is
+ * final for work whose stream has been synchronised.  The module-level entry points (as_*_forward, as_forward_test*) return
+ * AS_EDEVICE while any bit is set: results computed since it was raised are invalid; clear it to go on. */
+#define AS_EDEVICE (-3)
+enum { AS_STATUS_LSTM_TIMEOUT = 0, AS_STATUS_MAS_TIMEOUT = 1, AS_STATUS_BAD_TOKEN = 2, AS_STATUS_F16_RANGE = 3, AS_STATUS_KINDS = 4 };
+int as_device_status(int clear);
+/* test hook: raise `kind` from a kernel on `stream`, exactly as a failing kernel would */
+int as_device_status_raise_for_test(int kind, as_stream_t stream);
+/* debug switch: activations are not range-scaled (only the weights are, as_prep_weight_f16x2_host), so a value beyond fp16's range
+ * (|x| > 65504) enters its operand image as h = inf, l = -inf and turns every product it takes part in into NaN -- in the accumulators
+ * of the conv GEMM that consumes the image.  on = 1 makes every as_conv_gemm_f32 launch test its accumulators and raise
+ * AS_STATUS_F16_RANGE for a non-finite one (AS_DEBUG=1 in the environment also prints the launch's shape).  Off by default: the
+ * test costs 16 compares per accumulator tile. */
+int as_set_range_probe(int on);
+
 /* Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg; no
  * reference counterpart).  Classes: 0 conv-GEMM, 1 AdaIN, 2 LayerNorm, 3 attention, 4 LSTM, 5 MAS, 6 other.
  * as_prof_collect blocks until the recorded events have completed and returns, per class, the summed
@@ -127,19 +151,21 @@ typedef struct ConvGemmArgs {
     int32_t n_prod;        /* 0 or 3 = f16x3 (fp32-accurate); 1 = h*h only */
     int32_t dh[AS_MAX_TAPS];   /* tap row offsets */
     int32_t dw[AS_MAX_TAPS];   /* tap column offsets */
-    float in_slope, act_slope; /* LeakyReLU slopes of in_act / act; 0 = the path's 0.2 (a true slope of 0 is ReLU: act = 1; the path
-                                * never rectifies an operand while splitting it, so in_act has no slope-0 form) */
+    float in_slope, act_slope; /* LeakyReLU slopes of in_act / yh_lrelu and of act == 2, used exactly as given (the acoustic path's is
+                                * AS_SLOPE_PATH = 0.2, models.py:163; nothing is substituted for 0: a slope of 0 IS ReLU); must be finite */
     float acc_scale;           /* multiplies the accumulator: 1 / (weight scale of as_prep_weight_f16x2); 0 = 1 */
     /* Grouped launch: G layers of the same shape side by side along the column axis (the text and articulatory encoders,
      * RelTransformerEnc.py; the F0 / energy / TV branches of ArtsPredictor, models.py:606-618): columns
      * [g * group_cols, (g+1) * group_cols) use weight set g.  n_groups <= 1: off. */
     int32_t n_groups, group_cols;
+    uint32_t* status;          /* library-owned: as_conv_gemm_f32 overwrites it (the range probe's status words, or NULL) */
 } ConvGemmArgs;
+#define AS_SLOPE_PATH 0.2f
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
 /* Bytes of workspace this shape wants (0 = none): split-K slabs for shapes whose tile grid cannot fill the 256 CUs (a second
  * kernel sums the slabs in a fixed order: deterministic), then the split image of X when Xh is NULL. */
 size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host);
-/* X fp32 [K][ldx] (N columns) -> Xh (layout above).  in_act 2 applies LeakyReLU(in_slope; 0 = 0.2) first.  One image can
+/* X fp32 [K][ldx] (N columns) -> Xh (layout above).  in_act 2 applies LeakyReLU(in_slope) first (the slope as given).  One image can
  * feed every conv reading the same activations.  xh: 16-byte aligned, as_split_f16x2_bytes(K, N) bytes. */
 size_t as_split_f16x2_bytes(int K, int N);
 int as_split_f16x2_f32(const float* x, int ldx, int K, int N, int in_act, float in_slope, uint16_t* xh, as_stream_t stream);
@@ -330,9 +356,14 @@ int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32_t* col_off
  * every step through `xchg` -- a device buffer of as_bilstm_cluster_bytes(n_jobs, B) bytes that the caller zero-fills ONCE and then leaves
  * to the library (it carries launch epochs; launches that may overlap in time need separate buffers).  max_len = longest utterance.
  * Falls back to as_bilstm_f32 when the grid would not fit the chip at once, for other H, or with xchg == NULL. */
+/* A member's poll is bounded (~1 s); one that gives up raises AS_STATUS_LSTM_TIMEOUT (as_device_status above): the output is then void. */
 size_t as_bilstm_cluster_bytes(int n_jobs, int B);
 int as_bilstm_cluster_f32(const BiLstmJob* jobs_host, int n_jobs, const int32_t* col_off, int B, int H, int max_len, void* xchg,
                           size_t xchg_bytes, as_stream_t stream);
+
+/* test hooks: member `drop_member` (0..3; -1 = none) of every cluster exits at once and a poll gives up after spin_limit tries
+ * (0 = default), so that the failure path can be exercised in milliseconds */
+int as_bilstm_cluster_test_hooks(int drop_member, int spin_limit);
 
 /* ---------------------------------------------------------------------------------------------
  * HiFi-GAN generator glue (Vocoder/vocoder.py:75-125).  Its convolutions run through
@@ -397,6 +428,12 @@ int as_plan_set_timing(as_plan* p, int on);
  * (the 16-bit-operand mode BASELINE.md names for config C2; its error is reported by bench.py and tests/test_net_gpu.py) */
 int as_plan_set_operand_mode(as_plan* p, int n_prod);
 int as_plan_phase_ms(as_plan* p, float* ms, int n);
+/* The plan caches the device tables of every batch geometry it has seen (key: the whole length vector).  Above max_layouts entries
+ * (default 4096, minimum 64) the next entry point first waits for the device, drops the cache and frees its tables: memory stays
+ * bounded under ever new ragged batches.  A hipGraph captured from this plan holds table addresses -- give captured geometries a plan
+ * of their own.  as_plan_layout_flushes: how often that has happened. */
+int as_plan_set_layout_cap(as_plan* p, int max_layouts);
+int as_plan_layout_flushes(const as_plan* p);
 
 /* geometry of one batch: HOST arrays */
 typedef struct as_batch {
