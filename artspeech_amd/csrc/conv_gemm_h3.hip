@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, H3_OCC)
 conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
 {
     using C = H3Cfg<WM, WN, WK, KT, NS, NP, TM>;
-    static_assert(NS == 2 || NS == 3, "stages");
+    static_assert(NS >= 2 && NS <= 4, "stages");
     constexpr int BM = C::BM, BN = C::BN, ACH = C::ACH, BCH = C::BCH, NT = C::NT, QP = C::QP, KBS = C::KBS;
     static_assert(NT == 256 && ACH * NT == KBS * QP * BM && BCH * NT == KBS * QP * BN && ACH >= 1 && BCH >= 1, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -285,9 +285,19 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     constexpr int SLOT0 = 0;
     auto stage_micro = [&](auto m_, auto p_) {
         constexpr int Mi = decltype(m_)::value, P = (decltype(p_)::value + L) % NS;
+#if defined(H3_EXP_BSKIP)                                   // knock-out: activations staged for the first tap only (what sharing a tile across taps could save)
+        if constexpr (Mi < ACH) dma_a(std::integral_constant<int, Mi>{}, P);
+        else if constexpr (Mi < M_ADV) { if (s_t == 0) dma_b(std::integral_constant<int, Mi - ACH>{}, P); }
+        else advance();
+#elif defined(H3_EXP_ASKIP)                                 // knock-out: weights staged every other k-block
+        if constexpr (Mi < ACH) { if ((s_kb & 1) == 0) dma_a(std::integral_constant<int, Mi>{}, P); }
+        else if constexpr (Mi < M_ADV) dma_b(std::integral_constant<int, Mi - ACH>{}, P);
+        else advance();
+#else
         if constexpr (Mi < ACH) dma_a(std::integral_constant<int, Mi>{}, P);
         else if constexpr (Mi < M_ADV) dma_b(std::integral_constant<int, Mi - ACH>{}, P);
         else advance();
+#endif
     };
 #ifndef H3_PLAN
 #define H3_PLAN 0
@@ -422,6 +432,9 @@ static int launch_h3_tile(const ConvGemmArgs& a, int S, hipStream_t stream)
         if (kt == 2) return launch_h3<WM, WN, WK, 2, 3, 3>(a, S, stream);
     }
     if (ns == 2) return launch_h3<WM, WN, WK, 1, 2, 3>(a, S, stream);
+    if constexpr (H3Cfg<WM, WN, WK, 1, 4, 3>::LDS <= 160 * 1024) {
+        if (ns == 4) return launch_h3<WM, WN, WK, 1, 4, 3>(a, S, stream);
+    }
 #endif
     return launch_h3<WM, WN, WK, 1, 3, 3>(a, S, stream);
 }
