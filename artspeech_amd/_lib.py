@@ -44,13 +44,15 @@ class ConvGemmArgs(ctypes.Structure):
                 ("transpose_out", ctypes.c_int32), ("yh_lrelu", ctypes.c_int32), ("n_prod", ctypes.c_int32),
                 ("dh", ctypes.c_int32 * AS_MAX_TAPS), ("dw", ctypes.c_int32 * AS_MAX_TAPS),
                 ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float), ("acc_scale", ctypes.c_float),
-                ("n_groups", ctypes.c_int32), ("group_cols", ctypes.c_int32), ("status", ctypes.c_void_p)]
+                ("n_groups", ctypes.c_int32), ("group_cols", ctypes.c_int32), ("range_probe", ctypes.c_int32), ("status", ctypes.c_void_p)]
 
 
 _SIGNATURES.update({
     "as_make_meta": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "as_conv_gemm_f32": (c_i, [ctypes.POINTER(ConvGemmArgs), c_p]),
     "as_conv_gemm_workspace_bytes": (c_sz, [ctypes.POINTER(ConvGemmArgs)]),
+    "as_conv_gemm_plan": (c_i, [ctypes.POINTER(ConvGemmArgs), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                ctypes.POINTER(ctypes.c_int32)]),
     "as_split_f16x2_bytes": (c_sz, [c_i, c_i]),
     "as_split_f16x2_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "as_prep_weight_f16x2_bytes": (c_sz, [c_i, c_i, c_i, c_i]),

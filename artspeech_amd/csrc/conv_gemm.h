@@ -15,6 +15,41 @@ int as_split_f16x2_launch(const float* x, int ldx, int K, int N, int lrelu, floa
 
 static inline __host__ __device__ int as_kbx(int K) { return (((K + 15) >> 4) + 3) & ~3; }      // k-blocks of a split image: a multiple of 4
 
+// tap offsets packed one byte per tap, (dh+8) << 4 | (dw+8) (|dh|, |dw| <= 7, checked by the host), eight taps per
+// word: the k loop then selects a tap with scalar ALU only (a scalar or scratch load inside it would stall the wave)
+struct H3Taps {
+    unsigned long long w0, w1, w2, w3;
+    int wide;                             // 1: every dh = 0 and the byte is dw + 128 (dilated 1-D convs, |dw| <= 127)
+};
+
+// host: pack the tap offsets of `a` for the kernel (AS_EINVAL if they do not fit a byte)
+static inline int h3_pack_taps(const ConvGemmArgs& a, H3Taps* out)
+{
+    H3Taps tp = {0, 0, 0, 0, 0};
+    unsigned long long* w = &tp.w0;
+    for (int t = 0; t < a.T; ++t)
+        if (a.dh[t] < -7 || a.dh[t] > 7 || a.dw[t] < -7 || a.dw[t] > 7) tp.wide = 1;
+    for (int t = 0; t < a.T; ++t) {
+        if (tp.wide && (a.dh[t] != 0 || a.dw[t] < -127 || a.dw[t] > 127)) return AS_EINVAL;
+        const int byte = tp.wide ? a.dw[t] + 128 : ((a.dh[t] + 8) << 4) | (a.dw[t] + 8);
+        w[t >> 3] |= (unsigned long long)byte << ((t & 7) * 8);
+    }
+    *out = tp;
+    return AS_OK;
+}
+
+// Byte of tap t.  Written with masks: as a select chain hipcc turns it into scalar BRANCHES inside the k loop.
+#ifdef __HIPCC__
+static __device__ __forceinline__ unsigned long long h3_tap_word(const H3Taps& tp, int t)
+{
+    const int s = t >> 3;
+    const unsigned long long m0 = 0ull - (unsigned long long)(s == 0), m1 = 0ull - (unsigned long long)(s == 1),
+                             m2 = 0ull - (unsigned long long)(s == 2), m3 = 0ull - (unsigned long long)(s == 3);
+    return (tp.w0 & m0) | (tp.w1 & m1) | (tp.w2 & m2) | (tp.w3 & m3);
+}
+
+#endif
+
 #ifdef __HIPCC__
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -141,7 +176,7 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(
         a.Yh, 0, a.Yh ? (int)((unsigned)as_kbx(a.M) * 4u * ((unsigned)a.N + 1u) * 16u) : 0, 0x00020000);
     const float sc = a.acc_scale;
-    if (a.status) {                                        // range probe (as_set_range_probe): a wave-uniform branch, off by default
+    if (a.range_probe) {                                   // range probe (as_set_range_probe): a wave-uniform branch, off by default
         bool bad = false;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -215,7 +250,9 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
     }
 }
 
-template <int TM, int TN>
+// AUX: cache policy of the stores (0 = default; 16 = sc1, write-through to the memory side: what an in-launch hand-off to other
+// workgroups wants -- no release fence, MI355X_MICROARCH.md publish-large)
+template <int TM, int TN, int AUX = 0>
 static __device__ __forceinline__ void slab_store(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], __amdgpu_buffer_rsrc_t rs,
                                                   int rbase, int cbase, int l31, int n_end)
 {
@@ -232,9 +269,97 @@ static __device__ __forceinline__ void slab_store(const ConvGemmArgs& a, const f
                 float t = acc[i][jn][e];
                 asm volatile("" : "+v"(t));
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rs,
-                                                      v0 + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.N * 4), 0, 0);
+                                                      v0 + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.N * 4), 0, AUX);
             }
         }
+}
+
+// Split-K tail: y = epi(sum_s slab[s]) for the 8 rows 8 g .. 8 g + 7 of column j, slabs summed in the fixed order s = 0 .. S-1
+// (deterministic whatever order the slices finished in); slab s = fp32 [M][N] at a.ws + s M N.  j == N with Yh: the image's zero
+// column.  One 16-byte row of the consumer's split image when Yh is wanted.  (A device function: scripts/exp/conv_gemm_sn.hip, the
+// small-N kernel that was measured and not shipped, ran the same code inside its own launch.)
+static __device__ __forceinline__ void as_reduce_epilogue(const ConvGemmArgs& a, int S, int j, int g)
+{
+    if (j > a.N || (j == a.N && !a.Yh)) return;
+    const size_t total = (size_t)a.M * a.N;
+    const float* slab = reinterpret_cast<const float*>(a.ws);
+    const int grp = a.n_groups > 1 ? (j < a.N ? j : a.N - 1) / a.group_cols : 0;
+    // the slabs first, eight loads (the thread's rows of one slab) in flight at a time and none of them behind a branch: with the
+    // loads inside the per-row `if` every one of the 8 S waited for the one before (12.8 us per launch at batch 1, as long as the GEMM
+    // it follows).  Same order of additions per element: s ascending.
+    float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+        const int jc = j < a.N ? j : a.N - 1;
+        size_t idx[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = 8 * g + r;
+            idx[r] = (size_t)(row < a.M ? row : a.M - 1) * a.N + jc;
+        }
+        // four slabs' loads in flight at a time (a dependent trip per slab was S L2 round trips: 15-30 us at S = 16-24)
+        int s = 0;
+        for (; s + 4 <= S; s += 4) {
+            float t[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) t[u][r] = slab[(size_t)(s + u) * total + idx[r]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc8[r] += t[u][r];
+        }
+        for (; s < S; ++s) {
+            float t[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = slab[(size_t)s * total + idx[r]];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc8[r] += t[r];
+        }
+    }
+    float bias8[8], res8[8];                              // (likewise: loaded for all eight rows at once, used below)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = 8 * g + r < a.M ? 8 * g + r : a.M - 1;
+        bias8[r] = a.bias ? a.bias[(size_t)grp * a.M + row] : 0.f;
+        res8[r] = a.res ? a.res[(size_t)row * a.ldr + (j < a.N ? j : a.N - 1)] : 0.f;
+    }
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = 8 * g + r;
+        float x = 0.f;
+        if (row < a.M && j < a.N) {
+            x = acc8[r];
+            if (a.range_probe && !(fabsf(x) <= 3.0e38f)) as_status_raise(a.status, AS_STATUS_F16_RANGE);
+            x *= a.acc_scale;
+            if (a.bias) x += bias8[r];
+            if (a.res) x += res8[r];
+            if (a.div_sqrt2) x = x / 1.41421356237309504880f;
+            if (a.act == 1) x = x > 0.f ? x : 0.f;
+            else if (a.act == 2) x = x > 0.f ? x : a.act_slope * x;
+            else if (a.act == 3) x = tanhf(x);
+            else if (a.act == 4) x = fabsf(x);
+            else if (a.act == 5) x = x / (1.0f + expf(-x));
+            if (a.Y) {
+                if (a.transpose_out) a.Y[(size_t)j * a.ldy + row] = x;
+                else a.Y[(size_t)row * a.ldy + j] = x;
+            }
+        }
+        v[r] = x;
+    }
+    if (a.Yh && g < 2 * as_kbx(a.M)) {
+        if (a.yh_lrelu) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : a.in_slope * v[r];
+        }
+        u32x4_t h, l;
+        split2(v, h, l);
+        const size_t NX = (size_t)a.N + 1;
+        u32x4_t* yh = reinterpret_cast<u32x4_t*>(a.Yh) + ((size_t)(g >> 1) * 4 + (g & 1)) * NX + j;
+        yh[0] = h;
+        yh[2 * NX] = l;
+    }
 }
 
 template <int TM, int TN>

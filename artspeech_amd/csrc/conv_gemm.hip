@@ -169,79 +169,11 @@ conv_direct_cin1_kernel(const ConvGemmArgs a)
 }
 
 // y = epi(sum_s slab[s]) in a fixed order (deterministic, unlike float atomics).  A thread owns 8 consecutive rows of one
-// column -- one 16-byte row of the consumer's split image when Yh is wanted.
+// column -- one 16-byte row of the consumer's split image when Yh is wanted.  (The body is as_reduce_epilogue, conv_gemm.h.)
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const ConvGemmArgs a, int S)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int g = blockIdx.y;
-    if (j > a.N || (j == a.N && !a.Yh)) return;
-    const size_t total = (size_t)a.M * a.N;
-    const float* slab = reinterpret_cast<const float*>(a.ws);
-    const int grp = a.n_groups > 1 ? j / a.group_cols : 0;
-    // the slabs first, eight loads (the thread's rows of one slab) in flight at a time and none of them behind a branch: with the
-    // loads inside the per-row `if` every one of the 8 S waited for the one before (12.8 us per launch at batch 1, as long as the GEMM
-    // it follows).  Same order of additions per element: s ascending.
-    float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    {
-        const int jc = j < a.N ? j : a.N - 1;
-        size_t idx[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int row = 8 * g + r;
-            idx[r] = (size_t)(row < a.M ? row : a.M - 1) * a.N + jc;
-        }
-        for (int s = 0; s < S; ++s) {
-            float t[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) t[r] = slab[(size_t)s * total + idx[r]];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) acc8[r] += t[r];
-        }
-    }
-    float bias8[8], res8[8];                              // (likewise: loaded for all eight rows at once, used below)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int row = 8 * g + r < a.M ? 8 * g + r : a.M - 1;
-        bias8[r] = a.bias ? a.bias[(size_t)grp * a.M + row] : 0.f;
-        res8[r] = a.res ? a.res[(size_t)row * a.ldr + (j < a.N ? j : a.N - 1)] : 0.f;
-    }
-    float v[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int row = 8 * g + r;
-        float x = 0.f;
-        if (row < a.M && j < a.N) {
-            x = acc8[r];
-            if (a.status && !(fabsf(x) <= 3.0e38f)) as_status_raise(a.status, AS_STATUS_F16_RANGE);
-            x *= a.acc_scale;
-            if (a.bias) x += bias8[r];
-            if (a.res) x += res8[r];
-            if (a.div_sqrt2) x = x / 1.41421356237309504880f;
-            if (a.act == 1) x = x > 0.f ? x : 0.f;
-            else if (a.act == 2) x = x > 0.f ? x : a.act_slope * x;
-            else if (a.act == 3) x = tanhf(x);
-            else if (a.act == 4) x = fabsf(x);
-            else if (a.act == 5) x = x / (1.0f + expf(-x));
-            if (a.Y) {
-                if (a.transpose_out) a.Y[(size_t)j * a.ldy + row] = x;
-                else a.Y[(size_t)row * a.ldy + j] = x;
-            }
-        }
-        v[r] = x;
-    }
-    if (a.Yh && g < 2 * as_kbx(a.M)) {
-        if (a.yh_lrelu) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : a.in_slope * v[r];
-        }
-        u32x4_t h, l;
-        split2(v, h, l);
-        const size_t NX = (size_t)a.N + 1;
-        u32x4_t* yh = reinterpret_cast<u32x4_t*>(a.Yh) + ((size_t)(g >> 1) * 4 + (g & 1)) * NX + j;
-        yh[0] = h;
-        yh[2 * NX] = l;
-    }
+    as_reduce_epilogue(a, S, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
 }
 
 // as_set_range_probe: every launch tests its accumulators for inf / NaN (what an operand beyond fp16's range turns into)
@@ -354,6 +286,23 @@ extern "C" size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* a)
     return p.xh_bytes ? align256(p.slab_bytes) + p.xh_bytes : p.slab_bytes;
 }
 
+// which kernel a call with these arguments runs (tests, tuning): kind 0 = direct Cin = 1, 1 = tiled (tile = 22 / 21 / 12 / 11 / 2)
+extern "C" int as_conv_gemm_plan(const ConvGemmArgs* a, int32_t* kind, int32_t* tile, int32_t* slices)
+{
+    if (!a || !kind || !tile || !slices || a->M <= 0 || a->N <= 0 || a->Kp <= 0 || a->T <= 0) return AS_EINVAL;
+    ConvGemmArgs n = *a;
+    if (n.n_prod == 0) n.n_prod = 3;
+    if (n.n_groups < 1) n.n_groups = 1;
+    *tile = 0;
+    *slices = 1;
+    if (direct_cin1(n)) { *kind = 0; return AS_OK; }
+    const GemmPlan p = gemm_plan(n);
+    *kind = 1;
+    *tile = p.choice;
+    *slices = p.S;
+    return AS_OK;
+}
+
 extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -361,7 +310,8 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     ConvGemmArgs norm = *args_host;
     if (!(fabsf(norm.in_slope) <= 3.0e38f) || !(fabsf(norm.act_slope) <= 3.0e38f)) return AS_EINVAL;   // slopes are used as given
     if (norm.acc_scale == 0.f) norm.acc_scale = 1.0f;
-    norm.status = g_range_probe ? as_status_words_device() : nullptr;
+    norm.status = as_status_words_device();
+    norm.range_probe = g_range_probe;
     if (norm.n_prod == 0) norm.n_prod = 3;
     if (norm.n_groups < 1) norm.n_groups = 1;
     // a 1x1 conv reads every column from itself: no tap can leave the utterance, so the kernels need not fetch the column descriptors

@@ -45,38 +45,6 @@ static __device__ __forceinline__ void h3_for(F&& f)
     }
 }
 
-// tap offsets packed one byte per tap, (dh+8) << 4 | (dw+8) (|dh|, |dw| <= 7, checked by the host), eight taps per
-// word: the k loop then selects a tap with scalar ALU only (a scalar or scratch load inside it would stall the wave)
-struct H3Taps {
-    unsigned long long w0, w1, w2, w3;
-    int wide;                             // 1: every dh = 0 and the byte is dw + 128 (dilated 1-D convs, |dw| <= 127)
-};
-
-// host: pack the tap offsets of `a` for the kernel (AS_EINVAL if they do not fit a byte)
-static inline int h3_pack_taps(const ConvGemmArgs& a, H3Taps* out)
-{
-    H3Taps tp = {0, 0, 0, 0, 0};
-    unsigned long long* w = &tp.w0;
-    for (int t = 0; t < a.T; ++t)
-        if (a.dh[t] < -7 || a.dh[t] > 7 || a.dw[t] < -7 || a.dw[t] > 7) tp.wide = 1;
-    for (int t = 0; t < a.T; ++t) {
-        if (tp.wide && (a.dh[t] != 0 || a.dw[t] < -127 || a.dw[t] > 127)) return AS_EINVAL;
-        const int byte = tp.wide ? a.dw[t] + 128 : ((a.dh[t] + 8) << 4) | (a.dw[t] + 8);
-        w[t >> 3] |= (unsigned long long)byte << ((t & 7) * 8);
-    }
-    *out = tp;
-    return AS_OK;
-}
-
-// Byte of tap t.  Written with masks: as a select chain hipcc turns it into scalar BRANCHES inside the k loop.
-static __device__ __forceinline__ unsigned long long h3_tap_word(const H3Taps& tp, int t)
-{
-    const int s = t >> 3;
-    const unsigned long long m0 = 0ull - (unsigned long long)(s == 0), m1 = 0ull - (unsigned long long)(s == 1),
-                             m2 = 0ull - (unsigned long long)(s == 2), m3 = 0ull - (unsigned long long)(s == 3);
-    return (tp.w0 & m0) | (tp.w1 & m1) | (tp.w2 & m2) | (tp.w3 & m3);
-}
-
 // TM: 32-row MFMA tiles per wave (2: a wave owns 64 x 64; 4: 128 x 64 -- a third less LDS traffic per matrix-core product)
 template <int WM, int WN, int WK, int KT, int NS, int NP, int TM = 2>
 struct H3Cfg {

@@ -456,7 +456,9 @@ struct Ctx {
         const size_t o = off;
         off += align256(bytes ? bytes : 1);
         if (launch && !count && getenv("AS_DEBUG_ALLOC")) fprintf(stderr, "artspeech_hip: arena %p + %zu : %zu bytes\n", (void*)base, o, bytes);
-        if (count) return nullptr;
+        // counting: a non-null placeholder (never dereferenced: nothing launches), so that code which branches on "is there an operand
+        // image" takes the branch the run takes (their workspace needs differ)
+        if (count) return reinterpret_cast<void*>((size_t)1 << 20) ;
         if (off > cap) { fail(AS_ENOSPC); return nullptr; }
         return base + o;
     }
@@ -672,6 +674,9 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     q.Xh = in_image ? reinterpret_cast<const uint16_t*>(16) : nullptr;
     q.Yh = o.want_yh ? reinterpret_cast<uint16_t*>(16) : nullptr;
     const size_t wsb = as_conv_gemm_workspace_bytes(&q);
+    if (getenv("AS_DEBUG_ALLOC"))
+        fprintf(stderr, "artspeech_hip: conv %s M%d N%d K%d T%d G%d img%d -> ws %zu (arena at %zu)\n", c.count ? "count" : (c.launch ? "run" : "replay"), a.M,
+                a.N, a.K, a.T, a.n_groups, (int)in_image, wsb, c.off);
     a.ws = wsb ? c.raw_alloc(wsb) : nullptr;
     a.ws_bytes = wsb;
     if (!c.go()) return;

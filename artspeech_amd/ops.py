@@ -228,7 +228,7 @@ def project_cols(X, N, w, bias, Y):
 
 
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
-              use_meta=True, in_slope=0.2, act_slope=0.2, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None):
+              use_meta=True, in_slope=0.2, act_slope=0.2, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None, plan_out=None):
     """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt: prep_weight(...); X [K][*] fp32 or None with xs= (the split image of
     X: split_act / adain_split / channel_layernorm_split / another conv's yh=) and K=; Y [M][*] (or [N][*] transposed) or None
     when only yh (the output as the next conv's split image, new_image(M, N)) is wanted.  group_cols: Wt holds Wt.G weight
@@ -264,6 +264,10 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     if nbytes:                                       # split-K partial slabs, the split image of X (caller-owned scratch)
         ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=(Y if Y is not None else yh).device)
         a.ws, a.ws_bytes = ws.data_ptr(), nbytes
+    if plan_out is not None:                         # (tests: which kernel ran)
+        k, t, sl = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        check(L.as_conv_gemm_plan(ctypes.byref(a), ctypes.byref(k), ctypes.byref(t), ctypes.byref(sl)), "as_conv_gemm_plan")
+        plan_out.update(kind=k.value, tile=t.value, slices=sl.value)
     check(L.as_conv_gemm_f32(ctypes.byref(a), stream()), "as_conv_gemm_f32")
     return Y if Y is not None else yh
 

@@ -158,10 +158,14 @@ typedef struct ConvGemmArgs {
      * RelTransformerEnc.py; the F0 / energy / TV branches of ArtsPredictor, models.py:606-618): columns
      * [g * group_cols, (g+1) * group_cols) use weight set g.  n_groups <= 1: off. */
     int32_t n_groups, group_cols;
-    uint32_t* status;          /* library-owned: as_conv_gemm_f32 overwrites it (the range probe's status words, or NULL) */
+    int32_t range_probe;       /* library-owned (as_conv_gemm_f32 overwrites both): as_set_range_probe's switch ... */
+    uint32_t* status;          /* ... and the device's status words (as_device_status) */
 } ConvGemmArgs;
 #define AS_SLOPE_PATH 0.2f
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
+/* which kernel as_conv_gemm_f32 runs for these arguments (tests, tuning): *kind 0 = the direct Cin = 1 kernel, 1 = the tiled kernel
+ * (*tile = 22 / 21 / 12 / 11 / 2: 128x128, 128x64, 64x128, 64x64, 32x128); *slices = K slices */
+int as_conv_gemm_plan(const ConvGemmArgs* args_host, int32_t* kind, int32_t* tile, int32_t* slices);
 /* Bytes of workspace this shape wants (0 = none): split-K slabs for shapes whose tile grid cannot fill the 256 CUs (a second
  * kernel sums the slabs in a fixed order: deterministic), then the split image of X when Xh is NULL. */
 size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* args_host);

@@ -25,9 +25,12 @@ REP = 10
 print("lib:", _lib.LIB_PATH)
 for (M, N, K, T, L) in SHAPES:
     lay = ops.layout([L] * (N // L), dev)
+    ZERO = os.environ.get("ZERO", "0")              # 1: all-zero operands (the chip holds a higher clock: is the loop power-limited?); 2: zero activations only
     w = torch.randn(M, K, T) / (K * T) ** 0.5
-    wt = ops.prep_weight(w, dev)
+    if ZERO == "1": w = w * 0 + 1e-3 * (torch.arange(M * K * T).reshape(M, K, T) % 2 == 3)
+    wt = ops.prep_weight(w + (1e-30 if ZERO == "1" else 0), dev)
     X = torch.randn(K, lay.N, device=dev)
+    if ZERO in ("1", "2"): X.zero_()
     b = torch.randn(M, device=dev)
     taps = ops.taps_1d(T)
     xs = ops.split_act(X, lay)

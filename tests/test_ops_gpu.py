@@ -637,3 +637,4 @@ def test_conv_cin1_direct_kernel(cuda, two_d):
     y = ops.conv_gemm(ops.prep_weight(w, cuda), X.to(cuda), lay, lay.new(cout), taps, bias=b.to(cuda), in_act=ops.ACT_LRELU,
                       act=ops.ACT_LRELU)
     assert float((y.cpu() - want).abs().max()) <= 2e-6
+
