@@ -25,6 +25,7 @@ _SIGNATURES = {
     "as_prof_collect": (c_i, [c_p, c_p, c_p, c_p, c_i]),
     "as_prof_hint": (c_i, [ctypes.c_double, ctypes.c_double]),
     "as_prof_bracket_overhead": (c_i, [c_p, c_p]),
+    "as_prof_mfma_sustained": (c_i, [c_p, c_p, c_p]),
     "as_mas_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "as_mas_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "as_softmax_mas_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),

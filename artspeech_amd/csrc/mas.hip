@@ -24,6 +24,8 @@
 //
 // Algorithmic bytes: 4*Tx*Ty read per utterance + 4*Tx*Ty path written (memset) +
 // Tx*Ty/8 decision bits written and read.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 #include "artspeech_hip.h"
@@ -217,7 +219,7 @@ mas_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const i
 typedef __attribute__((address_space(3))) void mas_lds_void;
 #define MAS_BLK 32            // columns per block
 #define MAS_RING 6            // blocks in the LDS ring: ahead + the one in use + the lag of the band's second wave (a block) + slack
-#define MAS_AHEAD 3           // blocks of DMA in flight (the ring keeps one more slot than ahead + current: the DP never waits for the
+#define MAS_AHEAD 3           // blocks of DMA in flight per loader (the ring keeps more slots than ahead + current: the DP never waits for the
                               // loader's handshake)
 #define MAS_CHUNK_F 260       // floats per chunk in the ring: 8 rows x 32 columns + 4 of padding
 #define MAS_SLOT_F(R) (8 * (R) * MAS_CHUNK_F)
@@ -253,14 +255,18 @@ template <int N> static __device__ __forceinline__ void mas_wait_vmcnt() { asm v
 // 1: the first block of a lattice of >= 32 columns (column 0 is the only special one -- every wave's start waits for the first block of
 // the wave above, so this block is the pipeline's fill); 2: anything (tests per column).
 // in[j] = the row above the wave's first row at column j - 1 of the block (in[0]: the previous block's last column).
+// U = the row above the wave's first row: inp[q] = U[4q .. 4q+3] (the columns of this block), up_m1 = U[-1] (the previous block's last
+// column).  Column j needs U[j - 1]: the previous group's .w for the first column of a group -- a register rename, no shifted copy of U
+// is ever made.  cur / icur = the first groups of the lane's row and of U, already read (the block's combined poll fetched them).
+// lastp[j] <- the lane's new value of column j (lane 63's pointer is the hand-over row for the wave below, the others' a scratch row).
 template <bool TIE_MOVE, int MODE>
-static __device__ __forceinline__ void mas_dp_block(const float* __restrict__ slot, int x_local, int blk, int y_len, int ngroup, bool first_row_here,
-                                                    float& prev, const float* __restrict__ in, unsigned& bits, float* __restrict__ last)
+static __device__ __forceinline__ float mas_dp_block(const float4* __restrict__ rowp, const float4* __restrict__ inp, float4 cur, float4 icur,
+                                                     float up_m1, int blk, int y_len, int ngroup, bool first_row_here, float& prev,
+                                                     unsigned& bits, float* __restrict__ lastp)
 {
+    float iw_prev = up_m1;
 #if __HIP_DEVICE_COMPILE__
-    const float4* rowp = reinterpret_cast<const float4*>(slot + (x_local >> 3) * MAS_CHUNK_F + (x_local & 7) * 32);
-    const float4* inp = reinterpret_cast<const float4*>(in);
-    float4 cur = rowp[0], nxt = cur, icur = inp[0], inxt = icur;      // (the next group's values are read a group early: LDS latency)
+    float4 nxt = cur, inxt = icur;                         // (the next group's values are read a group early: LDS latency)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int g = blk * 8 + q;
@@ -279,7 +285,7 @@ static __device__ __forceinline__ void mas_dp_block(const float* __restrict__ sl
             } else {
                 // the row above is lane - 1's (DPP wave_shr:1); lane 0 keeps `old`: the wave / band above, read from LDS by every lane
                 const float a = prev;
-                const float s_up = (j4 == 0) ? icur.x : (j4 == 1) ? icur.y : (j4 == 2) ? icur.z : icur.w;
+                const float s_up = (j4 == 0) ? iw_prev : (j4 == 1) ? icur.x : (j4 == 2) ? icur.y : icur.z;
                 const float cc = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(s_up), __float_as_int(prev), 0x138, 0xf, 0xf, false));
                 // v1: direction = where(a > c, 0, -1);  v2/Triton: move iff c > a.  max = where(a > c, a, c).
                 const bool move = TIE_MOVE ? !(a > cc) : (cc > a);
@@ -293,25 +299,34 @@ static __device__ __forceinline__ void mas_dp_block(const float* __restrict__ sl
                 const float val = (j4 == 0) ? cur.x : (j4 == 1) ? cur.y : (j4 == 2) ? cur.z : cur.w;
                 asm("v_add_f32_e32 %0, %1, %2" : "=v"(prev) : "v"(val), "v"(m));
             }
-            last[j * 64] = prev;                           // (every lane writes: one ds_write, no lane select; lane 63's is the wave's last row)
+            lastp[j] = prev;                               // (every lane writes: one ds_write, no lane select; lane 63's lands in the hand-over row)
         }
+        iw_prev = icur.w;
         cur = nxt;
         icur = inxt;
     }
 #endif
+    return iw_prev;                                        // U[31]: the next block's U[-1]
 }
 
+template <int R>
+static __device__ __forceinline__ void mas_backtrack_wave(int b, int lane, int x_len, int y_len, int Tx, int Ty, int P, int nblk_max,
+                                                          const unsigned* __restrict__ masks, float* __restrict__ path, int* __restrict__ dur,
+                                                          int* __restrict__ rows);
+
+#define MAS_NL 2              // loader waves per band: ONE wave's LDS-DMA stream lands a 16 KB block every ~0.65 us (MI355X_MICROARCH.md,
+                              // ldsdma-fill) -- exactly what a DP wave needs for its 32 columns, so one loader paced the whole lattice
 template <int W, bool TIE_MOVE>
-__global__ void __launch_bounds__(64 * (W + 1))
+__global__ void __launch_bounds__(64 * (W + MAS_NL))
 mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, const int* __restrict__ t_y, int B, int Tx, int Ty, int P,
                 int nblk_max, u64* __restrict__ xchg, unsigned* __restrict__ masks, int n_band_wgs, float* __restrict__ path,
-                int* __restrict__ dur, int* __restrict__ rows, unsigned* __restrict__ status)
+                int* __restrict__ dur, int* __restrict__ rows, unsigned* __restrict__ status, int fused)
 {
 #if __HIP_DEVICE_COMPILE__
     if ((int)blockIdx.x >= n_band_wgs) {
         // the workgroups behind the bands clear the outputs on the CUs the DP leaves idle (the backtrack launch that follows writes the
         // path's ones, the row indices and the durations): no memset launches in front of the DP
-        const size_t z = blockIdx.x - n_band_wgs, nz = gridDim.x - n_band_wgs, nt = (size_t)64 * (W + 1);
+        const size_t z = blockIdx.x - n_band_wgs, nz = gridDim.x - n_band_wgs, nt = (size_t)64 * (W + MAS_NL);
         const size_t n_path = path ? (size_t)B * Tx * Ty : 0, n_dur = dur ? (size_t)B * Tx : 0, n_rows = rows ? (size_t)B * Ty : 0;
         for (size_t i = z * nt + threadIdx.x; i < n_path; i += nz * nt) path[i] = 0.f;
         for (size_t i = z * nt + threadIdx.x; i < n_dur; i += nz * nt) dur[i] = 0;
@@ -323,10 +338,11 @@ mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, co
     // needs ~4 cycles for each: that, not the DP, was the 0.4 us per column of the one-workgroup kernel).  16 bytes of padding per
     // chunk spread the DP's reads (lane = row, stride 128 bytes) over the banks.
     __shared__ __attribute__((aligned(16))) float ring[MAS_RING * MAS_SLOT_F(W)];
-    __shared__ int ctr[1 + 2 * W];                         // [0] blocks loaded, [1 + w] consumed by wave w, [1 + W + w] last rows published by w
-    __shared__ float lastrow[W][MAS_BLK * 64];             // [column of the block][lane]: the lanes' rows (lane 63 = the wave's last)
-    __shared__ float outrow[W][MAS_OUT_RING][MAS_BLK];     // lane 63's of the last blocks, for the wave below
-    __shared__ __attribute__((aligned(16))) float inrow[W][MAS_BLK + 4];   // the row above the wave's first row: [0] column -1 of the block, [1 + j] column j
+    __shared__ int ctr[MAS_NL + W];                        // [l] blocks loaded by loader l, [MAS_NL + w] blocks finished (consumed AND last row published) by wave w
+    __shared__ __attribute__((aligned(16))) float outrow[W][MAS_OUT_RING][MAS_BLK];   // lane 63's values of the last blocks: the row above the wave below
+    __shared__ float scratch[W][64 * 33];                  // where the other lanes' per-column writes go (33: conflict-free)
+    __shared__ __attribute__((aligned(16))) float uprow[2][MAS_BLK];   // band head: the band above's last row, this block's and the next's
+    __shared__ __attribute__((aligned(16))) float negrow[MAS_BLK];     // top band head: no row above
     // workgroups n, n+8, n+16, ... share an XCD: utterance b lives on XCD b % 8, its bands in dispatch order
     const int n = blockIdx.x, k = n >> 3;
     const int b = (k / P) * 8 + (n & 7), p = k % P;
@@ -337,29 +353,31 @@ mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, co
     const int band0 = p * 64 * W;
     if (x_len <= 0 || y_len <= 0 || band0 >= x_len) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 1 + 2 * W) ctr[tid] = 0;
-    if (tid < W * (MAS_BLK + 4)) (&inrow[0][0])[tid] = MAS_NEG;
+    if (tid < MAS_NL + W) ctr[tid] = 0;
+    if (tid < MAS_BLK) negrow[tid] = MAS_NEG;
     __syncthreads();
     const int nblk = (y_len + MAS_BLK - 1) / MAS_BLK;
     const int ngroup = (y_len + 3) >> 2;
 
-    if (wave == W) {
-        // ---- loader: instruction i of a block fetches rows band0 + 8 i .. + 7, lane = (row, 16-byte piece of its 128 bytes) ----
+    if (wave >= W) {
+        // ---- loader l of MAS_NL: instruction i of a block fetches rows band0 + 8 i .. + 7 (i = l, l + MAS_NL, ...), lane = (row, 16-byte piece) ----
+        const int l = wave - W;
+        constexpr int NI = 8 * W / MAS_NL;                                 // DMA instructions per block and loader
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(value + (size_t)b * Tx * Ty), 0,
                                                                             (int)((unsigned)Tx * (unsigned)Ty * 4u), 0x00020000);
-        unsigned rowoff[8 * W];
+        unsigned rowoff[NI];
 #pragma unroll
-        for (int i = 0; i < 8 * W; ++i) {
-            const int x = band0 + 8 * i + (lane >> 3);
-            rowoff[i] = x < x_len ? (unsigned)x * (unsigned)Ty * 4u : 0xFFFFFF00u;       // outside the descriptor: reads zero
+        for (int k = 0; k < NI; ++k) {
+            const int x = band0 + 8 * (l + MAS_NL * k) + (lane >> 3);
+            rowoff[k] = x < x_len ? (unsigned)x * (unsigned)Ty * 4u : 0xFFFFFF00u;       // outside the descriptor: reads zero
         }
         for (int blk = 0; blk < nblk + MAS_AHEAD; ++blk) {
             if (blk < nblk) {
                 while (true) {                             // the slot's previous block consumed by every DP wave
-                    int c = mas_lds_peek(&ctr[1]);
+                    int c = mas_lds_peek(&ctr[MAS_NL]);
 #pragma unroll
                     for (int w = 1; w < W; ++w) {
-                        const int cw = mas_lds_peek(&ctr[1 + w]);
+                        const int cw = mas_lds_peek(&ctr[MAS_NL + w]);
                         c = cw < c ? cw : c;
                     }
                     if (c >= blk - (MAS_RING - 1)) break;
@@ -368,15 +386,15 @@ mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, co
                 const int slot = blk % MAS_RING;
                 const unsigned col = (unsigned)(blk * 8 + (lane & 7)) * 16u;
 #pragma unroll
-                for (int i = 0; i < 8 * W; ++i) {
-                    const unsigned voff = (col < (unsigned)Ty * 4u && rowoff[i] != 0xFFFFFF00u) ? rowoff[i] + col : 0xFFFFFF00u;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (mas_lds_void*)(ring + slot * MAS_SLOT_F(W) + i * MAS_CHUNK_F), 16, voff, 0, 0, 0);
+                for (int k = 0; k < NI; ++k) {
+                    const unsigned voff = (col < (unsigned)Ty * 4u && rowoff[k] != 0xFFFFFF00u) ? rowoff[k] + col : 0xFFFFFF00u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (mas_lds_void*)(ring + slot * MAS_SLOT_F(W) + (l + MAS_NL * k) * MAS_CHUNK_F), 16, voff, 0, 0, 0);
                 }
             }
             if (blk >= MAS_AHEAD) {
-                if (blk < nblk) mas_wait_vmcnt<MAS_AHEAD * 8 * W>();
+                if (blk < nblk) mas_wait_vmcnt<MAS_AHEAD * NI>();
                 else mas_wait_vmcnt<0>();
-                if (lane == 0) mas_lds_poke(&ctr[0], blk - MAS_AHEAD + 1);
+                if (lane == 0) mas_lds_poke(&ctr[l], blk - MAS_AHEAD + 1);
             }
         }
         return;
@@ -385,25 +403,45 @@ mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, co
     // ---- DP wave `wave`: rows band0 + 64 wave + lane ----
     const int w = wave, x_local = 64 * w + lane;
     if (band0 + 64 * w >= x_len) {                         // no rows: never holds the ring back
-        if (lane == 0) __hip_atomic_store(&ctr[1 + w], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(&ctr[MAS_NL + w], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return;
     }
     const bool from_wave = w > 0, from_band = w == 0 && p > 0;
-    const bool to_wave = w + 1 < W && band0 + 64 * (w + 1) < x_len;
     const bool to_band = w + 1 == W && p + 1 < P && band0 + 64 * W < x_len;
     const int Typ = nblk_max * MAS_BLK;
     u64* xo = xchg + (size_t)(b * P + p) * Typ;
     const u64* xi = xchg + (size_t)(b * P + p - 1) * Typ;
     unsigned* mo = masks + (size_t)(b * P + p) * nblk_max * W * 64;
-    float prev = MAS_NEG, carry = MAS_NEG;
+    float prev = MAS_NEG, up_m1 = MAS_NEG;
     auto xcol = [&](int blk) {
         const int col = blk * MAS_BLK + (lane & 31);
         return col < y_len ? col : y_len - 1;
     };
+    // band head: the last row of the band above arrives as 8-byte {value, tag} words (written once per launch); a block's words are
+    // requested a block early (vnext) and put into uprow a block early too, so that neither the round trip to L2 nor the LDS write ->
+    // read sits between two blocks of the DP
     u64 vnext = 0;
-    if (from_band) vnext = __hip_atomic_load(xi + xcol(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto fetch_up = [&](int blk) {
+        u64 word = vnext;
+        const u64* wp = xi + xcol(blk);
+        for (int spin = 0; (unsigned)(word >> 32) != 1u && spin < (1 << 22); ++spin) {
+            __builtin_amdgcn_s_sleep(1);
+            word = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // gave up (the band above never got a CU, or died): what follows is not the alignment -- say so (as_device_status)
+        if ((unsigned)(word >> 32) != 1u) as_status_raise(status, AS_STATUS_MAS_TIMEOUT);
+        if (blk + 1 < nblk) vnext = __hip_atomic_load(xi + xcol(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < MAS_BLK) uprow[blk & 1][lane] = __uint_as_float((unsigned)word);
+    };
+    if (from_band) {
+        vnext = __hip_atomic_load(xi + xcol(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fetch_up(0);
+    }
+    auto lds_addr = [](const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p; };
+    static_assert(MAS_NL == 2, "the block's poll reads the two loaders' counters");
+    const unsigned a_c0 = lds_addr(&ctr[0]), a_c1 = lds_addr(&ctr[1]), a_cw = from_wave ? lds_addr(&ctr[MAS_NL + w - 1]) : a_c0;
 #ifdef AS_EXPERIMENTS
-    long long c_wait = 0, c_poll = 0, c_dp = 0, c_all = clock64();
+    long long c_wait = 0, c_dp = 0, c_all = clock64();
 #define MAS_T(v) const long long v = clock64()
 #define MAS_ACC(acc, a, b_) acc += (b_) - (a)
 #else
@@ -412,89 +450,141 @@ mas_band_kernel(const float* __restrict__ value, const int* __restrict__ t_x, co
 #endif
     for (int blk = 0; blk < nblk; ++blk) {
         MAS_T(t0);
-        while (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= blk) __builtin_amdgcn_s_sleep(1);
+        const float* slot = ring + (blk % MAS_RING) * MAS_SLOT_F(W);
+        const float4* rowp = reinterpret_cast<const float4*>(slot + (x_local >> 3) * MAS_CHUNK_F + (x_local & 7) * 32);
+        const float4* inp = reinterpret_cast<const float4*>(from_wave ? &outrow[w - 1][blk % MAS_OUT_RING][0] : (from_band ? &uprow[blk & 1][0] : &negrow[0]));
+        // ONE LDS round trip per block: the loader's counter, the counter of the wave above and -- speculatively, behind them in the
+        // queue -- the block's first operands.  The LDS serves a wave's requests in order, and both producers write their data before
+        // their counter: if the counters say "there", the operands read after them are the block's.
+        float4 cur0, i0;
+        while (true) {
+            int c0, c1, c2;
+            asm volatile("ds_read_b32 %0, %5\n\tds_read_b32 %1, %6\n\tds_read_b32 %2, %7\n\tds_read_b128 %3, %8\n\tds_read_b128 %4, %9\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(cur0), "=&v"(i0)
+                         : "v"(a_c0), "v"(a_c1), "v"(a_cw), "v"(lds_addr(rowp)), "v"(lds_addr(inp))
+                         : "memory");
+            if (__builtin_amdgcn_readfirstlane(c0) > blk && __builtin_amdgcn_readfirstlane(c1) > blk && __builtin_amdgcn_readfirstlane(c2) > blk) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
         MAS_T(t1);
         MAS_ACC(c_wait, t0, t1);
-        if (from_wave || from_band) {
-            float v;
-            if (from_wave) {
-                while (__hip_atomic_load(&ctr[1 + W + w - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= blk) __builtin_amdgcn_s_sleep(1);
-                v = outrow[w - 1][blk % MAS_OUT_RING][lane & 31];
-            } else {
-                // the word of this block was requested a block ago (once the band above is two blocks ahead it is there: no round
-                // trip to L2 in the loop); polled only while it is not
-                u64 word = vnext;
-                const u64* wp = xi + xcol(blk);
-                for (int spin = 0; (unsigned)(word >> 32) != 1u && spin < (1 << 22); ++spin) {
-                    __builtin_amdgcn_s_sleep(1);
-                    word = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                // gave up (the band above never got a CU, or died): what follows is not the alignment -- say so (as_device_status)
-                if ((unsigned)(word >> 32) != 1u) as_status_raise(status, AS_STATUS_MAS_TIMEOUT);
-                if (blk + 1 < nblk) vnext = __hip_atomic_load(xi + xcol(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v = __uint_as_float((unsigned)word);
-            }
-            if (lane < MAS_BLK) inrow[w][1 + lane] = v;
-            if (lane == MAS_BLK) inrow[w][0] = carry;
-            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
-        }
-        MAS_T(t2);
-        MAS_ACC(c_poll, t1, t2);
 #ifdef AS_EXPERIMENTS
         if (b == 0 && lane == 0 && blk == 0) mas_dbg2[(p * W + w) * 4 + 0] = wall_clock64();
 #endif
-        const float* slot = ring + (blk % MAS_RING) * MAS_SLOT_F(W);
+        float* lastp = lane == 63 ? &outrow[w][blk % MAS_OUT_RING][0] : &scratch[w][lane * 33];
         unsigned bits = 0u;
         const int ncol = (y_len - blk * MAS_BLK) < MAS_BLK ? (y_len - blk * MAS_BLK) : MAS_BLK;
         if (blk > 0 && ncol == MAS_BLK) {
-            mas_dp_block<TIE_MOVE, 0>(slot, x_local, blk, y_len, ngroup, false, prev, inrow[w], bits, &lastrow[w][lane]);
+            up_m1 = mas_dp_block<TIE_MOVE, 0>(rowp, inp, cur0, i0, up_m1, blk, y_len, ngroup, false, prev, bits, lastp);
         } else if (blk == 0 && ncol == MAS_BLK) {
-            mas_dp_block<TIE_MOVE, 1>(slot, x_local, blk, y_len, ngroup, band0 + x_local == 0, prev, inrow[w], bits, &lastrow[w][lane]);
+            up_m1 = mas_dp_block<TIE_MOVE, 1>(rowp, inp, cur0, i0, up_m1, blk, y_len, ngroup, band0 + x_local == 0, prev, bits, lastp);
         } else {
-            mas_dp_block<TIE_MOVE, 2>(slot, x_local, blk, y_len, ngroup, band0 + x_local == 0, prev, inrow[w], bits, &lastrow[w][lane]);
+            up_m1 = mas_dp_block<TIE_MOVE, 2>(rowp, inp, cur0, i0, up_m1, blk, y_len, ngroup, band0 + x_local == 0, prev, bits, lastp);
             const int have = blk == 0 ? ncol - 1 : ncol;   // decisions shifted in (column 0 has none)
             bits = have > 0 ? bits << (MAS_BLK - ncol) : 0u;
         }
         MAS_T(t3);
-        MAS_ACC(c_dp, t2, t3);
+        MAS_ACC(c_dp, t1, t3);
 #ifdef AS_EXPERIMENTS
         if (b == 0 && lane == 0 && blk == 0) mas_dbg2[(p * W + w) * 4 + 1] = wall_clock64();
         if (b == 0 && lane == 0 && blk == nblk - 1) mas_dbg2[(p * W + w) * 4 + 2] = wall_clock64();
 #endif
         mo[((size_t)blk * W + w) * 64 + lane] = bits;
-        if (to_wave) {
-            if (lane < MAS_BLK) outrow[w][blk % MAS_OUT_RING][lane] = lastrow[w][lane * 64 + 63];
-            if (lane == 0) __hip_atomic_store(&ctr[1 + W + w], blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else if (to_band && lane < ncol) {
-            __hip_atomic_store(xo + blk * MAS_BLK + lane, ((u64)1u << 32) | __float_as_uint(lastrow[w][lane * 64 + 63]), __ATOMIC_RELAXED,
+        if (to_band && lane < ncol)
+            __hip_atomic_store(xo + blk * MAS_BLK + lane, ((u64)1u << 32) | __float_as_uint(outrow[w][blk % MAS_OUT_RING][lane]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) __hip_atomic_store(&ctr[1 + w], blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // finished: the loader may reuse the slot, the wave below may read this block's last row (release: the row's ds_writes first)
+        if (lane == 0) __hip_atomic_store(&ctr[MAS_NL + w], blk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (from_band && blk + 1 < nblk) fetch_up(blk + 1);
+    }
+    if (fused) {
+        // Small lattices (one band, a few thousand cells): the whole search is ONE launch.  The band's own DP waves clear the utterance's
+        // outputs (no clearing workgroups, no second launch), wait for each other -- every wave's decision words and zeros are in memory
+        // (vmcnt(0)) before the barrier -- and the first wave walks the path back, block after block.  [32,40,100]: two launches were 26 us.
+        const int nlive = min(W, (x_len - band0 + 63) >> 6);                // DP waves that have rows (the others and the loader have exited)
+        const int t = 64 * w + lane, nt = 64 * nlive;
+        if (path) for (int i = t; i < Tx * Ty; i += nt) path[(size_t)b * Tx * Ty + i] = 0.f;
+        if (dur) for (int i = t; i < Tx; i += nt) dur[(size_t)b * Tx + i] = 0;
+        if (rows) for (int i = t; i < Ty; i += nt) rows[(size_t)b * Ty + i] = -1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (w == 0) mas_backtrack_wave<W>(b, lane, x_len, y_len, Tx, Ty, P, nblk_max, masks, path, dur, rows);
     }
 #ifdef AS_EXPERIMENTS
     if (b == 0 && p == 0 && tid == 0) {                      // the first wave of the first band of utterance 0
-        mas_dbg[0] = c_wait; mas_dbg[1] = c_poll; mas_dbg[2] = c_dp; mas_dbg[3] = clock64() - c_all;
+        mas_dbg[0] = c_wait; mas_dbg[1] = 0; mas_dbg[2] = c_dp; mas_dbg[3] = clock64() - c_all;
     }
 #endif
 #endif
 }
 
-// The walk.  Lane lambda of the wave holds the 32 decisions (one block of columns) of row base - lambda; a step is v_readlane of the
-// current row's word, a shift and an add, all in scalar registers; the words of the next block are fetched while this one is walked
-// (the row can only have moved up by 32 by then: 64 lanes cover it).  A block costs ~250 instructions of ONE wave (64 to make the
-// masks, ~100 of walk, the stores): that, ~0.6 us, is the launch's time -- fetching eight blocks of words at once into LDS (one L2 round
-// trip per batch instead of per block) was built and is slower (49 against 40 us).
-template <int R>
-__global__ void __launch_bounds__(64)
-mas_backtrack_kernel(const int* __restrict__ t_x, const int* __restrict__ t_y, int Tx, int Ty, int P, int nblk_max,
-                     const unsigned* __restrict__ masks, float* __restrict__ path, int* __restrict__ dur, int* __restrict__ rows)
+// The walk through ONE block of 32 columns.  Lane lambda of the wave holds the word W = the 32 decisions of row base - lambda; the path enters
+// the block (at its top column j_top) in row idx = base - off and leaves it d rows higher (returned; T = which steps moved).  A step is
+// a shift and an add in scalar registers (a full block: 32 lane masks made up front, then s_bfe / s_lshl1_add / s_add per column on
+// static registers).
+static __device__ __forceinline__ int mas_walk_steps(unsigned W, int off, int j_top, int j_low, unsigned& T)
 {
-#if __HIP_DEVICE_COMPILE__
-    const int b = blockIdx.x, lane = threadIdx.x;
-    int x_len = t_x[b], y_len = t_y[b];
-    x_len = x_len > Tx ? Tx : x_len;
-    y_len = y_len > Ty ? Ty : y_len;
-    if (x_len <= 0 || y_len <= 0) return;
+    int d = 0;
+    T = 0u;                                                // bit k: the step at column j_top - k moved up
+    if (j_top == 31 && j_low == 0) {
+        // a full block.  M[j] = the lane mask of "row (base - lane) moves up at column j" (a compare per column, all 32 up front):
+        // the walk is then three scalar instructions per column on static registers -- shift M[j] by the current lane, and, add.
+        u64 M[MAS_BLK];
+#pragma unroll
+        for (int j = 0; j < MAS_BLK; ++j) M[j] = __builtin_amdgcn_ballot_w64(((W >> (31 - j)) & 1u) != 0u);
+        // three scalar instructions per column: s_bfe_u64 takes the bit of M[j] at the current lane (offset in the low bits of its second
+        // operand, width 1 in bits 16..22 -- the running lane number carries the width field along), s_lshl1_add_u32 shifts it into T,
+        // s_add moves the lane on.  T collects the steps MSB first; reversed afterwards (bit k = the step at column 31 - k).
+        unsigned lamw = (unsigned)__builtin_amdgcn_readfirstlane(off) | (1u << 16);
+#pragma unroll
+        for (int j = 31; j >= 0; --j) {
+            u64 bb;
+            asm("s_bfe_u64 %0, %1, %2" : "=s"(bb) : "s"(M[j]), "s"(lamw));
+            const unsigned bit = (unsigned)bb;
+            asm("s_lshl1_add_u32 %0, %1, %2" : "=s"(T) : "s"(T), "s"(bit));
+            lamw += bit;
+        }
+        T = __builtin_bitreverse32(T);
+        const int lam = (int)(lamw & 0xFFFFu);
+        d = lam - off;
+    } else {
+        for (int j = j_top; j >= j_low; --j) {
+            const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)W, __builtin_amdgcn_readfirstlane(off + d));
+            const unsigned bit = (w >> (31 - j)) & 1u;
+            T |= bit << (j_top - j);
+            d += (int)bit;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(d);
+}
+// lane = column of the block: the row of column y - 1, the path cell, the duration count
+static __device__ __forceinline__ void mas_walk_emit(unsigned T, int idx, int blk, int j_top, int j_low, int b, int Tx, int Ty,
+                                                     float* __restrict__ path, int* __restrict__ dur, int* __restrict__ rows, int lane)
+{
+    if (lane >= j_low && lane <= j_top) {
+        const int kk = j_top - lane;
+        const int rr = idx - __popc(T & (0xFFFFFFFFu >> (31 - kk)));
+        const int col = blk * MAS_BLK + lane - 1;
+        if (path) path[((size_t)b * Tx + rr) * Ty + col] = 1.f;
+        if (rows) rows[(size_t)b * Ty + col] = rr;
+        if (dur) atomicAdd(dur + (size_t)b * Tx + rr, 1);
+    }
+}
+
+// word of row `row` in block `blk` of utterance b (R = DP waves per band: wave i / 64, lane i % 64 of band row / (64 R))
+template <int R>
+static __device__ __forceinline__ const unsigned* mas_word_ptr(const unsigned* __restrict__ masks, int b, int P, int nblk_max, int row, int blk)
+{
+    const int pp = row / (64 * R), i = row - pp * 64 * R;
+    return masks + (((size_t)(b * P + pp) * nblk_max + blk) * R + (i >> 6)) * 64 + (i & 63);
+}
+
+// The whole walk by ONE wave, block after block from the last column down (small lattices, inside the DP launch: mas_band_kernel's fused
+// tail).  The words of the next block are fetched while this one is walked (the row can only have moved up by 32 by then: 64 lanes cover it).
+template <int R>
+static __device__ __forceinline__ void mas_backtrack_wave(int b, int lane, int x_len, int y_len, int Tx, int Ty, int P, int nblk_max,
+                                                          const unsigned* __restrict__ masks, float* __restrict__ path, int* __restrict__ dur,
+                                                          int* __restrict__ rows)
+{
     int idx = x_len - 1;
     if (lane == 0) {
         if (path) path[((size_t)b * Tx + idx) * Ty + (y_len - 1)] = 1.f;
@@ -503,12 +593,11 @@ mas_backtrack_kernel(const int* __restrict__ t_x, const int* __restrict__ t_y, i
     }
     if (y_len < 2) return;
     // decisions of rows base - lane in block blk (row 0 never moves, rows above the lattice do not exist: zero).  The load is issued
-    // here and awaited by mas_arrive: the compiler would wait for it at the first v_readlane of the walk it is meant to overlap.
+    // here and awaited by arrive: the compiler would wait for it at the first v_readlane of the walk it is meant to overlap.
     auto issue = [&](unsigned& dst, int base, int blk) -> bool {
         const int row = base - lane;
         const bool ok = row > 0 && blk >= 0;
-        const int pp = ok ? row / (64 * R) : 0, i = ok ? row - pp * 64 * R : 0;      // R = DP waves per band: wave i / 64, lane i % 64
-        const unsigned* ptr = masks + (((size_t)(b * P + pp) * nblk_max + (ok ? blk : 0)) * R + (i >> 6)) * 64 + (i & 63);
+        const unsigned* ptr = mas_word_ptr<R>(masks, b, P, nblk_max, ok ? row : 0, ok ? blk : 0);
         asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
         return ok;
     };
@@ -523,56 +612,137 @@ mas_backtrack_kernel(const int* __restrict__ t_x, const int* __restrict__ t_y, i
     arrive(W, ok0);
     while (blk >= 0) {
         const bool okn = issue(Wn, idx, blk - 1);          // in flight during the walk
-        const int off = base - idx;                        // lane of the current row in W
         const int j_top = (blk == (y_len - 1) >> 5) ? ((y_len - 1) & 31) : 31;
         const int j_low = blk == 0 ? 1 : 0;
-        int d = 0;
-        unsigned T = 0u;                                   // bit k: the step at column j_top - k moved up
-        if (j_top == 31 && j_low == 0) {
-            // a full block.  M[j] = the lane mask of "row (base - lane) moves up at column j" (a compare per column, all 32 up front):
-            // the walk is then three scalar instructions per column on static registers -- shift M[j] by the current lane, and, add.
-            u64 M[MAS_BLK];
-#pragma unroll
-            for (int j = 0; j < MAS_BLK; ++j) M[j] = __builtin_amdgcn_ballot_w64(((W >> (31 - j)) & 1u) != 0u);
-            // three scalar instructions per column: s_bfe_u64 takes the bit of M[j] at the current lane (offset in the low bits of its second
-            // operand, width 1 in bits 16..22 -- the running lane number carries the width field along), s_lshl1_add_u32 shifts it into T,
-            // s_add moves the lane on.  T collects the steps MSB first; reversed afterwards (bit k = the step at column 31 - k).
-            unsigned lamw = (unsigned)__builtin_amdgcn_readfirstlane(off) | (1u << 16);
-#pragma unroll
-            for (int j = 31; j >= 0; --j) {
-                u64 b;
-                asm("s_bfe_u64 %0, %1, %2" : "=s"(b) : "s"(M[j]), "s"(lamw));
-                const unsigned bit = (unsigned)b;
-                asm("s_lshl1_add_u32 %0, %1, %2" : "=s"(T) : "s"(T), "s"(bit));
-                lamw += bit;
-            }
-            T = __builtin_bitreverse32(T);
-            const int lam = (int)(lamw & 0xFFFFu);
-            d = lam - off;
-        } else {
-            for (int j = j_top; j >= j_low; --j) {
-                const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)W, __builtin_amdgcn_readfirstlane(off + d));
-                const unsigned bit = (w >> (31 - j)) & 1u;
-                T |= bit << (j_top - j);
-                d += (int)bit;
-            }
-        }
-        d = __builtin_amdgcn_readfirstlane(d);
+        unsigned T;
+        const int d = mas_walk_steps(W, base - idx, j_top, j_low, T);
         arrive(Wn, okn);                                   // (before this block's stores are issued: vmcnt(0) would wait for them too)
-        if (lane >= j_low && lane <= j_top) {
-            const int kk = j_top - lane;
-            const int rr = idx - __popc(T & (0xFFFFFFFFu >> (31 - kk)));
-            const int col = blk * MAS_BLK + lane - 1;      // the row of column y - 1
-            if (path) path[((size_t)b * Tx + rr) * Ty + col] = 1.f;
-            if (rows) rows[(size_t)b * Ty + col] = rr;
-            if (dur) atomicAdd(dur + (size_t)b * Tx + rr, 1);
-        }
+        mas_walk_emit(T, idx, blk, j_top, j_low, b, Tx, Ty, path, dur, rows, lane);
         base = idx;
         idx -= d;
         W = Wn;
         --blk;
     }
-#endif
+}
+
+// ---- the parallel backtrack (lattices of more than one band, or too large to clear inside the DP's own workgroup) -----------------
+// The walk is a chain of 2000 dependent steps only if it is run as one: a block's decisions define a FUNCTION "row at the block's top
+// column -> row in front of its first column", and the path is the composition of the blocks' functions.
+//   exit   (all blocks x all rows in parallel): row r's exit from block blk.  The path stays in a row until the highest column below
+//          the current one whose decision bit is set in THAT row's word, then moves up one row: per move one LDS read at a
+//          predictable address (the words of rows r, r-1, r-2, ...), a mask and a find-first-bit -- no dependent memory round trips.
+//          The table holds r - exit(r) <= 32 in a byte.
+//   chain  (one workgroup per utterance): the table in LDS (63 blocks x 1024 rows = 63 KB), the entry row of every block by 62
+//          dependent LDS reads.
+//   emit   (all blocks in parallel, one wave each): the existing per-block walk from the block's now known entry row; rows, path cells
+//          and durations are written by the lanes.
+// [8,1024,2000]: 40 us as one chain of blocks -> three launches of a few microseconds.
+template <int R>
+__global__ void __launch_bounds__(1024)
+mas_exit_kernel(const int* __restrict__ t_x, const int* __restrict__ t_y, int Tx, int Ty, int P, int nblk_max, const unsigned* __restrict__ masks,
+                unsigned char* __restrict__ ex, int exs)
+{
+    extern __shared__ unsigned words[];                    // [4 + x_len] decision words of this block (four zero words in front: rows < 0)
+    const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    int x_len = t_x[b], y_len = t_y[b];
+    x_len = x_len > Tx ? Tx : x_len;
+    y_len = y_len > Ty ? Ty : y_len;
+    if (x_len <= 0 || y_len < 2 || blk > ((y_len - 1) >> 5)) return;
+    if (tid < 4) words[tid] = 0u;
+    for (int r = tid; r < x_len; r += 1024) words[4 + r] = r > 0 ? *mas_word_ptr<R>(masks, b, P, nblk_max, r, blk) : 0u;      // (row 0 never moves)
+    __syncthreads();
+    const int j_top = (blk == (y_len - 1) >> 5) ? ((y_len - 1) & 31) : 31;
+    const int j_low = blk == 0 ? 1 : 0;
+    // decision of column j = bit 31 - j: the columns j_low .. j_top are the bits 31 - j_top .. 31 - j_low
+    const unsigned valid = (0xFFFFFFFFu >> j_low) & (0xFFFFFFFFu << (31 - j_top));
+    unsigned char* out = ex + ((size_t)b * nblk_max + blk) * exs;      // (row stride exs: Tx rounded up to 16 bytes)
+    for (int r = tid; r < x_len; r += 1024) {
+        // the words of rows cur, cur - 1, cur - 2, cur - 3 are held ahead of their use: the addresses do not depend on the data, only
+        // the number of moves does, so the chain per move is a mask, a find-first-bit and a shift -- the LDS latency is three moves away
+        const unsigned* wp = words + 4 + r;
+        unsigned w0 = wp[0], w1 = wp[-1], w2 = wp[-2], w3 = wp[-3];
+        int moves = 0;
+        unsigned m = valid;                                // columns not yet passed
+        while (true) {
+            const unsigned w = w0 & m;
+            if (w == 0u) break;                            // stays in this row down to the block's first column
+            const int pbit = __builtin_ctz(w);             // the HIGHEST column with a set bit = the lowest bit index
+            ++moves;
+            if (pbit >= 31) break;
+            m = (0xFFFFFFFFu << (pbit + 1)) & valid;       // on with the columns below it (higher bit indices)
+            w0 = w1; w1 = w2; w2 = w3;
+            w3 = (r - moves - 3 >= -4) ? wp[-moves - 3] : 0u;
+        }
+        out[r] = (unsigned char)moves;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+mas_chain_kernel(const int* __restrict__ t_x, const int* __restrict__ t_y, int Tx, int Ty, int nblk_max, const unsigned char* __restrict__ ex,
+                 int exs, int* __restrict__ entry, int lds_bytes)
+{
+    extern __shared__ unsigned char tab[];                 // a chunk of blocks: [blocks][rowsP]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int x_len = t_x[b], y_len = t_y[b];
+    x_len = x_len > Tx ? Tx : x_len;
+    y_len = y_len > Ty ? Ty : y_len;
+    if (x_len <= 0 || y_len <= 0) return;
+    const int last = (y_len - 1) >> 5;
+    const int rowsP = (x_len + 15) & ~15;                  // 16-byte rows of the LDS copy
+    const int per = lds_bytes / rowsP;                     // blocks per chunk (>= 1: the host checks)
+    __shared__ int cur_row;
+    if (tid == 0) { cur_row = x_len - 1; entry[(size_t)b * nblk_max + last] = x_len - 1; }
+    for (int hi = last; hi >= 1; hi -= per) {              // blocks hi, hi - 1, ..., lo of this chunk (block 0's exit is not needed)
+        const int lo = hi - per + 1 > 1 ? hi - per + 1 : 1;
+        const int nb = hi - lo + 1;
+        __syncthreads();
+        // 16 bytes per load, whole rows of the table (its row stride is a multiple of 16; rows past x_len are never looked up)
+        const int vec_per_row = rowsP >> 4;
+        for (int i = tid; i < nb * vec_per_row; i += 1024) {
+            const int k = i / vec_per_row, v = i - k * vec_per_row;
+            reinterpret_cast<uint4*>(tab)[(size_t)k * vec_per_row + v] =
+                reinterpret_cast<const uint4*>(ex + ((size_t)b * nblk_max + lo + k) * exs)[v];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int r = cur_row;
+            for (int blk = hi; blk >= lo; --blk) {
+                r -= tab[(size_t)(blk - lo) * rowsP + r];
+                entry[(size_t)b * nblk_max + blk - 1] = r;
+            }
+            cur_row = r;
+        }
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(64)
+mas_emit_kernel(const int* __restrict__ t_x, const int* __restrict__ t_y, int Tx, int Ty, int P, int nblk_max, const unsigned* __restrict__ masks,
+                const int* __restrict__ entry, float* __restrict__ path, int* __restrict__ dur, int* __restrict__ rows)
+{
+    const int blk = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    int x_len = t_x[b], y_len = t_y[b];
+    x_len = x_len > Tx ? Tx : x_len;
+    y_len = y_len > Ty ? Ty : y_len;
+    if (x_len <= 0 || y_len <= 0) return;
+    const int last = (y_len - 1) >> 5;
+    if (blk > last) return;
+    if (blk == last && lane == 0) {                        // the path's last cell
+        const int idx = x_len - 1;
+        if (path) path[((size_t)b * Tx + idx) * Ty + (y_len - 1)] = 1.f;
+        if (rows) rows[(size_t)b * Ty + (y_len - 1)] = idx;
+        if (dur) atomicAdd(dur + (size_t)b * Tx + idx, 1);
+    }
+    if (y_len < 2) return;
+    const int idx = entry[(size_t)b * nblk_max + blk];
+    const int row = idx - lane;
+    const unsigned W = row > 0 ? *mas_word_ptr<R>(masks, b, P, nblk_max, row, blk) : 0u;
+    const int j_top = blk == last ? ((y_len - 1) & 31) : 31;
+    const int j_low = blk == 0 ? 1 : 0;
+    if (j_top < j_low) return;                             // (a one-column last block that is also block 0)
+    unsigned T;
+    (void)mas_walk_steps(W, 0, j_top, j_low, T);
+    mas_walk_emit(T, idx, blk, j_top, j_low, b, Tx, Ty, path, dur, rows, lane);
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -602,9 +772,12 @@ static int mas_geometry(int Tx, int* R, int* W)
 // banded variant: R DP waves of 64 rows per band (1 up to 64 rows, else 2; four waves per band were measured: each wave runs a block
 // behind the one above, so the ring must hold W + 3 blocks or the first wave starves -- 0.28 ms against 0.19), P bands, workspace = exchange words + decision words
 struct MasBands {
-    int R, P, nblk;
-    size_t xchg_bytes, mask_bytes;
+    int R, P, nblk, exs;
+    bool fused;                // one launch: DP, clearing and the walk inside the band's workgroup
+    size_t xchg_bytes, mask_bytes, ex_bytes, entry_bytes;
 };
+#define MAS_FUSED_CELLS 16384  /* Tx * Ty up to which the band's own waves clear the dense path (64 stores per lane at most) */
+#define MAS_CHAIN_LDS (128 * 1024)
 static MasBands mas_bands(int B, int Tx, int Ty)
 {
     MasBands g;
@@ -612,7 +785,11 @@ static MasBands mas_bands(int B, int Tx, int Ty)
     g.P = as_cdiv(Tx, 64 * g.R);
     g.nblk = as_cdiv(Ty, MAS_BLK);
     g.xchg_bytes = g.P > 1 ? (((size_t)B * g.P * g.nblk * MAS_BLK * sizeof(u64) + 255) & ~(size_t)255) : 0;
-    g.mask_bytes = (size_t)B * g.P * g.nblk * g.R * 64 * sizeof(unsigned);
+    g.mask_bytes = (((size_t)B * g.P * g.nblk * g.R * 64 * sizeof(unsigned)) + 255) & ~(size_t)255;
+    g.fused = g.P == 1 && (long)Tx * Ty <= MAS_FUSED_CELLS && !getenv("AS_MAS_NO_FUSE");
+    g.exs = (Tx + 15) & ~15;
+    g.ex_bytes = g.fused ? 0 : (((size_t)B * g.nblk * g.exs) + 255) & ~(size_t)255;       // exit table: a byte per (block, row)
+    g.entry_bytes = g.fused ? 0 : (((size_t)B * g.nblk * sizeof(int)) + 255) & ~(size_t)255;
     return g;
 }
 static bool mas_banded_ok(const float* value, int Tx, int Ty)
@@ -626,7 +803,7 @@ extern "C" size_t as_mas_workspace_bytes(int B, int Tx, int Ty)
     int R, W;
     if (B <= 0 || Tx <= 0 || Ty <= 0) return 0;
     const MasBands g = mas_bands(B, Tx, Ty);
-    const size_t banded = g.xchg_bytes + g.mask_bytes;
+    const size_t banded = g.xchg_bytes + g.mask_bytes + g.ex_bytes + g.entry_bytes;
     // rows that are not 16-byte aligned take the one-workgroup kernel (Tx <= 8192): the caller's buffer serves either
     const size_t one = mas_geometry(Tx, &R, &W) == AS_OK ? (size_t)B * ((Ty + 3) / 4) * 64 * W * sizeof(u64) : 0;
     if (one == 0) return 0;
@@ -676,22 +853,40 @@ extern "C" int as_mas_f32(const float* value, const int* t_x, const int* t_y, in
     if (B == 0) return AS_OK;
     if (mas_banded_ok(value, Tx, Ty)) {
         const MasBands g = mas_bands(B, Tx, Ty);
-        if (!ws || ws_bytes < g.xchg_bytes + g.mask_bytes) return AS_EINVAL;
+        if (!ws || ws_bytes < g.xchg_bytes + g.mask_bytes + g.ex_bytes + g.entry_bytes) return AS_EINVAL;
         u64* xchg = static_cast<u64*>(ws);
-        unsigned* masks = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(ws) + g.xchg_bytes);
+        unsigned char* wsb = static_cast<unsigned char*>(ws);
+        unsigned* masks = reinterpret_cast<unsigned*>(wsb + g.xchg_bytes);
+        unsigned char* ex = wsb + g.xchg_bytes + g.mask_bytes;
+        int* entry = reinterpret_cast<int*>(wsb + g.xchg_bytes + g.mask_bytes + g.ex_bytes);
         if (g.xchg_bytes) AS_CHECK(hipMemsetAsync(xchg, 0, g.xchg_bytes, stream));
         AsProfScope prof__(AS_CLS_MAS, 2.0 * B * Tx * (double)Ty, 4.0 * B * Tx * (double)Ty * (path ? 2 : 1), stream);
         const int n_band_wgs = 8 * as_cdiv(B, 8) * g.P;
-        const dim3 grid(n_band_wgs + 512);                 // + the workgroups that clear path / dur / rows
+        const dim3 grid(n_band_wgs + (g.fused ? 0 : 512));  // + the workgroups that clear path / dur / rows (the fused form clears by itself)
         unsigned* status = as_status_words_device();
+        const int fused = g.fused ? 1 : 0;
         if (g.R == 1) {
-            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<1, true>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status);
-            else hipLaunchKernelGGL((mas_band_kernel<1, false>), grid, dim3(128), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status);
-            hipLaunchKernelGGL((mas_backtrack_kernel<1>), dim3(B), dim3(64), 0, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, path, dur, rows);
+            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<1, true>), grid, dim3(64 * (1 + MAS_NL)), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status, fused);
+            else hipLaunchKernelGGL((mas_band_kernel<1, false>), grid, dim3(64 * (1 + MAS_NL)), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status, fused);
         } else {
-            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<2, true>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status);
-            else hipLaunchKernelGGL((mas_band_kernel<2, false>), grid, dim3(192), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status);
-            hipLaunchKernelGGL((mas_backtrack_kernel<2>), dim3(B), dim3(64), 0, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, path, dur, rows);
+            if (tie_mode) hipLaunchKernelGGL((mas_band_kernel<2, true>), grid, dim3(64 * (2 + MAS_NL)), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status, fused);
+            else hipLaunchKernelGGL((mas_band_kernel<2, false>), grid, dim3(64 * (2 + MAS_NL)), 0, stream, value, t_x, t_y, B, Tx, Ty, g.P, g.nblk, xchg, masks, n_band_wgs, path, dur, rows, status, fused);
+        }
+        if (!g.fused) {
+            // the walk as three short launches (see above): every block's row -> row function, their composition, the emission
+            const dim3 gb(g.nblk, B);
+            const size_t lds_words = ((size_t)Tx + 4) * sizeof(unsigned);
+            const int chain_lds = std::max(MAS_CHAIN_LDS / g.exs * g.exs, g.exs) > MAS_CHAIN_LDS ? g.exs : MAS_CHAIN_LDS;
+            static bool attr_set = false;
+            if (!attr_set) {
+                AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mas_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MAS_CHAIN_LDS));
+                attr_set = true;
+            }
+            if (g.R == 1) hipLaunchKernelGGL((mas_exit_kernel<1>), gb, dim3(1024), lds_words, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, ex, g.exs);
+            else hipLaunchKernelGGL((mas_exit_kernel<2>), gb, dim3(1024), lds_words, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, ex, g.exs);
+            hipLaunchKernelGGL(mas_chain_kernel, dim3(B), dim3(1024), chain_lds, stream, t_x, t_y, Tx, Ty, g.nblk, ex, g.exs, entry, chain_lds);
+            if (g.R == 1) hipLaunchKernelGGL((mas_emit_kernel<1>), gb, dim3(64), 0, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, entry, path, dur, rows);
+            else hipLaunchKernelGGL((mas_emit_kernel<2>), gb, dim3(64), 0, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, entry, path, dur, rows);
         }
         AS_CHECK_LAUNCH();
         return AS_OK;

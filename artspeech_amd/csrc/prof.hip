@@ -115,3 +115,89 @@ extern "C" int as_prof_bracket_overhead(as_stream_t stream_, double* overhead_ms
     *overhead_ms = o > 0 ? o : 0;
     return AS_OK;
 }
+
+// What the matrix cores of THIS device sustain on RANDOM fp16 operands (bench.py's roofline leg reports it beside the nominal peak).
+// The chip lowers its clock under matrix-core load on non-trivial data (MI355X_MICROARCH.md, DVFS give-back): a bare loop of the conv
+// GEMM's own MFMA (v_mfma_f32_32x32x16_f16, a wave's 2 x 2 accumulator tiles, the twelve products of one f16x3 k-block per trip) runs
+// far below the 2516.6 TFLOP/s of the data sheet, with the operands in registers and -- closer to the kernel -- re-read from LDS at
+// the kernel's ratio (8 ds_read_b128 per 12 MFMAs).  No global memory traffic, no barriers: an upper bound for any real kernel.
+typedef float prof_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 prof_f16x8 __attribute__((ext_vector_type(8)));
+template <int LDSF>
+__global__ void __launch_bounds__(256) as_prof_mfma_kernel(const prof_f16x8* __restrict__ src, float* __restrict__ out, int iters)
+{
+    __shared__ __attribute__((aligned(16))) prof_f16x8 lds[2048];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2048; i += 256) lds[i] = src[(blockIdx.x * 2048 + i) & 65535];
+    __syncthreads();
+    prof_f16x8 f[8];                                                     // A h x2, A l x2, B h x2, B l x2
+#pragma unroll
+    for (int q = 0; q < 8; ++q) f[q] = lds[(q * 64 + lane + wave * 17) & 2047];
+    prof_f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a >> 1][a & 1][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        if (LDSF) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] = lds[((q + (it & 7) * 8) * 64 + lane) & 2047];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[i], f[6 + j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 + i], f[4 + j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[i], f[4 + j], acc[i][j], 0, 0, 0);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += acc[a >> 1][a & 1][e];
+    out[blockIdx.x * 256 + tid] = sum;
+}
+
+extern "C" int as_prof_mfma_sustained(as_stream_t stream_, double* tflops_registers, double* tflops_lds_fed)
+{
+    if (!tflops_registers || !tflops_lds_fed) return AS_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int blocks = 512, iters = 12000;                               // two workgroups per CU, ~6 ms per launch
+    const size_t n = (size_t)65536 * 8;
+    std::vector<_Float16> h(n);
+    unsigned long long x = 88172645463325252ull;                         // xorshift: uniform in [-1, 1)
+    for (size_t i = 0; i < n; ++i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        h[i] = (_Float16)((float)((x >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f);
+    }
+    void *src = nullptr, *out = nullptr;
+    AS_CHECK(hipMalloc(&src, n * 2));
+    if (hipMalloc(&out, (size_t)blocks * 256 * 4) != hipSuccess) { (void)hipFree(src); return (int)hipErrorOutOfMemory; }
+    int rc = AS_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMemcpy(src, h.data(), n * 2, hipMemcpyHostToDevice) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        rc = (int)hipErrorUnknown;
+    for (int mode = 0; mode < 2 && rc == AS_OK; ++mode) {
+        float ms = 0.f;
+        for (int rep = 0; rep < 4; ++rep) {                              // the first launches let the clock settle; the last one is timed
+            if (rep == 3) (void)hipEventRecord(e0, stream);
+            if (mode == 0) hipLaunchKernelGGL(as_prof_mfma_kernel<0>, dim3(blocks), dim3(256), 0, stream, static_cast<const prof_f16x8*>(src), static_cast<float*>(out), iters);
+            else hipLaunchKernelGGL(as_prof_mfma_kernel<1>, dim3(blocks), dim3(256), 0, stream, static_cast<const prof_f16x8*>(src), static_cast<float*>(out), iters);
+        }
+        (void)hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess) { rc = (int)hipErrorUnknown; break; }
+        const double flop = (double)blocks * 4 * iters * 12 * 32768.0;
+        (mode == 0 ? *tflops_registers : *tflops_lds_fed) = flop / ms / 1e9;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(src);
+    (void)hipFree(out);
+    return rc;
+}

@@ -228,6 +228,14 @@ def bracket_overhead_ms():
     return _BRACKET_MS
 
 
+def mfma_sustained():
+    """TFLOP/s (fp16 MFMA) this device sustains on random operands: (operands in registers, operands re-read from LDS at the GEMM's ratio)"""
+    from artspeech_amd import _lib
+    a, b = ctypes.c_double(), ctypes.c_double()
+    _lib.check(_lib.lib().as_prof_mfma_sustained(_lib.stream(), ctypes.byref(a), ctypes.byref(b)), "as_prof_mfma_sustained")
+    return float(a.value), float(b.value)
+
+
 def profile_classes(net, runner, steps=3):
     """per-kernel-class time with HIP events on the launch stream, eager launches, the concurrent branches run back to back so that
     an event-bracketed duration is the kernel's own.  `ms_per_step` = the bracketed time minus the brackets' own cost (launches x
@@ -282,15 +290,27 @@ def bench_mas(dev):
         run = lambda: mas.maximum_path_lens(v, xt, yt, tie="stay", want=("path", "dur"))
         for _ in range(3):
             run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # n calls captured into ONE hipGraph and replayed: the device's time per call (called one by one from Python, the 20-30 us of
+        # host work per call would be what is measured on the small lattice)
         n = 20
         torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n):
+        graph, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(st):
             run()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=st):
+                for _ in range(n):
+                    run()
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
         e1.record()
         torch.cuda.synchronize()
-        sec = e0.elapsed_time(e1) / n / 1e3
+        sec = e0.elapsed_time(e1) / (n * reps) / 1e3
         cells = int(xl.astype(np.int64) @ yl.astype(np.int64))             # valid lattice cells
         nbytes = 4 * cells + 4 * value.size                                 # lattice read + dense 0/1 path written
         out[name] = dict(us=sec * 1e6, gcells_per_s=cells / sec / 1e9, us_per_column=sec * 1e6 / int(yl.max()),
@@ -554,6 +574,7 @@ def main():
     except Exception:
         pass
 
+    sus_reg, sus_lds = mfma_sustained()
     ms_per_step = elapsed / args.steps * 1e3
     value = frames_total * args.steps / elapsed
     line = {
@@ -575,6 +596,12 @@ def main():
                      "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s", "frac": gemm_tflops / gemm_peak,
                      "peak_basis": "dense fp16 MFMA 2516.6 TFLOP/s / 3 matrix-core products per fp32 product (achieved = algorithmic fp32 flop); "
                                    "round 1 ran six bf16 products per fp32 product (ceiling 419.4)",
+                     # measured live on this device: a bare loop of the kernel's own MFMA pattern on random operands (no memory traffic, no
+                     # barriers).  The chip lowers its clock under matrix-core load on non-trivial data: `peak` above is the data sheet's.
+                     "sustained_on_random_operands": {
+                         "mfma_f16_tflops_operands_in_registers": sus_reg, "mfma_f16_tflops_operands_from_lds": sus_lds,
+                         "as_f16x3_tflops_from_lds": sus_lds / 3.0, "frac_of_nominal_peak": sus_lds / PEAK_F16_MFMA_TFLOPS,
+                         "kernel_frac_of_sustained": gemm_tflops / (sus_lds / 3.0)},
                      "frac_of_fp32_mfma_peak": gemm_tflops / PEAK_F32_MFMA_TFLOPS,
                      "frac_of_round1_bf16x6_ceiling": gemm_tflops / PEAK_X6_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src,

@@ -64,6 +64,11 @@ int as_prof_hint(double flops, double bytes);
 /* what one event bracket adds to the kernel inside it (ms): the command processor's work between the two markers, which a kernel
  * trace does not count.  Measured with brackets of 1, 2, 4, 8 empty kernels (the intercept); blocks. */
 int as_prof_bracket_overhead(as_stream_t stream, double* overhead_ms);
+/* what this device's matrix cores SUSTAIN on random fp16 operands (TFLOP/s of v_mfma_f32_32x32x16_f16): a bare loop of the conv GEMM's
+ * own MFMA pattern with the operands in registers, and with them re-read from LDS at the GEMM's ratio (8 ds_read_b128 per 12 MFMAs).
+ * The chip lowers its clock under matrix-core load on non-trivial data, so this -- not the data sheet's 2516.6 -- is what any kernel
+ * can be compared with on this device.  Allocates and frees ~1.5 MB, blocks ~50 ms. */
+int as_prof_mfma_sustained(as_stream_t stream, double* tflops_registers, double* tflops_lds_fed);
 
 /* ---------------------------------------------------------------------------------------------
  * Monotonic alignment search (K1).
