@@ -17,7 +17,17 @@ PARGS="--steps 2 --warmup 1 --no-graph --no-concurrency --cpu-utts 0 --no-extras
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/prof_pmc_sq -o bench --output-format csv -- python3 $R/bench.py $PARGS > $OUT/prof_pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_pmc_fetch -o bench --output-format csv -- python3 $R/bench.py $PARGS > $OUT/prof_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_pmc_write -o bench --output-format csv -- python3 $R/bench.py $PARGS > $OUT/prof_pmc_write.log 2>&1
+# the library's own per-launch HIP-event log of the conv GEMM (class, shape / tile / split tag, ms, algorithmic flop and bytes)
+rm -f $OUT/gemm_launches_events.csv
+AS_PROF_CSV=$OUT/gemm_launches_events.csv python3 $R/bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-extras > $OUT/prof_events.log 2>&1
+# the multi-rank launch path on this one-GPU box (two ranks on GPU 0, gloo for the barrier: AS_BENCH_TEST_ONE_GPU=1), weak scaling and C4
+cd $R
+for mode in weak c4; do
+  if [ $mode = weak ]; then EXTRA="--steps 20 --warmup 5 --no-extras"; else EXTRA="--steps 5 --warmup 2 --global-batch 64"; fi
+  AS_BENCH_TEST_ONE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --cpu-utts 0 $EXTRA > $OUT/two_ranks_$mode.log 2>&1
+done
+cd /tmp
 # the stats CSVs are small; the raw traces are not: keep only what make_profiles.py reads
 for d in prof_trace prof_graph prof_c5; do rm -f $OUT/$d/bench_kernel_trace.csv; done
 ls $OUT/prof_trace $OUT/prof_graph $OUT/prof_c5 $OUT/prof_pmc_sq | head -20
-for f in prof_trace prof_graph prof_c5; do grep '^{' $OUT/$f.log | head -1 | cut -c1-400; done
+for f in prof_trace prof_graph prof_c5 two_ranks_weak two_ranks_c4; do grep '^{' $OUT/$f.log | head -1 | cut -c1-400; done

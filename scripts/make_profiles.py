@@ -13,6 +13,14 @@ for name in ("prof_trace", "prof_graph", "prof_c5"):        # the JSON line each
         if ln.startswith("{"):
             open(f"{P}/{tag}_{name[5:]}_bench_line.json", "w").write(ln)
 
+if os.path.exists(f"{G}/gemm_launches_events.csv"):
+    shutil.copy(f"{G}/gemm_launches_events.csv", f"{P}/{tag}_gemm_launches_events.csv")
+for mode in ("weak", "c4"):                                  # the two-rank launches on the one-GPU box
+    if os.path.exists(f"{G}/two_ranks_{mode}.log"):
+        for ln in open(f"{G}/two_ranks_{mode}.log"):
+            if ln.startswith("{"):
+                open(f"{P}/{tag}_two_ranks_{mode}_bench_line.json", "w").write(ln)
+
 def short(n):
     return n.split('(')[0].replace('void ', '')[:60]
 
