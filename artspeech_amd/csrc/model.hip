@@ -2085,7 +2085,7 @@ extern "C" int as_plan_layout_flushes(const as_plan* p) { return p ? p->layout_f
 
 extern "C" int as_encoder_forward(const as_model* m, as_plan* p, int which, const as_batch* batch, const int32_t* tokens, float* out, int ldo,
                                   void* ws, size_t ws_bytes, as_stream_t stream)
-{
+try {                                                                    // nothing may unwind through the C boundary
     if (!m || !p || !batch_ok(batch, true, false, false) || !tokens || !out || which < 0 || which > 2) return AS_EINVAL;
     Call k(m, p, ws, ws_bytes, stream);
     Ctx& c = k.c;
@@ -2098,11 +2098,15 @@ extern "C" int as_encoder_forward(const as_model* m, as_plan* p, int which, cons
     const int g = which == 0 ? ENC_TEXT : (which == 1 ? ENC_ARTS : ENC_DUR);
     copy_rows(c, out, ldo, eo.y[g], eo.ld[g], m->cfg.hidden_dim, lay->N);
     return k.done();
+} catch (const std::bad_alloc&) {
+    return (int)hipErrorOutOfMemory;
+} catch (...) {
+    return AS_EINVAL;
 }
 
 extern "C" int as_style_forward(const as_model* m, as_plan* p, const as_batch* batch, const float* mel, int ldm, const float* f0_raw,
                                 const float* ema_raw, int lde, float* feat12, int ldf, float* style, void* ws, size_t ws_bytes, as_stream_t stream)
-{
+try {                                                                    // nothing may unwind through the C boundary
     if (!m || !p || !batch_ok(batch, false, true, false) || !mel || !f0_raw || !ema_raw || !feat12 || !style) return AS_EINVAL;
     Call k(m, p, ws, ws_bytes, stream);
     Ctx& c = k.c;
@@ -2113,11 +2117,15 @@ extern "C" int as_style_forward(const as_model* m, as_plan* p, const as_batch* b
     const StyleIn si = style_inputs(c, feat12, ldf, mel, ldm, ref);
     if (si.l1) for (int t = 0; t < 4; ++t) style_tower(c, t, si, style);
     return k.done();
+} catch (const std::bad_alloc&) {
+    return (int)hipErrorOutOfMemory;
+} catch (...) {
+    return AS_EINVAL;
 }
 
 extern "C" int as_duration_forward(const as_model* m, as_plan* p, const as_batch* batch, const int32_t* tokens, const float* ema_ext, int lde,
                                    float* duration, void* ws, size_t ws_bytes, as_stream_t stream)
-{
+try {                                                                    // nothing may unwind through the C boundary
     if (!m || !p || !batch_ok(batch, true, true, false) || !tokens || !ema_ext || !duration) return AS_EINVAL;
     Call k(m, p, ws, ws_bytes, stream);
     Ctx& c = k.c;
@@ -2129,11 +2137,15 @@ extern "C" int as_duration_forward(const as_model* m, as_plan* p, const as_batch
     rel_encoder_multi(c, path_encoders(), tokens, tok, &eo, [](int) {});
     duration_tail(c, eo.y[ENC_DUR], ds, tok, duration);
     return k.done();
+} catch (const std::bad_alloc&) {
+    return (int)hipErrorOutOfMemory;
+} catch (...) {
+    return AS_EINVAL;
 }
 
 extern "C" int as_arts_forward(const as_model* m, as_plan* p, const as_batch* batch, const float* a_ens, int lda, const float* style, float* F0,
                                float* N, float* EMA, int ldp, void* ws, size_t ws_bytes, as_stream_t stream)
-{
+try {                                                                    // nothing may unwind through the C boundary
     if (!m || !p || !batch_ok(batch, false, false, true) || !a_ens || !style || !F0 || !N || !EMA) return AS_EINVAL;
     Call k(m, p, ws, ws_bytes, stream);
     Ctx& c = k.c;
@@ -2147,12 +2159,16 @@ extern "C" int as_arts_forward(const as_model* m, as_plan* p, const as_batch* ba
     copy_rows(c, N, ldp, fne + (size_t)N2, N2, 1, N2);
     copy_rows(c, EMA, ldp, fne + (size_t)2 * N2, N2, 10, N2);
     return k.done();
+} catch (const std::bad_alloc&) {
+    return (int)hipErrorOutOfMemory;
+} catch (...) {
+    return AS_EINVAL;
 }
 
 extern "C" int as_decoder_forward(const as_model* m, as_plan* p, const as_batch* batch, const float* asr, int lda, const float* style,
                                   const float* F0, const float* N, const float* EMA, int ldp, float* mel, int ldo, void* ws, size_t ws_bytes,
                                   as_stream_t stream)
-{
+try {                                                                    // nothing may unwind through the C boundary
     if (!m || !p || !batch_ok(batch, false, false, true) || !asr || !style || !F0 || !N || !EMA || !mel) return AS_EINVAL;
     Call k(m, p, ws, ws_bytes, stream);
     Ctx& c = k.c;
@@ -2179,21 +2195,29 @@ extern "C" int as_decoder_forward(const as_model* m, as_plan* p, const as_batch*
     const FcOut fc = adain_fc_all(c, "style", style_norms(*m), style, sd2, sd2, batch->B);
     decoder(c, x0, lay2, fne, lay2->N, fc, mel, ldo);
     return k.done();
+} catch (const std::bad_alloc&) {
+    return (int)hipErrorOutOfMemory;
+} catch (...) {
+    return AS_EINVAL;
 }
 
 extern "C" int as_forward_test_begin(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
                                      as_stream_t stream)
-{
+try {                                                                    // nothing may unwind through the C boundary
     if (!m || !p || !batch_ok(batch, true, true, false) || !io_ok(io, false)) return AS_EINVAL;
     Call k(m, p, ws_a, ws_a_bytes, stream);
     const PhaseA A = forward_a(k.c, batch, io);
     if (A.tok && A.ref) outputs_a(k.c, A, batch, io);
     return k.done();
+} catch (const std::bad_alloc&) {
+    return (int)hipErrorOutOfMemory;
+} catch (...) {
+    return AS_EINVAL;
 }
 
 extern "C" int as_forward_test_finish(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
                                       void* ws_b, size_t ws_b_bytes, as_stream_t stream)
-{
+try {                                                                    // nothing may unwind through the C boundary
     if (!m || !p || !batch_ok(batch, true, true, true) || !io_ok(io, true)) return AS_EINVAL;
     // recover where the first half left its results: the same allocation sequence, nothing launched
     Call ka(m, p, ws_a, ws_a_bytes, stream, false);
@@ -2202,11 +2226,15 @@ extern "C" int as_forward_test_finish(const as_model* m, as_plan* p, const as_ba
     Call kb(m, p, ws_b, ws_b_bytes, stream, true, false);
     forward_b(kb.c, A, batch, io);
     return kb.done();
+} catch (const std::bad_alloc&) {
+    return (int)hipErrorOutOfMemory;
+} catch (...) {
+    return AS_EINVAL;
 }
 
 extern "C" int as_forward_test(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
                                void* ws_b, size_t ws_b_bytes, int32_t* frames_host_out, as_stream_t stream)
-{
+try {                                                                    // nothing may unwind through the C boundary
     if (!m || !p || !batch_ok(batch, true, true, false) || !io_ok(io, true)) return AS_EINVAL;
     Call ka(m, p, ws_a, ws_a_bytes, stream);
     const PhaseA A = forward_a(ka.c, batch, io);
@@ -2228,4 +2256,8 @@ extern "C" int as_forward_test(const as_model* m, as_plan* p, const as_batch* ba
     if ((reinterpret_cast<uintptr_t>(ws_b) & 255) != 0) return AS_EINVAL;
     forward_b(cb, A, &b2, io);
     return cb.rc ? cb.rc : m->err;
+} catch (const std::bad_alloc&) {
+    return (int)hipErrorOutOfMemory;
+} catch (...) {
+    return AS_EINVAL;
 }
