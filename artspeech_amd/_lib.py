@@ -45,7 +45,8 @@ class ConvGemmArgs(ctypes.Structure):
                 ("transpose_out", ctypes.c_int32), ("yh_lrelu", ctypes.c_int32), ("n_prod", ctypes.c_int32),
                 ("dh", ctypes.c_int32 * AS_MAX_TAPS), ("dw", ctypes.c_int32 * AS_MAX_TAPS),
                 ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float), ("acc_scale", ctypes.c_float),
-                ("n_groups", ctypes.c_int32), ("group_cols", ctypes.c_int32), ("range_probe", ctypes.c_int32), ("status", ctypes.c_void_p)]
+                ("n_groups", ctypes.c_int32), ("group_cols", ctypes.c_int32), ("range_probe", ctypes.c_int32), ("status", ctypes.c_void_p),
+                ("Xh2", ctypes.c_void_p), ("K2", ctypes.c_int32)]
 
 
 _SIGNATURES.update({
@@ -58,6 +59,8 @@ _SIGNATURES.update({
     "as_split_f16x2_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "as_prep_weight_f16x2_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "as_prep_weight_f16x2_host": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "as_prep_weight_f16x2_sc_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "as_prep_weight_f16x2_sc_host": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "as_embed_groups_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "as_channel_layernorm_groups_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_i, c_p]),
     "as_channel_layernorm_split_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_p]),
@@ -170,6 +173,8 @@ def lib():
                 "(or __graft_entry__.build()).  There is no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
+            if os.environ.get("AS_LIB_PATH") and not hasattr(handle, name):
+                continue                        # (an experiment / older build named explicitly: A/B runs of scripts/exp)
             fn = getattr(handle, name)          # AttributeError if the header and the .so disagree
             fn.restype = res
             fn.argtypes = args

@@ -7,7 +7,7 @@
 #define OOB 0xFFFFFFFFu
 #define OOBH 0x80000000u   /* epilogue: out of range for every descriptor (< 2 GiB, host-checked) even after adding an in-range offset */
 
-// host: launch the f16x3 kernel for tile `choice` (22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64; 4 waves each) on a
+// host: launch the f16x3 kernel for tile `choice` (22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64, 14 = 64x256; 4 waves each) on a
 // grid of (tiles, S); returns AS_OK or a hipError_t.  (conv_gemm_h3.hip)
 int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream);
 // host: the kernel that writes the split image of X (no profiling scope of its own)

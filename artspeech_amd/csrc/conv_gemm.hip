@@ -186,9 +186,9 @@ extern "C" int as_set_range_probe(int on)
 
 static void tile_dims(int choice, int* bm, int* bn)
 {
-    // 42 / 22 / 21 / 12 / 11 / 2: 256x128, 128x128, 128x64, 64x128, 64x64, 32x128 (4 waves each)
+    // 42 / 22 / 21 / 12 / 11 / 14 / 2: 256x128, 128x128, 128x64, 64x128, 64x64, 64x256, 32x128 (4 waves each)
     *bm = choice == 42 ? 256 : (choice == 22 || choice == 21) ? 128 : choice == 2 ? 32 : 64;
-    *bn = (choice == 42 || choice == 22 || choice == 12 || choice == 2) ? 128 : 64;
+    *bn = choice == 14 ? 256 : (choice == 42 || choice == 22 || choice == 12 || choice == 2) ? 128 : 64;
 }
 
 // Tile choice, fitted to sweeps on MI355X (scripts/gemm_bench.py, round 2).  The time of a launch is the time of its busiest CU:
@@ -198,9 +198,13 @@ static void tile_dims(int choice, int* bm, int* bn)
 // (240); M512 N1280 K512 T3: 25.6 / 17.8 / 15.2 us for 40 / 80 / 160 tiles.
 static int gemm_tile_choice(int M, int N, int n_prod, int Kp)
 {
-    const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 42, 22, 21, 12, 11
+    const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only: 42, 22, 21, 12, 11, 14
     if (env && atoi(env) > 0) return atoi(env);
     if (M <= 32 && n_prod == 3) return 2;                              // a 64-row tile would be half empty (HiFi-GAN's last stage: 32 channels, 1.9 M columns)
+    // <= 64 output channels over many columns (the towers' first convs, 64 x 509 440): the 64 x 128 tile splits K over wave pairs and
+    // reads six fragments per six products; 64 x 256 gives every wave a 64 x 64 block over the whole k (eight per twelve, like 128 x 128):
+    // M64 N509440 K64 T9 167 -> 139 us, N128000 41 -> 34, N63680 20.8 -> 19.7; below one round of the chip (N6400: 8.6 -> 10.8) it loses.
+    if (M <= 64 && n_prod == 3 && as_cdiv(N, 256) >= 240) return 14;
     const bool tall = M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512);   // a 128-row tile is not half empty
     static const int choices[5] = {42, 22, 21, 12, 11};
     // 256x128 (a wave owns 128 x 64): a third less LDS traffic per matrix-core product, but 364 registers: ONE workgroup per CU.
@@ -236,14 +240,14 @@ static int gemm_tile_choice(int M, int N, int n_prod, int Kp)
 // K slices: only where even the smallest tiles leave most CUs idle (the towers' last convs: a few hundred columns, K = 12800).
 // Everywhere else one launch without the reduce pass is as fast or faster (M1024 N2560 K512 T9: 94 us unsplit, 100 + 17 in four
 // slices; M512 N1280 K512 T3: 16 against 31).
-static int gemm_ksplit(int M, int N, int Kp, int T, int choice)
+static int gemm_ksplit(int M, int N, int Kp, int T, int choice, int K2 = 0)
 {
     const char* env = getenv("AS_GEMM_KSPLIT");          // tuning/experiments only
     int bm, bn;
     tile_dims(choice, &bm, &bn);
     const long tiles = (long)as_cdiv(M, bm) * as_cdiv(N, bn);
     const int wk = choice == 2 ? 2 : bm * bn >= 4 * 64 * 64 ? 1 : 4 * 64 * 64 / (bm * bn);   // waves that split K inside the workgroup
-    const int nkt = T * as_cdiv(Kp / 16, wk);             // iterations (k-tile = 16 * WK)
+    const int nkt = T * as_cdiv(Kp / 16, wk) + as_cdiv(as_cdiv(K2, 16), wk);   // iterations (k-tile = 16 * WK)
     int s = 1;
     if (env && atoi(env) > 0) s = atoi(env);
     else if (tiles < 64) {
@@ -266,7 +270,7 @@ static GemmPlan gemm_plan(const ConvGemmArgs& a)
 {
     GemmPlan p = {};
     p.choice = gemm_tile_choice(a.M, a.N, a.n_prod ? a.n_prod : 3, a.Kp);
-    p.S = gemm_ksplit(a.M, a.N, a.Kp, a.T, p.choice);
+    p.S = gemm_ksplit(a.M, a.N, a.Kp, a.T, p.choice, a.K2);
     p.slab_bytes = p.S > 1 ? (size_t)p.S * a.M * a.N * sizeof(float) : 0;
     p.xh_bytes = a.Xh ? 0 : as_split_f16x2_bytes(a.K, a.N);
     return p;
@@ -274,7 +278,7 @@ static GemmPlan gemm_plan(const ConvGemmArgs& a)
 
 static bool direct_cin1(const ConvGemmArgs& a)
 {
-    return a.K == 1 && a.W && a.X && (!a.Yh || a.T <= 9) && !a.res && !a.div_sqrt2 && !a.transpose_out && a.M <= DIRECT_MAX_M && a.n_groups <= 1 &&
+    return a.K == 1 && !a.K2 && a.W && a.X && (!a.Yh || a.T <= 9) && !a.res && !a.div_sqrt2 && !a.transpose_out && a.M <= DIRECT_MAX_M && a.n_groups <= 1 &&
            !getenv("AS_GEMM_NO_DIRECT");
 }
 
@@ -286,7 +290,7 @@ extern "C" size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* a)
     return p.xh_bytes ? align256(p.slab_bytes) + p.xh_bytes : p.slab_bytes;
 }
 
-// which kernel a call with these arguments runs (tests, tuning): kind 0 = direct Cin = 1, 1 = tiled (tile = 22 / 21 / 12 / 11 / 2)
+// which kernel a call with these arguments runs (tests, tuning): kind 0 = direct Cin = 1, 1 = tiled (tile = 22 / 21 / 12 / 11 / 14 / 2)
 extern "C" int as_conv_gemm_plan(const ConvGemmArgs* a, int32_t* kind, int32_t* tile, int32_t* slices)
 {
     if (!a || !kind || !tile || !slices || a->M <= 0 || a->N <= 0 || a->Kp <= 0 || a->T <= 0) return AS_EINVAL;
@@ -322,13 +326,16 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if ((!a.Wh && !(a.W && a.K == 1)) || (!a.X && !a.Xh) || (!a.Y && !a.Yh) || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS)
         return AS_EINVAL;
     if (a.Kp < a.K || a.Kp % 16 || a.Kp - a.K >= 16) return AS_EINVAL;
+    if (a.K2 < 0 || (a.K2 > 0 && (!a.Xh2 || !a.Xh || !a.Wh || (reinterpret_cast<uintptr_t>(a.Xh2) & 15) != 0 ||
+                                  (double)as_kbx(a.K2) * 64.0 * (a.N + 1.0) >= 2147483648.0)))
+        return AS_EINVAL;                                                // the second operand comes as an image, beside an image
     if (a.n_groups > 1 && (a.group_cols <= 0 || (long)a.group_cols * a.n_groups < a.N)) return AS_EINVAL;
     if ((a.X && a.ldx < a.N) || (a.Y && a.ldy < (a.transpose_out ? a.M : a.N)) || (a.res && (a.ldr < a.N || a.transpose_out)) ||
         (a.Yh && a.transpose_out))
         return AS_EINVAL;
     if (((reinterpret_cast<uintptr_t>(a.Wh) | reinterpret_cast<uintptr_t>(a.Xh) | reinterpret_cast<uintptr_t>(a.Yh)) & 15) != 0) return AS_EINVAL;
     // 32-bit byte offsets inside the buffer descriptors
-    if ((double)a.T * as_kbx(a.K) * 64.0 * a.M >= 2147483648.0 || (a.X && (double)a.K * a.ldx * 4.0 + 16.0 >= 4294967296.0)) return AS_EINVAL;
+    if (((double)a.T * as_kbx(a.K) + (a.K2 ? as_kbx(a.K2) : 0)) * 64.0 * a.M >= 2147483648.0 || (a.X && (double)a.K * a.ldx * 4.0 + 16.0 >= 4294967296.0)) return AS_EINVAL;
     if ((a.Y && (double)(a.transpose_out ? a.N : a.M) * a.ldy * 4.0 >= 2147483648.0) || (double)a.M * a.ldr * 4.0 >= 2147483648.0 ||
         (double)a.M * a.N * 4.0 >= 2147483648.0 || (a.Yh && (double)as_kbx(a.M) * 64.0 * (a.N + 1.0) >= 2147483648.0))
         return AS_EINVAL;
@@ -359,12 +366,13 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
         plan.slab_bytes = 0;
     }
     const int S = plan.S;
-    char tag[64];
-    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d tile%d S%d%s%s%s", a.M, a.N, a.K, a.T, plan.choice, S, a.n_prod == 1 ? " h1" : "",
+    char tag[80], sc[24] = "";
+    if (a.K2) snprintf(sc, sizeof(sc), " +K%d", a.K2);
+    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d%s tile%d S%d%s%s%s", a.M, a.N, a.K, a.T, sc, plan.choice, S, a.n_prod == 1 ? " h1" : "",
              a.Xh ? "" : " +split", a.Yh ? (a.Y ? " y+yh" : " yh") : "");
-    // algorithmic work of this launch: 2*M*N*K*T flop; bytes = weights + input + output once (4 bytes per element)
-    AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.K * a.T,
-                       4.0 * ((double)a.T * a.K * a.M * a.n_groups + (double)a.K * a.N + (double)a.M * a.N), stream, tag);
+    // algorithmic work of this launch: 2*M*N*(K*T + K2) flop; bytes = weights + inputs + output once (4 bytes per element)
+    AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * ((double)a.K * a.T + a.K2),
+                       4.0 * (((double)a.T * a.K + a.K2) * a.M * a.n_groups + ((double)a.K + a.K2) * a.N + (double)a.M * a.N), stream, tag);
     if (!a.Xh) {                                                        // split once, behind the K slabs in the workspace
         uint16_t* xh = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(a.ws) + align256(plan.slab_bytes));
         const int rc = as_split_f16x2_launch(a.X, a.ldx, a.K, a.N, a.in_act == 2, a.in_slope, xh, stream);

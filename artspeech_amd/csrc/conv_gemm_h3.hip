@@ -95,14 +95,18 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     const int KB = a.Kp >> 4, KBx = (KB + 3) & ~3;
     const int NX = a.N + 1;                                              // columns of the activation image (the last one is zero)
 
-    const unsigned w_bytes = (unsigned)a.T * KBx * 4u * a.M * 16u;       // one weight set
+    const int KB2 = (a.K2 + 15) >> 4, KBx2 = (KB2 + 3) & ~3;             // the second operand's k-blocks (0: none)
+    const unsigned w_bytes = ((unsigned)a.T * KBx + KBx2) * 4u * a.M * 16u;   // one weight set
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.Wh) + (size_t)grp * w_bytes), 0, (int)w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.Xh), 0, (int)((unsigned)KBx * 4u * NX * 16u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(KB2 ? a.Xh2 : a.Xh), 0, (int)((unsigned)KBx2 * 4u * NX * 16u), 0x00020000);
 
     (void)rsW;
     (void)rsX;      // (the host pass does not see the LDS-DMA builtins that use them)
+    (void)rsX2;
     // chunk c = tid + NT i of an iteration's image [kblk][plane][row] -> LDS offset 16 c (both operands).  The global image
     // always has four planes per k-block; with NP = 1 only planes 0, 1 (the h parts) are staged.
     unsigned a_voff[ACH];
@@ -141,8 +145,10 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
 
     // iterations: an iteration covers KBS k-blocks of one tap (the tail of a tap re-reads zero blocks: KBx is a multiple of 4
     // and the weights' zero rows make them harmless as long as KBS divides 4 or the cursor clamps -- see advance)
+    // The second operand (ConvGemmArgs.Xh2: a block's learned shortcut) is one more "tap" after the last: no column shift, its own
+    // image and k-block count, its weights behind the taps' in the weight set.
     const int it_per_tap = (KB + KBS - 1) / KBS;
-    const int nit_all = a.T * it_per_tap;
+    const int nit_all = a.T * it_per_tap + (KB2 + KBS - 1) / KBS;
     const int S = gridDim.y;
     const int it_lo = (int)((long)nit_all * blockIdx.y / S);
     const int n_it = (int)((long)nit_all * (blockIdx.y + 1) / S) - it_lo;
@@ -152,13 +158,19 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     // CHANGES, once per KB / KBS iterations, behind a wave-uniform branch.  (Round 2 PMC: with the decode in every iteration the
     // loop carried 43 scalar + 23 vector instructions per 12 MFMAs and the waves' issue slots, not the matrix cores, set the pace.)
     // Past the end the cursor stays on the last tile (loading it again into a stage nobody reads is harmless).
-    int s_t = it_lo / it_per_tap, s_kb = (it_lo - s_t * it_per_tap) * KBS;
+    int s_t = min(it_lo / it_per_tap, a.T), s_kb = (it_lo - s_t * it_per_tap) * KBS;
+    int kb_lim = s_t < a.T ? KB : KB2;                                   // k-blocks of the staged tap
+    __amdgpu_buffer_rsrc_t rsXc = s_t < a.T ? rsX : rsX2;                // the image the staged tap reads
     const int a_step = KBS * 4 * a.M * 16, b_step = KBS * 4 * NX * 16;
     int a_soff = (s_t * KBx + s_kb) * 4 * a.M * 16, b_soff = s_kb * 4 * NX * 16;
     unsigned bv[BCH];                                                    // voffset of this thread's activation chunks for the staged tap
     auto set_tap = [&](int t) {                                          // an invalid tap reads the zero column N
-        const int byte = (int)(h3_tap_word(tp, t) >> ((t & 7) * 8)) & 0xff;
-        const unsigned ok = 0u - ((tapmask >> t) & 1u);                  // all ones / zero: arithmetic select, no exec branch
+        int byte = (int)(h3_tap_word(tp, t) >> ((t & 7) * 8)) & 0xff;
+        unsigned ok = 0u - ((tapmask >> (t & 31)) & 1u);                 // all ones / zero: arithmetic select, no exec branch
+        if (t >= a.T) {                                                  // (wave-uniform) the second operand: the column itself
+            byte = tp.wide ? 128 : 0x88;
+            ok = 0u - (unsigned)(j < n_end);
+        }
         const unsigned src = ((unsigned)((byte >> 4) * tA + (byte & 15) + tC) & ok) | ((unsigned)a.N & ~ok);
 #pragma unroll
         for (int i = 0; i < BCH; ++i) bv[i] = b_plane[i] + src * 16u;
@@ -168,12 +180,16 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
         s_kb += KBS;
         a_soff += a_step;
         b_soff += b_step;
-        if (s_kb >= KB) {                                                // wave-uniform, once per tap
-            if (s_t + 1 < a.T) {
+        if (s_kb >= kb_lim) {                                            // wave-uniform, once per tap
+            if (s_t + 1 < a.T || (s_t + 1 == a.T && KB2 > 0)) {
                 s_t += 1;
                 s_kb = 0;
                 a_soff = s_t * KBx * 4 * a.M * 16;
                 b_soff = 0;
+                if (s_t == a.T) {
+                    kb_lim = KB2;
+                    rsXc = rsX2;
+                }
                 set_tap(s_t);
             } else {
                 s_kb -= KBS;
@@ -192,13 +208,14 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     auto dma_b = [&](auto i_, int stage) {
 #if __HIP_DEVICE_COMPILE__ && !defined(H3_EXP_NODMA)
         constexpr int i = decltype(i_)::value;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(smem + stage * C::STAGE + C::A_ST + wave * 1024 + i * (NT * 16)), 16, bv[i],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsXc, (lds_void*)(smem + stage * C::STAGE + C::A_ST + wave * 1024 + i * (NT * 16)), 16, bv[i],
                                                  b_soff, 0, 0);
 #endif
     };
     (void)bv;
     (void)a_soff;
     (void)b_soff;
+    (void)rsXc;
     // fragments: [set][32-row / 32-column tile][part]
     f16x8 fa[2][TM][2], fb[2][2][2];
     const int a_frag = (wk * KT * QP + lk) * BM * 16 + (wm * 32 * TM + l31) * 16;
@@ -422,6 +439,9 @@ int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t
     case 22: return launch_h3_tile<2, 2, 1>(a, S, stream);
     case 21: return launch_h3_tile<2, 1, 2>(a, S, stream);
     case 12: return launch_h3_tile<1, 2, 2>(a, S, stream);
+    case 14:                                                            // 64 x 256: four waves side by side, each 64 x 64 over the whole k
+        if (a.n_prod == 1) return launch_h3_tile<1, 2, 2>(a, S, stream);   // (h-only operands: half a weight chunk per thread -- the 64 x 128 tile)
+        return launch_h3<1, 4, 1, 1, 3, 3>(a, S, stream);
     case 11: return launch_h3_tile<1, 1, 4>(a, S, stream);
     default: return AS_EINVAL;
     }
@@ -492,19 +512,22 @@ extern "C" int as_split_f16x2_f32(const float* x, int ldx, int K, int N, int in_
 }
 
 // host-side weight preparation (see the header)
-extern "C" size_t as_prep_weight_f16x2_bytes(int G, int Cout, int Cin, int T)
+extern "C" size_t as_prep_weight_f16x2_sc_bytes(int G, int Cout, int Cin, int T, int Cin2)
 {
-    if (G <= 0 || Cout <= 0 || Cin <= 0 || T <= 0) return 0;
-    return (size_t)G * T * as_kbx(Cin) * 4 * (size_t)Cout * 16;
+    if (G <= 0 || Cout <= 0 || Cin <= 0 || T <= 0 || Cin2 < 0) return 0;
+    return (size_t)G * ((size_t)T * as_kbx(Cin) + (Cin2 ? as_kbx(Cin2) : 0)) * 4 * (size_t)Cout * 16;
 }
+extern "C" size_t as_prep_weight_f16x2_bytes(int G, int Cout, int Cin, int T) { return as_prep_weight_f16x2_sc_bytes(G, Cout, Cin, T, 0); }
 
-extern "C" int as_prep_weight_f16x2_host(const float* w, int G, int Cout, int Cin, int T, uint16_t* wh, float* scale_out)
+extern "C" int as_prep_weight_f16x2_sc_host(const float* w, const float* w2, int G, int Cout, int Cin, int T, int Cin2, uint16_t* wh,
+                                            float* scale_out)
 {
-    if (!w || !wh || !scale_out || G <= 0 || Cout <= 0 || Cin <= 0 || T <= 0) return AS_EINVAL;
-    const size_t n = (size_t)G * Cout * Cin * T;
+    if (!w || !wh || !scale_out || G <= 0 || Cout <= 0 || Cin <= 0 || T <= 0 || Cin2 < 0 || ((Cin2 > 0) != (w2 != nullptr))) return AS_EINVAL;
+    const size_t n = (size_t)G * Cout * Cin * T, n2 = (size_t)G * Cout * Cin2;
     float mx = 0.f;
-    for (size_t i = 0; i < n; ++i) {
-        const float v = w[i] < 0 ? -w[i] : w[i];
+    for (size_t i = 0; i < n + n2; ++i) {
+        const float x = i < n ? w[i] : w2[i - n];
+        const float v = x < 0 ? -x : x;
         if (!(v <= 3.0e38f)) return AS_EINVAL;                           // NaN / inf
         mx = v > mx ? v : mx;
     }
@@ -514,26 +537,33 @@ extern "C" int as_prep_weight_f16x2_host(const float* w, int G, int Cout, int Ci
         frexpf(mx, &e);                                                  // mx = f * 2^e, f in [0.5, 1): mx in [2^(e-1), 2^e)
         scale = ldexpf(1.0f, 14 - e);                                    // max |w| * scale in [2^13, 2^14)
     }
-    const int KBx = as_kbx(Cin);
-    const size_t total = as_prep_weight_f16x2_bytes(G, Cout, Cin, T) / 2;
+    const int KBx = as_kbx(Cin), KBx2 = Cin2 ? as_kbx(Cin2) : 0;
+    const size_t blocks = (size_t)T * KBx + KBx2;                        // k-blocks of one weight set
+    const size_t total = as_prep_weight_f16x2_sc_bytes(G, Cout, Cin, T, Cin2) / 2;
     for (size_t i = 0; i < total; ++i) wh[i] = 0;
+    auto put = [&](size_t block, int k, int m, float x) {                // element k of k-block `block` (absolute), output row m
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        const int kh = (k >> 3) & 1, e8 = k & 7;
+        const size_t base = block * 4 * (size_t)Cout * 8;
+        uint16_t hb, lb;
+        __builtin_memcpy(&hb, &h, 2);
+        __builtin_memcpy(&lb, &l, 2);
+        wh[base + ((size_t)(0 * 2 + kh) * Cout + m) * 8 + e8] = hb;
+        wh[base + ((size_t)(1 * 2 + kh) * Cout + m) * 8 + e8] = lb;
+    };
     for (int g = 0; g < G; ++g)
-        for (int m = 0; m < Cout; ++m)
+        for (int m = 0; m < Cout; ++m) {
             for (int k = 0; k < Cin; ++k)
-                for (int t = 0; t < T; ++t) {
-                    const float x = w[(((size_t)g * Cout + m) * Cin + k) * T + t] * scale;
-                    const _Float16 h = (_Float16)x;
-                    const _Float16 l = (_Float16)(x - (float)h);
-                    const int kb = k >> 4, kh = (k >> 3) & 1, e8 = k & 7;
-                    const size_t base = ((((size_t)g * T + t) * KBx + kb) * 4) * (size_t)Cout * 8;
-                    uint16_t hb, lb;
-                    __builtin_memcpy(&hb, &h, 2);
-                    __builtin_memcpy(&lb, &l, 2);
-                    wh[base + ((size_t)(0 * 2 + kh) * Cout + m) * 8 + e8] = hb;
-                    wh[base + ((size_t)(1 * 2 + kh) * Cout + m) * 8 + e8] = lb;
-                }
+                for (int t = 0; t < T; ++t) put((size_t)g * blocks + (size_t)t * KBx + (k >> 4), k, m, w[(((size_t)g * Cout + m) * Cin + k) * T + t] * scale);
+            for (int k = 0; k < Cin2; ++k) put((size_t)g * blocks + (size_t)T * KBx + (k >> 4), k, m, w2[((size_t)g * Cout + m) * Cin2 + k] * scale);
+        }
     *scale_out = scale;
     return AS_OK;
+}
+extern "C" int as_prep_weight_f16x2_host(const float* w, int G, int Cout, int Cin, int T, uint16_t* wh, float* scale_out)
+{
+    return as_prep_weight_f16x2_sc_host(w, nullptr, G, Cout, Cin, T, 0, wh, scale_out);
 }
 
 // ----------------------------------------------------------------------------------------------------------------

@@ -78,6 +78,7 @@ struct GemmW {                  // a conv / linear weight prepared for as_conv_g
     float* w32 = nullptr;       // [T][Kp][M] fp32 (Cin = 1: the direct kernel)
     float scale = 1.f;
     int T = 0, Kp = 0, M = 0, K = 0, G = 1;
+    int K2 = 0;                 // channels of the second operand whose 1x1 weights follow the taps (ConvGemmArgs.Xh2: a folded shortcut)
 };
 struct Vec {
     float* p = nullptr;
@@ -117,13 +118,13 @@ struct as_model {
         return d;
     }
     // a weight given as host data [G][Cout][Cin][T]
-    const GemmW* gemm_from(const std::string& key, const float* w, int G, int Cout, int Cin, int T) const
+    const GemmW* gemm_from(const std::string& key, const float* w, int G, int Cout, int Cin, int T, const float* w2 = nullptr, int Cin2 = 0) const
     {
         GemmW g;
-        g.T = T; g.K = Cin; g.Kp = (Cin + 15) / 16 * 16; g.M = Cout; g.G = G;
-        const size_t bytes = as_prep_weight_f16x2_bytes(G, Cout, Cin, T);
+        g.T = T; g.K = Cin; g.Kp = (Cin + 15) / 16 * 16; g.M = Cout; g.G = G; g.K2 = Cin2;
+        const size_t bytes = as_prep_weight_f16x2_sc_bytes(G, Cout, Cin, T, Cin2);
         std::vector<uint16_t> img(bytes / 2);
-        if (as_prep_weight_f16x2_host(w, G, Cout, Cin, T, img.data(), &g.scale) != AS_OK) { if (!err) err = AS_EINVAL; return nullptr; }
+        if (as_prep_weight_f16x2_sc_host(w, w2, G, Cout, Cin, T, Cin2, img.data(), &g.scale) != AS_OK) { if (!err) err = AS_EINVAL; return nullptr; }
         g.wh = static_cast<uint16_t*>(pool.alloc(bytes));
         if (!g.wh || hipMemcpy(g.wh, img.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { if (!err) err = (int)hipErrorOutOfMemory; return nullptr; }
         if (Cin == 1 && G == 1) {                                          // the direct kernel's fp32 image [T][Kp][M]
@@ -153,6 +154,30 @@ struct as_model {
             w.insert(w.end(), b->v.begin(), b->v.end());
         }
         return gemm_from(key, w.data(), (int)names.size(), Cout, Cin, T);
+    }
+    // the same with the blocks' learned shortcuts `sc_names` ([Cout][Cin2][1], no bias: models.py:77,123,178) behind the taps of every
+    // weight set: the shortcut is evaluated by the launch of the block's last conv (ConvGemmArgs.Xh2 / K2)
+    const GemmW* conv_fold(const std::vector<std::string>& names, const std::vector<std::string>& sc_names) const
+    {
+        std::string key = "FOLD:";
+        for (size_t i = 0; i < names.size(); ++i) key += names[i] + "+" + sc_names[i] + "|";
+        auto it = gemm.find(key);
+        if (it != gemm.end()) return &it->second;
+        if (frozen) { if (!err) { err = AS_EINVAL; fprintf(stderr, "artspeech_hip: '%s' was not prepared by as_model_create\n", key.c_str()); } return nullptr; }
+        const HostT *a = host(names[0] + ".weight"), *s0 = host(sc_names[0] + ".weight");
+        if (!a || !s0 || names.size() != sc_names.size()) { if (!err) err = AS_EINVAL; return nullptr; }
+        const int Cout = a->dim(0), Cin = a->dim(1), T = (int)(a->numel() / ((size_t)Cout * Cin)), Cin2 = s0->dim(1);
+        std::vector<float> w, w2;
+        for (size_t i = 0; i < names.size(); ++i) {
+            const HostT *b = host(names[i] + ".weight"), *sc = host(sc_names[i] + ".weight");
+            if (!b || !sc || b->dims != a->dims || sc->dims != s0->dims || sc->dim(0) != Cout || sc->numel() != (size_t)Cout * Cin2) {
+                if (!err) err = AS_EINVAL;
+                return nullptr;
+            }
+            w.insert(w.end(), b->v.begin(), b->v.end());
+            w2.insert(w2.end(), sc->v.begin(), sc->v.end());
+        }
+        return gemm_from(key, w.data(), (int)names.size(), Cout, Cin, T, w2.data(), Cin2);
     }
     const GemmW* conv(const std::string& name, const std::string& name2 = std::string()) const
     {
@@ -562,9 +587,29 @@ struct Ctx {
     }
 };
 
+#ifdef AS_EXPERIMENTS
+// timing experiments only (results are wrong): AS_EXP_SKIP="avgpool,dwconv" drops the RUN launches whose call text holds one of the words
+static bool exp_skip(const char* call)
+{
+    static const char* e = getenv("AS_EXP_SKIP");
+    if (!e || !*e) return false;
+    std::string words(e);
+    size_t a = 0;
+    while (a <= words.size()) {
+        size_t b = words.find(',', a);
+        if (b == std::string::npos) b = words.size();
+        if (b > a && strstr(call, words.substr(a, b - a).c_str())) return true;
+        a = b + 1;
+    }
+    return false;
+}
+#define EXP_SKIP(call) exp_skip(#call)
+#else
+#define EXP_SKIP(call) false
+#endif
 #define RUN(c, call)                                   \
     do {                                               \
-        if ((c).go()) {                                \
+        if ((c).go() && !EXP_SKIP(call)) {             \
             const int r__ = (call);                    \
             if (r__ != AS_OK) (c).fail(r__, #call, __LINE__); \
         }                                              \
@@ -645,6 +690,8 @@ struct ConvOpt {
     uint16_t* yh = nullptr;
     bool yh_lrelu = false;
     bool in_image = false;        // set by conv(): the input is an operand image (xh), not fp32
+    const uint16_t* x2h = nullptr; // second operand image (K2 channels) of a weight made by conv_fold
+    int K2 = 0;
 };
 
 // Y = epi(conv(W, X)); the input is fp32 X [K][ldx] (split by the library into the workspace) or the operand image xh
@@ -652,7 +699,7 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
                int ldy, const ConvOpt& o)
 {
     if (!w || !lay) { c.fail(AS_EINVAL); return; }
-    if (w->T != taps.n || K > w->Kp || K <= w->Kp - 16) { c.fail(AS_EINVAL); return; }
+    if (w->T != taps.n || K > w->Kp || K <= w->Kp - 16 || w->K2 != o.K2 || (o.K2 && !o.in_image)) { c.fail(AS_EINVAL); return; }
     const bool in_image = o.in_image;
     ConvGemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -665,6 +712,7 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     a.in_slope = a.act_slope = AS_SLOPE_PATH;                           // LeakyReLU(0.2) everywhere on the path (models.py:163)
     a.n_prod = c.p.n_prod;
     a.n_groups = w->G; a.group_cols = o.group_cols;
+    a.Xh2 = o.x2h; a.K2 = o.K2;
     for (int i = 0; i < taps.n; ++i) { a.dh[i] = taps.dh[i]; a.dw[i] = taps.dw[i]; }
     const bool pointwise = taps.n == 1 && taps.dh[0] == 0 && taps.dw[0] == 0;
     if (lay->N == 0) return;
@@ -673,6 +721,7 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     q.X = in_image ? nullptr : reinterpret_cast<const float*>(16);
     q.Xh = in_image ? reinterpret_cast<const uint16_t*>(16) : nullptr;
     q.Yh = o.want_yh ? reinterpret_cast<uint16_t*>(16) : nullptr;
+    q.Xh2 = o.K2 ? reinterpret_cast<const uint16_t*>(16) : nullptr;
     const size_t wsb = as_conv_gemm_workspace_bytes(&q);
     if (getenv("AS_DEBUG_ALLOC"))
         fprintf(stderr, "artspeech_hip: conv %s M%d N%d K%d T%d G%d img%d -> ws %zu (arena at %zu)\n", c.count ? "count" : (c.launch ? "run" : "replay"), a.M,
@@ -792,6 +841,7 @@ struct BlkOpt {
     bool want_yh = false;              // also write the output as an operand image
     uint16_t* yh = nullptr;            // (where; null with want_yh: from the workspace)
     float* sc_tmp = nullptr;           // learned-shortcut result when `out` aliases rows of X (decoder: in-place on the concat buffer)
+    bool yh_over_x = false;            // `yh` is X's own image (the same blocks): the shortcut cannot be read by the launch that overwrites it
 };
 
 Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
@@ -800,8 +850,11 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
     Act Y;
     const int G = (int)o.names.size();
     auto sfx = [&](const char* s) { std::vector<std::string> v(o.names); for (auto& n : v) n += s; return v; };
-    const GemmW *w1 = m.conv_stack(sfx(".conv1")), *w2 = m.conv_stack(sfx(".conv2"));
     const bool has_sc = m.has(o.names[0] + ".conv1x1.weight");
+    // A learned shortcut whose input exists as an operand image is summed by conv2's launch (K2 more channels of its reduction)
+    // -- unless that launch writes its result image over the very image it would read (the decoder's in-place blocks).
+    const bool fold = has_sc && X.h && !o.upsample && !o.yh_over_x;
+    const GemmW *w1 = m.conv_stack(sfx(".conv1")), *w2 = fold ? m.conv_fold(sfx(".conv2"), sfx(".conv1x1")) : m.conv_stack(sfx(".conv2"));
     if (!w1 || !w2 || !X.lay) { c.fail(AS_EINVAL); return Y; }
     const int din = X.C, dout = w1->M;
     const Lay* lay_in = o.upsample && o.lay_out ? o.lay_out : X.lay;     // utterances of the block's (pre-doubling) output layout
@@ -831,7 +884,7 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
     q1.bias = m.bias_stack(sfx(".conv1"));
     q1.group_cols = gc2;
     float* h1 = conv_h_new(c, w1, xs, din, lay2, k3, q1);
-    if (has_sc) {                                                       // learned shortcut (models.py:185-186), no bias
+    if (has_sc && !fold) {                                              // learned shortcut (models.py:185-186), no bias
         ConvOpt q;
         q.group_cols = gc2;
         float* dst = o.sc_tmp ? o.sc_tmp : out;
@@ -846,8 +899,13 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
     adain_image(c, h1, N2, dout, o.n2, lay2, nullptr, N2, xs2);
     ConvOpt q2;
     q2.bias = m.bias_stack(sfx(".conv2"));
-    q2.res = sc;
-    q2.ldr = ldsc;
+    if (fold) {
+        q2.x2h = X.h;
+        q2.K2 = din;
+    } else {
+        q2.res = sc;
+        q2.ldr = ldsc;
+    }
     q2.div_sqrt2 = true;                                                // (res + sc) / sqrt(2), models.py:201
     q2.group_cols = gc2;
     if (o.want_yh) {
@@ -1053,29 +1111,30 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
     as_prof_hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
     RUN(c, as_dwconv_down_image_f32(r, lay->N, lay->d_off, lay->d_w, lay->H, lay2->d_off, lay2->d_w, lay2->H, dww, dwb, half ? 3 : 1, B, cin,
                                     lay2->max_cols(), 1, r2h, lay2->N, c.s));
-    const GemmW* w2 = m.conv(p + ".conv2");
+    const bool has_sc = m.has(p + ".conv1x1.weight");
+    const GemmW* w2 = has_sc ? m.conv_fold({p + ".conv2"}, {p + ".conv1x1"}) : m.conv(p + ".conv2");
     if (!w2) { c.fail(AS_EINVAL); return Y; }
     ConvOpt o2;
     o2.bias = m.bias(p + ".conv2");
-    float* r3 = conv_h_new(c, w2, r2h, cin, lay2, taps, o2);
     float* out;
     uint16_t* outh = want_image ? c.image(w2->M, lay2->N) : nullptr;
-    if (m.has(p + ".conv1x1.weight")) {
+    if (has_sc) {
         // shortcut = avgpool(conv1x1(x)) (models.py:79-84).  Both are linear and the 1x1 conv has no bias, so it is evaluated as
-        // conv1x1(avgpool(x)): a quarter of the columns, and the merge (x + r)/sqrt(2) becomes the GEMM's epilogue.
+        // conv1x1(avgpool(x)): a quarter of the columns -- as `cin` more channels of conv2's reduction (conv_fold), the merge
+        // (x + r)/sqrt(2) in that launch's epilogue: the residual branch never exists on its own.
         uint16_t* xsh = c.image(cin, lay2->N);
         as_prof_hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
         RUN(c, as_avgpool_down_image_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, nullptr, 0, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, nullptr,
                                          0, B, cin, lay2->max_cols(), xsh, lay2->N, 0, c.s));
-        ConvOpt o3;
-        o3.res = r3;
-        o3.ldr = lay2->N;
-        o3.div_sqrt2 = true;
-        o3.want_yh = want_image;
-        o3.yh = outh;
-        o3.yh_lrelu = true;
-        out = conv_h_new(c, m.conv(p + ".conv1x1"), xsh, cin, lay2, taps_1d(1), o3);
+        o2.x2h = xsh;
+        o2.K2 = cin;
+        o2.div_sqrt2 = true;
+        o2.want_yh = want_image;
+        o2.yh = outh;
+        o2.yh_lrelu = true;
+        out = conv_h_new(c, w2, r2h, cin, lay2, taps, o2);
     } else {
+        float* r3 = conv_h_new(c, w2, r2h, cin, lay2, taps, o2);
         out = c.f32((size_t)w2->M * N2);
         as_prof_hint(0, 4.0 * cin * ((double)lay->N + (want_image ? 3.0 : 2.0) * lay2->N));
         if (want_image)
@@ -1482,6 +1541,7 @@ void decoder(Ctx& c, float* x0, const Lay* lay2, const float* fne, int ldp, cons
         o.out = catb; o.ldo = N2;
         o.want_yh = true; o.yh = cath;
         o.sc_tmp = sc_tmp;
+        o.yh_over_x = true;
         adain_resblk1d(c, xc, o);
     }
     Act y;

@@ -148,14 +148,28 @@ def split_f16x2_weight(w4):
     return img.contiguous().view(torch.int16).reshape(G, T, kx // 16, 4, M, 8), scale
 
 
-def prep_weight(w, device=None, stack=None):
+def prep_weight(w, device=None, stack=None, sc=None):
     """conv / linear weight [Cout, Cin, *kernel] -> GemmWeight.  stack: further weights of the same shape (a grouped launch:
-    weight set g serves the columns [g * group_cols, (g+1) * group_cols))."""
+    weight set g serves the columns [g * group_cols, (g+1) * group_cols)).  sc: the weight(s) [Cout, Cin2] of a 1x1 conv on a second
+    operand (conv_gemm(..., x2s=, K2=): a block's learned shortcut summed by the same launch), one per weight set."""
     ws = [w] + list(stack or [])
     cout, cin = w.shape[0], w.shape[1]
     w4 = torch.stack([x.reshape(cout, cin, -1).float() for x in ws], 0).cpu()
     T = w4.shape[3]
     kp = (cin + KTILE - 1) // KTILE * KTILE
+    if sc is not None:
+        scs = list(sc) if isinstance(sc, (list, tuple)) else [sc]
+        w2 = torch.stack([x.reshape(cout, -1).float() for x in scs], 0).cpu().contiguous()      # [G][Cout][Cin2]
+        G, cin2 = len(ws), w2.shape[2]
+        assert w2.shape[0] == G
+        L = _lib.lib()
+        nbytes = L.as_prep_weight_f16x2_sc_bytes(G, cout, cin, T, cin2)
+        img = torch.empty(nbytes // 2, dtype=torch.int16)
+        scale = ctypes.c_float()
+        w4c = w4.contiguous()
+        check(L.as_prep_weight_f16x2_sc_host(w4c.data_ptr(), w2.data_ptr(), G, cout, cin, T, cin2, img.data_ptr(), ctypes.byref(scale)),
+              "as_prep_weight_f16x2_sc_host")
+        return GemmWeight(img.to(device) if device is not None else img, scale.value, (T, kp, cout), G, None)
     img, scale = split_f16x2_weight(w4)
     w32 = None
     if cin == 1 and len(ws) == 1:
@@ -228,11 +242,13 @@ def project_cols(X, N, w, bias, Y):
 
 
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
-              use_meta=True, in_slope=0.2, act_slope=0.2, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None, plan_out=None):
+              use_meta=True, in_slope=0.2, act_slope=0.2, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None, plan_out=None,
+              x2s=None, K2=0):
     """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt: prep_weight(...); X [K][*] fp32 or None with xs= (the split image of
     X: split_act / adain_split / channel_layernorm_split / another conv's yh=) and K=; Y [M][*] (or [N][*] transposed) or None
     when only yh (the output as the next conv's split image, new_image(M, N)) is wanted.  group_cols: Wt holds Wt.G weight
-    sets (and bias [G][M]); columns [g * group_cols, (g+1) * group_cols) use set g."""
+    sets (and bias [G][M]); columns [g * group_cols, (g+1) * group_cols) use set g.  x2s / K2: the split image of a second operand
+    whose 1x1 conv (weights: prep_weight(..., sc=)) is summed into the same accumulators (needs xs=)."""
     T, Kp, M = Wt.shape
     if X is None:
         if xs is None or K is None:
@@ -254,6 +270,7 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     a.ldr = _ld(res) if res is not None else 0
     a.act, a.div_sqrt2, a.in_act, a.transpose_out = act, int(div_sqrt2), in_act, int(transpose_out)
     a.yh_lrelu = int(yh_lrelu)
+    a.Xh2, a.K2 = _p(x2s), K2
     a.n_prod = n_prod if n_prod is not None else (1 if GEMM_IMPL == "h1" else 3)
     a.in_slope, a.act_slope = in_slope, act_slope          # used as given (the acoustic path's LeakyReLU slope is 0.2)
     assert len(taps) == T

@@ -238,7 +238,7 @@ def mfma_sustained():
 
 def profile_classes(net, runner, steps=3):
     """per-kernel-class time with HIP events on the launch stream, eager launches, the concurrent branches run back to back so that
-    an event-bracketed duration is the kernel's own.  `ms_per_step` = the bracketed time minus the brackets' own cost (launches x
+    an event-bracketed duration is the kernel's own; per class the median of `steps` steps.  `ms_per_step` = the bracketed time minus the brackets' own cost (launches x
     bracket_overhead_ms(): the command processor's work between two event markers, ~4-5 us, which a kernel trace does not count --
     with it removed the figures agree with rocprofv3's kernel durations, profiles/README.md); `ms_per_step_bracketed` = as measured."""
     from artspeech_amd import _lib
@@ -247,18 +247,26 @@ def profile_classes(net, runner, steps=3):
     runner.step()
     torch.cuda.synchronize()
     o = bracket_overhead_ms()
-    L.as_prof_enable(1)
-    for _ in range(steps):
-        runner.step()
     n = len(CLASSES)
-    ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
-    cnt = (ctypes.c_int32 * n)()
-    _lib.check(L.as_prof_collect(ms, fl, by, cnt, n), "as_prof_collect")
+    per_step = []
+    for _ in range(steps):                                  # one collection per step: the MEDIAN step per class (an eager launch that the host
+        L.as_prof_enable(1)                                 # submits late, e.g. under a profiler, stretches its bracket by milliseconds)
+        runner.step()
+        ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+        cnt = (ctypes.c_int32 * n)()
+        _lib.check(L.as_prof_collect(ms, fl, by, cnt, n), "as_prof_collect")
+        per_step.append((list(ms), list(fl), list(by), list(cnt)))
     L.as_prof_enable(0)
     net.rt.set_serial(False)
-    return {CLASSES[i]: dict(ms_per_step=max(ms[i] - cnt[i] * o, 0.0) / steps, ms_per_step_bracketed=ms[i] / steps,
-                             launches_per_step=cnt[i] // steps, gflop_per_step=fl[i] / steps / 1e9,
-                             gbyte_per_step=by[i] / steps / 1e9) for i in range(n) if cnt[i]}
+    out = {}
+    for i in range(n):
+        if not per_step[0][3][i]:
+            continue
+        order = sorted(range(steps), key=lambda k: per_step[k][0][i])
+        ms_i, fl_i, by_i, cnt_i = (per_step[order[steps // 2]][j][i] for j in range(4))
+        out[CLASSES[i]] = dict(ms_per_step=max(ms_i - cnt_i * o, 0.0), ms_per_step_bracketed=ms_i, launches_per_step=cnt_i,
+                               gflop_per_step=fl_i / 1e9, gbyte_per_step=by_i / 1e9)
+    return out
 
 
 def gemm_roofline(kern, n_prod):

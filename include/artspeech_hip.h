@@ -165,11 +165,17 @@ typedef struct ConvGemmArgs {
     int32_t n_groups, group_cols;
     int32_t range_probe;       /* library-owned (as_conv_gemm_f32 overwrites both): as_set_range_probe's switch ... */
     uint32_t* status;          /* ... and the device's status words (as_device_status) */
+    /* A 1x1 convolution of a SECOND operand summed into the same accumulators before the epilogue -- a residual block's learned
+     * shortcut (models.py:79-84,185-186: conv1x1, no bias) evaluated by the launch of the block's last conv, as K2 more channels
+     * of the reduction: Y = epi(sum_t W_t X(t) + W2 X2).  Xh2: split image [KBx2][4][N+1][8] of X2 (same N and column order as
+     * Xh); its weights follow the T taps inside every weight set (as_prep_weight_f16x2_sc_host).  K2 = 0: none.  Needs Xh. */
+    const uint16_t* Xh2;
+    int32_t K2;
 } ConvGemmArgs;
 #define AS_SLOPE_PATH 0.2f
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
 /* which kernel as_conv_gemm_f32 runs for these arguments (tests, tuning): *kind 0 = the direct Cin = 1 kernel, 1 = the tiled kernel
- * (*tile = 22 / 21 / 12 / 11 / 2: 128x128, 128x64, 64x128, 64x64, 32x128); *slices = K slices */
+ * (*tile = 22 / 21 / 12 / 11 / 14 / 2: 128x128, 128x64, 64x128, 64x64, 64x256, 32x128); *slices = K slices */
 int as_conv_gemm_plan(const ConvGemmArgs* args_host, int32_t* kind, int32_t* tile, int32_t* slices);
 /* Bytes of workspace this shape wants (0 = none): split-K slabs for shapes whose tile grid cannot fill the 256 CUs (a second
  * kernel sums the slabs in a fixed order: deterministic), then the split image of X when Xh is NULL. */
@@ -183,6 +189,11 @@ int as_split_f16x2_f32(const float* x, int ldx, int K, int N, int in_act, float 
  * scaled by *scale_out = the power of two that puts max |w| in [2^13, 2^14).  Pass ConvGemmArgs.acc_scale = 1 / *scale_out. */
 size_t as_prep_weight_f16x2_bytes(int G, int Cout, int Cin, int T);
 int as_prep_weight_f16x2_host(const float* w_host, int G, int Cout, int Cin, int T, uint16_t* wh_host, float* scale_out);
+/* The same with the weights w2 fp32 [G][Cout][Cin2] of a 1x1 convolution on a second operand (ConvGemmArgs.Xh2 / K2) appended to every
+ * weight set: wh [G][T * KBx + KBx2][4][Cout][8], one common scale.  Cin2 = 0 (w2 NULL): exactly the functions above. */
+size_t as_prep_weight_f16x2_sc_bytes(int G, int Cout, int Cin, int T, int Cin2);
+int as_prep_weight_f16x2_sc_host(const float* w_host, const float* w2_host, int G, int Cout, int Cin, int T, int Cin2, uint16_t* wh_host,
+                                 float* scale_out);
 
 /* ---------------------------------------------------------------------------------------------
  * Bandwidth-bound kernels on packed frames.  col_off int32 [B+1] = first column of each utterance.

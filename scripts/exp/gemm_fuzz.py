@@ -46,7 +46,7 @@ for case in range(n_cases):
     if act == 2: ref = torch.where(ref > 0, ref, 0.2 * ref)
     wt = ops.prep_weight(w, dev)
     scale = float(ref.abs().max()) + 1.0
-    for tile in ("", "11", "12", "21", "22", "2"):
+    for tile in ("", "11", "12", "14", "21", "22", "2"):
         if tile == "2" and M > 32: continue
         if tile in ("21", "22") and M <= 64: continue
         for ks in ("", "3"):

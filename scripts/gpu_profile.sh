@@ -23,7 +23,7 @@ AS_PROF_CSV=$OUT/gemm_launches_events.csv python3 $R/bench.py --steps 5 --warmup
 # the multi-rank launch path on this one-GPU box (two ranks on GPU 0, gloo for the barrier: AS_BENCH_TEST_ONE_GPU=1), weak scaling and C4
 cd $R
 for mode in weak c4; do
-  if [ $mode = weak ]; then EXTRA="--steps 20 --warmup 5 --no-extras"; else EXTRA="--steps 5 --warmup 2 --global-batch 64"; fi
+  if [ $mode = weak ]; then EXTRA="--steps 20 --warmup 5 --no-extras"; else EXTRA="--steps 3 --warmup 1 --global-batch 256"; fi
   AS_BENCH_TEST_ONE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --cpu-utts 0 $EXTRA > $OUT/two_ranks_$mode.log 2>&1
 done
 cd /tmp

@@ -43,7 +43,7 @@ def split_ref(x):
 
 @pytest.mark.parametrize("cin,cout,k,lens", [(64, 128, 3, [50, 13, 1, 200]), (10, 64, 1, [7, 9]), (1, 32, 1, [33]),
                                              (96, 80, 5, [40, 41]), (130, 257, 9, [17, 300, 64]), (512, 1024, 3, [128] * 8)])
-@pytest.mark.parametrize("tile", ["", "11", "21", "22", "12"] + (["42"] if EXPERIMENTS else []))
+@pytest.mark.parametrize("tile", ["", "11", "21", "22", "12", "14"] + (["42"] if EXPERIMENTS else []))
 def test_conv1d_gemm(cuda, monkeypatch, impl, cin, cout, k, lens, tile):
     if tile:
         monkeypatch.setenv("AS_GEMM_TILE", tile)
@@ -60,6 +60,38 @@ def test_conv1d_gemm(cuda, monkeypatch, impl, cin, cout, k, lens, tile):
     y = ops.conv_gemm(wt, packed(xs).to(cuda), lay, lay.new(cout), taps_1d(k), bias=b.to(cuda), res=packed(res).to(cuda), div_sqrt2=True)
     err = float((y.cpu() - want).abs().max())
     assert err <= 2e-5, err
+
+
+@pytest.mark.parametrize("cin,cout,cin2,k,lens,groups", [(64, 128, 64, 3, [50, 13, 1, 200], 1), (128, 64, 40, 9, [300], 1), (16, 512, 1216, 3, [128] * 8, 1),
+                                                          (512, 256, 512, 3, [40] * 9, 3), (96, 80, 200, 1, [40, 41], 1)])
+@pytest.mark.parametrize("tile,ksplit", [("", ""), ("11", ""), ("21", "3"), ("22", ""), ("12", "2"), ("14", "")])
+def test_conv_gemm_second_operand(cuda, monkeypatch, impl, cin, cout, cin2, k, lens, groups, tile, ksplit):
+    """ConvGemmArgs.Xh2 / K2: a block's learned shortcut (models.py:79-84,185-186: conv1x1, no bias) as K2 more channels of the
+    reduction of the block's last conv -- against conv(x) + conv1x1(x2) in float64, every tile, split-K, grouped weight sets."""
+    if tile:
+        monkeypatch.setenv("AS_GEMM_TILE", tile)
+    if ksplit:
+        monkeypatch.setenv("AS_GEMM_KSPLIT", ksplit)
+    g = torch.Generator().manual_seed(cin + 3 * cout + cin2 + k)
+    G = groups
+    ws = [torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k) for _ in range(G)]
+    w2 = [torch.randn(cout, cin2, generator=g) / np.sqrt(cin2) * 3.0 for _ in range(G)]       # (another magnitude: one common scale)
+    b = torch.randn(G, cout, generator=g)
+    per = len(lens) // G
+    xs = [torch.randn(cin, L, generator=g) for L in lens]
+    x2 = [torch.randn(cin2, L, generator=g) for L in lens]
+    want = packed([(F.conv1d(x[None].double(), ws[i // per].double(), b[i // per].double(), padding=k // 2)[0] + w2[i // per].double() @ z.double()) / np.sqrt(2)
+                   for i, (x, z) in enumerate(zip(xs, x2))])
+    lay = Layout(lens, cuda)
+    gc = sum(lens[:per]) if G > 1 else 0
+    wt = ops.prep_weight(ws[0], cuda, stack=ws[1:], sc=w2)
+    X, X2 = packed(xs).to(cuda), packed(x2).to(cuda)
+    xh, x2h = ops.split_act(X, lay), ops.split_act(X2, lay)
+    yh = ops.new_image(cout, lay.N, cuda)
+    y = ops.conv_gemm(wt, None, lay, lay.new(cout), taps_1d(k), bias=b.to(cuda), div_sqrt2=True, xs=xh, K=cin, x2s=x2h, K2=cin2, group_cols=gc, yh=yh)
+    err = float((y.double().cpu() - want).abs().max())
+    assert err <= 3e-5, err
+    assert torch.equal(yh, ops.split_act(y, lay))
 
 
 @pytest.mark.parametrize("widths", [[23, 8, 40], [23, 23, 23], [12, 8, 40]])
@@ -102,7 +134,7 @@ def test_split_activations(cuda, K, lens, lrelu):
 
 
 @pytest.mark.parametrize("M,K,lens,tile,ksplit", [(128, 64, [50, 13, 1, 200], "22", "")] + ([(300, 64, [50, 13, 1, 200], "42", ""), (256, 48, [129], "42", "2")] if EXPERIMENTS else []) + [(80, 96, [40, 41], "21", ""), (257, 130, [17, 300, 64], "", ""),
-                                                  (64, 64, [333], "12", ""), (200, 200, [33, 70], "", "3"), (512, 512, [40] * 32, "", "")])
+                                                  (64, 64, [333], "12", ""), (64, 64, [333, 300], "14", ""), (40, 48, [700], "14", "2"), (200, 200, [33, 70], "", "3"), (512, 512, [40] * 32, "", "")])
 @pytest.mark.parametrize("lrelu", [False, True])
 def test_epilogue_writes_split_image(cuda, monkeypatch, M, K, lens, tile, ksplit, lrelu):
     """ConvGemmArgs.Yh: the GEMM's epilogue (and the split-K reduce kernel) writes its output as the split operand image of the
