@@ -320,7 +320,7 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if (norm.n_groups < 1) norm.n_groups = 1;
     // a 1x1 conv reads every column from itself: no tap can leave the utterance, so the kernels need not fetch the column descriptors
     // (one dependent global load at the head of every workgroup)
-    if (norm.T == 1 && norm.dh[0] == 0 && norm.dw[0] == 0) norm.meta = nullptr;
+    if (norm.T == 1 && norm.dh[0] == 0 && norm.dw[0] == 0 && !norm.src_col) norm.meta = nullptr;
     const ConvGemmArgs& a = norm;
     if (a.act < 0 || a.act > 5 || (a.in_act != 0 && a.in_act != 2) || (a.n_prod != 1 && a.n_prod != 3)) return AS_EINVAL;
     if ((!a.Wh && !(a.W && a.K == 1)) || (!a.X && !a.Xh) || (!a.Y && !a.Yh) || a.M <= 0 || a.N < 0 || a.K <= 0 || a.T <= 0 || a.T > AS_MAX_TAPS)
@@ -329,6 +329,7 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if (a.K2 < 0 || (a.K2 > 0 && (!a.Xh2 || !a.Xh || !a.Wh || (reinterpret_cast<uintptr_t>(a.Xh2) & 15) != 0 ||
                                   (double)as_kbx(a.K2) * 64.0 * (a.N + 1.0) >= 2147483648.0)))
         return AS_EINVAL;                                                // the second operand comes as an image, beside an image
+    if (a.src_col && (!a.Xh || !a.meta || a.K2 || a.N_in <= 0)) return AS_EINVAL;   // own input layout: an image, with the input positions
     if (a.n_groups > 1 && (a.group_cols <= 0 || (long)a.group_cols * a.n_groups < a.N)) return AS_EINVAL;
     if ((a.X && a.ldx < a.N) || (a.Y && a.ldy < (a.transpose_out ? a.M : a.N)) || (a.res && (a.ldr < a.N || a.transpose_out)) ||
         (a.Yh && a.transpose_out))

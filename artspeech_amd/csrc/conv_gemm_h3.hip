@@ -93,7 +93,7 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
         n_end = min(a.N, (grp + 1) * a.group_cols);
     }
     const int KB = a.Kp >> 4, KBx = (KB + 3) & ~3;
-    const int NX = a.N + 1;                                              // columns of the activation image (the last one is zero)
+    const int NX = (a.src_col ? a.N_in : a.N) + 1;                       // columns of the activation image (the last one is zero)
 
     const int KB2 = (a.K2 + 15) >> 4, KBx2 = (KB2 + 3) & ~3;             // the second operand's k-blocks (0: none)
     const unsigned w_bytes = ((unsigned)a.T * KBx + KBx2) * 4u * a.M * 16u;   // one weight set
@@ -141,7 +141,9 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     }
     // source column of a tap for this thread's column, one formula for both encodings:
     //   src = j + (byte >> 4) * tA + (byte & 15) + tC;  narrow: tA = Wj, tC = -8 Wj - 8;  wide: tA = 16, tC = -128
-    const int tA = tp.wide ? 16 : Wj, tC = j + (tp.wide ? -128 : -8 * Wj - 8);
+    // (strided / valid convs: the output column's tap (0, 0) reads input column src_col[j]; meta describes that input position)
+    const int jsrc = a.src_col ? (j < n_end ? a.src_col[j] : 0) : j;
+    const int tA = tp.wide ? 16 : Wj, tC = jsrc + (tp.wide ? -128 : -8 * Wj - 8);
 
     // iterations: an iteration covers KBS k-blocks of one tap (the tail of a tap re-reads zero blocks: KBx is a multiple of 4
     // and the weights' zero rows make them harmless as long as KBS divides 4 or the cursor clamps -- see advance)
@@ -171,7 +173,7 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
             byte = tp.wide ? 128 : 0x88;
             ok = 0u - (unsigned)(j < n_end);
         }
-        const unsigned src = ((unsigned)((byte >> 4) * tA + (byte & 15) + tC) & ok) | ((unsigned)a.N & ~ok);
+        const unsigned src = ((unsigned)((byte >> 4) * tA + (byte & 15) + tC) & ok) | ((unsigned)(NX - 1) & ~ok);
 #pragma unroll
         for (int i = 0; i < BCH; ++i) bv[i] = b_plane[i] + src * 16u;
     };
@@ -426,7 +428,7 @@ static int launch_h3_tile(const ConvGemmArgs& a, int S, hipStream_t stream)
 
 int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream)
 {
-    if ((double)as_kbx(a.K) * 4.0 * (a.N + 1.0) * 16.0 >= 2147483648.0) return AS_EINVAL;   // 32-bit offsets in the descriptor
+    if ((double)as_kbx(a.K) * 4.0 * ((a.src_col ? a.N_in : a.N) + 1.0) * 16.0 >= 2147483648.0) return AS_EINVAL;   // 32-bit offsets in the descriptor
     switch (choice) {
 #ifdef AS_EXPERIMENTS
     case 42:                                                            // 256 x 128, a wave owns 128 x 64

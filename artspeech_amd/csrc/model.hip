@@ -692,6 +692,9 @@ struct ConvOpt {
     bool in_image = false;        // set by conv(): the input is an operand image (xh), not fp32
     const uint16_t* x2h = nullptr; // second operand image (K2 channels) of a weight made by conv_fold
     int K2 = 0;
+    const int32_t* src_col = nullptr;   // strided / valid conv: `lay` is the OUTPUT layout, the image has N_in columns, output column j
+    const uint64_t* src_meta = nullptr; // reads input column src_col[j] (+ taps), src_meta[j] = that input position (ConvGemmArgs.src_col)
+    int N_in = 0;
 };
 
 // Y = epi(conv(W, X)); the input is fp32 X [K][ldx] (split by the library into the workspace) or the operand image xh
@@ -713,6 +716,7 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     a.n_prod = c.p.n_prod;
     a.n_groups = w->G; a.group_cols = o.group_cols;
     a.Xh2 = o.x2h; a.K2 = o.K2;
+    a.N_in = o.N_in;
     for (int i = 0; i < taps.n; ++i) { a.dh[i] = taps.dh[i]; a.dw[i] = taps.dw[i]; }
     const bool pointwise = taps.n == 1 && taps.dh[0] == 0 && taps.dw[0] == 0;
     if (lay->N == 0) return;
@@ -729,7 +733,9 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     a.ws = wsb ? c.raw_alloc(wsb) : nullptr;
     a.ws_bytes = wsb;
     if (!c.go()) return;
-    a.meta = pointwise ? nullptr : c.meta(lay);
+    if (o.N_in && !o.src_col) { c.fail(AS_EINVAL); return; }
+    a.meta = o.N_in ? o.src_meta : (pointwise ? nullptr : c.meta(lay));
+    a.src_col = o.src_col;
     RUN(c, as_conv_gemm_f32(&a, c.s));
 }
 
@@ -1173,7 +1179,7 @@ void tower2d(Ctx& c, const std::string& p, const float* X, const Lay* lay, const
     Act x = tower_stem(c, p + ".0", X, lay->N, lay, taps_2d(3, 3));
     if (!x.lay) return;
     for (size_t i = 0; i < halves.size(); ++i) {
-        x = resblk_down(c, p + "." + std::to_string(i + 1), x, halves[i], false, i + 1 < halves.size());
+        x = resblk_down(c, p + "." + std::to_string(i + 1), x, halves[i], false, true);   // (the last block's LeakyReLU image feeds the valid conv)
         if (!x.lay) return;
     }
     const int K = 5, C = x.C;
@@ -1185,23 +1191,37 @@ void tower2d(Ctx& c, const std::string& p, const float* X, const Lay* lay, const
         return;
     }
     const std::string ln = p + "." + std::to_string(last_idx);
-    const HostT* wraw = m.host(ln + ".weight");
-    if (!wraw) return;
-    const GemmW* wl = nullptr;
-    {
-        const std::string key = "IM2COL:" + p;                              // [Cout][C][5][5] -> one tap with K = C*25 (im2col row order)
-        auto it = m.gemm.find(key);
-        wl = it != m.gemm.end() ? &it->second : (m.frozen ? nullptr : m.gemm_from(key, wraw->v.data(), 1, wraw->dim(0), C * K * K, 1));
-        if (!wl) { c.fail(AS_EINVAL); return; }
-    }
-    // LeakyReLU -> im2col (models.py:390-391,398-399,534-535), written as the last conv's operand image
-    uint16_t* colh = c.image(C * K * K, lout->N);
-    as_prof_hint(0, 4.0 * C * ((double)x.lay->N + (double)K * K * lout->N));
-    RUN(c, as_im2col_valid_image_f32(x.p, x.ld, x.lay->d_off, x.lay->d_w, lout->d_off, lout->d_w, K, last_stride, 1, lay->B, C, colh, c.s));
+    const GemmW* wl = m.conv(ln);
+    if (!wl || wl->T != K * K || wl->K != C) { c.fail(AS_EINVAL); return; }
+    // LeakyReLU -> K x K valid conv (models.py:390-391,398-399,534-535) straight from the last block's LeakyReLU image: the outputs are their
+    // own layout, output (ho, wo) reads the input at (ho s + a, wo s + d), a, d = 0 .. K-1 (ConvGemmArgs.src_col).  No im2col matrix.
+    const Lay* lin = x.lay;
+    std::string key = "valid:" + std::to_string(K) + ":" + std::to_string(last_stride) + ":" + std::to_string(lin->H);
+    for (int v : lin->w) key += ":" + std::to_string(v);
+    const int32_t* tab = c.itable(lout, key, [&]() {                      // [N_out] source columns, then [N_out] descriptors (two words each)
+        std::vector<int32_t> t((size_t)lout->N * 3 + 1, 0);
+        const size_t mo = ((size_t)lout->N + 1) & ~(size_t)1;             // 8-byte aligned start of the descriptors
+        for (int b = 0, j = 0; b < lout->B; ++b)
+            for (int ho = 0; ho < lout->H; ++ho)
+                for (int wo = 0; wo < lout->w[b]; ++wo, ++j) {
+                    const int h = ho * last_stride, w = wo * last_stride;
+                    t[j] = lin->off[b] + h * lin->w[b] + w;
+                    const uint64_t md = (uint64_t)h | ((uint64_t)w << 16) | ((uint64_t)lin->H << 32) | ((uint64_t)lin->w[b] << 48);
+                    memcpy(&t[mo + 2 * (size_t)j], &md, 8);
+                }
+        return t;
+    });
     ConvOpt o2;
     o2.bias = m.bias(ln);
     o2.act = ACT_LRELU;
-    float* z = conv_h_new(c, wl, colh, C * K * K, lout, taps_1d(1), o2);
+    o2.src_col = tab;
+    o2.src_meta = tab ? reinterpret_cast<const uint64_t*>(tab + (((size_t)lout->N + 1) & ~(size_t)1)) : nullptr;
+    o2.N_in = lin->N;
+    Taps tv;
+    tv.n = K * K;
+    for (int a = 0; a < K; ++a)
+        for (int d = 0; d < K; ++d) { tv.dh[a * K + d] = a; tv.dw[a * K + d] = d; }
+    float* z = conv_h_new(c, wl, x.h, C, lout, tv, o2);
     float* pooled = c.f32((size_t)lay->B * wl->M);
     RUN(c, as_mean_pool_f32(z, lout->N, lout->d_off, lay->B, wl->M, 0, pooled, wl->M, c.s));
     const HostT* lw = m.host(linear + ".weight");

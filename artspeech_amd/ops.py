@@ -180,6 +180,20 @@ def prep_weight(w, device=None, stack=None, sc=None):
     return GemmWeight(img, scale, (T, kp, cout), len(ws), w32)
 
 
+def strided_source(lay_in, lay_out, stride, device):
+    """(src_col int32 [N_out], src_meta int64 [N_out]) of a valid conv with taps (a, d) >= 0 from lay_in to lay_out: output (ho, wo)
+    of utterance b reads input position (ho * stride + a, wo * stride + d); descriptor = h | w << 16 | H << 32 | W << 48 of the INPUT."""
+    cols, metas = [], []
+    for b in range(lay_out.B):
+        Wi, Wo = lay_in.widths_host[b], lay_out.widths_host[b]
+        for ho in range(lay_out.H):
+            for wo in range(Wo):
+                h, w = ho * stride, wo * stride
+                cols.append(lay_in.off_host[b] + h * Wi + w)
+                metas.append(h | (w << 16) | (lay_in.H << 32) | (Wi << 48))
+    return torch.tensor(cols, dtype=torch.int32, device=device), torch.tensor(metas, dtype=torch.int64, device=device)
+
+
 def taps_1d(k):
     return [(0, t - k // 2) for t in range(k)]
 
@@ -243,12 +257,14 @@ def project_cols(X, N, w, bias, Y):
 
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
               use_meta=True, in_slope=0.2, act_slope=0.2, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None, plan_out=None,
-              x2s=None, K2=0):
+              x2s=None, K2=0, src_col=None, src_meta=None, N_in=0):
     """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt: prep_weight(...); X [K][*] fp32 or None with xs= (the split image of
     X: split_act / adain_split / channel_layernorm_split / another conv's yh=) and K=; Y [M][*] (or [N][*] transposed) or None
     when only yh (the output as the next conv's split image, new_image(M, N)) is wanted.  group_cols: Wt holds Wt.G weight
     sets (and bias [G][M]); columns [g * group_cols, (g+1) * group_cols) use set g.  x2s / K2: the split image of a second operand
-    whose 1x1 conv (weights: prep_weight(..., sc=)) is summed into the same accumulators (needs xs=)."""
+    whose 1x1 conv (weights: prep_weight(..., sc=)) is summed into the same accumulators (needs xs=).  src_col / src_meta / N_in: a
+    strided or valid conv -- `lay` is the OUTPUT layout, xs an image over N_in input columns, output column j reads input column
+    src_col[j] + dh * W_in + dw and src_meta[j] (strided_source) describes that input position."""
     T, Kp, M = Wt.shape
     if X is None:
         if xs is None or K is None:
@@ -271,6 +287,8 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     a.act, a.div_sqrt2, a.in_act, a.transpose_out = act, int(div_sqrt2), in_act, int(transpose_out)
     a.yh_lrelu = int(yh_lrelu)
     a.Xh2, a.K2 = _p(x2s), K2
+    if src_col is not None:
+        a.src_col, a.N_in, a.meta = _p(src_col), N_in, _p(src_meta)
     a.n_prod = n_prod if n_prod is not None else (1 if GEMM_IMPL == "h1" else 3)
     a.in_slope, a.act_slope = in_slope, act_slope          # used as given (the acoustic path's LeakyReLU slope is 0.2)
     assert len(taps) == T

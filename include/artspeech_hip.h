@@ -171,6 +171,12 @@ typedef struct ConvGemmArgs {
      * Xh); its weights follow the T taps inside every weight set (as_prep_weight_f16x2_sc_host).  K2 = 0: none.  Needs Xh. */
     const uint16_t* Xh2;
     int32_t K2;
+    /* Strided / valid convolutions (the 5x5 valid convs that close the 2-D towers, models.py:391,399,535): the OUTPUT columns are their
+     * own layout (N of them) and output column j reads the input image at column src_col[j] + dh * W_in + dw, where meta[j] now
+     * describes that INPUT position (h, w of tap (0, 0), H and W of the input image: taps outside it read zero) and Xh has N_in columns
+     * (+ its zero column).  src_col NULL: off (the input is laid out like the output).  Needs Xh and meta; not with Xh2. */
+    const int32_t* src_col;
+    int32_t N_in;
 } ConvGemmArgs;
 #define AS_SLOPE_PATH 0.2f
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);

@@ -94,6 +94,32 @@ def test_conv_gemm_second_operand(cuda, monkeypatch, impl, cin, cout, cin2, k, l
     assert torch.equal(yh, ops.split_act(y, lay))
 
 
+@pytest.mark.parametrize("cin,cout,K,stride,H,widths", [(512, 512, 5, 1, 5, [13, 9, 13, 5]), (256, 128, 5, 2, 10, [25, 24, 6]), (16, 48, 3, 2, 7, [40]),
+                                                         (32, 64, 5, 1, 5, [5, 5])])
+@pytest.mark.parametrize("tile,ksplit", [("", ""), ("11", "4"), ("21", ""), ("22", "2"), ("12", "")])
+def test_conv_gemm_valid_strided(cuda, monkeypatch, impl, cin, cout, K, stride, H, widths, tile, ksplit):
+    """ConvGemmArgs.src_col / N_in: the K x K valid (strided) convs that close the 2-D towers (models.py:391,399,535) straight from the
+    previous block's operand image -- the output columns are their own layout -- against F.conv2d in float64."""
+    if tile:
+        monkeypatch.setenv("AS_GEMM_TILE", tile)
+    if ksplit:
+        monkeypatch.setenv("AS_GEMM_KSPLIT", ksplit)
+    g = torch.Generator().manual_seed(cin + cout + K + stride)
+    w = torch.randn(cout, cin, K, K, generator=g) / np.sqrt(cin * K * K)
+    b = torch.randn(cout, generator=g)
+    xs = [torch.randn(cin, H, W, generator=g) for W in widths]
+    want = packed([F.leaky_relu(F.conv2d(x[None].double(), w.double(), b.double(), stride=stride)[0], 0.2).reshape(cout, -1) for x in xs])
+    lin = Layout(widths, cuda, H=H)
+    lout = Layout([(W - K) // stride + 1 for W in widths], cuda, H=(H - K) // stride + 1)
+    xh = ops.split_act(packed([x.reshape(cin, -1) for x in xs]).to(cuda), lin)
+    col, meta = ops.strided_source(lin, lout, stride, cuda)
+    taps = [(a, d) for a in range(K) for d in range(K)]
+    y = ops.conv_gemm(ops.prep_weight(w, cuda), None, lout, lout.new(cout), taps, bias=b.to(cuda), act=ops.ACT_LRELU, xs=xh, K=cin,
+                      src_col=col, src_meta=meta, N_in=lin.N)
+    err = float((y.double().cpu() - want).abs().max())
+    assert err <= 2e-5, err
+
+
 @pytest.mark.parametrize("widths", [[23, 8, 40], [23, 23, 23], [12, 8, 40]])
 def test_conv2d_gemm_and_transpose_out(cuda, impl, widths):
     g = torch.Generator().manual_seed(3)
