@@ -75,6 +75,7 @@ _SIGNATURES.update({
     "as_ref_features_f32": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p]),
     "as_crop_f32": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "as_rows_to_images_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p]),
+    "as_stem_pool_image_f32": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "as_dwconv_down_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "as_frame_signal_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "as_spec_power_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),

@@ -835,6 +835,90 @@ extern "C" int as_avgpool_down_image_f32(const float* x, int ldx, const int32_t*
                           (hipStream_t)stream);
 }
 
+// The learned shortcut's input of a tower's FIRST block, avgpool(stem(x)) (models.py:79-84 after the tower's Cin = 1 stem conv, :385,393),
+// straight from the one-channel input: the stem's fp32 output (64 x 509 440 floats at the mel tower) is then neither written nor read
+// back -- its only other consumer, the block's conv1, reads the LeakyReLU image the stem writes.  w = the stem's fp32 image [T][Kp][M]
+// (k = 0 rows), taps in taps_2d(3, 3) / taps_1d(3) order, zero padding; then DownSample's (pool_h x 2) average with the last column
+// replicated when W is odd, summed in avgpool_down_kernel's order.  Workgroup = 8 channels of one utterance, thread = one output position.
+__global__ void __launch_bounds__(256)
+stem_pool_image_kernel(const float* __restrict__ x, const int* __restrict__ in_off, const int* __restrict__ in_w, int Hin,
+                       const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout, int ph, const float* __restrict__ w, int Kp,
+                       const float* __restrict__ bias, int KH, int C, u32x4_t* __restrict__ yh, int Nout)
+{
+    __shared__ float ws[8][10];                                         // the eight channels' taps and bias
+    const int b = blockIdx.y, g = blockIdx.z, c0 = g * 8;
+    const int Wi = in_w[b], Wo = out_w[b];
+    const size_t NX = (size_t)Nout + 1, plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + Nout] = u32x4_t{0u, 0u, 0u, 0u};
+    if (threadIdx.x < 80) {
+        const int r = threadIdx.x / 10, k = threadIdx.x % 10, c = c0 + r;
+        ws[r][k] = c < C ? (k < 9 ? (k < KH * 3 ? w[(size_t)k * Kp * C + c] : 0.f) : (bias ? bias[c] : 0.f)) : 0.f;
+    }
+    __syncthreads();
+    const int ib = in_off[b], ob = out_off[b], pad = KH / 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
+        const int ho = i / Wo, wo = i - ho * Wo;
+        float win[4][4];                                                // rows ho ph - pad .. + ph + KH - 2, columns 2 wo - 1 .. 2 wo + 2 (zero outside)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hi = ho * ph - pad + r;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int wi = 2 * wo - 1 + cc;
+                const bool ok = r < ph + KH - 1 && hi >= 0 && hi < Hin && wi >= 0 && wi < Wi;
+                win[r][cc] = ok ? x[ib + hi * Wi + wi] : 0.f;
+            }
+        }
+        const bool dup = 2 * wo + 1 >= Wi;                              // odd width: the last column stands for its missing neighbour
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (a >= ph) break;
+                float v[2];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int ta = 0; ta < 3; ++ta) {
+                        if (ta >= KH) break;
+#pragma unroll
+                        for (int td = 0; td < 3; ++td) sum += ws[r][ta * 3 + td] * win[a + ta][cc + td];
+                    }
+                    v[cc] = sum + ws[r][9];
+                }
+                s += v[0];
+                s += dup ? v[0] : v[1];
+            }
+            t[r] = c0 + r < C ? s / (float)(2 * ph) : 0.f;
+        }
+        u32x4_t h, l;
+        split2(t, h, l);
+        const size_t at = plane + ob + i;
+        yh[at] = h;
+        yh[at + 2 * NX] = l;
+    }
+}
+
+extern "C" int as_stem_pool_image_f32(const float* x, const int32_t* in_off, const int32_t* in_w, int Hin, const int32_t* out_off,
+                                      const int32_t* out_w, int Hout, int pool_h, const float* w, int Kp, const float* bias, int kh, int B, int C,
+                                      int max_out, uint16_t* yh, int n_out, as_stream_t stream)
+{
+    if (!x || !in_off || !in_w || !out_off || !out_w || !w || !yh || (pool_h != 1 && pool_h != 2) || (kh != 1 && kh != 3) || B < 0 || C <= 0 ||
+        Kp <= 0 || n_out < 0 || (reinterpret_cast<uintptr_t>(yh) & 15) != 0)
+        return AS_EINVAL;
+    if (B == 0 || max_out <= 0) return AS_OK;
+    int gx = as_cdiv(max_out, 256);
+    gx = gx > 32 ? 32 : gx;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(stem_pool_image_kernel, dim3(gx, B, 2 * as_kbx(C)), dim3(256), 0, (hipStream_t)stream, x, in_off, in_w, Hin, out_off, out_w,
+                       Hout, pool_h, w, Kp, bias, kh, C, reinterpret_cast<u32x4_t*>(yh), n_out);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
 // im2col for the valid KxK convs that close the 2-D towers (models.py:391,399,535), with the LeakyReLU that
 // precedes them (models.py:390,398,534) applied on the fly.  col[(c*K*K + a*K + d)][out_off[b] + ho*Wo + wo]
 __global__ void __launch_bounds__(256)

@@ -831,6 +831,12 @@ struct Act {                     // fp32 activation [C][ld] on a layout (+ optio
     int C = 0, ld = 0;
     const Lay* lay = nullptr;
     const uint16_t* h = nullptr;
+    // a tower stem's output that exists only as its LeakyReLU image h (p null): the one-channel input and the stem's fp32 weights,
+    // from which the first block's shortcut is computed directly (as_stem_pool_image_f32)
+    const float* stem_x = nullptr;
+    const GemmW* stem_w = nullptr;
+    const float* stem_b = nullptr;
+    int stem_kh = 0;
 };
 
 // AdainResBlk1d.forward (models.py:189-202), G blocks of the same shape side by side along the column axis when names.size() > 1
@@ -1130,8 +1136,12 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
         // (x + r)/sqrt(2) in that launch's epilogue: the residual branch never exists on its own.
         uint16_t* xsh = c.image(cin, lay2->N);
         as_prof_hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
-        RUN(c, as_avgpool_down_image_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, nullptr, 0, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, nullptr,
-                                         0, B, cin, lay2->max_cols(), xsh, lay2->N, 0, c.s));
+        if (X.stem_x)
+            RUN(c, as_stem_pool_image_f32(X.stem_x, lay->d_off, lay->d_w, lay->H, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, X.stem_w->w32,
+                                          X.stem_w->Kp, X.stem_b, X.stem_kh, B, cin, lay2->max_cols(), xsh, lay2->N, c.s));
+        else
+            RUN(c, as_avgpool_down_image_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, nullptr, 0, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1,
+                                             nullptr, 0, B, cin, lay2->max_cols(), xsh, lay2->N, 0, c.s));
         o2.x2h = xsh;
         o2.K2 = cin;
         o2.div_sqrt2 = true;
@@ -1155,7 +1165,8 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
 }
 
 // first conv of a tower (Cin = 1: the direct kernel): fp32 output for the first block's shortcut + the LeakyReLU image its conv1 reads
-Act tower_stem(Ctx& c, const std::string& name, const float* X, int ldx, const Lay* lay, const Taps& taps)
+// (image_only: a one-channel stem whose first block has a learned shortcut -- that shortcut is computed from X itself, resblk_down)
+Act tower_stem(Ctx& c, const std::string& name, const float* X, int ldx, const Lay* lay, const Taps& taps, bool image_only)
 {
     Act x;
     const GemmW* w0 = c.m.conv(name);
@@ -1165,7 +1176,12 @@ Act tower_stem(Ctx& c, const std::string& name, const float* X, int ldx, const L
     o.want_yh = true;
     o.yh = c.image(w0->M, lay->N);
     o.yh_lrelu = true;
-    x.p = conv_x_new(c, w0, X, ldx, w0->K, lay, taps, o);
+    if (image_only && w0->K == 1 && w0->w32 && (taps.n == 9 || taps.n == 3)) {
+        conv_x(c, w0, X, ldx, w0->K, lay, taps, nullptr, lay->N, o);
+        x.stem_x = X; x.stem_w = w0; x.stem_b = o.bias; x.stem_kh = taps.n == 9 ? 3 : 1;
+    } else {
+        x.p = conv_x_new(c, w0, X, ldx, w0->K, lay, taps, o);
+    }
     x.C = w0->M; x.ld = lay->N; x.lay = lay; x.h = o.yh;
     return x;
 }
@@ -1176,7 +1192,7 @@ void tower2d(Ctx& c, const std::string& p, const float* X, const Lay* lay, const
 {
     const as_model& m = c.m;
     if (!lay) { c.fail(AS_EINVAL); return; }
-    Act x = tower_stem(c, p + ".0", X, lay->N, lay, taps_2d(3, 3));
+    Act x = tower_stem(c, p + ".0", X, lay->N, lay, taps_2d(3, 3), m.has(p + ".1.conv1x1.weight"));
     if (!x.lay) return;
     for (size_t i = 0; i < halves.size(); ++i) {
         x = resblk_down(c, p + "." + std::to_string(i + 1), x, halves[i], false, true);   // (the last block's LeakyReLU image feeds the valid conv)
@@ -1235,7 +1251,7 @@ void tower1d(Ctx& c, const std::string& p, const float* X, int ldx, const Lay* l
 {
     const as_model& m = c.m;
     if (!lay) { c.fail(AS_EINVAL); return; }
-    Act x = tower_stem(c, p + ".0", X, ldx, lay, taps_1d(3));
+    Act x = tower_stem(c, p + ".0", X, ldx, lay, taps_1d(3), m.has(p + ".1.conv1x1.weight"));
     if (!x.lay) return;
     for (int i = 1; i <= 4; ++i) {
         x = resblk_down(c, p + "." + std::to_string(i), x, false, true, i < 4);

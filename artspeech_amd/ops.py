@@ -433,6 +433,17 @@ def avgpool_down_image(X, lin, Y, lout, pool_h, res=None, yh_lrelu=False):
     return yh
 
 
+def stem_pool_image(x1, lin, lout, pool_h, Wt, bias, kh):
+    """avgpool_down(stem conv(x1)) of a one-channel input x1 [N_in] as the operand image over lout (as_stem_pool_image_f32); Wt =
+    prep_weight of the Cin = 1 stem ([C][1][kh][3])"""
+    C = Wt.shape[2]
+    yh = new_image(C, lout.N, x1.device)
+    check(_lib.lib().as_stem_pool_image_f32(_p(x1), _p(lin.col_off), _p(lin.widths), lin.H, _p(lout.col_off), _p(lout.widths), lout.H, pool_h,
+                                            _p(Wt.w32), Wt.shape[1], _p(bias), kh, lin.B, C, lout.max_cols, _p(yh), lout.N, stream()),
+          "as_stem_pool_image_f32")
+    return yh
+
+
 def im2col_valid_image(X, lin, lout, K, stride, lrelu):
     yh = new_image(X.shape[0] * K * K, lout.N, X.device)
     check(_lib.lib().as_im2col_valid_image_f32(_p(X), _ld(X), _p(lin.col_off), _p(lin.widths), _p(lout.col_off), _p(lout.widths), K, stride,

@@ -320,6 +320,13 @@ int as_dwconv_down_image_f32(const float* x, int ldx, const int32_t* in_off, con
 int as_avgpool_down_image_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy,
                               const int32_t* out_off, const int32_t* out_w, int Hout, int pool_h, const float* res, int ldr, int B,
                               int C, int max_out, uint16_t* yh, int n_out, int yh_lrelu, as_stream_t stream);
+/* avgpool_down(stem(x)) for a tower's Cin = 1 stem conv (models.py:385,393 followed by the first block's shortcut, :79-84), from the
+ * ONE-channel input x [sum H*W_b]: w = the stem's fp32 weight image [T][Kp][C] (row k = 0; T = 3 kh taps in taps_2d(3, 3) / taps_1d(3)
+ * order), bias [C] or NULL, zero padding; (pool_h x 2) average with the last column replicated for odd widths; result as the operand
+ * image yh over the n_out pooled columns.  The stem's own fp32 output is then never needed. */
+int as_stem_pool_image_f32(const float* x, const int32_t* in_off, const int32_t* in_w, int Hin, const int32_t* out_off,
+                           const int32_t* out_w, int Hout, int pool_h, const float* w, int Kp, const float* bias, int kh, int B, int C,
+                           int max_out, uint16_t* yh, int n_out, as_stream_t stream);
 int as_im2col_valid_image_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, const int32_t* out_off,
                               const int32_t* out_w, int K, int stride, int lrelu, int B, int C, uint16_t* yh, as_stream_t stream);
 int as_mean_pool_f32(const float* x, int ldx, const int32_t* col_off, int B, int C, int lrelu, float* y, int ldy,

@@ -563,6 +563,35 @@ def test_down_sampling(cuda, kind):
     assert torch.equal(col, want)
 
 
+@pytest.mark.parametrize("kind,H,widths,C", [("half", 10, [25, 8, 13], 20), ("channelpreserve", 10, [25, 8, 13], 64), ("1d", 1, [199, 66, 7], 64),
+                                            ("half", 80, [199, 120], 64)])
+def test_stem_pool_image(cuda, kind, H, widths, C):
+    """as_stem_pool_image_f32: the first tower block's shortcut input avgpool(stem(x)) from the one-channel input, against
+    conv2d -> (replicate the last column of odd widths) -> avg_pool2d in float64 (the image's 22 bits)."""
+    g = torch.Generator().manual_seed(5 + H)
+    kh = 1 if kind == "1d" else 3
+    w = torch.randn(C, 1, kh, 3, generator=g) / 3
+    b = torch.randn(C, generator=g)
+    xs = [torch.randn(1, H, W, generator=g) for W in widths]
+    ph = 2 if kind == "half" else 1
+    want = []
+    for x in xs:
+        y = F.conv2d(x[None].double(), w.double(), b.double(), padding=(kh // 2, 1))
+        if y.shape[-1] % 2:
+            y = torch.cat([y, y[..., -1:]], -1)
+        want.append(F.avg_pool2d(y, (ph, 2))[0].reshape(C, -1))
+    want = packed(want)
+    lay = Layout(widths, cuda, H=H)
+    lay2 = lay.halved(kind == "half")
+    x1 = packed([x.reshape(1, -1) for x in xs])[0].contiguous().to(cuda)
+    wt = ops.prep_weight(w.reshape(C, 1, kh * 3), cuda)
+    img = ops.stem_pool_image(x1, lay, lay2, ph, wt, b.to(cuda), kh)
+    parts = image_parts(img, C, lay2.N)
+    got = (parts[0, :C, : lay2.N].double() + parts[1, :C, : lay2.N].double()).cpu()
+    assert float((got - want).abs().max()) <= 3e-6 * float(want.abs().max())
+    assert not parts[:, C:].any() and not parts[:, :, lay2.N].any()
+
+
 @pytest.mark.parametrize("kind", ["half", "channelpreserve"])
 def test_tower_producers_write_images(cuda, kind):
     """The style towers' non-GEMM producers (depthwise down-sampling conv, average pooling with / without the residual merge, im2col, the
