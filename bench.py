@@ -446,7 +446,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-concurrency", action="store_true", help="run the independent branches back to back (profiling)")
     ap.add_argument("--no-extras", action="store_true", help="skip the MAS / C2 / C5 / transfer lines (profiling runs)")
-    ap.add_argument("--config", default="C3", choices=["C3", "C5"], help="workload of the timed region (profiling runs; the headline is C3)")
+    ap.add_argument("--config", default="C3", choices=["C3", "C5", "C2"], help="workload of the timed region (profiling runs; the headline is C3)")
     ap.add_argument("--global-batch", type=int, default=0, help="C4: ONE ragged batch of this many utterances sharded over the ranks")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU: consecutive steps are replayed on this many HIP streams "
                     "(each with its own plan and workspaces on the same weights); 1 = one step at a time (the step's latency)")
@@ -497,6 +497,10 @@ def main():
         host, g = make_inputs(dev, 8, 1024, 1024, 200, seed0=DATA_SEED + 1000)
         frames_total = world * 2 * sum(host["frames"])
         workload = "C5: long form, batch 8 per GPU, 1024 tokens -> 2048 mel frames per utterance, T_ref=200 (profiling run)"
+    elif args.config == "C2":
+        host, g = make_inputs(dev, 1, 30, 75, 150, seed0=DATA_SEED + 1000)
+        frames_total = world * 2 * sum(host["frames"])
+        workload = "C2: one utterance, 30 tokens -> 150 mel frames, T_ref=150 (profiling run)"
     else:
         host, g = make_inputs(dev)
         frames_total = world * 2 * sum(host["frames"])
