@@ -657,6 +657,7 @@ extern "C" int as_bn_lrelu_maxpool_rows_f32(const float* x, int ldx, const int32
 // Branch-free: every tap is loaded from a clamped position and multiplied by its weight or by zero (a tap outside the image), so the
 // 8 x 3 KH loads of a thread are all in flight together -- with `continue` in the tap loops each load sat in its own divergent
 // region and paid its own memory round trip (the 64-channel 509 440-column launch: 82 us for 200 MB).  Same summation order as before.
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));      // a pair of floats at any 4-byte address (odd row starts)
 template <int KH>
 __global__ void __launch_bounds__(256)
 dwconv_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off, const int* __restrict__ in_w, int Hin,
@@ -674,42 +675,75 @@ dwconv_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__
         ws[r][k] = c < C ? (k < KH * 3 ? w[(size_t)c * KH * 3 + k] : bias[c]) : 0.f;
     }
     __syncthreads();
-    const int ib = in_off[b], ob = out_off[b];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
-        const int ho = i / Wo, wo = i - ho * Wo;
-        int pos[KH * 3];
-        bool ok[KH * 3];
+    const int ib = in_off[b], ob = out_off[b], lane = threadIdx.x & 63;
+    // The window's columns 2 wo, 2 wo + 1 come as ONE 8-byte load per row and channel (a wave's loads are then whole cache lines; as three
+    // 4-byte loads at a stride of two floats every instruction touched its lines half-used and the address path, not the memory, set
+    // the pace: 2.5 TB/s); column 2 wo - 1 is the previous lane's second value -- the first lane of a wave fetches its own.  Rows of
+    // one column (Wi = 1) and the last column of an odd row (no right neighbour) take the pair from one float earlier.
+    for (int i0 = blockIdx.x * blockDim.x; i0 < Hout * Wo; i0 += gridDim.x * blockDim.x) {      // (whole waves stay in the loop: shuffles)
+        const int i = i0 + threadIdx.x, ic = min(i, Hout * Wo - 1);
+        const int ho = ic / Wo, wo = ic - ho * Wo;
+        const bool has_r = 2 * wo + 1 < Wi;                              // the right neighbour exists
+        const int pc = Wi >= 2 ? (has_r ? 2 * wo : 2 * wo - 1) : 0;      // first column of the pair that is loaded
+        const bool own_left = lane == 0 && wo > 0;
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t[r] = 0.f;
+        // every load of the window is issued before anything waits for one (the pairs; then, in ONE divergent region, the first lane's
+        // own left neighbours): a shuffle or a branch between the loads would serialise 24 memory round trips
+        f32x2u p2[8][KH];
+        float lo[8][KH];
+        bool okh[KH];
+        int base[KH];
 #pragma unroll
         for (int a = 0; a < KH; ++a) {
             const int hi = ho * sh - ph + a, hc = min(max(hi, 0), Hin - 1);
+            okh[a] = hi >= 0 && hi < Hin;
+            base[a] = ib + hc * Wi;
+        }
+        if (Wi >= 2) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const int wi = wo * 2 - 1 + d, wc = min(max(wi, 0), Wi - 1);
-                ok[a * 3 + d] = hi >= 0 && hi < Hin && wi >= 0 && wi < Wi;
-                pos[a * 3 + d] = ib + hc * Wi + wc;
+            for (int a = 0; a < KH; ++a)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) p2[r][a] = *reinterpret_cast<const f32x2u*>(x + (size_t)min(c0 + r, C - 1) * ldx + base[a] + pc);
+        } else {
+#pragma unroll
+            for (int a = 0; a < KH; ++a)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { const float e = x[(size_t)min(c0 + r, C - 1) * ldx + base[a]]; p2[r][a] = f32x2u{e, e}; }
+        }
+        if (own_left) {
+#pragma unroll
+            for (int a = 0; a < KH; ++a)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) lo[r][a] = x[(size_t)min(c0 + r, C - 1) * ldx + base[a] + 2 * wo - 1];
+        }
+        float v[8][KH][3];
+#pragma unroll
+        for (int a = 0; a < KH; ++a)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float x0 = (has_r || Wi < 2) ? p2[r][a].x : p2[r][a].y, x1 = p2[r][a].y;   // (no right neighbour: x1 unused, its weight is skipped)
+                const float xl = __shfl_up(x1, 1);                       // previous lane: (ho, wo - 1)'s right value = column 2 wo - 1
+                v[r][a][0] = own_left ? lo[r][a] : xl; v[r][a][1] = x0; v[r][a][2] = x1;
             }
-        }
-        float v[8][KH * 3];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const float* xr = x + (size_t)min(c0 + r, C - 1) * ldx;
-#pragma unroll
-            for (int k = 0; k < KH * 3; ++k) v[r][k] = xr[pos[k]];
-        }
-        float t[8];
+        // a previous lane whose pair was shifted (its has_r false) cannot be this lane's neighbour: that lane ends a row, this one starts the next (wo = 0)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < KH * 3; ++k)
-                if (ok[k]) s += v[r][k] * ws[r][k];
+            for (int a = 0; a < KH; ++a) {
+                if (okh[a] && wo > 0) s += v[r][a][0] * ws[r][a * 3 + 0];
+                if (okh[a]) s += v[r][a][1] * ws[r][a * 3 + 1];
+                if (okh[a] && has_r) s += v[r][a][2] * ws[r][a * 3 + 2];
+            }
             s += ws[r][KH * 3];
             if (act) s = lrelu02(s);
             if (c0 + r >= C) s = 0.f;
-            else if (y) y[(size_t)(c0 + r) * ldy + ob + i] = s;
+            else if (y && i < Hout * Wo) y[(size_t)(c0 + r) * ldy + ob + i] = s;
             t[r] = s;
         }
-        if (yh) {
+        if (yh && i < Hout * Wo) {
             u32x4_t h, l;
             split2(t, h, l);
             const size_t at = plane + ob + i;
@@ -778,11 +812,21 @@ avgpool_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict_
             float s = 0.f;
             if (c < C) {
                 const float* xr = x + (size_t)c * ldx + in_off[b];
+                // the pair (2 wo, 2 wo + 1) as one 8-byte load (whole cache lines per wave); the last column of an odd row stands for its
+                // missing neighbour: there the pair is loaded one float earlier and its second value is used twice
+                const bool has_r = 2 * wo + 1 < Wi;
                 for (int a = 0; a < ph; ++a) {
                     const int hi = ho * ph + a;
-                    const int w0 = 2 * wo, w1 = (2 * wo + 1 < Wi) ? 2 * wo + 1 : Wi - 1;
-                    s += xr[(size_t)hi * Wi + w0];
-                    s += xr[(size_t)hi * Wi + w1];
+                    float x0, x1;
+                    if (Wi >= 2) {
+                        const f32x2u p2 = *reinterpret_cast<const f32x2u*>(xr + (size_t)hi * Wi + (has_r ? 2 * wo : 2 * wo - 1));
+                        x0 = has_r ? p2.x : p2.y;
+                        x1 = p2.y;
+                    } else {
+                        x0 = x1 = xr[(size_t)hi * Wi];
+                    }
+                    s += x0;
+                    s += x1;
                 }
                 s = s / (float)(2 * ph);
                 if (res) s = (s + res[(size_t)c * ldr + out_off[b] + i]) / 1.41421356237309504880f;
@@ -873,6 +917,9 @@ stem_pool_image_kernel(const float* __restrict__ x, const int* __restrict__ in_o
         float t[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
+            float wr[10];                                               // (registers: the products below would otherwise re-read LDS 36 times)
+#pragma unroll
+            for (int k = 0; k < 10; ++k) wr[k] = ws[r][k];
             float s = 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -885,9 +932,9 @@ stem_pool_image_kernel(const float* __restrict__ x, const int* __restrict__ in_o
                     for (int ta = 0; ta < 3; ++ta) {
                         if (ta >= KH) break;
 #pragma unroll
-                        for (int td = 0; td < 3; ++td) sum += ws[r][ta * 3 + td] * win[a + ta][cc + td];
+                        for (int td = 0; td < 3; ++td) sum += wr[ta * 3 + td] * win[a + ta][cc + td];
                     }
-                    v[cc] = sum + ws[r][9];
+                    v[cc] = sum + wr[9];
                 }
                 s += v[0];
                 s += dup ? v[0] : v[1];
