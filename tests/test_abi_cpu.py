@@ -77,3 +77,65 @@ def test_weight_preparation_host_matches_python():
         parts = img.view(torch.float16).reshape(G, T, -1, 2, 2, M, 8).float()            # [G][T][kb][p][kh][M][8]
         back = (parts[:, :, :, 0] + parts[:, :, :, 1]).permute(0, 4, 2, 3, 5, 1).reshape(G, M, -1, T)[:, :, :K]
         assert float((back / scale - w).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+
+
+def test_weight_preparation_with_shortcut_host():
+    """as_prep_weight_f16x2_sc_host: the conv's weight sets with a learned shortcut's [Cout][Cin2] weights behind the taps of each set
+    (ConvGemmArgs.Xh2 / K2), ONE common power-of-two scale; with Cin2 = 0 it is as_prep_weight_f16x2_host."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from artspeech_amd import ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    for G, M, K, T, K2 in [(1, 80, 130, 3, 40), (3, 64, 16, 9, 64), (1, 128, 64, 1, 1216)]:
+        w = torch.randn(G, M, K, T, generator=g) * 0.05
+        w2 = torch.randn(G, M, K2, generator=g) * 0.4                     # the shortcut sets the scale here
+        n = L.as_prep_weight_f16x2_sc_bytes(G, M, K, T, K2)
+        kbx, kbx2 = ops.kbx(K), ops.kbx(K2)
+        assert n == G * (T * kbx + kbx2) * 4 * M * 16
+        out = np.zeros(n // 2, np.int16)
+        sc = ctypes.c_float(0)
+        wn, w2n = np.ascontiguousarray(w.numpy()), np.ascontiguousarray(w2.numpy())
+        assert L.as_prep_weight_f16x2_sc_host(wn.ctypes.data, w2n.ctypes.data, G, M, K, T, K2, out.ctypes.data, ctypes.byref(sc)) == 0
+        mx = max(float(w.abs().max()), float(w2.abs().max()))
+        assert 2.0 ** 13 <= mx * sc.value < 2.0 ** 14
+        img = torch.from_numpy(out).view(torch.float16).reshape(G, T * kbx + kbx2, 2, 2, M, 8).float()      # [G][block][p][kh][M][8]
+        full = (img[:, :, 0] + img[:, :, 1]).permute(0, 3, 1, 2, 4)                                           # [G][M][block][kh][8]
+        main = full[:, :, : T * kbx].reshape(G, M, T, kbx * 16)[:, :, :, :K].permute(0, 1, 3, 2)
+        short = full[:, :, T * kbx:].reshape(G, M, kbx2 * 16)
+        assert float((main / sc.value - w).abs().max()) <= 2.0 ** -21 * mx
+        assert float((short[:, :, :K2] / sc.value - w2).abs().max()) <= 2.0 ** -21 * mx and not short[:, :, K2:].any()
+        # no shortcut: the plain function's bytes
+        n0 = L.as_prep_weight_f16x2_bytes(G, M, K, T)
+        assert L.as_prep_weight_f16x2_sc_bytes(G, M, K, T, 0) == n0
+        a, b = np.zeros(n0 // 2, np.int16), np.zeros(n0 // 2, np.int16)
+        sa, sb = ctypes.c_float(0), ctypes.c_float(0)
+        assert L.as_prep_weight_f16x2_host(wn.ctypes.data, G, M, K, T, a.ctypes.data, ctypes.byref(sa)) == 0
+        assert L.as_prep_weight_f16x2_sc_host(wn.ctypes.data, None, G, M, K, T, 0, b.ctypes.data, ctypes.byref(sb)) == 0
+        assert np.array_equal(a, b) and sa.value == sb.value
+    # a shortcut weight without a width (and the reverse) is refused
+    assert L.as_prep_weight_f16x2_sc_host(wn.ctypes.data, None, G, M, K, T, 8, out.ctypes.data, ctypes.byref(sc)) == -1
+    assert L.as_prep_weight_f16x2_sc_host(wn.ctypes.data, w2n.ctypes.data, G, M, K, T, 0, out.ctypes.data, ctypes.byref(sc)) == -1
+
+
+def test_conv_gemm_second_operand_and_source_arguments_are_validated():
+    """ConvGemmArgs.Xh2 / K2 and src_col / N_in: inconsistent combinations return AS_EINVAL before anything touches a device."""
+    import ctypes
+    L = _lib.lib()
+    def args(**kw):
+        a = _lib.ConvGemmArgs()
+        a.Wh, a.Xh, a.Y = 4096, 8192, 16384                   # (never dereferenced: every case below is refused by the checks)
+        a.M, a.N, a.K, a.T, a.Kp, a.ldy, a.acc_scale, a.n_prod, a.in_slope, a.act_slope = 64, 100, 64, 1, 64, 100, 1.0, 3, 0.2, 0.2
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+    assert L.as_conv_gemm_f32(ctypes.byref(args(K2=64)), None) == -1                          # a width without an image
+    assert L.as_conv_gemm_f32(ctypes.byref(args(K2=-1, Xh2=4096)), None) == -1
+    assert L.as_conv_gemm_f32(ctypes.byref(args(K2=64, Xh2=4096 + 8)), None) == -1            # 16-byte alignment
+    assert L.as_conv_gemm_f32(ctypes.byref(args(K2=64, Xh2=4096, Xh=None, X=8192, ldx=100)), None) == -1   # beside an image only
+    assert L.as_conv_gemm_f32(ctypes.byref(args(src_col=4096, N_in=400)), None) == -1         # own positions need the descriptors
+    assert L.as_conv_gemm_f32(ctypes.byref(args(src_col=4096, N_in=0, meta=4096)), None) == -1
+    assert L.as_conv_gemm_f32(ctypes.byref(args(src_col=4096, N_in=400, meta=4096, K2=64, Xh2=4096)), None) == -1   # not both
