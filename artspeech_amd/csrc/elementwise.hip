@@ -793,52 +793,59 @@ extern "C" int as_dwconv_down_image_f32(const float* x, int ldx, const int32_t* 
 
 // DownSample (models.py:43-57) / ResBlk1d.downsample (:127-130): replicate the last column when W is odd,
 // then average pool (ph x 2); optionally  y = (pool(x) + res) / sqrt(2)  (the block's output, models.py:99-100).
+template <int PH>
 __global__ void __launch_bounds__(256)
 avgpool_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off, const int* __restrict__ in_w, int Hin,
-                    float* __restrict__ y, int ldy, const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout, int ph,
+                    float* __restrict__ y, int ldy, const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout,
                     const float* __restrict__ res, int ldr, int C, u32x4_t* __restrict__ yh, int Nout, int yh_lrelu)
 {
     // 8 consecutive channels per workgroup, one output position of all eight per thread (as dwconv_down_kernel)
     const int b = blockIdx.y, g = blockIdx.z, c0 = g * 8;
-    const int Wi = in_w[b], Wo = out_w[b];
+    const int Wi = in_w[b], Wo = out_w[b], ib = in_off[b], ob = out_off[b];
     const size_t NX = (size_t)Nout + 1, plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;
     if (yh && b == 0 && blockIdx.x == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + Nout] = u32x4_t{0u, 0u, 0u, 0u};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
         const int ho = i / Wo, wo = i - ho * Wo;
+        // the pair (2 wo, 2 wo + 1) as one 8-byte load (whole cache lines per wave); the last column of an odd row stands for its
+        // missing neighbour: there the pair is loaded one float earlier and its second value is used twice.  Every load of the
+        // thread (8 channels x PH rows, the residual's 8) is issued before the first sum.
+        const bool has_r = 2 * wo + 1 < Wi;
+        const int pc = Wi >= 2 ? (has_r ? 2 * wo : 2 * wo - 1) : 0;
+        f32x2u p2[8][PH];
+        float rv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float* xr = x + (size_t)min(c0 + r, C - 1) * ldx + ib;
+#pragma unroll
+            for (int a = 0; a < PH; ++a) {
+                if (Wi >= 2) p2[r][a] = *reinterpret_cast<const f32x2u*>(xr + (size_t)(ho * PH + a) * Wi + pc);
+                else { const float e = xr[(size_t)(ho * PH + a) * Wi]; p2[r][a] = f32x2u{e, e}; }
+            }
+            rv[r] = res ? res[(size_t)min(c0 + r, C - 1) * ldr + ob + i] : 0.f;
+        }
         float t[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int c = c0 + r;
             float s = 0.f;
-            if (c < C) {
-                const float* xr = x + (size_t)c * ldx + in_off[b];
-                // the pair (2 wo, 2 wo + 1) as one 8-byte load (whole cache lines per wave); the last column of an odd row stands for its
-                // missing neighbour: there the pair is loaded one float earlier and its second value is used twice
-                const bool has_r = 2 * wo + 1 < Wi;
-                for (int a = 0; a < ph; ++a) {
-                    const int hi = ho * ph + a;
-                    float x0, x1;
-                    if (Wi >= 2) {
-                        const f32x2u p2 = *reinterpret_cast<const f32x2u*>(xr + (size_t)hi * Wi + (has_r ? 2 * wo : 2 * wo - 1));
-                        x0 = has_r ? p2.x : p2.y;
-                        x1 = p2.y;
-                    } else {
-                        x0 = x1 = xr[(size_t)hi * Wi];
-                    }
-                    s += x0;
-                    s += x1;
-                }
-                s = s / (float)(2 * ph);
-                if (res) s = (s + res[(size_t)c * ldr + out_off[b] + i]) / 1.41421356237309504880f;
-                if (y) y[(size_t)c * ldy + out_off[b] + i] = s;
+#pragma unroll
+            for (int a = 0; a < PH; ++a) {
+                s += (has_r || Wi < 2) ? p2[r][a].x : p2[r][a].y;
+                s += p2[r][a].y;
+            }
+            s = s / (float)(2 * PH);
+            if (res) s = (s + rv[r]) / 1.41421356237309504880f;
+            if (c0 + r < C) {
+                if (y) y[(size_t)(c0 + r) * ldy + ob + i] = s;
                 if (yh_lrelu) s = lrelu02(s);
+            } else {
+                s = 0.f;
             }
             t[r] = s;
         }
         if (yh) {
             u32x4_t h, l;
             split2(t, h, l);
-            const size_t at = plane + out_off[b] + i;
+            const size_t at = plane + ob + i;
             yh[at] = h;
             yh[at + 2 * NX] = l;
         }
@@ -856,8 +863,12 @@ static int avgpool_launch(const float* x, int ldx, const int32_t* in_off, const 
     gx = gx > 32 ? 32 : gx;
     const int groups = yh ? 2 * as_kbx(C) : as_cdiv(C, 8);
     AsProfScope prof__(AS_FILE_CLS, 0, 0, stream);
-    hipLaunchKernelGGL(avgpool_down_kernel, dim3(gx, B, groups), dim3(256), 0, stream, x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout,
-                       pool_h, res, ldr, C, reinterpret_cast<u32x4_t*>(yh), Nout, yh_lrelu);
+    if (pool_h == 2)
+        hipLaunchKernelGGL(avgpool_down_kernel<2>, dim3(gx, B, groups), dim3(256), 0, stream, x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout,
+                           res, ldr, C, reinterpret_cast<u32x4_t*>(yh), Nout, yh_lrelu);
+    else
+        hipLaunchKernelGGL(avgpool_down_kernel<1>, dim3(gx, B, groups), dim3(256), 0, stream, x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout,
+                           res, ldr, C, reinterpret_cast<u32x4_t*>(yh), Nout, yh_lrelu);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
