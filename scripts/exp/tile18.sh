@@ -1,0 +1,5 @@
+#!/bin/bash
+# batch-1 shapes: 64x64 tile with EIGHT waves splitting K inside the workgroup (no slabs, no reduce launch) against the 4-wave tile + K slices
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r3p; mkdir -p $O
+TILES=,11,18 KSPLITS=,1,2 python3 $R/scripts/gemm_bench.py 512,150,512,3,150 1024,150,1024,3,150 1024,150,1216,3,150 1024,286,512,9,143 512,30,512,3,30 512,286,512,5,143 256,450,512,3,150 512,190,512,9,190 2>&1 | grep "us " | tee $O/t18.log
