@@ -59,7 +59,30 @@ def _cases(dev, g):
         X, w, b, Y = R(256, lay.N), R(10, 256), R(10), lay.new(10)
         return lambda: ops.project_cols(X, lay.N, w, b, Y).clone()
 
-    return {"attention 40": attention(40, 64), "attention 300": attention(300, 8), "lstm H128": lstm(128, 100, 32, False),
+    def towers():
+        # the pooling kernels of round 3 (pair loads, neighbour values by shuffle, LDS-staged taps) and the stem's pooled shortcut
+        C, H, widths = 64, 20, [199, 120, 57, 8]
+        lay = Layout(widths, dev, H=H)
+        lay2 = lay.halved(True)
+        X, w, b = R(C, lay.N), R(C, 9), R(C)
+        x1 = R(lay.N)
+        wt = ops.prep_weight(torch.randn(C, 1, 9, generator=g) / 3, dev)
+
+        def run():
+            a = ops.dwconv_down_image(X, lay, lay2, w, b, 3, True)
+            p = ops.avgpool_down_image(X, lay, None, lay2, 2)
+            s = ops.stem_pool_image(x1, lay, lay2, 2, wt, b, 3)
+            return torch.cat([a.flatten(), p.flatten(), s.flatten()]).clone()
+        return run
+
+    def gemm_second_operand():
+        lay = Layout([100] * 16, dev)
+        wt = ops.prep_weight(torch.randn(256, 128, 3, generator=g) / 20, dev, sc=[torch.randn(256, 320, generator=g) / 18])
+        xh, x2h = ops.split_act(R(128, lay.N), lay), ops.split_act(R(320, lay.N), lay)
+        b, Y = R(256), lay.new(256)
+        return lambda: ops.conv_gemm(wt, None, lay, Y, ops.taps_1d(3), bias=b, div_sqrt2=True, xs=xh, K=128, x2s=x2h, K2=320).clone()
+
+    return {"tower pooling kernels": towers(), "gemm with a folded shortcut": gemm_second_operand(), "attention 40": attention(40, 64), "attention 300": attention(300, 8), "lstm H128": lstm(128, 100, 32, False),
             "lstm H256 clustered": lstm(256, 40, 32, True), "layernorm image": layernorm(), "adain": adain(False), "adain x2": adain(True),
             "project_cols": project(), "mas 8 bands": mas_lattice(4, 1024, 600), "mas 3 bands": mas_lattice(16, 300, 500)}
 
