@@ -14,11 +14,15 @@ as ONE call of the library's as_forward_test (csrc/model.hip) captured into a hi
 then timed again with the host <-> device copies inside the region ("transfers": per lane one pinned H2D copy -> replay -> D2H of the mel
 on the lane's own stream, the reference's test.py:96-113 boundary) -- the two differ by a few per cent because a lane's copies overlap
 the other lane's kernels.
-Consecutive steps are independent batches: by default TWO are kept in flight per GPU (`--in-flight 2`: a second plan + workspaces on
-the same weights, its own hipGraph and HIP stream; the K timed steps alternate between the lanes), so that one batch's tail rounds and
-latency-bound stretches are filled by the other's kernels; every lane has its own batch (other seeds) in its own buffers.  `value` / `ms_per_step` are K steps / wall time; `ms_per_step_one_in_flight`
-is the same K steps one at a time (a step's latency).  Every lane's result is compared bitwise with its own first eager step; if a lane ever
-differed the in-flight timing would be discarded for the one-at-a-time number (`in_flight_note`).
+Consecutive steps are independent batches: by default FOUR are kept in flight per GPU (`--in-flight 4`: each lane its own plan +
+workspaces on the same weights, its own hipGraph and HIP stream; the K timed steps alternate between the lanes), so that one batch's tail
+rounds, launch gaps and latency-bound stretches are filled by the others' kernels; every lane has its own batch (other seeds) in its own
+buffers.  A lane in flight runs its step as ONE chain on ONE stream (`as_plan_set_serial`: the step's independent branches back to
+back) -- measured on one box: four single-stream lanes 3.84 ms per step, three 3.94, five 4.19, two lanes with their branches on side
+streams (rounds 2-3's arrangement, `--lane-branches`) 4.42; DESIGN.md section 5.  `value` / `ms_per_step` are K steps / wall time; `ms_per_step_one_in_flight` is the same K steps one
+at a time with the branches on side streams (the best latency of a step).  Every lane's result is compared bitwise with its own first
+eager step and lane 0's with the one-at-a-time run; if a lane ever differed the in-flight timing would be discarded for the
+one-at-a-time number (`in_flight_note`).
 With N > 1 every rank runs its own 32-utterance batch on its own GPU (utterance batches shard embarrassingly; no data-path
 collective) => weak scaling; the only torch.distributed use is the barrier and the max-over-ranks of the elapsed time.
 `--global-batch G` instead builds ONE length-varied batch of G utterances, shards it over the ranks (artspeech_amd.shard) and
@@ -448,8 +452,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the MAS / C2 / C5 / transfer lines (profiling runs)")
     ap.add_argument("--config", default="C3", choices=["C3", "C5", "C2"], help="workload of the timed region (profiling runs; the headline is C3)")
     ap.add_argument("--global-batch", type=int, default=0, help="C4: ONE ragged batch of this many utterances sharded over the ranks")
-    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU: consecutive steps are replayed on this many HIP streams "
+    ap.add_argument("--in-flight", type=int, default=4, help="batches in flight per GPU: consecutive steps are replayed on this many HIP streams "
                     "(each with its own plan and workspaces on the same weights); 1 = one step at a time (the step's latency)")
+    ap.add_argument("--lane-branches", action="store_true", help="lanes in flight keep their step's branches on side streams (default: a "
+                    "lane in flight is one chain on one stream)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -522,15 +528,24 @@ def main():
     in_flight_note = None
     lanes = [(runner, run, torch.cuda.Stream())]
     if n_fl > 1:
-        firsts = [mel_first]
-        for i in range(1, n_fl):
-            if args.config == "C5":
+        firsts = []
+        lanes = []
+        for i in range(n_fl):
+            if i == 0:
+                gi = g
+            elif args.config == "C5":
                 _, gi = make_inputs(dev, 8, 1024, 1024, 200, seed0=DATA_SEED + 1000 + 100 * i)
+            elif args.config == "C2":
+                _, gi = make_inputs(dev, 1, 30, 75, 150, seed0=DATA_SEED + 1000 + 100 * i)
             else:
                 _, gi = make_inputs(dev, seed0=DATA_SEED + 100 * i)
-            r2 = Runner(net.replica(), gi)
+            twin = net.replica()
+            if not args.lane_branches:
+                twin.rt.set_serial(True)                     # a lane in flight: one chain on one stream
+            r2 = Runner(twin, gi)
             firsts.append(r2.step()["mel"].clone())
             lanes.append((r2, r2.capture(), torch.cuda.Stream()))
+        assert torch.equal(firsts[0], mel_first), "a step as one chain and the step with its branches on side streams differ"
         it = [0]
 
         def run_lanes():
@@ -597,7 +612,7 @@ def main():
         "config": {"workload": workload, "global_batch": args.global_batch or len(g["frames"]) * world, "frames_per_step": frames_total,
                    "parallelism": f"batch-shard x{world}, no collectives",
                    "launch": "eager (C ABI as_forward_test)" if args.no_graph else "hipGraph replay of one as_forward_test call",
-                   "in_flight": n_fl},
+                   "in_flight": n_fl, "lane_streams": "branches on side streams" if (args.lane_branches or n_fl == 1) else "one chain per lane"},
         "ms_per_step_one_in_flight": single_ms,
         "in_flight_note": in_flight_note,
         "rtf": (elapsed / args.steps) / (frames_total * FRAME_SEC),
