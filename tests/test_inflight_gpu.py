@@ -34,3 +34,38 @@ def test_two_batches_in_flight_are_bit_identical():
             torch.cuda.synchronize()
             bad += int(not torch.equal(a.out["mel"], want)) + int(not torch.equal(b.out["mel"], want))
     assert bad == 0, f"{bad} of 30 checks differed from the step run alone"
+
+
+def test_four_single_stream_batches_in_flight_are_bit_identical():
+    """bench.py's default arrangement since the end of round 3: four batches in flight, each ONE chain on one stream (as_plan_set_serial:
+    the step's branches back to back).  A chain produces the bits of the step with its branches on side streams, and four of them
+    replayed side by side keep producing them."""
+    import bench
+    from artspeech_amd import models, synth
+    from artspeech_amd.weights import DEFAULT_STATS, load_distribution
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    sd = synth.synth_state_dict(512, 64, seed=bench.WEIGHT_SEED)
+    model = models.build_model(models.Munch(hidden_dim=512, dim_in=64, style_dim=256, n_mels=80), None, "second", load_distribution(DEFAULT_STATS), dev)
+    models.load_checkpoint(model, None, {"net": {"ArtsSpeech": sd}})
+    net = model.ArtsSpeech
+    lanes, wants = [], []
+    for i in range(4):
+        _, g = bench.make_inputs(dev, seed0=bench.DATA_SEED + 100 * i)
+        want = bench.Runner(net, g).step()["mel"].clone()          # branches on side streams, alone
+        twin = net.replica()
+        twin.rt.set_serial(True)
+        r = bench.Runner(twin, g)
+        assert torch.equal(r.step()["mel"], want), "a step as one chain differs from the step with its branches on side streams"
+        lanes.append((r, r.capture(), torch.cuda.Stream()))
+        wants.append(want)
+    torch.cuda.synchronize()
+    bad = 0
+    for i in range(160):
+        r, run, st = lanes[i % 4]
+        with torch.cuda.stream(st):
+            run()
+        if i % 16 == 15:
+            torch.cuda.synchronize()
+            bad += sum(int(not torch.equal(r.out["mel"], w)) for (r, _, _), w in zip(lanes, wants))
+    assert bad == 0, f"{bad} of 40 checks differed from the step run alone"
