@@ -149,6 +149,13 @@ _SIGNATURES.update({
     "as_forward_test_begin": (c_i, [c_p, c_p, _pB, _pIO, c_p, c_sz, c_p]),
     "as_forward_test_finish": (c_i, [c_p, c_p, _pB, _pIO, c_p, c_sz, c_p, c_sz, c_p]),
     "as_forward_test": (c_i, [c_p, c_p, _pB, _pIO, c_p, c_sz, c_p, c_sz, ctypes.POINTER(ctypes.c_int32), c_p]),
+    "as_lanes_create": (c_i, [c_p, c_i, ctypes.POINTER(c_p)]),
+    "as_lanes_destroy": (c_i, [c_p]),
+    "as_lanes_count": (c_i, [c_p]),
+    "as_lanes_next": (c_i, [c_p]),
+    "as_lanes_stream": (c_p, [c_p, c_i]),
+    "as_lanes_submit": (c_i, [c_p, _pB, _pIO, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "as_lanes_wait": (c_i, [c_p, c_i]),
 })
 
 

@@ -411,6 +411,61 @@ class ArtsSpeech(_Module):
         return res
 
 
+class Lanes:
+    """as_lanes (csrc/lanes.hip): n batches in flight on one model's weights, every batch one chain on a stream of its own -- the
+    throughput arrangement (DESIGN.md section 5) as a piece of the library.  `submit` takes the packed tensors of `forward_packed`;
+    keep them (and the returned dict) alive and unchanged until `wait`."""
+
+    def __init__(self, net, n_lanes=4):
+        self.rt = net.rt
+        self.h = ctypes.c_void_p()
+        check(_lib.lib().as_lanes_create(self.rt.model, n_lanes, ctypes.byref(self.h)), "as_lanes_create")
+        self.n = n_lanes
+        self._keep = [None] * n_lanes
+
+    def close(self):
+        if self.h:
+            _lib.lib().as_lanes_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, forced=None, frames=None, out=None, capacity=None):
+        """-> (lane, dict with the output tensors).  frames (per-utterance half-rate frame counts) known: graph-replayed from the second
+        submit of the same tensors on a lane; None: predicted durations, `capacity` = the mel frames the output buffer is made for."""
+        rt, L = self.rt, _lib.lib()
+        dev = rt.device
+        tok_lens, ref_lens = [int(v) for v in tok_lens], [int(v) for v in ref_lens]
+        B, Nt = len(tok_lens), sum(tok_lens)
+        res = out if out is not None else {}
+        with torch.cuda.device(dev):
+            io = _lib.ForwardIO()
+            io.tokens, io.mel, io.ld_mel = _p(tok), _p(mel_p), mel_p.stride(0)
+            io.f0_raw, io.ema_raw, io.ld_ema = _p(f0_p), _p(ema_p), ema_p.stride(0)
+            io.forced_dur = _p(forced)
+            n2 = 2 * sum(int(f) for f in frames) if frames is not None else int(capacity)
+            if "mel" not in res:
+                res["mel"] = torch.empty((rt.cfg.n_mels, max(n2, 1)), dtype=torch.float32, device=dev)
+                res["dur_i"] = torch.empty((max(Nt, 1),), dtype=torch.int32, device=dev)
+                res["frame_off"] = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+            io.mel_out, io.ld_out = _p(res["mel"]), res["mel"].stride(0)
+            io.dur_i, io.frame_off = _p(res["dur_i"]), _p(res["frame_off"])
+            ba = rt.batch(tok_lens=tok_lens, ref_lens=ref_lens, frames=frames)
+            fr = (ctypes.c_int32 * B)()
+            lane = ctypes.c_int32(-1)
+            check(L.as_lanes_submit(self.h, ctypes.byref(ba), ctypes.byref(io), fr, ctypes.byref(lane)), "as_lanes_submit")
+            res["frames"] = [int(v) for v in fr] if frames is None else [int(f) for f in frames]
+            self._keep[lane.value] = (ba, io, tok, mel_p, f0_p, ema_p, forced, res)
+        return lane.value, res
+
+    def wait(self, lane=-1):
+        check(_lib.lib().as_lanes_wait(self.h, lane), "as_lanes_wait")
+
+
 def build_model(args, text_aligner=None, stage="second", distribution=None, device=None):
     """models.py:680-683.  Returns Munch(ArtsSpeech, discriminator, text_aligner); the discriminator is a
     training-only component and is None here."""

@@ -36,6 +36,7 @@ Prints ONE JSON line (rank 0).  Beside the contract's keys:
                  reference-generated golden paths
   configs        C2 (batch 1, 150 frames: latency; also in the 16-bit-operand mode with its measured error) and C5 (long form)
   transfers      host->device of tokens / reference features and device->host of the mel, and the step rate including them
+  lanes_native   the same K steps through the library's own lanes (as_lanes_submit: plans, streams, workspaces, hipGraphs kept in C++)
   cpu_baseline   the oracle's CPU restatement timed on this box's host cores on a bounded sample of the same workload
 """
 import argparse
@@ -421,6 +422,35 @@ def bench_transfers(lanes, steps, warmup, barrier=lambda: None):
                      "own stream (a lane's copies overlap the other lane's kernels)")
 
 
+def bench_native_lanes(net, batches, firsts, steps, warmup):
+    """The same K steps through the LIBRARY's own lanes (as_lanes, csrc/lanes.hip: serial plans, streams, workspaces and hipGraphs kept by
+    the C++ runtime; one as_lanes_submit per batch) instead of this script's graphs and streams: the arrangement of the headline number
+    as a C-ABI object.  Results are compared bitwise with the lanes' own first eager steps."""
+    from artspeech_amd import models
+    n = len(batches)
+    lanes = models.Lanes(net, n)
+    outs = [None] * n
+
+    def submit(i):
+        g = batches[i % n]
+        _, outs[i % n] = lanes.submit(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
+                                      frames=g["frames"], out=outs[i % n])
+    for i in range(max(warmup, 3 * n)):                       # (eager, captured, replayed)
+        submit(i)
+    lanes.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        submit(i)
+    lanes.wait()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = all(torch.equal(o["mel"], f) for o, f in zip(outs, firsts))
+    lanes.close()
+    return dict(ms_per_step=el / steps * 1e3, lanes=n, results_bitwise_equal=ok,
+                note="as_lanes_submit per batch: the library keeps the serial plans, streams, workspaces and hipGraphs")
+
+
 def c4_check(net, host, mel_mine, mine, world, rank, dev, dist):
     """merge the ranks' shards on rank 0 and compare with rank 0 running the whole global batch alone"""
     from artspeech_amd import shard
@@ -563,6 +593,9 @@ def main():
             in_flight_note = "results of the batches in flight differed from the one-at-a-time result: in-flight timing discarded"
             n_fl = 1
             lanes = lanes[:1]
+    native = None
+    if n_fl > 1 and rank == 0 and not args.no_extras:
+        native = bench_native_lanes(net, [r.g for r, _, _ in lanes], firsts, args.steps, args.warmup)
     # the same K steps with the host <-> device copies inside the timed region (every rank; max over ranks like the headline)
     transfers = None
     if not args.no_graph and not args.global_batch and not args.no_extras:
@@ -649,6 +682,8 @@ def main():
     extras = rank == 0 and not args.no_extras and not args.global_batch and args.config == "C3"
     if transfers:
         line["transfers"] = transfers
+    if native:
+        line["lanes_native"] = native
     if extras:
         line["mas"] = bench_mas(dev)
         line["configs"] = {

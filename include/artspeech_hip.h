@@ -535,6 +535,27 @@ int as_forward_test_finish(const as_model* m, as_plan* p, const as_batch* batch,
 int as_forward_test(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
                     void* ws_b, size_t ws_b_bytes, int32_t* frames_host_out, as_stream_t stream);
 
+/* ---- batches in flight (csrc/lanes.hip; DESIGN.md section 5: the throughput arrangement) -----------------------------------------------
+ * as_lanes = n lanes on ONE model: per lane a serial plan (as_plan_set_serial), a HIP stream of its own, its two workspaces (grown on
+ * demand) and the hipGraphs of the (geometry, io) pairs it has replayed.  as_lanes_submit enqueues ONE batch (ArtsSpeech.forward(
+ * step="test"), as as_forward_test) on the next lane, round robin, and returns at once; before it does it waits until that lane's
+ * PREVIOUS batch has finished -- so the device buffers named by a lane's as_forward_io may be refilled once the submit that follows them
+ * on the same lane has been entered, or after as_lanes_wait.  Fill a lane's input buffers on ITS stream (as_lanes_stream(q,
+ * as_lanes_next(q))) or synchronise before submitting.  With batch->frames given (forced durations, or a second pass) the second submit of
+ * a (geometry, io) pair on a lane is captured into a hipGraph and later ones are one hipGraphLaunch; with frames == NULL (predicted
+ * durations) every submit runs as_forward_test eagerly, which synchronises that lane's stream once to read the frame counts, and a
+ * workspace too small for them is re-sized and the call repeated (AS_ENOSPC only if io->ld_out itself is too small: frames_host_out then
+ * says what is needed).  Not thread-safe: one host thread per as_lanes.  as_lanes_wait(q, lane): lane < 0 = all; AS_EDEVICE if a kernel
+ * raised a status bit (as_device_status). */
+typedef struct as_lanes as_lanes;
+int as_lanes_create(const as_model* m, int n_lanes, as_lanes** out);
+int as_lanes_destroy(as_lanes* q);
+int as_lanes_count(const as_lanes* q);
+int as_lanes_next(const as_lanes* q);
+as_stream_t as_lanes_stream(const as_lanes* q, int lane);
+int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out);
+int as_lanes_wait(as_lanes* q, int lane);
+
 #ifdef __cplusplus
 }
 #endif
