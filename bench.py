@@ -331,10 +331,18 @@ def bench_mas(dev):
     return out
 
 
-def bench_config(net, dev, name, n_utt, n_tok, m_half, t_ref, steps, n_prod_modes=(3,)):
-    """another BASELINE config on the same model: graph-replayed step time, frames/s, its conv-GEMM rate"""
+def bench_config(net, dev, name, n_utt, n_tok, m_half, t_ref, steps, n_prod_modes=(3,), lanes=0):
+    """another BASELINE config on the same model: graph-replayed step time, frames/s, its conv-GEMM rate; lanes > 0: also the rate with
+    that many batches of the config in flight (as_lanes)"""
     host, g = make_inputs(dev, n_utt, n_tok, m_half, t_ref, seed0=DATA_SEED + 1000)
     res = {}
+    if lanes:
+        batches = [g] + [make_inputs(dev, n_utt, n_tok, m_half, t_ref, seed0=DATA_SEED + 1000 + 100 * i)[1] for i in range(1, lanes)]
+        firsts = [Runner(net, b).step()["mel"].clone() for b in batches]
+        nl = bench_native_lanes(net, batches, firsts, 4 * steps, 0)
+        res["in_flight"] = dict(lanes=lanes, ms_per_step=nl["ms_per_step"], ms_per_utt=nl["ms_per_step"] / n_utt,
+                                frames_per_s=2 * sum(g["frames"]) / (nl["ms_per_step"] * 1e-3), results_bitwise_equal=nl["results_bitwise_equal"],
+                                note="throughput with this many batches of the config in flight (as_lanes); ms_per_step above is ONE batch alone")
     ref_mel = None
     for n_prod in n_prod_modes:
         net.rt.set_operand_mode(n_prod)
@@ -687,8 +695,8 @@ def main():
     if extras:
         line["mas"] = bench_mas(dev)
         line["configs"] = {
-            "C2": bench_config(net, dev, "C2 (LJSpeech-like latency)", 1, 30, 75, 150, 50, n_prod_modes=(3, 1)),
-            "C5": bench_config(net, dev, "C5 (long form)", 8, 1024, 1024, 200, 10),
+            "C2": bench_config(net, dev, "C2 (LJSpeech-like latency)", 1, 30, 75, 150, 50, n_prod_modes=(3, 1), lanes=4),
+            "C5": bench_config(net, dev, "C5 (long form)", 8, 1024, 1024, 200, 10, lanes=4),
         }
     if rank == 0 and args.cpu_utts > 0 and not args.global_batch and args.config == "C3":
         cb, outs = cpu_baseline(host, sd, args.cpu_utts)
