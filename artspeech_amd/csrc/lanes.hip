@@ -81,7 +81,8 @@ extern "C" int as_lanes_destroy(as_lanes* q)
     return AS_OK;
 }
 
-extern "C" int as_lanes_create(const as_model* m, int n_lanes, as_lanes** out)
+// (nothing may leave through the C boundary: the bodies below allocate host memory)
+static int lanes_create(const as_model* m, int n_lanes, as_lanes** out)
 {
     if (!m || !out || n_lanes < 1 || n_lanes > 64) return AS_EINVAL;
     *out = nullptr;
@@ -102,6 +103,15 @@ extern "C" int as_lanes_create(const as_model* m, int n_lanes, as_lanes** out)
     return AS_OK;
 }
 
+extern "C" int as_lanes_create(const as_model* m, int n_lanes, as_lanes** out)
+{
+    try {
+        return lanes_create(m, n_lanes, out);
+    } catch (...) {
+        return (int)hipErrorOutOfMemory;
+    }
+}
+
 extern "C" int as_lanes_count(const as_lanes* q) { return q ? (int)q->lanes.size() : 0; }
 extern "C" int as_lanes_next(const as_lanes* q) { return q ? q->next : -1; }
 extern "C" as_stream_t as_lanes_stream(const as_lanes* q, int lane)
@@ -118,7 +128,7 @@ extern "C" int as_lanes_wait(as_lanes* q, int lane)
     return as_device_status(0) ? AS_EDEVICE : AS_OK;
 }
 
-extern "C" int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out)
+static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out)
 {
     if (!q || !batch || !io || batch->B <= 0 || !batch->tok_lens || !batch->ref_lens) return AS_EINVAL;
     const int lane = q->next;
@@ -187,4 +197,13 @@ extern "C" int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forw
     L.graphs[key] = exec;
     if (frames_host_out) memcpy(frames_host_out, batch->frames, sizeof(int32_t) * batch->B);
     return hipGraphLaunch(exec, L.stream) == hipSuccess ? AS_OK : (int)hipErrorUnknown;
+}
+
+extern "C" int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out)
+{
+    try {
+        return lanes_submit(q, batch, io, frames_host_out, lane_out);
+    } catch (...) {
+        return (int)hipErrorOutOfMemory;
+    }
 }
