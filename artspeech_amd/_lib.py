@@ -139,6 +139,8 @@ _SIGNATURES.update({
     "as_plan_phase_ms": (c_i, [c_p, ctypes.POINTER(ctypes.c_float), c_i]),
     "as_plan_set_layout_cap": (c_i, [c_p, c_i]),
     "as_plan_layout_flushes": (c_i, [c_p]),
+    "as_plan_layout_count": (c_i, [c_p]),
+    "as_plan_reset_layouts": (c_i, [c_p]),
     "as_bilstm_cluster_test_hooks": (c_i, [c_i, c_i]),
     "as_module_workspace_bytes": (c_sz, [c_p, c_p, c_i, _pB]),
     "as_encoder_forward": (c_i, [c_p, c_p, c_i, _pB, c_p, c_p, c_i, c_p, c_sz, c_p]),
@@ -156,6 +158,9 @@ _SIGNATURES.update({
     "as_lanes_stream": (c_p, [c_p, c_i]),
     "as_lanes_submit": (c_i, [c_p, _pB, _pIO, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "as_lanes_wait": (c_i, [c_p, c_i]),
+    "as_lanes_set_graph_cap": (c_i, [c_p, c_i]),
+    "as_lanes_set_layout_cap": (c_i, [c_p, c_i]),
+    "as_lanes_stats": (c_i, [c_p, c_i, ctypes.POINTER(ctypes.c_int64)]),
 })
 
 

@@ -542,12 +542,7 @@ static int launch_attention_image(const AttnImageArgs& a, int heads, int B, int 
 {
     constexpr int NQ = NW * 32;
     const size_t smem = (size_t)(2 * (2 * 8 * 2 * FK) + 2 * 4 * 2 * 128 + 2 * 8 * 2 * 32 + 2 * 2 * 128) * 16 + sizeof(float) * (NQ * MAXREL + NQ * 16);
-    static bool attr = false;
-    if (!attr) {
-        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_image_kernel<NW>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    AS_LDS_OPT_IN(relpos_attention_image_kernel<NW>, 160 * 1024);
     AsProfScope prof__(AS_FILE_CLS, 0, 0, stream);
     hipLaunchKernelGGL(relpos_attention_image_kernel<NW>, dim3(as_cdiv(max_len, NQ), heads, B), dim3(NW * 64), smem, stream, a);
     AS_CHECK_LAUNCH();
@@ -584,12 +579,7 @@ extern "C" int as_relpos_attention_groups_f32(const float* qkv, int ld, int C, i
     if (dk > MAXDK || 2 * window + 1 > MAXREL || window < 0 || B < 0) return AS_EINVAL;
     if (B == 0 || max_len <= 0) return AS_OK;
     const size_t smem = sizeof(float) * ((size_t)2 * dk * KPAD + QT * dk + 4 * KT * 4 + QT * MAXREL + 2 * MAXREL * dk);
-    static bool attr_set = false;                          // > 64 KiB of dynamic LDS needs an explicit opt-in
-    if (!attr_set) {
-        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    AS_LDS_OPT_IN(relpos_attention_kernel, 160 * 1024);   // > 64 KiB of dynamic LDS needs an explicit opt-in
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(relpos_attention_kernel, dim3(as_cdiv(max_len, QT), heads, B), dim3(256), smem, (hipStream_t)stream,
                        qkv, ld, C, heads, window, emb_rel_k, emb_rel_v, emb_rel_k2, emb_rel_v2, b_split, col_off, out, ldo);

@@ -28,6 +28,30 @@ int as_status_peek();                   // host view: bit k = kind k raised
 
 static inline int as_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// The opt-in for more than 64 KiB of dynamic LDS is a per-device function attribute: one of these per call site sets it once on every
+// device the process drives (the library keeps per-device state elsewhere too: status.hip), from any host thread.
+struct AsLdsOptIn {
+    unsigned long long done = 0;        // bit d: set on device d (read / written with __atomic builtins)
+    int ensure(const void* fn, int bytes)
+    {
+        int d = 0;
+        hipError_t e = hipGetDevice(&d);
+        if (e != hipSuccess) return (int)e;
+        const unsigned long long bit = 1ull << (d & 63);
+        if (__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit) return AS_OK;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+        return AS_OK;
+    }
+};
+#define AS_LDS_OPT_IN(fn, bytes)                                                   \
+    do {                                                                           \
+        static AsLdsOptIn opt__;                                                   \
+        const int r__ = opt__.ensure(reinterpret_cast<const void*>(fn), (bytes));  \
+        if (r__ != AS_OK) return r__;                                              \
+    } while (0)
+
 #define AS_WAVE 64
 
 // kernel classes for the optional event profiler (prof.hip)

@@ -165,12 +165,7 @@ extern "C" int as_xl_attention_f32(const float* qkv, int ld, int C, int heads, c
     if (!qkv || !pos || !u_bias || !v_bias || !col_off || !out || C <= 0 || heads <= 0 || C != heads * XDK || B < 0) return AS_EINVAL;
     if (B == 0 || max_len <= 0) return AS_OK;
     const size_t smem = sizeof(float) * ((size_t)2 * XDK * XPAD + XDK * XPP + XQT * XDK + (XQT + 1) * XDK + 4 * XKT * 4);
-    static bool attr_set = false;                          // > 64 KiB of dynamic LDS needs an explicit opt-in
-    if (!attr_set) {
-        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(xl_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-        attr_set = true;
-    }
+    AS_LDS_OPT_IN(xl_attention_kernel, 160 * 1024);       // > 64 KiB of dynamic LDS needs an explicit opt-in
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(xl_attention_kernel, dim3(as_cdiv(max_len, XQT), heads, B), dim3(256), smem, (hipStream_t)stream, qkv, ld, C,
                        pos, ldp, u_bias, v_bias, inv_scale, col_off, out, ldo);

@@ -388,12 +388,7 @@ template <int WM, int WN, int WK, int KT, int NS, int NP, int TM = 2>
 static int launch_h3(const ConvGemmArgs& a, int S, hipStream_t stream)
 {
     using C = H3Cfg<WM, WN, WK, KT, NS, NP, TM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP, TM>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        attr_set = true;
-    }
+    AS_LDS_OPT_IN((&conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP, TM>), C::LDS);
     H3Taps tp;
     if (h3_pack_taps(a, &tp) != AS_OK) return AS_EINVAL;
     const int tiles_n = a.n_groups > 1 ? a.n_groups * as_cdiv(a.group_cols, C::BN) : as_cdiv(a.N, C::BN);

@@ -1,18 +1,27 @@
 // The throughput arrangement of the path as a piece of the library: N batches in flight on ONE model, every batch
 // one chain on its own stream.  Built on the module-level C ABI only (as_plan_*, as_module_workspace_bytes, as_forward_test): a lane = a
-// serial plan (as_plan_set_serial: the step's independent branches back to back) + a HIP stream + its two workspaces + the hipGraphs of
+// HIP stream + its two workspaces + two serial plans (as_plan_set_serial: the step's independent branches back to back) + the hipGraphs of
 // the batch geometries it has replayed.  The reference has no counterpart (models.py:361-362 processes one utterance at a time; a
 // server calling it would keep several requests in flight exactly like this).
 //
-//   first submit of a geometry on a lane   as_forward_test eagerly (a plan's first call with a geometry uploads its tables: not capturable)
-//   second submit                          the same call captured into a hipGraph (needs batch->frames: with predicted durations the
-//                                          call reads the frame counts back in the middle and stays eager), instantiated, launched
-//   later submits                          one hipGraphLaunch
-// A graph bakes the pointers in: it is reused only for the same geometry AND the same as_forward_io (a serving loop keeps one set of
-// device buffers per lane and copies requests into them).
+//   first submit of a (geometry, io) pair   as_forward_test eagerly on the lane's EAGER plan
+//   second submit                           eagerly on the lane's GRAPH plan (a plan's first call with a geometry uploads its tables: not
+//                                           capturable) -- only geometries that come back reach that plan
+//   third submit                            the same call captured from the graph plan into a hipGraph (needs batch->frames: with predicted
+//                                           durations the call reads the frame counts back in the middle and stays eager), launched
+//   later submits                           one hipGraphLaunch
+// A graph bakes in the pointers of the caller's buffers, of the workspaces and of the GRAPH plan's geometry tables:
+//   * it is reused only for the same geometry AND the same as_forward_io (a serving loop keeps one set of device buffers per lane);
+//   * the eager plan's layout cache may be flushed at any entry point (ever new ragged batches: as_plan_set_layout_cap) -- no graph
+//     refers to it.  The graph plan never flushes by itself (cap = INT_MAX); its tables die together with the graphs: when a lane would
+//     hold more than `graph_cap` graphs, or its workspaces move, the lane's stream is drained, every graph destroyed and the graph plan
+//     reset (as_plan_reset_layouts: the table memory is reused, nothing is freed);
+//   * nothing here frees device memory while other lanes may be busy (a hipFree synchronises the device): an outgrown workspace is
+//     parked until as_lanes_wait(q, -1) / as_lanes_destroy.
 #include "common.h"
 #include "artspeech_hip.h"
 #include <algorithm>
+#include <climits>
 #include <cstring>
 #include <new>
 #include <string>
@@ -22,39 +31,45 @@
 namespace {
 
 struct Lane {
-    as_plan* plan = nullptr;
+    as_plan* plan = nullptr;                                      // eager calls, workspace queries: flushed whenever its cap says so
+    as_plan* gplan = nullptr;                                     // geometries that are (about to be) replayed from graphs; reset with them
     hipStream_t stream = nullptr;
     void *wa = nullptr, *wb = nullptr;
     size_t na = 0, nb = 0;
     std::unordered_map<std::string, hipGraphExec_t> graphs;      // key -> instantiated graph
-    std::unordered_map<std::string, int> seen;                    // key -> eager calls so far
+    std::unordered_map<std::string, int> seen;                    // key -> eager calls so far (1: eager plan; 2: graph plan)
+    int64_t n_drops = 0, n_launch = 0, n_eager = 0, n_capture = 0;
 };
 
+// the lane's stream is idle (lanes_submit synchronises it first): no graph is running, nothing reads the graph plan's tables
 void drop_graphs(Lane& L)
 {
-    for (auto& kv : L.graphs) hipGraphExecDestroy(kv.second);
+    if (L.graphs.empty() && L.seen.empty()) return;
+    for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
     L.graphs.clear();
+    L.seen.clear();
+    (void)as_plan_reset_layouts(L.gplan);
+    ++L.n_drops;
 }
 
-bool grow(void** p, size_t* have, size_t need)
+template <typename T>
+void put(std::string& k, const T& v)
 {
-    if (need <= *have) return true;
-    if (*p) hipFree(*p);
-    *p = nullptr;
-    *have = 0;
-    const size_t n = need + need / 8;                             // some slack: lengths vary from batch to batch
-    if (hipMalloc(p, n) != hipSuccess) return false;
-    *have = n;
-    return true;
+    k.append(reinterpret_cast<const char*>(&v), sizeof(T));
 }
 
+// Named fields only: the struct's padding bytes are whatever the caller's memory held
 std::string key_of(const as_batch* b, const as_forward_io* io)
 {
-    std::string k(reinterpret_cast<const char*>(&b->B), sizeof(b->B));
+    std::string k;
+    put(k, b->B);
     k.append(reinterpret_cast<const char*>(b->tok_lens), sizeof(int32_t) * b->B);
     k.append(reinterpret_cast<const char*>(b->ref_lens), sizeof(int32_t) * b->B);
     if (b->frames) k.append(reinterpret_cast<const char*>(b->frames), sizeof(int32_t) * b->B);
-    k.append(reinterpret_cast<const char*>(io), sizeof(*io));
+    put(k, io->tokens); put(k, io->mel); put(k, io->ld_mel); put(k, io->f0_raw); put(k, io->ema_raw); put(k, io->ld_ema);
+    put(k, io->forced_dur); put(k, io->mel_out); put(k, io->ld_out); put(k, io->duration); put(k, io->dur_i); put(k, io->frame_off);
+    put(k, io->style); put(k, io->feat12); put(k, io->ld_feat); put(k, io->t_en); put(k, io->a_en); put(k, io->ld_en);
+    put(k, io->F0); put(k, io->N); put(k, io->EMA); put(k, io->ld_pred);
     return k;
 }
 
@@ -63,20 +78,50 @@ std::string key_of(const as_batch* b, const as_forward_io* io)
 struct as_lanes {
     const as_model* m = nullptr;
     std::vector<Lane> lanes;
+    std::vector<void*> retired;                                   // outgrown workspaces: freed when every lane is idle
     int next = 0;
+    size_t graph_cap = 256;
 };
+
+namespace {
+
+void free_retired(as_lanes* q)
+{
+    for (void* p : q->retired) (void)hipFree(p);
+    q->retired.clear();
+}
+
+bool grow(as_lanes* q, void** p, size_t* have, size_t need)
+{
+    if (need <= *have) return true;
+    if (*p) q->retired.push_back(*p);                             // (not hipFree: it would stall the other lanes' batches)
+    *p = nullptr;
+    *have = 0;
+    const size_t n = need + need / 8;                             // some slack: lengths vary from batch to batch
+    if (hipMalloc(p, n) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    *have = n;
+    return true;
+}
+
+}  // namespace
 
 extern "C" int as_lanes_destroy(as_lanes* q)
 {
     if (!q) return AS_OK;
+    for (Lane& L : q->lanes)
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
     for (Lane& L : q->lanes) {
-        if (L.stream) hipStreamSynchronize(L.stream);
-        drop_graphs(L);
-        if (L.wa) hipFree(L.wa);
-        if (L.wb) hipFree(L.wb);
+        for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
+        if (L.wa) (void)hipFree(L.wa);
+        if (L.wb) (void)hipFree(L.wb);
         if (L.plan) as_plan_destroy(L.plan);
-        if (L.stream) hipStreamDestroy(L.stream);
+        if (L.gplan) as_plan_destroy(L.gplan);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
     }
+    free_retired(q);
     delete q;
     return AS_OK;
 }
@@ -93,6 +138,9 @@ static int lanes_create(const as_model* m, int n_lanes, as_lanes** out)
     for (Lane& L : q->lanes) {
         int rc = as_plan_create(m, &L.plan);
         if (rc == AS_OK) rc = as_plan_set_serial(L.plan, 1);
+        if (rc == AS_OK) rc = as_plan_create(m, &L.gplan);
+        if (rc == AS_OK) rc = as_plan_set_serial(L.gplan, 1);
+        if (rc == AS_OK) rc = as_plan_set_layout_cap(L.gplan, INT_MAX);     // never flushes on its own: reset with the graphs
         if (rc == AS_OK && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) rc = (int)hipErrorOutOfMemory;
         if (rc != AS_OK) {
             as_lanes_destroy(q);
@@ -119,12 +167,43 @@ extern "C" as_stream_t as_lanes_stream(const as_lanes* q, int lane)
     return (q && lane >= 0 && lane < (int)q->lanes.size()) ? static_cast<as_stream_t>(q->lanes[lane].stream) : nullptr;
 }
 
+extern "C" int as_lanes_set_graph_cap(as_lanes* q, int max_graphs)
+{
+    if (!q || max_graphs < 1) return AS_EINVAL;
+    q->graph_cap = (size_t)max_graphs;
+    return AS_OK;
+}
+
+extern "C" int as_lanes_set_layout_cap(as_lanes* q, int max_layouts)
+{
+    if (!q) return AS_EINVAL;
+    for (Lane& L : q->lanes) {
+        const int rc = as_plan_set_layout_cap(L.plan, max_layouts);
+        if (rc != AS_OK) return rc;
+    }
+    return AS_OK;
+}
+
+extern "C" int as_lanes_stats(const as_lanes* q, int lane, int64_t* out6)
+{
+    if (!q || !out6 || lane < 0 || lane >= (int)q->lanes.size()) return AS_EINVAL;
+    const Lane& L = q->lanes[lane];
+    out6[0] = (int64_t)L.graphs.size();
+    out6[1] = L.n_drops;
+    out6[2] = as_plan_layout_flushes(L.plan);
+    out6[3] = L.n_launch;
+    out6[4] = L.n_eager;
+    out6[5] = L.n_capture;
+    return AS_OK;
+}
+
 extern "C" int as_lanes_wait(as_lanes* q, int lane)
 {
     if (!q || lane >= (int)q->lanes.size()) return AS_EINVAL;
     for (int i = 0; i < (int)q->lanes.size(); ++i)
         if (lane < 0 || lane == i)
             if (hipStreamSynchronize(q->lanes[i].stream) != hipSuccess) return (int)hipErrorUnknown;
+    if (lane < 0) free_retired(q);                                // every lane is idle: a free's device synchronisation costs nothing now
     return as_device_status(0) ? AS_EDEVICE : AS_OK;
 }
 
@@ -136,6 +215,7 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
     if (lane_out) *lane_out = lane;
     // the lane's previous batch has left its workspaces (and the caller's buffers of that lane)
     if (hipStreamSynchronize(L.stream) != hipSuccess) return (int)hipErrorUnknown;
+    // (sizes come from the eager plan: a count pass adds host-side layout entries, which that plan may flush; the graph plan stays small)
     const size_t na = as_module_workspace_bytes(q->m, L.plan, AS_MOD_FORWARD_A, batch);
     if (!na) return AS_EINVAL;
     // workspace B depends on the frame counts: known (forced durations / a second pass), or sized for what the output buffer can hold
@@ -148,7 +228,7 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
     size_t nb = as_module_workspace_bytes(q->m, L.plan, AS_MOD_FORWARD_B, &bb);
     if (!nb) return AS_EINVAL;
     if (na > L.na || nb > L.nb) drop_graphs(L);                   // the graphs hold the old workspaces' addresses
-    if (!grow(&L.wa, &L.na, na) || !grow(&L.wb, &L.nb, nb)) return (int)hipErrorOutOfMemory;
+    if (!grow(q, &L.wa, &L.na, na) || !grow(q, &L.wb, &L.nb, nb)) return (int)hipErrorOutOfMemory;
     q->next = (lane + 1) % (int)q->lanes.size();
 
     if (!batch->frames) {
@@ -156,6 +236,7 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
         // small for what came out -- frames_host_out says what is needed: size B for it and run again (the header's contract)
         std::vector<int32_t> fr(batch->B, 0);
         int32_t* fh = frames_host_out ? frames_host_out : fr.data();
+        ++L.n_eager;
         int rc = as_forward_test(q->m, L.plan, batch, io, L.wa, L.na, L.wb, L.nb, fh, L.stream);
         if (rc == AS_ENOSPC) {
             as_batch fit = *batch;
@@ -165,37 +246,62 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
             if (2 * total > io->ld_out) return AS_ENOSPC;           // the caller's output buffer itself is too small
             nb = as_module_workspace_bytes(q->m, L.plan, AS_MOD_FORWARD_B, &fit);
             if (!nb) return AS_EINVAL;
-            drop_graphs(L);
-            if (!grow(&L.wb, &L.nb, nb)) return (int)hipErrorOutOfMemory;
+            if (hipStreamSynchronize(L.stream) != hipSuccess) return (int)hipErrorUnknown;
+            if (nb > L.nb) drop_graphs(L);
+            if (!grow(q, &L.wb, &L.nb, nb)) return (int)hipErrorOutOfMemory;
             rc = as_forward_test(q->m, L.plan, batch, io, L.wa, L.na, L.wb, L.nb, fh, L.stream);
         }
         return rc;
     }
+    if (frames_host_out) memcpy(frames_host_out, batch->frames, sizeof(int32_t) * batch->B);
     const std::string key = key_of(batch, io);
     auto g = L.graphs.find(key);
-    if (g != L.graphs.end()) return hipGraphLaunch(g->second, L.stream) == hipSuccess ? AS_OK : (int)hipErrorUnknown;
-    int& n_seen = L.seen[key];
-    if (n_seen == 0) {                                              // first call with this geometry: tables are uploaded, the stream synchronised
-        n_seen = 1;
-        if (L.seen.size() > 256) { L.seen.clear(); drop_graphs(L); }
-        return as_forward_test(q->m, L.plan, batch, io, L.wa, L.na, L.wb, L.nb, frames_host_out, L.stream);
+    if (g != L.graphs.end()) {
+        ++L.n_launch;
+        return hipGraphLaunch(g->second, L.stream) == hipSuccess ? AS_OK : (int)hipErrorUnknown;
     }
+    auto it = L.seen.find(key);
+    int state = it == L.seen.end() ? 0 : it->second;
+    if (state >= 1 && L.graphs.size() >= q->graph_cap) {            // no room for one more graph: all graphs and the graph plan's tables go
+        drop_graphs(L);
+        state = 1;                                                  // (this pair has been seen; the graph plan has to meet it again)
+    }
+    if (state == 0) {                                               // first call with this pair: the eager plan (flushable), nothing kept but the count
+        if (L.seen.size() >= 4 * q->graph_cap) drop_graphs(L);      // (the count map itself stays bounded under ever new geometries)
+        L.seen[key] = 1;
+        ++L.n_eager;
+        return as_forward_test(q->m, L.plan, batch, io, L.wa, L.na, L.wb, L.nb, nullptr, L.stream);
+    }
+    if (state == 1) {                                               // it came back: the graph plan meets it eagerly (uploads its tables)
+        L.seen[key] = 2;
+        ++L.n_eager;
+        return as_forward_test(q->m, L.gplan, batch, io, L.wa, L.na, L.wb, L.nb, nullptr, L.stream);
+    }
+    // third call: capture from the graph plan (its tables for this geometry exist; its cap is never reached, so no flush can fall into
+    // the capture -- and as_plan's flush skips a capturing stream anyway)
     if (hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return (int)hipErrorUnknown;
-    const int rc = as_forward_test(q->m, L.plan, batch, io, L.wa, L.na, L.wb, L.nb, nullptr, L.stream);
+    const int rc = as_forward_test(q->m, L.gplan, batch, io, L.wa, L.na, L.wb, L.nb, nullptr, L.stream);
     hipGraph_t graph = nullptr;
     const hipError_t ec = hipStreamEndCapture(L.stream, &graph);
     if (rc != AS_OK || ec != hipSuccess || !graph) {
-        if (graph) hipGraphDestroy(graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
         if (rc != AS_OK) return rc;
         // not capturable after all: run it eagerly
-        return as_forward_test(q->m, L.plan, batch, io, L.wa, L.na, L.wb, L.nb, frames_host_out, L.stream);
+        ++L.n_eager;
+        return as_forward_test(q->m, L.gplan, batch, io, L.wa, L.na, L.wb, L.nb, nullptr, L.stream);
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
-    if (ei != hipSuccess || !exec) return as_forward_test(q->m, L.plan, batch, io, L.wa, L.na, L.wb, L.nb, frames_host_out, L.stream);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) {
+        (void)hipGetLastError();
+        ++L.n_eager;
+        return as_forward_test(q->m, L.gplan, batch, io, L.wa, L.na, L.wb, L.nb, nullptr, L.stream);
+    }
     L.graphs[key] = exec;
-    if (frames_host_out) memcpy(frames_host_out, batch->frames, sizeof(int32_t) * batch->B);
+    ++L.n_capture;
+    ++L.n_launch;
     return hipGraphLaunch(exec, L.stream) == hipSuccess ? AS_OK : (int)hipErrorUnknown;
 }
 

@@ -476,12 +476,7 @@ extern "C" int as_bilstm_f32(const BiLstmJob* jobs_host, int n_jobs, const int32
 #endif
         constexpr int KREG = LSTM_KREG, KLDS = 36;                    
         const size_t sm_big = smem + sizeof(float) * (size_t)KLDS * 1024;
-        static bool attr_set = false;
-        if (!attr_set) {
-            AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_big_kernel<256, KREG, KLDS>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big));   // (+ 16 bytes static: 160 KB would be refused)
-            attr_set = true;
-        }
+        AS_LDS_OPT_IN((bilstm_big_kernel<256, KREG, KLDS>), (int)sm_big);   // (+ 16 bytes static: 160 KB would be refused)
         if (getenv("AS_LSTM_STREAM")) hipLaunchKernelGGL(bilstm_kernel<0>, grid, block, smem, (hipStream_t)stream, jobs, col_off, B, H);
         else hipLaunchKernelGGL((bilstm_big_kernel<256, KREG, KLDS>), grid, dim3(512), sm_big, (hipStream_t)stream, jobs, col_off, B);
         break;

@@ -877,11 +877,7 @@ extern "C" int as_mas_f32(const float* value, const int* t_x, const int* t_y, in
             const dim3 gb(g.nblk, B);
             const size_t lds_words = ((size_t)Tx + 4) * sizeof(unsigned);
             const int chain_lds = std::max(MAS_CHAIN_LDS / g.exs * g.exs, g.exs) > MAS_CHAIN_LDS ? g.exs : MAS_CHAIN_LDS;
-            static bool attr_set = false;
-            if (!attr_set) {
-                AS_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mas_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MAS_CHAIN_LDS));
-                attr_set = true;
-            }
+            AS_LDS_OPT_IN(&mas_chain_kernel, MAS_CHAIN_LDS);
             if (g.R == 1) hipLaunchKernelGGL((mas_exit_kernel<1>), gb, dim3(1024), lds_words, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, ex, g.exs);
             else hipLaunchKernelGGL((mas_exit_kernel<2>), gb, dim3(1024), lds_words, stream, t_x, t_y, Tx, Ty, g.P, g.nblk, masks, ex, g.exs);
             hipLaunchKernelGGL(mas_chain_kernel, dim3(B), dim3(1024), chain_lds, stream, t_x, t_y, Tx, Ty, g.nblk, ex, g.exs, entry, chain_lds);

@@ -38,29 +38,48 @@ inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 // ------------------------------------------------------------------------------------------------------------------
 struct DevPool {
     std::vector<void*> chunks;
+    std::vector<size_t> sizes;
+    size_t idx = 0;               // chunk being filled (chunks behind it are full, chunks after it are free: rewind() keeps them)
     char* cur = nullptr;
     size_t left = 0, chunk_bytes;
     explicit DevPool(size_t chunk) : chunk_bytes(chunk) {}
     void* alloc(size_t n)
     {
         n = align256(n ? n : 1);
-        if (n > left) {
-            const size_t c = n > chunk_bytes ? n : chunk_bytes;
-            void* p = nullptr;
-            if (hipMalloc(&p, c) != hipSuccess) return nullptr;
-            chunks.push_back(p);
-            cur = static_cast<char*>(p);
-            left = c;
+        while (n > left) {
+            if (cur && idx + 1 < chunks.size()) {              // a chunk kept by rewind()
+                ++idx;
+            } else if (!cur && !chunks.empty()) {
+                idx = 0;
+            } else {
+                const size_t c = n > chunk_bytes ? n : chunk_bytes;
+                void* p = nullptr;
+                if (hipMalloc(&p, c) != hipSuccess) return nullptr;
+                chunks.push_back(p);
+                sizes.push_back(c);
+                idx = chunks.size() - 1;
+            }
+            cur = static_cast<char*>(chunks[idx]);
+            left = sizes[idx];
         }
         void* r = cur;
         cur += n;
         left -= n;
         return r;
     }
+    // everything handed out so far is dead: start over in the memory already held (no hipFree: a free synchronises the whole device)
+    void rewind()
+    {
+        idx = 0;
+        cur = nullptr;
+        left = 0;
+    }
     void release()
     {
         for (void* p : chunks) (void)hipFree(p);
         chunks.clear();
+        sizes.clear();
+        idx = 0;
         cur = nullptr;
         left = 0;
     }
@@ -414,22 +433,45 @@ struct as_plan {
     }
     // Layout cache.  A key is a whole length vector, so a server that sees ever new ragged batches adds ~10-20 entries per batch.
     // trim() runs at the START of an entry point, when no `const Lay*` of an earlier call is alive: above the cap it waits for the
-    // device (kernels of earlier calls may still read the tables), drops every layout and rewinds the table pool, so neither the host
-    // map nor device memory grows without bound.  A hipGraph captured from this plan holds table addresses: use a plan of its own
-    // for captured geometries (bench.py does), or watch layout_flushes.
+    // streams this plan has launched on (kernels of earlier calls may still read the tables) -- not for the device: other plans' work
+    // goes on --, drops every layout and rewinds the table pool (the memory is kept: a hipFree would synchronise the device), so neither
+    // the host map nor device memory grows without bound.  Never while `s` is being captured (a synchronisation is illegal there): the
+    // trim then waits for the next entry point.  A hipGraph captured from this plan holds table addresses: captured geometries get a plan
+    // of their own that is reset only together with its graphs (as_plan_reset_layouts; csrc/lanes.hip does exactly that), or the owner
+    // watches layout_flushes.
     size_t lay_cap = 4096;
     int layout_flushes = 0;
-    int trim()
+    std::vector<hipStream_t> used;        // calling streams of the run entry points since the last flush
+    void note_stream(hipStream_t s)
     {
-        if (lays.size() <= lay_cap) return AS_OK;
-        const hipError_t e = hipDeviceSynchronize();
-        if (e != hipSuccess) return (int)e;
+        if (std::find(used.begin(), used.end(), s) == used.end()) used.push_back(s);
+    }
+    int drop_layouts()
+    {
         lays.clear();
-        pool.release();
+        pool.rewind();
         lstm_xchg = nullptr;
         lstm_xchg_bytes = 0;
+        used.clear();
         ++layout_flushes;
         return AS_OK;
+    }
+    int trim(hipStream_t s)
+    {
+        if (lays.size() <= lay_cap) return AS_OK;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return AS_OK; }
+        if (cs != hipStreamCaptureStatusNone) return AS_OK;
+        note_stream(s);
+        for (hipStream_t u : used) {
+            const hipError_t e = hipStreamSynchronize(u);
+            if (e != hipSuccess) return (int)e;
+        }
+        for (hipStream_t u : side) {
+            const hipError_t e = hipStreamSynchronize(u);
+            if (e != hipSuccess) return (int)e;
+        }
+        return drop_layouts();
     }
     std::vector<int> frames_host;         // as_forward_test with unknown frame counts reads them here
     void* lstm_xchg = nullptr;            // as_bilstm_cluster_f32's exchange buffer (zero-filled once, then the library's)
@@ -2171,8 +2213,9 @@ struct Call {                     // common prologue of the run entry points
     {
         if (launch) {
             p->next_event = 0;
-            const int t = first ? p->trim() : AS_OK;       // (as_forward_test_finish continues _begin's call: it needs _begin's layouts)
+            const int t = first ? p->trim(static_cast<hipStream_t>(stream)) : AS_OK;   // (as_forward_test_finish continues _begin's call: it needs _begin's layouts)
             if (t != AS_OK) c.fail(t);
+            p->note_stream(static_cast<hipStream_t>(stream));
             if (as_status_peek()) c.fail(AS_EDEVICE);      // a kernel of earlier work reported a failure: sticky until as_device_status(1)
         }
         if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) c.fail(AS_EINVAL);
@@ -2197,6 +2240,13 @@ extern "C" int as_plan_set_layout_cap(as_plan* p, int max_layouts)
 }
 
 extern "C" int as_plan_layout_flushes(const as_plan* p) { return p ? p->layout_flushes : AS_EINVAL; }
+extern "C" int as_plan_layout_count(const as_plan* p) { return p ? (int)p->lays.size() : AS_EINVAL; }
+
+extern "C" int as_plan_reset_layouts(as_plan* p)
+{
+    if (!p) return AS_EINVAL;
+    return p->drop_layouts();
+}
 
 extern "C" int as_encoder_forward(const as_model* m, as_plan* p, int which, const as_batch* batch, const int32_t* tokens, float* out, int ldo,
                                   void* ws, size_t ws_bytes, as_stream_t stream)

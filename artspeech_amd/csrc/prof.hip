@@ -62,7 +62,11 @@ extern "C" int as_prof_collect(double* ms, double* flops, double* bytes, int32_t
     std::lock_guard<std::mutex> g(g_mu);
     for (int i = 0; i < n_classes; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
     const char* csv = getenv("AS_PROF_CSV");
-    FILE* f = csv ? fopen(csv, "a") : nullptr;
+    struct Csv {                                          // (closed on every path out of this function)
+        FILE* f;
+        ~Csv() { if (f) fclose(f); }
+    } out{csv ? fopen(csv, "a") : nullptr};
+    FILE* f = out.f;
     for (auto& r : g_recs) {
         AS_CHECK(hipEventSynchronize(r.b));
         float t = 0.f;
@@ -71,7 +75,6 @@ extern "C" int as_prof_collect(double* ms, double* flops, double* bytes, int32_t
         ms[c] += t; flops[c] += r.flops; bytes[c] += r.bytes; launches[c] += 1;
         if (f) fprintf(f, "%d,%s,%.6f,%.0f,%.0f\n", r.cls, r.tag, t, r.flops, r.bytes);
     }
-    if (f) fclose(f);
     return AS_OK;
 }
 

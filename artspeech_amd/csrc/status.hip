@@ -27,8 +27,10 @@ Slot* slot_of_current_device()
 {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEV) return nullptr;
-    std::lock_guard<std::mutex> lk(g_mu);
     Slot& s = g_slot[d];
+    // fast path (every conv / embedding / LSTM launch asks): the slot exists -- `dev` is published last, with release order
+    if (__atomic_load_n(&s.dev, __ATOMIC_ACQUIRE)) return &s;
+    std::lock_guard<std::mutex> lk(g_mu);
     if (!s.host) {
         void* h = nullptr;
         if (hipHostMalloc(&h, AS_STATUS_KINDS * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
@@ -43,7 +45,7 @@ Slot* slot_of_current_device()
             return nullptr;
         }
         s.host = static_cast<unsigned*>(h);
-        s.dev = static_cast<unsigned*>(dp);
+        __atomic_store_n(&s.dev, static_cast<unsigned*>(dp), __ATOMIC_RELEASE);
     }
     return &s;
 }

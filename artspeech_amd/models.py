@@ -465,6 +465,18 @@ class Lanes:
     def wait(self, lane=-1):
         check(_lib.lib().as_lanes_wait(self.h, lane), "as_lanes_wait")
 
+    def set_graph_cap(self, max_graphs):
+        check(_lib.lib().as_lanes_set_graph_cap(self.h, int(max_graphs)), "as_lanes_set_graph_cap")
+
+    def set_layout_cap(self, max_layouts):
+        check(_lib.lib().as_lanes_set_layout_cap(self.h, int(max_layouts)), "as_lanes_set_layout_cap")
+
+    def stats(self, lane):
+        """dict(graphs, graph_drops, layout_flushes, graph_launches, eager_calls, captures) of one lane"""
+        v = (ctypes.c_int64 * 6)()
+        check(_lib.lib().as_lanes_stats(self.h, int(lane), v), "as_lanes_stats")
+        return dict(zip(("graphs", "graph_drops", "layout_flushes", "graph_launches", "eager_calls", "captures"), [int(x) for x in v]))
+
 
 def build_model(args, text_aligner=None, stage="second", distribution=None, device=None):
     """models.py:680-683.  Returns Munch(ArtsSpeech, discriminator, text_aligner); the discriminator is a

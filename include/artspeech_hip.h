@@ -462,11 +462,17 @@ int as_plan_set_timing(as_plan* p, int on);
 int as_plan_set_operand_mode(as_plan* p, int n_prod);
 int as_plan_phase_ms(as_plan* p, float* ms, int n);
 /* The plan caches the device tables of every batch geometry it has seen (key: the whole length vector).  Above max_layouts entries
- * (default 4096, minimum 64) the next entry point first waits for the device, drops the cache and frees its tables: memory stays
- * bounded under ever new ragged batches.  A hipGraph captured from this plan holds table addresses -- give captured geometries a plan
- * of their own.  as_plan_layout_flushes: how often that has happened. */
+ * (default 4096, minimum 64) the next entry point first waits for the streams THIS plan has launched on (not for the device: other plans'
+ * work goes on), drops the cache and reuses its table memory: memory stays bounded under ever new ragged batches.  The flush never runs
+ * while the calling stream is being captured (it then waits for the next entry point).  A hipGraph captured from a plan holds table
+ * addresses -- give captured geometries a plan of their own whose cap is never reached, and reset it (as_plan_reset_layouts) only
+ * together with its graphs: as_lanes does.  as_plan_layout_flushes: how often the cache has been dropped; as_plan_layout_count: entries
+ * held now.  as_plan_reset_layouts: drop the cache now -- the caller guarantees that no work launched from this plan is in flight and that
+ * no graph captured from it will be launched again. */
 int as_plan_set_layout_cap(as_plan* p, int max_layouts);
 int as_plan_layout_flushes(const as_plan* p);
+int as_plan_layout_count(const as_plan* p);
+int as_plan_reset_layouts(as_plan* p);
 
 /* geometry of one batch: HOST arrays */
 typedef struct as_batch {
@@ -536,17 +542,21 @@ int as_forward_test(const as_model* m, as_plan* p, const as_batch* batch, const 
                     void* ws_b, size_t ws_b_bytes, int32_t* frames_host_out, as_stream_t stream);
 
 /* ---- batches in flight (csrc/lanes.hip; DESIGN.md section 5: the throughput arrangement) -----------------------------------------------
- * as_lanes = n lanes on ONE model: per lane a serial plan (as_plan_set_serial), a HIP stream of its own, its two workspaces (grown on
- * demand) and the hipGraphs of the (geometry, io) pairs it has replayed.  as_lanes_submit enqueues ONE batch (ArtsSpeech.forward(
- * step="test"), as as_forward_test) on the next lane, round robin, and returns at once; before it does it waits until that lane's
- * PREVIOUS batch has finished -- so the device buffers named by a lane's as_forward_io may be refilled once the submit that follows them
- * on the same lane has been entered, or after as_lanes_wait.  Fill a lane's input buffers on ITS stream (as_lanes_stream(q,
- * as_lanes_next(q))) or synchronise before submitting.  With batch->frames given (forced durations, or a second pass) the second submit of
- * a (geometry, io) pair on a lane is captured into a hipGraph and later ones are one hipGraphLaunch; with frames == NULL (predicted
- * durations) every submit runs as_forward_test eagerly, which synchronises that lane's stream once to read the frame counts, and a
- * workspace too small for them is re-sized and the call repeated (AS_ENOSPC only if io->ld_out itself is too small: frames_host_out then
- * says what is needed).  Not thread-safe: one host thread per as_lanes.  as_lanes_wait(q, lane): lane < 0 = all; AS_EDEVICE if a kernel
- * raised a status bit (as_device_status). */
+ * as_lanes = n lanes on ONE model: per lane a HIP stream of its own, its two workspaces (grown on demand), TWO serial plans
+ * (as_plan_set_serial) -- one for eager calls, whose layout cache may be flushed at any entry point, and one that only ever sees the
+ * geometries that are replayed from hipGraphs and is reset only together with them -- and the hipGraphs of the (geometry, io) pairs it
+ * has replayed.  as_lanes_submit enqueues ONE batch (ArtsSpeech.forward(step="test"), as as_forward_test) on the next lane, round robin,
+ * and returns at once; before it does it waits until that lane's PREVIOUS batch has finished -- so the device buffers named by a lane's
+ * as_forward_io may be refilled once the submit that follows them on the same lane has been entered, or after as_lanes_wait.  Fill a
+ * lane's input buffers on ITS stream (as_lanes_stream(q, as_lanes_next(q))) or synchronise before submitting.  With batch->frames given
+ * (forced durations, or a second pass) a (geometry, io) pair runs eagerly twice on a lane (first on the eager plan, then on the graph
+ * plan, which uploads its tables), the third submit is captured into a hipGraph and later ones are one hipGraphLaunch; a lane keeps at
+ * most as_lanes_set_graph_cap graphs (default 256) and drops them all -- with the graph plan's tables -- when one more is wanted.  With
+ * frames == NULL (predicted durations) every submit runs as_forward_test eagerly, which synchronises that lane's stream once to read the
+ * frame counts, and a workspace too small for them is re-sized and the call repeated (AS_ENOSPC only if io->ld_out itself is too small:
+ * frames_host_out then says what is needed).  A workspace that is outgrown is kept until as_lanes_wait(q, -1) / as_lanes_destroy (freeing
+ * it would synchronise the device under the other lanes).  Not thread-safe: one host thread per as_lanes.  as_lanes_wait(q, lane):
+ * lane < 0 = all; AS_EDEVICE if a kernel raised a status bit (as_device_status). */
 typedef struct as_lanes as_lanes;
 int as_lanes_create(const as_model* m, int n_lanes, as_lanes** out);
 int as_lanes_destroy(as_lanes* q);
@@ -555,6 +565,12 @@ int as_lanes_next(const as_lanes* q);
 as_stream_t as_lanes_stream(const as_lanes* q, int lane);
 int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out);
 int as_lanes_wait(as_lanes* q, int lane);
+/* tuning / tests: graphs a lane keeps (>= 1), and the layout cap of every lane's eager plan (as_plan_set_layout_cap) */
+int as_lanes_set_graph_cap(as_lanes* q, int max_graphs);
+int as_lanes_set_layout_cap(as_lanes* q, int max_layouts);
+/* counters of lane `lane`: [0] graphs held, [1] times all graphs were dropped, [2] layout flushes of the eager plan, [3] graph launches,
+ * [4] eager calls, [5] captures */
+int as_lanes_stats(const as_lanes* q, int lane, int64_t* out6);
 
 #ifdef __cplusplus
 }

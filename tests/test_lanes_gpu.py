@@ -33,7 +33,8 @@ def test_lanes_forced_durations_graph_replay_bitwise():
     torch.cuda.synchronize()
     lanes = models.Lanes(net, n_lanes)
     outs = [None] * n_lanes
-    for r in range(rounds):                                   # round 0 eager, round 1 captured + launched, rounds 2.. replayed
+    rounds += 1
+    for r in range(rounds):                                   # rounds 0, 1 eager (eager plan, graph plan), round 2 captured + launched, then replayed
         for i, g in enumerate(gs):
             lane, outs[i] = lanes.submit(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
                                          frames=g["frames"], out=outs[i])
@@ -47,7 +48,7 @@ def test_lanes_forced_durations_graph_replay_bitwise():
     want_big = net.forward_packed(big["tok"], big["tok_lens"], big["mel"], big["f0"], big["ema"], big["ref_lens"], forced=big["forced"],
                                   frames_hint=big["frames"])["mel"].clone()
     ob = None
-    for r in range(3 * n_lanes):
+    for r in range(4 * n_lanes):
         _, ob = lanes.submit(big["tok"], big["tok_lens"], big["mel"], big["f0"], big["ema"], big["ref_lens"], forced=big["forced"],
                              frames=big["frames"], out=ob)
         lanes.wait()
@@ -81,3 +82,126 @@ def test_lanes_predicted_durations():
         lanes.submit(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], capacity=cap // 2)
     lanes.wait()
     lanes.close()
+
+
+def _tiny_net(dev):
+    from artspeech_amd import models, synth
+    from artspeech_amd.weights import DEFAULT_STATS, load_distribution
+    sd = synth.synth_state_dict(64, 8, seed=11)
+    model = models.build_model(models.Munch(hidden_dim=64, dim_in=8, style_dim=256, n_mels=80), None, "second", load_distribution(DEFAULT_STATS), dev)
+    models.load_checkpoint(model, None, {"net": {"ArtsSpeech": sd}})
+    return model.ArtsSpeech
+
+
+def test_lanes_survive_layout_flushes_and_graph_eviction():
+    """VERDICT r3 / ADVICE r3 (high): a lane's graphs hold geometry-table addresses.  The eager plan's layout cache is flushed again and
+    again here (cap 64, > 300 ragged geometries with known frame counts through 4 lanes) while hot geometries keep being replayed from
+    their graphs, and the graph cache itself is driven past its cap: every result stays bitwise equal to as_forward_test run alone."""
+    import itertools
+    import bench
+    from artspeech_amd import _lib, models
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    net = _tiny_net(dev)
+    host, _ = bench.make_inputs(None, 14, 20, 44, 96, seed0=bench.DATA_SEED + 300, vary=True)
+    subsets = [c for k in (2, 3) for c in itertools.combinations(range(14), k)]     # 91 + 364 distinct ragged geometries
+    n_lanes = 4
+
+    def alone(g):
+        return net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
+                                  frames_hint=g["frames"])["mel"].clone()
+
+    def submit(lanes, g, out=None):
+        return lanes.submit(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"], frames=g["frames"], out=out)
+
+    lanes = models.Lanes(net, n_lanes)
+    lanes.set_layout_cap(64)
+    lanes.set_graph_cap(2)
+    # three hot sets of one geometry per lane: with a cap of two graphs per lane the third set evicts
+    hot = []
+    for k in range(3 * n_lanes):
+        g = bench.pack_inputs(host, list(subsets[k]), dev)
+        hot.append(dict(g=g, want=alone(g), out=None))
+    torch.cuda.synchronize()
+
+    def hot_round(k):                                          # set k: lane i gets hot[k * n_lanes + i]
+        for i in range(n_lanes):
+            h = hot[k * n_lanes + i]
+            lane, h["out"] = submit(lanes, h["g"], h["out"])
+            assert lane == i
+        lanes.wait()
+        for i in range(n_lanes):
+            h = hot[k * n_lanes + i]
+            assert torch.equal(h["out"]["mel"], h["want"]), (k, i)
+            h["out"]["mel"].zero_()
+
+    # the whole pool as one batch first, once per lane: the workspaces get their final size (a workspace that moves drops the lane's graphs,
+    # which is not what this test is after)
+    gall = bench.pack_inputs(host, list(range(14)), dev)
+    want_all = alone(gall)
+    for i in range(n_lanes):
+        _, o = submit(lanes, gall)
+        lanes.wait()
+        assert torch.equal(o["mel"], want_all)
+    for _ in range(5):                                         # eager, eager (graph plan), captured, replayed, replayed
+        hot_round(0)
+    st = lanes.stats(0)
+    assert st["graphs"] == 1 and st["captures"] == 1 and st["graph_launches"] >= 3, st
+    drops0 = [lanes.stats(i)["graph_drops"] for i in range(n_lanes)]
+    # > 300 new ragged geometries, each once (they never reach the graph plan), the hot set replayed in between
+    n_new = 0
+    for r in range(80):
+        fresh = []
+        for i in range(n_lanes):
+            g = bench.pack_inputs(host, list(subsets[3 * n_lanes + n_new]), dev)
+            n_new += 1
+            lane, o = submit(lanes, g)
+            fresh.append((g, o))
+        lanes.wait()
+        for g, o in fresh:
+            assert torch.equal(o["mel"], alone(g)), r
+        if r % 8 == 7:
+            hot_round(0)
+    assert n_new > 300
+    for i in range(n_lanes):
+        st = lanes.stats(i)
+        assert st["layout_flushes"] >= 3, st                  # the eager plan was flushed under the graphs ...
+        assert st["captures"] == 1 and st["graph_drops"] == drops0[i], st   # ... which were never rebuilt
+    hot_round(0)
+    # drive the graph cache past its cap: sets 1 and 2 come in, set 0 is revisited after the eviction
+    for k in (1, 2, 0, 1, 2, 0):
+        for _ in range(4):
+            hot_round(k)
+    st = lanes.stats(0)
+    assert st["graph_drops"] >= drops0[0] + 2 and st["graphs"] <= 2, st
+    assert _lib.lib().as_device_status(0) == 0
+    lanes.close()
+
+
+def test_lanes_clustered_lstm_soak():
+    """four lanes' clustered H = 256 recurrences share the chip.  Batch-1 requests (C2's shape) and a longer batch, a few hundred
+    steps in flight: no poll gives up (as_lanes_wait reports AS_EDEVICE if one did) and the results stay those of a step run alone."""
+    import bench
+    from artspeech_amd import models
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    net = _net(dev)
+    for n_utt, n_tok, m_half, rounds in ((1, 30, 75, 60), (8, 96, 200, 12)):
+        gs, wants, outs = [], [], []
+        for i in range(4):
+            _, g = bench.make_inputs(dev, n_utt, n_tok, m_half, 150, seed0=bench.DATA_SEED + 900 + 10 * i, vary=n_utt > 1)
+            gs.append(g)
+            wants.append(net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
+                                            frames_hint=g["frames"])["mel"].clone())
+            outs.append(None)
+        torch.cuda.synchronize()
+        lanes = models.Lanes(net, 4)
+        for r in range(rounds):
+            for i, g in enumerate(gs):
+                _, outs[i] = lanes.submit(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
+                                          frames=g["frames"], out=outs[i])
+            if r % 10 == 9 or r == rounds - 1:
+                lanes.wait()                                   # raises on AS_EDEVICE (a timed-out poll)
+                for i in range(4):
+                    assert torch.equal(outs[i]["mel"], wants[i]), (n_utt, r, i)
+        lanes.close()
