@@ -160,6 +160,7 @@ _SIGNATURES.update({
     "as_lanes_wait": (c_i, [c_p, c_i]),
     "as_lanes_set_graph_cap": (c_i, [c_p, c_i]),
     "as_lanes_set_layout_cap": (c_i, [c_p, c_i]),
+    "as_lanes_reserve": (c_i, [c_p, c_sz, c_sz]),
     "as_lanes_stats": (c_i, [c_p, c_i, ctypes.POINTER(ctypes.c_int64)]),
 })
 

@@ -26,6 +26,7 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -37,17 +38,19 @@ struct Lane {
     void *wa = nullptr, *wb = nullptr;
     size_t na = 0, nb = 0;
     std::unordered_map<std::string, hipGraphExec_t> graphs;      // key -> instantiated graph
-    std::unordered_map<std::string, int> seen;                    // key -> eager calls so far (1: eager plan; 2: graph plan)
+    std::unordered_set<std::string> once;                         // pairs that ran once, on the eager plan (a bounded memory of candidates)
+    std::unordered_set<std::string> met;                          // pairs the graph plan has met eagerly: captured at their next submit
     int64_t n_drops = 0, n_launch = 0, n_eager = 0, n_capture = 0;
 };
 
 // the lane's stream is idle (lanes_submit synchronises it first): no graph is running, nothing reads the graph plan's tables
 void drop_graphs(Lane& L)
 {
-    if (L.graphs.empty() && L.seen.empty()) return;
+    if (L.graphs.empty() && L.met.empty()) return;
     for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
     L.graphs.clear();
-    L.seen.clear();
+    for (const std::string& k : L.met) L.once.insert(k);          // (they have been seen; the graph plan has to meet them again)
+    L.met.clear();
     (void)as_plan_reset_layouts(L.gplan);
     ++L.n_drops;
 }
@@ -184,6 +187,18 @@ extern "C" int as_lanes_set_layout_cap(as_lanes* q, int max_layouts)
     return AS_OK;
 }
 
+extern "C" int as_lanes_reserve(as_lanes* q, size_t bytes_a, size_t bytes_b)
+{
+    if (!q) return AS_EINVAL;
+    for (Lane& L : q->lanes) {
+        if (bytes_a <= L.na && bytes_b <= L.nb) continue;
+        if (hipStreamSynchronize(L.stream) != hipSuccess) return (int)hipErrorUnknown;
+        drop_graphs(L);                                           // the graphs hold the old workspaces' addresses
+        if (!grow(q, &L.wa, &L.na, bytes_a) || !grow(q, &L.wb, &L.nb, bytes_b)) return (int)hipErrorOutOfMemory;
+    }
+    return AS_OK;
+}
+
 extern "C" int as_lanes_stats(const as_lanes* q, int lane, int64_t* out6)
 {
     if (!q || !out6 || lane < 0 || lane >= (int)q->lanes.size()) return AS_EINVAL;
@@ -260,23 +275,23 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
         ++L.n_launch;
         return hipGraphLaunch(g->second, L.stream) == hipSuccess ? AS_OK : (int)hipErrorUnknown;
     }
-    auto it = L.seen.find(key);
-    int state = it == L.seen.end() ? 0 : it->second;
-    if (state >= 1 && L.graphs.size() >= q->graph_cap) {            // no room for one more graph: all graphs and the graph plan's tables go
-        drop_graphs(L);
-        state = 1;                                                  // (this pair has been seen; the graph plan has to meet it again)
-    }
-    if (state == 0) {                                               // first call with this pair: the eager plan (flushable), nothing kept but the count
-        if (L.seen.size() >= 4 * q->graph_cap) drop_graphs(L);      // (the count map itself stays bounded under ever new geometries)
-        L.seen[key] = 1;
+    int state = L.met.count(key) ? 2 : (L.once.count(key) ? 1 : 0);
+    // graphs + pairs the graph plan has met (each may become a graph, and its tables already live there) never exceed the cap: a pair
+    // that comes back when there is no room sends every graph and the graph plan's tables away first
+    if (state == 1 && L.graphs.size() + L.met.size() + 1 > q->graph_cap) drop_graphs(L);
+    if (state == 0) {                                               // first call with this pair: the eager plan (flushable); only the key is kept
+        if (L.once.size() >= 4096) L.once.clear();                  // (ever new geometries: forget the candidates, never the graphs)
+        L.once.insert(key);
         ++L.n_eager;
         return as_forward_test(q->m, L.plan, batch, io, L.wa, L.na, L.wb, L.nb, nullptr, L.stream);
     }
     if (state == 1) {                                               // it came back: the graph plan meets it eagerly (uploads its tables)
-        L.seen[key] = 2;
+        L.once.erase(key);
+        L.met.insert(key);
         ++L.n_eager;
         return as_forward_test(q->m, L.gplan, batch, io, L.wa, L.na, L.wb, L.nb, nullptr, L.stream);
     }
+    L.met.erase(key);                                               // (whatever happens below, the pair leaves the waiting set)
     // third call: capture from the graph plan (its tables for this geometry exist; its cap is never reached, so no flush can fall into
     // the capture -- and as_plan's flush skips a capturing stream anyway)
     if (hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return (int)hipErrorUnknown;

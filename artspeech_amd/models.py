@@ -471,6 +471,9 @@ class Lanes:
     def set_layout_cap(self, max_layouts):
         check(_lib.lib().as_lanes_set_layout_cap(self.h, int(max_layouts)), "as_lanes_set_layout_cap")
 
+    def reserve(self, bytes_a, bytes_b):
+        check(_lib.lib().as_lanes_reserve(self.h, int(bytes_a), int(bytes_b)), "as_lanes_reserve")
+
     def stats(self, lane):
         """dict(graphs, graph_drops, layout_flushes, graph_launches, eager_calls, captures) of one lane"""
         v = (ctypes.c_int64 * 6)()

@@ -459,8 +459,9 @@ def bench_native_lanes(net, batches, firsts, steps, warmup):
                 note="as_lanes_submit per batch: the library keeps the serial plans, streams, workspaces and hipGraphs")
 
 
-def c4_check(net, host, mel_mine, mine, world, rank, dev, dist):
-    """merge the ranks' shards on rank 0 and compare with rank 0 running the whole global batch alone"""
+def c4_check(net, host, mel_mine, mine, world, rank, dev, dist, dump=None):
+    """merge the ranks' shards on rank 0 and compare with rank 0 running the whole global batch alone; `dump`: an .npz that gets the
+    merged mel of three utterances (shortest, median, longest) for the caller to hold against the oracle (tests/test_multirank_gpu.py)"""
     from artspeech_amd import shard
     mels = [m.copy() for m in shard.split_utterances(mel_mine.cpu().numpy(), [2 * host["frames"][i] for i in mine])]
     if world > 1:
@@ -475,6 +476,10 @@ def c4_check(net, host, mel_mine, mine, world, rank, dev, dist):
     whole = Runner(net, g_all).step()["mel"].cpu().numpy()
     ref = shard.split_utterances(whole, [2 * f for f in host["frames"]])
     worst = max(float(np.abs(a - b).max()) for a, b in zip(merged, ref))
+    if dump:
+        order = sorted(range(len(merged)), key=lambda i: host["frames"][i])
+        pick = [order[0], order[len(order) // 2], order[-1]]
+        np.savez(dump, idx=np.asarray(pick), **{f"mel_{i}": merged[i] for i in pick})
     return dict(utterances=len(ref), shards=world, max_abs_sharded_vs_single_rank=worst,
                 note="not bitwise: the GEMM's tile choice depends on a shard's total column count (bound 5e-5)")
 
@@ -490,6 +495,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the MAS / C2 / C5 / transfer lines (profiling runs)")
     ap.add_argument("--config", default="C3", choices=["C3", "C5", "C2"], help="workload of the timed region (profiling runs; the headline is C3)")
     ap.add_argument("--global-batch", type=int, default=0, help="C4: ONE ragged batch of this many utterances sharded over the ranks")
+    ap.add_argument("--c4-dump", default=None, help="with --global-batch: .npz for the merged mel of three utterances (tests hold them against the oracle)")
     ap.add_argument("--in-flight", type=int, default=4, help="batches in flight per GPU: consecutive steps are replayed on this many HIP streams "
                     "(each with its own plan and workspaces on the same weights); 1 = one step at a time (the step's latency)")
     ap.add_argument("--lane-branches", action="store_true", help="lanes in flight keep their step's branches on side streams (default: a "
@@ -620,7 +626,7 @@ def main():
         transfers["frames_per_s_including_transfers"] = frames_total * args.steps / transfers["elapsed_s"]
         transfers["vs_resident_inputs"] = transfers["elapsed_s"] / elapsed
     if args.global_batch:
-        c4 = c4_check(net, host, runner.out["mel"], mine, world, rank, dev, dist)
+        c4 = c4_check(net, host, runner.out["mel"], mine, world, rank, dev, dist, dump=args.c4_dump)
 
     # ---- phase times of one eager step with the branches concurrent (HIP events between the phases, on the calling stream)
     prunner = Runner(net, g)

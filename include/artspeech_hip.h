@@ -568,6 +568,9 @@ int as_lanes_wait(as_lanes* q, int lane);
 /* tuning / tests: graphs a lane keeps (>= 1), and the layout cap of every lane's eager plan (as_plan_set_layout_cap) */
 int as_lanes_set_graph_cap(as_lanes* q, int max_graphs);
 int as_lanes_set_layout_cap(as_lanes* q, int max_layouts);
+/* every lane's workspaces A / B get at least this many bytes now: a server that knows its largest batch (as_module_workspace_bytes) never
+ * re-sizes a workspace -- which would drop that lane's graphs -- in the middle of traffic */
+int as_lanes_reserve(as_lanes* q, size_t bytes_a, size_t bytes_b);
 /* counters of lane `lane`: [0] graphs held, [1] times all graphs were dropped, [2] layout flushes of the eager plan, [3] graph launches,
  * [4] eager calls, [5] captures */
 int as_lanes_stats(const as_lanes* q, int lane, int64_t* out6);

@@ -320,3 +320,19 @@ def forward_test(W, tokens, mel, f0_raw, ema_raw, dist, forced_dur=None):
         mel_out = decoder(W, "decoder", t_ex, style, f0, n, ema)
     return dict(t_en=t_en, a_en=a_en, f0_ext=f0_ext, n_ext=n_ext, ema_ext=ema_ext, style=style,
                 duration=duration, pred_dur=pred_dur, F0=f0, N=n, EMA=ema, mel=mel_out)
+
+
+def forward_test_allin(W, W_jdc, W_ema, tokens, mel, dist, forced_dur=None):
+    """forward(step="test") with the two frozen extractors in the loop, as test.py:113 runs it: StyleEncoder.forward's first lines,
+    models.py:431-433 -- n_ext = log_norm(mel); f0_ext = pitch_extractor(mel.unsqueeze(1)); ema_ext = ema_extractor(f0_ext, n_ext, mel),
+    all three BEFORE the stats normalisation of :447-449 -- then the path of forward_test.  W_jdc / W_ema: the extractors' state dicts.
+    Pinned by tests/golden/net_allin_*.npz (the reference's own modules end to end)."""
+    from . import ema as oema
+    from . import jdc as ojdc
+    with torch.no_grad():
+        n_raw = log_norm(mel)[None] if log_norm(mel).dim() == 1 else log_norm(mel)  # [1, T]
+        f0_raw = ojdc.jdcnet(W_jdc, mel)                                            # [1, T]  (models.py:432)
+        ema_raw = oema.ema_predictor(W_ema, f0_raw, n_raw, mel)                     # [10, T] (models.py:433: raw f0, raw energy, mel)
+    out = forward_test(W, tokens, mel, f0_raw, ema_raw, dist, forced_dur)
+    out["f0_raw"], out["ema_raw"] = f0_raw, ema_raw
+    return out

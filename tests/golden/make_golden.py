@@ -13,6 +13,8 @@ What is pinned
   mas_large.npz          [8,1024,2000] case: hash-generated input (seed only) + row-of-column paths
   net_tiny_*.npz         hidden_dim=64, dim_in=8: every module-boundary tensor of forward(step="test")
   net_full_*.npz         hidden_dim=512, dim_in=64 (the shipped config): outputs of forward(step="test")
+  net_allin_*.npz        forward(step="test") with the reference's REAL JDCNet / EMA_Predictor in the loop (models.py:426-449 feeding
+                         :356-371; no stub): tokens + mel in; f0_ext, n_ext, ema_ext, Style, pred_dur, mel out.  Tiny and shipped config.
 Weights are artspeech_amd.synth.synth_state_dict(seed) loaded with load_state_dict -- the GPU box
 regenerates the identical tensors from the seed.
 """
@@ -220,6 +222,60 @@ def make_net():
             np.savez_compressed(os.path.join(HERE, f"net_{tag}_N{n_tok}_T{t_ref}_s{seed}.npz"), **out)
 
 
+def make_allin():
+    """ArtsSpeech.forward(step="test") as test.py:113 runs it: the reference's own JDCNet and EMA_Predictor (seeded synthetic weights:
+    artspeech_amd.jdc.synth_jdc_state_dict / artspeech_amd.ema.synth_ema_state_dict, loaded strictly) inside StyleEncoder.forward --
+    log_norm -> pitch_extractor(mel.unsqueeze(1)) -> ema_extractor(f0_ext, n_ext, mel) -> stats normalisation (models.py:426-449) --
+    feeding the rest of the path (models.py:356-371).  B = 1, as the reference runs inference."""
+    from artspeech_amd import ema as E
+    from artspeech_amd import jdc as J
+    # the seeded JDCNet's |classifier| output lives in 0.1 .. 0.4: against Data/stats.json's pitch scale (137 +- 78 Hz) that is a constant.
+    # Its last Linear is scaled (fixture and test alike) so that F0 varies by a few tens of Hz per utterance and the glue between the
+    # extractors -- which tensor goes where, raw or normalised -- shows in f0_ext, in what EMA_Predictor makes of it, and in the mel.
+    F0_GAIN = 400.0
+    jsd = {k: np.asarray(v) for k, v in J.synth_jdc_state_dict(1, seed=3407).items()}
+    for k in ("classifier.weight", "classifier.bias"):
+        jsd[k] = (jsd[k] * np.float32(F0_GAIN)).astype(np.float32)
+    for tag, hd, di, cases in (("tiny", 64, 8, [(12, 70, 21), (30, 150, 22)]), ("full", 512, 64, [(30, 150, 23), (40, 200, 24)])):
+        net, sd = build_reference(hd, di)
+        se = net.style_encoder
+        se.pitch_extractor.load_state_dict({k: torch.from_numpy(v) for k, v in jsd.items()})
+        se.ema_extractor.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in E.synth_ema_state_dict(seed=3407).items()})
+        for (n_tok, t_ref, seed) in cases:
+            tokens = synth.synth_tokens(n_tok, seed)
+            mel, _, _ = synth.synth_ref_features(t_ref, seed)
+            grabbed = {}
+
+            def hook(name):
+                def f(mod, inp, out):
+                    grabbed[name] = out
+                return f
+
+            hs = [getattr(net, n).register_forward_hook(hook(n)) for n in ("style_encoder", "durationPredictor", "artsPredictor")]
+            with torch.no_grad():
+                text = torch.from_numpy(tokens)[None]
+                out = net([text, torch.LongTensor([text.shape[-1]]), torch.from_numpy(mel)[None], torch.LongTensor([mel.shape[-1]]),
+                           None, None, None], None, None, step="test")
+            for h in hs:
+                h.remove()
+            f0_ext, n_ext, ema_ext, style = grabbed["style_encoder"]
+            duration = grabbed["durationPredictor"][0]
+            F0, N, EMA = grabbed["artsPredictor"]
+            frac = np.abs(duration.numpy() - np.floor(duration.numpy()) - 0.5)
+            res = {"ref/f0_ext": f0_ext[0], "ref/n_ext": n_ext[0], "ref/ema_ext": ema_ext[0], "ref/style": style[0], "ref/duration": duration,
+                   "ref/pred_dur": torch.round(duration).clamp(min=1).to(torch.int64), "ref/F0": F0[0], "ref/N": N[0], "ref/EMA": EMA[0],
+                   "ref/mel": out[0]}
+            res = {k: v.detach().numpy().copy() for k, v in res.items()}
+            assert all(np.isfinite(v).all() for v in res.values())
+            print(f"allin {tag} N={n_tok} T={t_ref} seed={seed}: M={int(res['ref/pred_dur'].sum())} dur margin {frac.min():.4f} "
+                  f"f0_ext std {res['ref/f0_ext'].std():.3f} |ema_ext|max {np.abs(res['ref/ema_ext']).max():.3f} "
+                  f"|style|max {np.abs(res['ref/style']).max():.3f} |mel|max {np.abs(res['ref/mel']).max():.3f}")
+            np.savez_compressed(os.path.join(HERE, f"net_allin_{tag}_N{n_tok}_T{t_ref}_s{seed}.npz"), tokens=tokens, mel_in=mel,
+                                t_ref=np.array(t_ref), seed=np.array(seed), weight_seed=np.array(WEIGHT_SEED), extractor_seed=np.array(3407),
+                                jdc_classifier_gain=np.array(F0_GAIN),
+                                hidden_dim=np.array(hd), dim_in=np.array(di), dur_margin=np.array(frac.min()), **res)
+
+
 def make_text():
     """symbol table + token ids produced by the reference's own TextCleaner (meldataset.py:14-29; test.py:19-38 is a
     copy that prints and drops unknown characters) on real IPA lines of the shipped validation lists."""
@@ -328,6 +384,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["ema"]:
         make_ema()
+        sys.exit(0)
+    if sys.argv[1:] == ["allin"]:
+        make_allin()
         sys.exit(0)
     if sys.argv[1:] == ["vocoder"]:
         make_vocoder()

@@ -50,7 +50,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.as_lanes_create(None, 4, None) == -1 and L.as_lanes_submit(None, None, None, None, None) == -1
     assert L.as_lanes_count(None) == 0 and L.as_lanes_next(None) == -1 and L.as_lanes_wait(None, -1) == -1 and L.as_lanes_destroy(None) == 0
     assert not L.as_lanes_stream(None, 0)
-    assert L.as_lanes_set_graph_cap(None, 4) == -1 and L.as_lanes_set_layout_cap(None, 64) == -1 and L.as_lanes_stats(None, 0, None) == -1
+    assert L.as_lanes_set_graph_cap(None, 4) == -1 and L.as_lanes_set_layout_cap(None, 64) == -1 and L.as_lanes_stats(None, 0, None) == -1 and L.as_lanes_reserve(None, 0, 0) == -1
     assert L.as_plan_layout_count(None) == -1 and L.as_plan_reset_layouts(None) == -1
     assert L.as_embed_groups_f32(None, 0, None, None, 0, 8, 8, 8, 1.0, None, 8, None) == -1
     assert L.as_split_f16x2_bytes(0, 10) == 0 and L.as_split_f16x2_bytes(20, 10) == 4 * 4 * 11 * 16      # 20 channels: 2 k-blocks, padded to 4; 4 planes; N + 1 columns of 16 bytes

@@ -135,14 +135,9 @@ def test_lanes_survive_layout_flushes_and_graph_eviction():
             assert torch.equal(h["out"]["mel"], h["want"]), (k, i)
             h["out"]["mel"].zero_()
 
-    # the whole pool as one batch first, once per lane: the workspaces get their final size (a workspace that moves drops the lane's graphs,
-    # which is not what this test is after)
-    gall = bench.pack_inputs(host, list(range(14)), dev)
-    want_all = alone(gall)
-    for i in range(n_lanes):
-        _, o = submit(lanes, gall)
-        lanes.wait()
-        assert torch.equal(o["mel"], want_all)
+    # workspaces at their final size from the start (a workspace that moves drops the lane's graphs -- not what this test is after; and a
+    # smaller batch can need MORE room than a larger one: split-K slabs exist only where the tile grid is small)
+    lanes.reserve(256 << 20, 256 << 20)
     for _ in range(5):                                         # eager, eager (graph plan), captured, replayed, replayed
         hot_round(0)
     st = lanes.stats(0)

@@ -40,9 +40,32 @@ def test_two_ranks_weak_scaling_line(cuda):
     assert line["value"] > 0 and abs(line["value"] - line["config"]["frames_per_step"] * 6 / (line["ms_per_step"] * 6e-3)) < 1e-6 * line["value"]
 
 
-def test_two_ranks_c4_global_batch_sharded(cuda):
-    line = launch(["--steps", "3", "--warmup", "1", "--global-batch", "64"])
+def test_two_ranks_c4_global_batch_sharded(cuda, tmp_path):
+    """BASELINE config C4 at its stated size: ONE ragged batch of 256 utterances, sharded (here over two ranks sharing the one GPU; the
+    8-GPU form is the driver's to launch), merged on rank 0.  Against rank 0 running all 256 alone -- and three of the merged
+    utterances (shortest, median, longest) against the CPU oracle with the same forced durations: 1e-4, the north-star bound."""
+    import numpy as np
+    import torch
+    import bench
+    from artspeech_amd import synth
+    from artspeech_amd.weights import DEFAULT_STATS, fold_state_dict, load_distribution
+    from oracle import acoustic
+    dump = str(tmp_path / "c4.npz")
+    line = launch(["--steps", "3", "--warmup", "1", "--global-batch", "256", "--c4-dump", dump])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     c4 = line["c4_shard_check"]
-    assert c4["utterances"] == 64 and c4["shards"] == 2
+    assert c4["utterances"] == 256 and c4["shards"] == 2
     assert c4["max_abs_sharded_vs_single_rank"] <= 5e-5, c4
+    host, _ = bench.make_inputs(None, 256, vary=True)
+    W = fold_state_dict(synth.synth_state_dict(512, 64, seed=bench.WEIGHT_SEED))
+    dist = load_distribution(DEFAULT_STATS)
+    z = np.load(dump)
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
+    for i in z["idx"]:
+        i = int(i)
+        ref = acoustic.forward_test(W, torch.from_numpy(host["tokens"][i]), torch.from_numpy(host["mel"][i]), torch.from_numpy(host["f0"][i]),
+                                    torch.from_numpy(host["ema"][i]), dist, forced_dur=host["forced"][i])["mel"].numpy()
+        got = z[f"mel_{i}"]
+        assert got.shape == ref.shape, (i, got.shape, ref.shape)
+        d = float(np.abs(got - ref).max())
+        assert d <= 1e-4, (i, d)

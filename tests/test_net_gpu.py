@@ -192,6 +192,52 @@ def test_pipeline_surface(cuda, golden_dir):
         tts.synthesis("hello", "ref.wav", "out.wav")
 
 
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_allin_surface_matches_reference(cuda, golden_dir, tag):
+    """The whole test.py:113 surface against the reference itself: pipeline.ArtSpeech with the HIP JDCNet and EMA_Predictor attached,
+    phonemes + reference mel in, nothing else.  The fixture (tests/golden/net_allin_*.npz, make_golden.py allin) is the reference's
+    ArtsSpeech.forward(step="test") with its REAL extractors in the loop (models.py:426-449 feeding :356-371): log_norm ->
+    pitch_extractor(mel.unsqueeze(1)) -> ema_extractor(f0_ext, n_ext, mel) -> stats normalisation -> style towers, duration
+    predictor, predictors, decoder.  Durations identical, features / style within 5e-5, mel within 1e-4."""
+    from artspeech_amd.pipeline import ArtSpeech
+    from artspeech_amd.text import symbols
+    from test_oracle_golden import allin_extractor_weights
+    files = sorted(glob.glob(os.path.join(golden_dir, f"net_allin_{tag}_*.npz")))
+    assert files
+    tts = None
+    for f in files:
+        g = np.load(f)
+        hd, di = int(g["hidden_dim"]), int(g["dim_in"])
+        if tts is None:
+            tts = ArtSpeech(config={"model_params": {"hidden_dim": hd, "dim_in": di, "max_conv_dim": hd}},
+                            checkpoint={"net": {"ArtsSpeech": synth.synth_state_dict(hd, di, seed=int(g["weight_seed"]))}}, device=cuda)
+            jsd, esd = allin_extractor_weights(float(g["jdc_classifier_gain"]))
+            tts.attach_pitch_extractor({"net": jsd})
+            tts.attach_ema_extractor({"model": esd})
+        tokens = [int(t) for t in g["tokens"]]
+        # through the text front end when the ids survive the round trip (the table holds one character twice: test.py:19-38)
+        text = "".join(symbols[t] for t in tokens)
+        net = tts.model.ArtsSpeech
+        if tts.textcleaner(text) == tokens:
+            mel = tts.synthesis_mel(text, g["mel_in"])
+            assert tts._last_frames == [2 * int(g["ref/pred_dur"].sum())]
+            d = float((mel[0].cpu() - torch.from_numpy(g["ref/mel"])).abs().max())
+            assert d <= MEL_TOL, (f, "pipeline mel", d)
+        # and the model call itself, test.py:113, with the module-boundary tensors
+        batch = [torch.tensor(tokens)[None], torch.tensor([len(tokens)]), torch.from_numpy(g["mel_in"])[None], torch.tensor([g["mel_in"].shape[-1]]),
+                 None, None, None]
+        out, aux = net(batch, None, None, step="test", return_aux=True)
+        assert np.array_equal(aux["dur_i"][: len(tokens)].cpu().numpy(), g["ref/pred_dur"].astype(np.int32)), f
+        f0_ext, n_ext, ema_ext, style = net.style_encoder(batch[2], batch[3])
+        worst = {}
+        for k, v in (("f0_ext", f0_ext[0]), ("n_ext", n_ext[0]), ("ema_ext", ema_ext[0]), ("style", style[0])):
+            worst[k] = float((v.cpu() - torch.from_numpy(g["ref/" + k])).abs().max())
+            assert worst[k] <= AUX_TOL, (f, k, worst[k])
+        d = float((out[0].cpu() - torch.from_numpy(g["ref/mel"])).abs().max())
+        print(f"{os.path.basename(f)}: mel max-abs {d:.2e} vs the reference with its extractors in the loop; {worst}")
+        assert d <= MEL_TOL, (f, d)
+
+
 def test_encoders_ragged_batch(cuda, golden_dir):
     """The text and articulatory encoders run inside the library as ONE double-width encoder (stacked weight sets, per-column
     parameter choice).  On a ragged batch whose column count needs the 128-column filler, each half must equal the reference's own

@@ -75,6 +75,35 @@ def test_oracle_matches_reference(golden_dir, tag):
         assert out["mel"].shape == (80, 2 * int(g["ref/pred_dur"].sum()))
 
 
+def allin_extractor_weights(gain):
+    """the extractors' seeded checkpoints as tests/golden/make_golden.py allin loads them into the reference (JDCNet's last Linear scaled)"""
+    from artspeech_amd import ema as E
+    from artspeech_amd import jdc as J
+    jsd = {k: np.asarray(v) for k, v in J.synth_jdc_state_dict(1, seed=3407).items()}
+    for k in ("classifier.weight", "classifier.bias"):
+        jsd[k] = (jsd[k] * np.float32(gain)).astype(np.float32)
+    esd = {k: np.asarray(v) for k, v in E.synth_ema_state_dict(seed=3407).items()}
+    return jsd, esd
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_oracle_allin_matches_reference(golden_dir, tag):
+    """forward(step="test") with the reference's real JDCNet and EMA_Predictor in the loop (models.py:426-449 feeding :356-371)"""
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    files = sorted(glob.glob(os.path.join(golden_dir, f"net_allin_{tag}_*.npz")))
+    assert files
+    for f in files:
+        g = np.load(f)
+        W = folded(int(g["hidden_dim"]), int(g["dim_in"]), int(g["weight_seed"]))
+        jsd, esd = allin_extractor_weights(float(g["jdc_classifier_gain"]))
+        out = acoustic.forward_test_allin(W, {k: torch.from_numpy(v) for k, v in jsd.items()}, {k: torch.from_numpy(v) for k, v in esd.items()},
+                                          torch.from_numpy(g["tokens"]), torch.from_numpy(g["mel_in"]), load_distribution(DEFAULT_STATS))
+        assert np.array_equal(out["pred_dur"].numpy(), g["ref/pred_dur"]), f
+        for k in ("f0_ext", "n_ext", "ema_ext", "style", "duration", "F0", "N", "EMA", "mel"):
+            d = np.abs(out[k].numpy() - g["ref/" + k]).max()
+            assert d <= TOL, (f, k, d)
+
+
 def test_tokens_have_pad_ends():
     t = synth.synth_tokens(40, 1234)
     assert t[0] == 0 and t[-1] == 0 and t[1:-1].min() >= 1 and t.max() <= 177
