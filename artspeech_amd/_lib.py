@@ -53,6 +53,8 @@ _SIGNATURES.update({
     "as_make_meta": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "as_conv_gemm_f32": (c_i, [ctypes.POINTER(ConvGemmArgs), c_p]),
     "as_conv_gemm_workspace_bytes": (c_sz, [ctypes.POINTER(ConvGemmArgs)]),
+    "as_conv_gemm_multi_f32": (c_i, [ctypes.POINTER(ConvGemmArgs), c_i, c_p]),
+    "as_conv_gemm_multi_tile": (c_i, [ctypes.POINTER(ConvGemmArgs), c_i]),
     "as_conv_gemm_plan": (c_i, [ctypes.POINTER(ConvGemmArgs), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
                                 ctypes.POINTER(ctypes.c_int32)]),
     "as_split_f16x2_bytes": (c_sz, [c_i, c_i]),

@@ -7,9 +7,9 @@
 #define OOB 0xFFFFFFFFu
 #define OOBH 0x80000000u   /* epilogue: out of range for every descriptor (< 2 GiB, host-checked) even after adding an in-range offset */
 
-// host: launch the f16x3 kernel for tile `choice` (22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64, 14 = 64x256; 4 waves each) on a
-// grid of (tiles, S); returns AS_OK or a hipError_t.  (conv_gemm_h3.hip)
-int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream);
+// host: launch the f16x3 kernel for tile `choice` (22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64, 14 = 64x256; 4 waves each) over the
+// tiles of `n` independent problems (1 <= n <= H3_MAXP), problem i in S[i] K slices; returns AS_OK or a hipError_t.  (conv_gemm_h3.hip)
+int as_conv_gemm_h3_launch(const ConvGemmArgs* const* a, const int* S, int n, int choice, hipStream_t stream);
 // host: the kernel that writes the split image of X (no profiling scope of its own)
 int as_split_f16x2_launch(const float* x, int ldx, int K, int N, int lrelu, float slope, uint16_t* xh, hipStream_t stream);
 
@@ -67,13 +67,29 @@ static __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsi
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// ONE launch, several independent problems ("tile list"): the grid is the concatenation of the problems' workgroups, problem i owns
+// the physical ids [wg0, wg0 + wgs) -- wgs = tiles x K slices rounded up to a multiple of 8 (the spare ones exit at once).  A small
+// problem that would own the chip alone at a fraction of its width rides in the tail of a large one: the launch costs what its busiest CU
+// costs.  The host lists the problems longest tile first.  Passed BY VALUE (kernel argument segment: every field a wave reads is a scalar
+// load from constant memory, for any problem index).
+#define H3_MAXP 6
+struct H3Prob {
+    ConvGemmArgs a;
+    H3Taps tp;
+    int32_t wg0, wgs;       // first workgroup, workgroups (a multiple of 8)
+    int32_t tiles, S;       // output tiles, K slices: workgroup (tile, slice) = logical id % tiles, / tiles
+};
+struct H3Multi {
+    int32_t n, pad_;
+    H3Prob p[H3_MAXP];
+};
+
 // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
-// run of logical tiles -- the output-channel tiles of one column range then share that XCD's L2 copy of the
-// activation columns.  Bijective for any grid size.
-static __device__ __forceinline__ int logical_tile()
+// run of a problem's logical tiles -- the output-channel tiles of one column range then share that XCD's L2 copy of the
+// activation columns.  local = physical id - wg0 (wg0 and wgs are multiples of 8: local % 8 is the XCD).
+static __device__ __forceinline__ int logical_of(int local, int wgs)
 {
-    const int nb = gridDim.x, xcd = blockIdx.x & 7, q8 = nb >> 3, r8 = nb & 7;
-    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    return (local & 7) * (wgs >> 3) + (local >> 3);
 }
 
 // two fp32 -> (h, l) fp16 pairs with x = h + l to 22 bits: v_cvt_pk_f16_f32 (RNE), the residual is exact in fp32
@@ -385,7 +401,7 @@ static __device__ __forceinline__ void epilogue_dispatch(const ConvGemmArgs& a, 
 // `active` = this wave holds a result (false for the waves of a K group that already folded theirs into group 0).
 template <int TM, int TN>
 static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
-                                                int wn, int l31, int lk, int S, bool active, int grp, int n_end)
+                                                int wn, int l31, int lk, int S, int slice, bool active, int grp, int n_end)
 {
     if (!active) return;
     const int rbase = m0 + wm * 32 * TM + 4 * lk;          // this lane's first row; element e adds i*32 + (e&3) + 8*(e>>2)
@@ -395,7 +411,7 @@ static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32
         return;
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<float*>(a.ws) + (size_t)blockIdx.y * a.M * a.N, 0, (int)((unsigned)a.M * a.N * 4u), 0x00020000);
+        reinterpret_cast<float*>(a.ws) + (size_t)slice * a.M * a.N, 0, (int)((unsigned)a.M * a.N * 4u), 0x00020000);
     slab_store<TM, TN>(a, acc, rs, rbase, cbase, l31, n_end);
 }
 #endif

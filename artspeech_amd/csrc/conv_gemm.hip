@@ -307,11 +307,11 @@ extern "C" int as_conv_gemm_plan(const ConvGemmArgs* a, int32_t* kind, int32_t* 
     return AS_OK;
 }
 
-extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream_)
+// argument checks and defaults shared by the single and the multi-problem entry point: `norm` becomes what the kernels are given
+static int conv_gemm_normalise(const ConvGemmArgs* args_host, ConvGemmArgs& norm)
 {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!args_host) return AS_EINVAL;
-    ConvGemmArgs norm = *args_host;
+    norm = *args_host;
     if (!(fabsf(norm.in_slope) <= 3.0e38f) || !(fabsf(norm.act_slope) <= 3.0e38f)) return AS_EINVAL;   // slopes are used as given
     if (norm.acc_scale == 0.f) norm.acc_scale = 1.0f;
     norm.status = as_status_words_device();
@@ -340,6 +340,36 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     if ((a.Y && (double)(a.transpose_out ? a.N : a.M) * a.ldy * 4.0 >= 2147483648.0) || (double)a.M * a.ldr * 4.0 >= 2147483648.0 ||
         (double)a.M * a.N * 4.0 >= 2147483648.0 || (a.Yh && (double)as_kbx(a.M) * 64.0 * (a.N + 1.0) >= 2147483648.0))
         return AS_EINVAL;
+    return AS_OK;
+}
+
+static void gemm_tag(const ConvGemmArgs& a, char* tag, size_t n)
+{
+    char sc[24] = "";
+    if (a.K2) snprintf(sc, sizeof(sc), "+K%d", a.K2);
+    snprintf(tag, n, "M%d N%d K%d T%d%s", a.M, a.N, a.K, a.T, sc);
+}
+static double gemm_flops(const ConvGemmArgs& a) { return 2.0 * a.M * a.N * ((double)a.K * a.T + a.K2); }
+// algorithmic bytes: weights + inputs + output once (4 bytes per element)
+static double gemm_bytes(const ConvGemmArgs& a)
+{
+    return 4.0 * (((double)a.T * a.K + a.K2) * a.M * a.n_groups + ((double)a.K + a.K2) * a.N + (double)a.M * a.N);
+}
+static int launch_reduce(const ConvGemmArgs& a, int S, hipStream_t stream)
+{
+    const int rows = a.Yh ? (16 * as_kbx(a.M) > a.M ? 16 * as_kbx(a.M) : a.M) : a.M;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(as_cdiv(a.N + 1, 256), as_cdiv(rows, 8)), dim3(256), 0, stream, a, S);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ConvGemmArgs norm;
+    const int rn = conv_gemm_normalise(args_host, norm);
+    if (rn != AS_OK) return rn;
+    const ConvGemmArgs& a = norm;
     if (a.N == 0) return AS_OK;
     if (direct_cin1(a)) {
         char tag[64];
@@ -367,25 +397,139 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
         plan.slab_bytes = 0;
     }
     const int S = plan.S;
-    char tag[80], sc[24] = "";
-    if (a.K2) snprintf(sc, sizeof(sc), " +K%d", a.K2);
-    snprintf(tag, sizeof(tag), "M%d N%d K%d T%d%s tile%d S%d%s%s%s", a.M, a.N, a.K, a.T, sc, plan.choice, S, a.n_prod == 1 ? " h1" : "",
-             a.Xh ? "" : " +split", a.Yh ? (a.Y ? " y+yh" : " yh") : "");
+    char tag[96], shape[64];
+    gemm_tag(a, shape, sizeof(shape));
+    snprintf(tag, sizeof(tag), "%s tile%d S%d%s%s%s", shape, plan.choice, S, a.n_prod == 1 ? " h1" : "", a.Xh ? "" : " +split",
+             a.Yh ? (a.Y ? " y+yh" : " yh") : "");
     // algorithmic work of this launch: 2*M*N*(K*T + K2) flop; bytes = weights + inputs + output once (4 bytes per element)
-    AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * ((double)a.K * a.T + a.K2),
-                       4.0 * (((double)a.T * a.K + a.K2) * a.M * a.n_groups + ((double)a.K + a.K2) * a.N + (double)a.M * a.N), stream, tag);
+    AsProfScope prof__(AS_CLS_GEMM, gemm_flops(a), gemm_bytes(a), stream, tag);
     if (!a.Xh) {                                                        // split once, behind the K slabs in the workspace
         uint16_t* xh = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(a.ws) + align256(plan.slab_bytes));
         const int rc = as_split_f16x2_launch(a.X, a.ldx, a.K, a.N, a.in_act == 2, a.in_slope, xh, stream);
         if (rc != AS_OK) return rc;
         norm.Xh = xh;
     }
-    const int rc = as_conv_gemm_h3_launch(a, plan.choice, S, stream);
+    const ConvGemmArgs* one = &a;
+    const int rc = as_conv_gemm_h3_launch(&one, &S, 1, plan.choice, stream);
     if (rc != AS_OK) return rc;
-    if (S > 1) {
-        const int rows = a.Yh ? (16 * as_kbx(a.M) > a.M ? 16 * as_kbx(a.M) : a.M) : a.M;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(as_cdiv(a.N + 1, 256), as_cdiv(rows, 8)), dim3(256), 0, stream, a, S);
-        AS_CHECK_LAUNCH();
+    if (S > 1) return launch_reduce(a, S, stream);
+    return AS_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Several independent convolutions as ONE launch (include/artspeech_hip.h: as_conv_gemm_multi_f32).
+// ----------------------------------------------------------------------------------------------------------------
+static bool multi_tall(int M) { return M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512); }
+
+// one tile for the whole set: the cost model of gemm_tile_choice on the SUM of the problems' tiles
+static int multi_tile_choice(const ConvGemmArgs* a, int n)
+{
+    const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only
+    if (env && atoi(env) > 0) return atoi(env);
+    bool all_tall = true, all_short = true, small_k = false;
+    for (int i = 0; i < n; ++i) {
+        all_tall = all_tall && multi_tall(a[i].M);
+        all_short = all_short && a[i].M <= 64;
+        small_k = small_k || a[i].Kp <= 32;
+    }
+    static const int choices[5] = {22, 21, 12, 11, 14};
+    static const double t1[5] = {1.0, 0.78, 0.78, 0.59, 1.3};   // (64 x 256 from M64 N509440 K64 T9: 139 us against 167 with 64 x 128)
+    int best = 11;
+    double best_cost = 1e30;
+    for (int c = 0; c < 5; ++c) {
+        int bm, bn;
+        tile_dims(choices[c], &bm, &bn);
+        if (bm >= 128 && !all_tall) continue;
+        if (choices[c] == 14 && (!all_short || a[0].n_prod != 3)) continue;
+        double tiles = 0;
+        for (int i = 0; i < n; ++i)
+            tiles += (double)as_cdiv(a[i].M, bm) * (a[i].n_groups > 1 ? a[i].n_groups * as_cdiv(a[i].group_cols, bn) : as_cdiv(a[i].N, bn));
+        if (choices[c] == 14 && tiles < 240) continue;
+        const double r = ceil(tiles / 256.0);
+        const double cost = t1[c] * (r > 1.0 ? 0.71 * r : 1.0);
+        if (cost < best_cost * 0.97) { best_cost = cost; best = choices[c]; }
+    }
+    if (small_k && best == 11) best = 12;               // (see gemm_tile_choice: images written by the 32-row tile)
+    return best;
+}
+
+extern "C" int as_conv_gemm_multi_tile(const ConvGemmArgs* list_host, int n)
+{
+    if (!list_host || n < 1 || n > H3_MAXP) return AS_EINVAL;
+    ConvGemmArgs norm[H3_MAXP];
+    for (int i = 0; i < n; ++i) {
+        norm[i] = list_host[i];
+        if (norm[i].n_prod == 0) norm[i].n_prod = 3;
+        if (norm[i].n_groups < 1) norm[i].n_groups = 1;
+    }
+    return multi_tile_choice(norm, n);
+}
+
+extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_stream_t stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!list_host || n < 1 || n > AS_MAX_MULTI) return AS_EINVAL;
+    static_assert(AS_MAX_MULTI == H3_MAXP, "header and kernel disagree");
+    if (n == 1) return as_conv_gemm_f32(list_host, stream_);
+    ConvGemmArgs norm[H3_MAXP];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const int r = conv_gemm_normalise(&list_host[i], norm[m]);
+        if (r != AS_OK) return r;
+        if (norm[m].N == 0) continue;                                    // nothing to do for this one
+        // in one launch only what the tiled kernel runs from operand images with the same arithmetic
+        if (direct_cin1(norm[m]) || !norm[m].Wh || !norm[m].Xh || norm[m].n_prod != norm[0].n_prod) return AS_EINVAL;
+        ++m;
+    }
+    if (m == 0) return AS_OK;
+    if (m == 1) return as_conv_gemm_f32(&norm[0], stream_);
+    const int choice = multi_tile_choice(norm, m);
+    int bm, bn;
+    tile_dims(choice, &bm, &bn);
+    long tiles = 0;
+    for (int i = 0; i < m; ++i)
+        tiles += (long)as_cdiv(norm[i].M, bm) * (norm[i].n_groups > 1 ? norm[i].n_groups * as_cdiv(norm[i].group_cols, bn) : as_cdiv(norm[i].N, bn));
+    // K slices only when even together the problems leave most of the chip idle (the towers' closing convs side by side); a problem
+    // takes no more slices than its workspace holds slabs for
+    const int wk = choice == 2 ? 2 : bm * bn >= 4 * 64 * 64 ? 1 : 4 * 64 * 64 / (bm * bn);
+    const int s_target = tiles < 64 ? std::min(16, as_cdiv(192, tiles)) : 1;
+    // longest tile first: the short ones fill the tail of the launch
+    int order[H3_MAXP], S[H3_MAXP];
+    double len[H3_MAXP];
+    for (int i = 0; i < m; ++i) {
+        const ConvGemmArgs& a = norm[i];
+        const int nkt = a.T * as_cdiv(a.Kp / 16, wk) + as_cdiv(as_cdiv(a.K2, 16), wk);
+        int s = std::min(s_target, nkt / std::max(1, 24 / wk));
+        const size_t slab = (size_t)a.M * a.N * sizeof(float);
+        if (s > 1 && (!a.ws || a.ws_bytes / slab < (size_t)s)) s = a.ws ? (int)std::min<size_t>(a.ws_bytes / slab, (size_t)s) : 1;
+        S[i] = s < 1 ? 1 : s;
+        len[i] = (double)nkt / S[i];
+        order[i] = i;
+    }
+    std::sort(order, order + m, [&](int x, int y) { return len[x] > len[y]; });
+    const ConvGemmArgs* ptr[H3_MAXP];
+    int So[H3_MAXP];
+    double flops = 0, bytes = 0;
+    char tag[160];
+    int at = snprintf(tag, sizeof(tag), "multi%d tile%d:", m, choice);
+    for (int k = 0; k < m; ++k) {
+        ptr[k] = &norm[order[k]];
+        So[k] = S[order[k]];
+        flops += gemm_flops(*ptr[k]);
+        bytes += gemm_bytes(*ptr[k]);
+        char shape[64];
+        gemm_tag(*ptr[k], shape, sizeof(shape));
+        if (at < (int)sizeof(tag) - 1) at += snprintf(tag + at, sizeof(tag) - at, " %s%s", shape, k + 1 < m ? " |" : "");
+    }
+    {
+        AsProfScope prof__(AS_CLS_GEMM, flops, bytes, stream, tag);
+        const int rc = as_conv_gemm_h3_launch(ptr, So, m, choice, stream);
+        if (rc != AS_OK) return rc;
+        for (int k = 0; k < m; ++k)
+            if (So[k] > 1) {
+                const int rr = launch_reduce(*ptr[k], So[k], stream);
+                if (rr != AS_OK) return rr;
+            }
     }
     return AS_OK;
 }

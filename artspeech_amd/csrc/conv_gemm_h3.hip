@@ -25,6 +25,7 @@
 // vmcnt(this iteration's DMAs) -- only the PREVIOUS iteration's must have landed -- followed by a raw s_barrier
 // (__syncthreads() would wait for vmcnt(0)).
 #include "conv_gemm.h"
+#include <cstring>
 #include <type_traits>
 
 // knock-out switches of experiment builds only (scripts/build_exp.sh NAME -DH3_EXP_NOMFMA / _NODMA / _NOFRAG): what bounds the k loop
@@ -68,7 +69,7 @@ struct H3Cfg {
 #endif
 template <int WM, int WN, int WK, int KT, int NS, int NP, int TM = 2>
 __global__ void __launch_bounds__(64 * WM * WN * WK, H3_OCC)
-conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
+conv_gemm_h3_kernel(const H3Multi mm)
 {
     using C = H3Cfg<WM, WN, WK, KT, NS, NP, TM>;
     static_assert(NS >= 2 && NS <= 4, "stages");
@@ -80,8 +81,18 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn % WM, wn = wmn / WM;
     const int l31 = lane & 31, lk = lane >> 5;
+    // which problem this workgroup belongs to (wave-uniform: scalar compares on the kernel arguments), then its (tile, K slice)
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < H3_MAXP; ++i) pi += (i < mm.n && (int)blockIdx.x >= mm.p[i].wg0) ? 1 : 0;
+    const H3Prob& prob = mm.p[pi];
+    const ConvGemmArgs& a = prob.a;
+    const H3Taps& tp = prob.tp;
+    const int lt = logical_of((int)blockIdx.x - prob.wg0, prob.wgs);
+    const int S = prob.S;
+    if (lt >= prob.tiles * S) return;                                    // (the padding up to a multiple of 8; the whole workgroup)
+    const int slice = lt / prob.tiles, tile = lt - slice * prob.tiles;
     const int tiles_m = (a.M + BM - 1) / BM;
-    const int tile = logical_tile();
     const int m0 = (tile % tiles_m) * BM;
     // column tiles: per weight set when the launch is grouped (a group's columns are [grp * group_cols, (grp + 1) * group_cols);
     // its last tile is cut at the group's end, so group_cols needs no alignment)
@@ -151,9 +162,8 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
     // image and k-block count, its weights behind the taps' in the weight set.
     const int it_per_tap = (KB + KBS - 1) / KBS;
     const int nit_all = a.T * it_per_tap + (KB2 + KBS - 1) / KBS;
-    const int S = gridDim.y;
-    const int it_lo = (int)((long)nit_all * blockIdx.y / S);
-    const int n_it = (int)((long)nit_all * (blockIdx.y + 1) / S) - it_lo;
+    const int it_lo = (int)((long)nit_all * slice / S);
+    const int n_it = (int)((long)nit_all * (slice + 1) / S) - it_lo;
 
     // Cursor of the next tile to stage.  Inside a tap an iteration only adds constants to two scalar offsets; the tap's decode
     // (source column of every thread's rows; weights / activation offsets back to the tap's first k-block) runs when the tap
@@ -381,19 +391,30 @@ conv_gemm_h3_kernel(const ConvGemmArgs a, const H3Taps tp)
                             for (int c = 0; c < 4; ++c) acc[i][jn][4 * e4 + c] += v[c];
                         }
     }
-    epilogue<TM, 2>(a, acc, m0, n0, wm, wn, l31, lk, S, wk == 0, grp, n_end);
+    epilogue<TM, 2>(a, acc, m0, n0, wm, wn, l31, lk, S, slice, wk == 0, grp, n_end);
 }
 
 template <int WM, int WN, int WK, int KT, int NS, int NP, int TM = 2>
-static int launch_h3(const ConvGemmArgs& a, int S, hipStream_t stream)
+static int launch_h3(const ConvGemmArgs* const* a, const int* S, int n, hipStream_t stream)
 {
     using C = H3Cfg<WM, WN, WK, KT, NS, NP, TM>;
     AS_LDS_OPT_IN((&conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP, TM>), C::LDS);
-    H3Taps tp;
-    if (h3_pack_taps(a, &tp) != AS_OK) return AS_EINVAL;
-    const int tiles_n = a.n_groups > 1 ? a.n_groups * as_cdiv(a.group_cols, C::BN) : as_cdiv(a.N, C::BN);
-    const dim3 grid(as_cdiv(a.M, C::BM) * tiles_n, S);
-    hipLaunchKernelGGL((conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP, TM>), grid, dim3(C::NT), C::LDS, stream, a, tp);
+    H3Multi mm;
+    memset(&mm, 0, sizeof(mm));
+    mm.n = n;
+    int wg = 0;
+    for (int i = 0; i < n; ++i) {
+        H3Prob& p = mm.p[i];
+        p.a = *a[i];
+        if (h3_pack_taps(p.a, &p.tp) != AS_OK) return AS_EINVAL;
+        const int tiles_n = p.a.n_groups > 1 ? p.a.n_groups * as_cdiv(p.a.group_cols, C::BN) : as_cdiv(p.a.N, C::BN);
+        p.tiles = as_cdiv(p.a.M, C::BM) * tiles_n;
+        p.S = S[i];
+        p.wg0 = wg;
+        p.wgs = (p.tiles * p.S + 7) & ~7;
+        wg += p.wgs;
+    }
+    hipLaunchKernelGGL((conv_gemm_h3_kernel<WM, WN, WK, KT, NS, NP, TM>), dim3(wg), dim3(C::NT), C::LDS, stream, mm);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
@@ -404,42 +425,46 @@ static int launch_h3(const ConvGemmArgs& a, int S, hipStream_t stream)
 #define H3_KT 1
 #endif
 template <int WM, int WN, int WK>
-static int launch_h3_tile(const ConvGemmArgs& a, int S, hipStream_t stream)
+static int launch_h3_tile(const ConvGemmArgs* const* a, const int* S, int n, hipStream_t stream)
 {
-    if (a.n_prod == 1) return launch_h3<WM, WN, WK, 1, 3, 1>(a, S, stream);
+    if (a[0]->n_prod == 1) return launch_h3<WM, WN, WK, 1, 3, 1>(a, S, n, stream);
 #ifdef AS_EXPERIMENTS   // (-DAS_EXPERIMENTS builds only: the shipped library carries the one pipeline shape the path launches)
     const char *ekt = getenv("AS_H3_KT"), *ens = getenv("AS_H3_NS");
     const int kt = ekt ? atoi(ekt) : H3_KT, ns = ens ? atoi(ens) : 3;
     if constexpr (H3Cfg<WM, WN, WK, 2, 3, 3>::LDS <= 160 * 1024) {
-        if (kt == 2) return launch_h3<WM, WN, WK, 2, 3, 3>(a, S, stream);
+        if (kt == 2) return launch_h3<WM, WN, WK, 2, 3, 3>(a, S, n, stream);
     }
-    if (ns == 2) return launch_h3<WM, WN, WK, 1, 2, 3>(a, S, stream);
+    if (ns == 2) return launch_h3<WM, WN, WK, 1, 2, 3>(a, S, n, stream);
     if constexpr (H3Cfg<WM, WN, WK, 1, 4, 3>::LDS <= 160 * 1024) {
-        if (ns == 4) return launch_h3<WM, WN, WK, 1, 4, 3>(a, S, stream);
+        if (ns == 4) return launch_h3<WM, WN, WK, 1, 4, 3>(a, S, n, stream);
     }
 #endif
-    return launch_h3<WM, WN, WK, 1, 3, 3>(a, S, stream);
+    return launch_h3<WM, WN, WK, 1, 3, 3>(a, S, n, stream);
 }
 
-int as_conv_gemm_h3_launch(const ConvGemmArgs& a, int choice, int S, hipStream_t stream)
+int as_conv_gemm_h3_launch(const ConvGemmArgs* const* a, const int* S, int n, int choice, hipStream_t stream)
 {
-    if ((double)as_kbx(a.K) * 4.0 * ((a.src_col ? a.N_in : a.N) + 1.0) * 16.0 >= 2147483648.0) return AS_EINVAL;   // 32-bit offsets in the descriptor
+    if (n < 1 || n > H3_MAXP) return AS_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        if (a[i]->n_prod != a[0]->n_prod || S[i] < 1) return AS_EINVAL;
+        if ((double)as_kbx(a[i]->K) * 4.0 * ((a[i]->src_col ? a[i]->N_in : a[i]->N) + 1.0) * 16.0 >= 2147483648.0) return AS_EINVAL;   // 32-bit offsets in the descriptor
+    }
     switch (choice) {
 #ifdef AS_EXPERIMENTS
     case 42:                                                            // 256 x 128, a wave owns 128 x 64
-        if (a.n_prod == 1) return AS_EINVAL;
-        return launch_h3<2, 2, 1, 1, 3, 3, 4>(a, S, stream);
+        if (a[0]->n_prod == 1) return AS_EINVAL;
+        return launch_h3<2, 2, 1, 1, 3, 3, 4>(a, S, n, stream);
 #endif
     case 2:                                                             // 32 x 128 (a wave owns 32 x 64): the vocoder's 32-channel stage, M <= 32
-        if (a.n_prod == 1) return AS_EINVAL;
-        return launch_h3<1, 2, 2, 1, 3, 3, 1>(a, S, stream);
-    case 22: return launch_h3_tile<2, 2, 1>(a, S, stream);
-    case 21: return launch_h3_tile<2, 1, 2>(a, S, stream);
-    case 12: return launch_h3_tile<1, 2, 2>(a, S, stream);
+        if (a[0]->n_prod == 1) return AS_EINVAL;
+        return launch_h3<1, 2, 2, 1, 3, 3, 1>(a, S, n, stream);
+    case 22: return launch_h3_tile<2, 2, 1>(a, S, n, stream);
+    case 21: return launch_h3_tile<2, 1, 2>(a, S, n, stream);
+    case 12: return launch_h3_tile<1, 2, 2>(a, S, n, stream);
     case 14:                                                            // 64 x 256: four waves side by side, each 64 x 64 over the whole k
-        if (a.n_prod == 1) return launch_h3_tile<1, 2, 2>(a, S, stream);   // (h-only operands: half a weight chunk per thread -- the 64 x 128 tile)
-        return launch_h3<1, 4, 1, 1, 3, 3>(a, S, stream);
-    case 11: return launch_h3_tile<1, 1, 4>(a, S, stream);
+        if (a[0]->n_prod == 1) return launch_h3_tile<1, 2, 2>(a, S, n, stream);   // (h-only operands: half a weight chunk per thread -- the 64 x 128 tile)
+        return launch_h3<1, 4, 1, 1, 3, 3>(a, S, n, stream);
+    case 11: return launch_h3_tile<1, 1, 4>(a, S, n, stream);
     default: return AS_EINVAL;
     }
 }

@@ -11,7 +11,7 @@
 #include <mutex>
 #include <vector>
 
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; char tag[64]; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; char tag[160]; };
 static bool g_on = false;
 static thread_local double g_hint_flops = 0, g_hint_bytes = 0;      // what the caller knows about the next launch (as_prof_hint)
 static std::vector<ProfRec> g_recs;

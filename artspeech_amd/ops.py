@@ -257,8 +257,9 @@ def project_cols(X, N, w, bias, Y):
 
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
               use_meta=True, in_slope=0.2, act_slope=0.2, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None, plan_out=None,
-              x2s=None, K2=0, src_col=None, src_meta=None, N_in=0):
-    """Y = epi(sum_t Wt[t]^T X shifted by tap t).  Wt: prep_weight(...); X [K][*] fp32 or None with xs= (the split image of
+              x2s=None, K2=0, src_col=None, src_meta=None, N_in=0, defer=None):
+    """Y = epi(sum_t Wt[t]^T X shifted by tap t).  defer: a list -- the call is not launched but appended to it (conv_gemm_multi
+    launches the whole list as ONE kernel: as_conv_gemm_multi_f32).  Wt: prep_weight(...); X [K][*] fp32 or None with xs= (the split image of
     X: split_act / adain_split / channel_layernorm_split / another conv's yh=) and K=; Y [M][*] (or [N][*] transposed) or None
     when only yh (the output as the next conv's split image, new_image(M, N)) is wanted.  group_cols: Wt holds Wt.G weight
     sets (and bias [G][M]); columns [g * group_cols, (g+1) * group_cols) use set g.  x2s / K2: the split image of a second operand
@@ -303,8 +304,21 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
         k, t, sl = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
         check(L.as_conv_gemm_plan(ctypes.byref(a), ctypes.byref(k), ctypes.byref(t), ctypes.byref(sl)), "as_conv_gemm_plan")
         plan_out.update(kind=k.value, tile=t.value, slices=sl.value)
+    if defer is not None:
+        defer.append((a, [Wt, X, xs, Y, yh, bias, res, x2s, src_col, src_meta, lay, (ws if nbytes else None)]))
+        return Y if Y is not None else yh
     check(L.as_conv_gemm_f32(ctypes.byref(a), stream()), "as_conv_gemm_f32")
     return Y if Y is not None else yh
+
+
+def conv_gemm_multi(deferred, tile_out=None):
+    """the conv_gemm(..., defer=list) calls collected in `deferred` (independent problems) as one launch"""
+    n = len(deferred)
+    arr = (ConvGemmArgs * n)(*[d[0] for d in deferred])
+    L = _lib.lib()
+    if tile_out is not None:
+        tile_out.append(L.as_conv_gemm_multi_tile(arr, n))
+    check(L.as_conv_gemm_multi_f32(arr, n, stream()), "as_conv_gemm_multi_f32")
 
 
 def embed(tokens_i32, emb, scale, Y, group2=None, n_cols=None):

@@ -180,6 +180,17 @@ typedef struct ConvGemmArgs {
 } ConvGemmArgs;
 #define AS_SLOPE_PATH 0.2f
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
+/* Several INDEPENDENT convolutions (no problem reads what another writes) as ONE launch: the grid walks the tiles of all of them, longest
+ * tiles first, so a problem that would own the chip alone at a fraction of its width -- the 40-tile convs of the duration predictor beside
+ * the encoders' 240-tile ones, the small towers beside the mel tower: branches of ArtsSpeech.forward with no edge between them,
+ * models.py:356-360, 417-424, 540-546 -- costs what it adds to the busiest CU, not a launch of its own.  Every problem as in
+ * as_conv_gemm_f32 (own epilogue, groups, second operand, source positions), with these limits: operand images only (Xh given), no
+ * Cin = 1 direct launches, one n_prod; 1 <= n <= AS_MAX_MULTI.  One tile shape serves the set (the cost model of the single launch on the
+ * summed tile count: as_conv_gemm_multi_tile says which), so a problem's result can differ in the last bits from its single launch where
+ * that one would have split K inside the workgroup -- same arithmetic, other order of the partial sums.  n == 1 is as_conv_gemm_f32. */
+#define AS_MAX_MULTI 6
+int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_stream_t stream);
+int as_conv_gemm_multi_tile(const ConvGemmArgs* list_host, int n);
 /* which kernel as_conv_gemm_f32 runs for these arguments (tests, tuning): *kind 0 = the direct Cin = 1 kernel, 1 = the tiled kernel
  * (*tile = 22 / 21 / 12 / 11 / 14 / 2: 128x128, 128x64, 64x128, 64x64, 64x256, 32x128); *slices = K slices */
 int as_conv_gemm_plan(const ConvGemmArgs* args_host, int32_t* kind, int32_t* tile, int32_t* slices);

@@ -725,3 +725,117 @@ def test_conv_cin1_direct_kernel(cuda, two_d):
                       act=ops.ACT_LRELU)
     assert float((y.cpu() - want).abs().max()) <= 2e-6
 
+
+
+def _multi_problems(cuda, g, specs):
+    """specs: (cin, cout, k, lens, flavour) -- independent conv problems of the kinds the path merges.  Returns the deferred launch list,
+    the outputs and float64 references."""
+    deferred, outs, wants, checks = [], [], [], []
+    for cin, cout, k, lens, flavour in specs:
+        lay = Layout(lens, cuda)
+        if flavour == "grouped":                                 # three weight sets side by side (the triple encoder / the predictor branches)
+            G, per = 3, len(lens) // 3
+            ws = [torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k) for _ in range(G)]
+            b = torch.randn(G, cout, generator=g)
+            xs = [torch.randn(cin, L, generator=g) for L in lens]
+            want = packed([F.relu(F.conv1d(x[None].double(), ws[i // per].double(), b[i // per].double(), padding=k // 2)[0]) for i, x in enumerate(xs)])
+            xh = ops.split_act(packed(xs).to(cuda), lay)
+            y = lay.new(cout)
+            ops.conv_gemm(ops.prep_weight(ws[0], cuda, stack=ws[1:]), None, lay, y, taps_1d(k), bias=b.to(cuda), act=ops.ACT_RELU, xs=xh, K=cin,
+                          group_cols=sum(lens[:per]), defer=deferred)
+        elif flavour == "shortcut":                              # learned shortcut folded in + the result also as an operand image
+            cin2 = cin // 2 + 8
+            w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+            w2 = torch.randn(cout, cin2, generator=g) / np.sqrt(cin2)
+            b = torch.randn(cout, generator=g)
+            xs = [torch.randn(cin, L, generator=g) for L in lens]
+            x2 = [torch.randn(cin2, L, generator=g) for L in lens]
+            want = packed([(F.conv1d(x[None].double(), w.double(), b.double(), padding=k // 2)[0] + w2.double() @ z.double()) / np.sqrt(2)
+                           for x, z in zip(xs, x2)])
+            xh, x2h = ops.split_act(packed(xs).to(cuda), lay), ops.split_act(packed(x2).to(cuda), lay)
+            y, yh = lay.new(cout), ops.new_image(cout, lay.N, cuda)
+            ops.conv_gemm(ops.prep_weight(w, cuda, sc=[w2]), None, lay, y, taps_1d(k), bias=b.to(cuda), div_sqrt2=True, xs=xh, K=cin, x2s=x2h,
+                          K2=cin2, yh=yh, defer=deferred)
+            checks.append((yh, y, lay))
+        else:                                                    # plain conv + residual, LeakyReLU epilogue
+            w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+            b = torch.randn(cout, generator=g)
+            xs = [torch.randn(cin, L, generator=g) for L in lens]
+            res = [torch.randn(cout, L, generator=g) for L in lens]
+            want = packed([F.leaky_relu(F.conv1d(x[None].double(), w.double(), b.double(), padding=k // 2)[0] + r.double(), 0.2) for x, r in zip(xs, res)])
+            xh = ops.split_act(packed(xs).to(cuda), lay)
+            y = lay.new(cout)
+            ops.conv_gemm(ops.prep_weight(w, cuda), None, lay, y, taps_1d(k), bias=b.to(cuda), res=packed(res).to(cuda), act=ops.ACT_LRELU, xs=xh,
+                          K=cin, defer=deferred)
+        outs.append(y)
+        wants.append(want)
+    return deferred, outs, wants, checks
+
+
+MULTI_SETS = {
+    "enc+dur": [(512, 1024, 9, [40] * 32, "plain"), (512, 512, 3, [40] * 12, "shortcut"), (256, 512, 1, [33, 40, 17] * 3, "grouped")],
+    "towers": [(64, 128, 3, [199, 66, 150, 80], "plain"), (128, 256, 3, [100, 33, 75, 40], "shortcut"), (128, 128, 1, [7], "plain"),
+               (256, 256, 5, [13, 9, 13, 5, 1, 2], "plain"), (96, 160, 9, [300], "plain"), (512, 130, 3, [64, 1, 129], "plain")],
+    "short": [(64, 64, 3, [3000, 1000], "plain"), (64, 48, 9, [1500], "plain")],
+    "long_k": [(512, 256, 9, [20, 9], "plain"), (1024, 128, 5, [11, 30], "plain")],
+}
+
+
+@pytest.mark.parametrize("name", sorted(MULTI_SETS))
+@pytest.mark.parametrize("tile", ["", "22", "21", "12", "11"])
+def test_conv_gemm_multi(cuda, monkeypatch, impl, name, tile):
+    """as_conv_gemm_multi_f32: independent convolutions of the shapes the path's branches hold (encoder FFN beside the duration
+    predictor's blocks, tower blocks of several widths, two closing long-K convs that need K slices even together) as ONE launch, each with
+    its own epilogue / groups / second operand -- every problem against float64 torch, operand images against `h + l = y`, and bitwise
+    against the same problems launched one by one with the same tile."""
+    specs = MULTI_SETS[name]
+    if tile:
+        if name == "short" and tile in ("22", "21"):
+            pytest.skip("128-row tiles are not offered for <= 64 output channels")
+        monkeypatch.setenv("AS_GEMM_TILE", tile)
+    else:
+        monkeypatch.delenv("AS_GEMM_TILE", raising=False)
+    g = torch.Generator().manual_seed(len(name) * 131 + len(specs))
+    deferred, outs, wants, checks = _multi_problems(cuda, g, specs)
+    chosen = []
+    ops.conv_gemm_multi(deferred, tile_out=chosen)
+    torch.cuda.synchronize()
+    for (cin, cout, k, lens, fl), y, want in zip(specs, outs, wants):
+        err = float((y.double().cpu() - want).abs().max())
+        assert err <= 3e-5, (name, cin, cout, k, fl, err, chosen)
+    for yh, y, lay in checks:
+        assert torch.equal(yh, ops.split_act(y, lay))
+    # one by one with the set's tile: the same bits (same k order inside a tile; K slices are summed in slice order either way)
+    monkeypatch.setenv("AS_GEMM_TILE", str(chosen[0]))
+    g = torch.Generator().manual_seed(len(name) * 131 + len(specs))
+    deferred1, outs1, _, _ = _multi_problems(cuda, g, specs)
+    L = ops._lib.lib()
+    import ctypes
+    alone_slices = []
+    for a, _keep in deferred1:
+        k, t, sl = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        ops.check(L.as_conv_gemm_plan(ctypes.byref(a), ctypes.byref(k), ctypes.byref(t), ctypes.byref(sl)), "as_conv_gemm_plan")
+        assert t.value == chosen[0]
+        alone_slices.append(sl.value)
+        ops.check(L.as_conv_gemm_f32(ctypes.byref(a), ops.stream()), "as_conv_gemm_f32")
+    torch.cuda.synchronize()
+    for y, y1, sl in zip(outs, outs1, alone_slices):
+        if sl == 1:                                             # (alone a tiny problem takes K slices: another order of partial sums)
+            assert torch.equal(y, y1)
+        else:
+            assert float((y - y1).abs().max()) <= 2e-5
+
+
+def test_conv_gemm_multi_rejects_what_it_cannot_merge(cuda):
+    g = torch.Generator().manual_seed(1)
+    lay = Layout([50, 20], cuda)
+    w = torch.randn(64, 32, 3, generator=g)
+    x = torch.randn(32, lay.N, generator=g).to(cuda)
+    d = []
+    ops.conv_gemm(ops.prep_weight(w, cuda), x, lay, lay.new(64), taps_1d(3), defer=d)                          # fp32 input: no operand image
+    ops.conv_gemm(ops.prep_weight(w, cuda), None, lay, lay.new(64), taps_1d(3), xs=ops.split_act(x, lay), K=32, defer=d)
+    with pytest.raises(ops._lib.HipLibraryError):
+        ops.conv_gemm_multi(d)
+    ops.conv_gemm_multi(d[1:])                                  # n == 1: the single launch
+    with pytest.raises(ops._lib.HipLibraryError):
+        ops.conv_gemm_multi(d[1:] * 7)                          # more than AS_MAX_MULTI
