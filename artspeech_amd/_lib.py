@@ -55,6 +55,7 @@ _SIGNATURES.update({
     "as_conv_gemm_workspace_bytes": (c_sz, [ctypes.POINTER(ConvGemmArgs)]),
     "as_conv_gemm_multi_f32": (c_i, [ctypes.POINTER(ConvGemmArgs), c_i, c_p]),
     "as_conv_gemm_multi_tile": (c_i, [ctypes.POINTER(ConvGemmArgs), c_i]),
+    "as_conv_gemm_multi_workspace_bytes": (c_sz, [ctypes.POINTER(ConvGemmArgs)]),
     "as_conv_gemm_plan": (c_i, [ctypes.POINTER(ConvGemmArgs), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
                                 ctypes.POINTER(ctypes.c_int32)]),
     "as_split_f16x2_bytes": (c_sz, [c_i, c_i]),
@@ -136,6 +137,7 @@ _SIGNATURES.update({
     "as_plan_create": (c_i, [c_p, ctypes.POINTER(c_p)]),
     "as_plan_destroy": (c_i, [c_p]),
     "as_plan_set_serial": (c_i, [c_p, c_i]),
+    "as_plan_set_merge": (c_i, [c_p, c_i]),
     "as_plan_set_timing": (c_i, [c_p, c_i]),
     "as_plan_set_operand_mode": (c_i, [c_p, c_i]),
     "as_plan_phase_ms": (c_i, [c_p, ctypes.POINTER(ctypes.c_float), c_i]),

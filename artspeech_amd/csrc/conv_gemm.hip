@@ -290,6 +290,20 @@ extern "C" size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* a)
     return p.xh_bytes ? align256(p.slab_bytes) + p.xh_bytes : p.slab_bytes;
 }
 
+// Room for the K slices a problem may be cut into inside a multi-problem launch (as_conv_gemm_multi_f32 takes no more slices than
+// a.ws_bytes holds slabs for): up to 16 slabs of a small output (<= 4 MB: anything larger has tiles enough to never need them), each
+// slice keeping >= 384 k; never less than the single launch wants.
+extern "C" size_t as_conv_gemm_multi_workspace_bytes(const ConvGemmArgs* a)
+{
+    const size_t single = as_conv_gemm_workspace_bytes(a);
+    if (!a || a->M <= 0 || a->N <= 0 || a->Kp <= 0 || a->T <= 0 || !a->Xh) return single;
+    const size_t slab = (size_t)a->M * a->N * sizeof(float);
+    if (slab > ((size_t)4 << 20)) return single;
+    const int nkt = a->T * (a->Kp / 16) + as_cdiv(a->K2, 16);
+    const int s = std::min(16, nkt / 24);
+    return std::max(single, s > 1 ? (size_t)s * slab : (size_t)0);
+}
+
 // which kernel a call with these arguments runs (tests, tuning): kind 0 = direct Cin = 1, 1 = tiled (tile = 22 / 21 / 12 / 11 / 14 / 2)
 extern "C" int as_conv_gemm_plan(const ConvGemmArgs* a, int32_t* kind, int32_t* tile, int32_t* slices)
 {
@@ -486,24 +500,28 @@ extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_s
     const int choice = multi_tile_choice(norm, m);
     int bm, bn;
     tile_dims(choice, &bm, &bn);
-    long tiles = 0;
-    for (int i = 0; i < m; ++i)
-        tiles += (long)as_cdiv(norm[i].M, bm) * (norm[i].n_groups > 1 ? norm[i].n_groups * as_cdiv(norm[i].group_cols, bn) : as_cdiv(norm[i].N, bn));
-    // K slices only when even together the problems leave most of the chip idle (the towers' closing convs side by side); a problem
-    // takes no more slices than its workspace holds slabs for
+    // K slices: a launch costs what its longest chain of k iterations on one CU costs.  With W = all problems' tiles x iterations spread
+    // over the chip's 512 workgroup slots, a problem whose tile alone runs longer than that share (the towers' closing 5 x 5 convs: 800
+    // k-blocks on a dozen tiles, beside convs of 30-300) is cut into slices of about that length -- as many as its workspace holds slabs
+    // for, each keeping >= 384 k.  (That is also the rule of the single launch for grids that leave most of the chip idle.)
     const int wk = choice == 2 ? 2 : bm * bn >= 4 * 64 * 64 ? 1 : 4 * 64 * 64 / (bm * bn);
-    const int s_target = tiles < 64 ? std::min(16, as_cdiv(192, tiles)) : 1;
-    // longest tile first: the short ones fill the tail of the launch
-    int order[H3_MAXP], S[H3_MAXP];
-    double len[H3_MAXP];
+    int order[H3_MAXP], S[H3_MAXP], nkt[H3_MAXP];
+    double len[H3_MAXP], W = 0;
     for (int i = 0; i < m; ++i) {
         const ConvGemmArgs& a = norm[i];
-        const int nkt = a.T * as_cdiv(a.Kp / 16, wk) + as_cdiv(as_cdiv(a.K2, 16), wk);
-        int s = std::min(s_target, nkt / std::max(1, 24 / wk));
+        nkt[i] = a.T * as_cdiv(a.Kp / 16, wk) + as_cdiv(as_cdiv(a.K2, 16), wk);
+        W += (double)nkt[i] * as_cdiv(a.M, bm) * (a.n_groups > 1 ? a.n_groups * as_cdiv(a.group_cols, bn) : as_cdiv(a.N, bn));
+    }
+    const double share = std::max(W / 512.0, 1.0);
+    for (int i = 0; i < m; ++i) {
+        const ConvGemmArgs& a = norm[i];
+        const int min_kt = std::max(1, 24 / wk);
+        int s = nkt[i] > 1.5 * share ? (int)ceil(nkt[i] / share) : 1;
+        s = std::min(std::min(s, 16), nkt[i] / min_kt);
         const size_t slab = (size_t)a.M * a.N * sizeof(float);
         if (s > 1 && (!a.ws || a.ws_bytes / slab < (size_t)s)) s = a.ws ? (int)std::min<size_t>(a.ws_bytes / slab, (size_t)s) : 1;
         S[i] = s < 1 ? 1 : s;
-        len[i] = (double)nkt / S[i];
+        len[i] = (double)nkt[i] / S[i];
         order[i] = i;
     }
     std::sort(order, order + m, [&](int x, int y) { return len[x] > len[y]; });

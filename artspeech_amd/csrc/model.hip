@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <new>
@@ -421,7 +422,8 @@ struct as_plan {
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
-    bool serial = false;                  // run the independent branches back to back on the calling stream (profiling)
+    bool serial = false;                  // run the independent branches back to back on the calling stream (one chain per batch)
+    bool merge = true;                    // (serial plans) conv GEMMs of independent branches share launches: as_plan_set_merge
     bool timing = false;                  // record phase marks on the calling stream (as_plan_phase_ms)
     int n_prod = 3;                       // matrix-core products per fp32 product (as_plan_set_operand_mode)
     hipEvent_t marks[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -499,6 +501,25 @@ struct as_plan {
 
 namespace {
 
+// Deferred launches (serial plans with `merge`): inside a Fork every launch of a branch is RECORDED into the branch's queue instead of being
+// enqueued; the root Fork's join() then plays the queues out on the calling stream in an order that keeps every queue's own order and the
+// fork / join edges, and hands conv GEMMs that are ready at the same time to ONE launch (as_conv_gemm_multi_f32): on one stream a step costs
+// the sum of its kernels' durations, and a 40-tile conv beside a 2 000-tile one costs next to nothing.
+struct Op {
+    int kind = 0;                                  // 0: a recorded launch, 1: a conv GEMM (as_conv_gemm_f32 arguments), 2: wait for other queues
+    std::function<int()> fn;
+    ConvGemmArgs g;
+    hipStream_t s = nullptr;
+    double hint_f = 0, hint_b = 0;                 // as_prof_hint that goes with the launch
+    std::vector<std::pair<int, size_t>> deps;      // kind 2: queue q has played >= n ops
+    const char* what = nullptr;
+    int line = 0;
+};
+struct Sched {
+    std::vector<std::vector<Op>> q;
+    int new_queue() { q.emplace_back(); return (int)q.size() - 1; }
+};
+
 struct Ctx {
     const as_model& m;
     as_plan& p;
@@ -508,6 +529,25 @@ struct Ctx {
     bool launch;                  // false: allocate only (count pass; prepare pass; the first half of as_forward_test_finish)
     bool count;                   // true: nothing behind the arena, geometry tables stay on the host
     int rc = 0;
+    std::shared_ptr<Sched> sched; // launches are being recorded (inside a Fork of a serial, merging plan)
+    int cur_q = -1;
+    double hint_f = 0, hint_b = 0;
+    bool deferring() const { return sched != nullptr && cur_q >= 0; }
+    Op& push(int kind)
+    {
+        sched->q[cur_q].emplace_back();
+        Op& o = sched->q[cur_q].back();
+        o.kind = kind;
+        o.s = s;
+        o.hint_f = hint_f; o.hint_b = hint_b;
+        hint_f = hint_b = 0;
+        return o;
+    }
+    void hint(double f, double b)                  // as_prof_hint for the NEXT launch: it has to travel with a recorded one
+    {
+        if (deferring()) { hint_f = f; hint_b = b; }
+        else as_prof_hint(f, b);
+    }
 
     Ctx(const as_model& m_, as_plan& p_, hipStream_t s_, void* ws, size_t ws_bytes, bool launch_, bool count_)
         : m(m_), p(p_), s(s_), base(static_cast<char*>(ws)), cap(ws_bytes), launch(launch_), count(count_) {}
@@ -667,14 +707,123 @@ static bool exp_dup(const char* call)
 #define EXP_SKIP(call) false
 #define EXP_DUP(call) false
 #endif
+// (recorded form: the closure copies what the call names -- argument structs and job arrays included -- and sees the stream as `c.s`)
 #define RUN(c, call)                                   \
     do {                                               \
         if ((c).go() && !EXP_SKIP(call)) {             \
-            int r__ = (call);                          \
-            if (r__ == AS_OK && EXP_DUP(call)) r__ = (call); \
-            if (r__ != AS_OK) (c).fail(r__, #call, __LINE__); \
+            if ((c).deferring()) {                     \
+                const hipStream_t s__ = (c).s;         \
+                Op& o__ = (c).push(0);                 \
+                o__.what = #call; o__.line = __LINE__; \
+                o__.fn = [=]() -> int {                \
+                    struct { hipStream_t s; } c = {s__}; \
+                    (void)c;                           \
+                    int r__ = (call);                  \
+                    if (r__ == AS_OK && EXP_DUP(call)) r__ = (call); \
+                    return r__;                        \
+                };                                     \
+            } else {                                   \
+                int r__ = (call);                      \
+                if (r__ == AS_OK && EXP_DUP(call)) r__ = (call); \
+                if (r__ != AS_OK) (c).fail(r__, #call, __LINE__); \
+            }                                          \
         }                                              \
     } while (0)
+
+// Play the recorded queues out on stream `s` (see Op).  Greedy: every queue runs ahead through its plain launches; when every live head
+// is a conv GEMM (or waits for another queue), the heads that can share a launch -- operand images in, the tiled kernel, one row class --
+// go out together.
+static bool gemm_mergeable(const ConvGemmArgs& g)
+{
+    if (!g.Xh || g.N <= 0) return false;
+    int32_t kind = 0, tile = 0, slices = 0;
+    return as_conv_gemm_plan(&g, &kind, &tile, &slices) == AS_OK && kind == 1;
+}
+static bool gemm_tall(int M) { return M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512); }   // (a 128-row tile is not half empty: conv_gemm.hip)
+
+static void play(Ctx& c, Sched& S)
+{
+    const int nq = (int)S.q.size();
+    std::vector<size_t> head(nq, 0);
+    auto fail = [&](int r, const Op& o) { c.fail(r, o.what, o.line); };
+    static const bool no_merge = getenv("AS_NO_MERGE") != nullptr;    // experiments: the recorded order, one launch per conv
+    static const bool trace = getenv("AS_DEBUG_SCHED") != nullptr;     // print what goes out, in order
+    if (trace) {
+        fprintf(stderr, "artspeech_hip: playing %d recorded queues:", nq);
+        for (int qi = 0; qi < nq; ++qi) fprintf(stderr, " %zu", S.q[qi].size());
+        fprintf(stderr, " ops\n");
+    }
+    for (;;) {
+        bool progress = false;
+        for (int qi = 0; qi < nq && !c.rc; ++qi) {
+            while (head[qi] < S.q[qi].size()) {
+                Op& o = S.q[qi][head[qi]];
+                if (o.kind == 2) {
+                    bool ok = true;
+                    for (auto& d : o.deps) ok = ok && head[d.first] >= d.second;
+                    if (!ok) break;
+                } else if (o.kind == 0) {
+                    if (o.hint_f > 0 || o.hint_b > 0) as_prof_hint(o.hint_f, o.hint_b);
+                    if (trace) fprintf(stderr, "  q%d  %.60s\n", qi, o.what ? o.what : "?");
+                    const int r = o.fn();
+                    if (r != AS_OK) { fail(r, o); break; }
+                } else {
+                    break;                                               // a conv GEMM: decided below, with the other queues' heads
+                }
+                ++head[qi];
+                progress = true;
+            }
+        }
+        if (c.rc) return;
+        if (progress) continue;
+        // every live head is a GEMM or a wait
+        int heads[64], nh = 0;
+        bool live = false;
+        for (int qi = 0; qi < nq; ++qi)
+            if (head[qi] < S.q[qi].size()) {
+                live = true;
+                if (S.q[qi][head[qi]].kind == 1 && nh < 64) heads[nh++] = qi;
+            }
+        if (!live) return;
+        if (nh == 0) { c.fail(AS_EINVAL, "recorded queues wait for each other", __LINE__); return; }
+        // a head that cannot share a launch (fp32 input still to be split, the direct Cin = 1 kernel) goes out first and alone: its queue
+        // moves on to heads that can.  Otherwise the set = the mergeable heads of the row class that holds the most work.
+        int pick[AS_MAX_MULTI], np = 0, lone = -1;
+        for (int i = 0; i < nh && lone < 0; ++i)
+            if (no_merge || !gemm_mergeable(S.q[heads[i]][head[heads[i]]].g)) lone = heads[i];
+        if (lone < 0) {
+            double work[2] = {0, 0};
+            for (int i = 0; i < nh; ++i) {
+                const ConvGemmArgs& g = S.q[heads[i]][head[heads[i]]].g;
+                work[gemm_tall(g.M) ? 1 : 0] += (double)g.M * g.N * ((double)g.K * g.T + g.K2);
+            }
+            const int cls = work[1] >= work[0] ? 1 : 0;
+            for (int i = 0; i < nh && np < AS_MAX_MULTI; ++i) {
+                const ConvGemmArgs& g = S.q[heads[i]][head[heads[i]]].g;
+                if ((gemm_tall(g.M) ? 1 : 0) == cls && (np == 0 || g.n_prod == S.q[pick[0]][head[pick[0]]].g.n_prod)) pick[np++] = heads[i];
+            }
+            if (np < 2) lone = pick[0];
+        }
+        if (np >= 2) {
+            ConvGemmArgs list[AS_MAX_MULTI];
+            for (int i = 0; i < np; ++i) list[i] = S.q[pick[i]][head[pick[i]]].g;
+            if (trace) {
+                fprintf(stderr, "  GEMM x%d:", np);
+                for (int i = 0; i < np; ++i) fprintf(stderr, " q%d M%d N%d K%d T%d |", pick[i], list[i].M, list[i].N, list[i].K, list[i].T);
+                fprintf(stderr, "\n");
+            }
+            const int r = as_conv_gemm_multi_f32(list, np, S.q[pick[0]][head[pick[0]]].s);
+            if (r != AS_OK) { fail(r, S.q[pick[0]][head[pick[0]]]); return; }
+            for (int i = 0; i < np; ++i) ++head[pick[i]];
+        } else {
+            Op& o = S.q[lone][head[lone]];
+            if (trace) fprintf(stderr, "  GEMM alone: q%d M%d N%d K%d T%d (%d heads)\n", lone, o.g.M, o.g.N, o.g.K, o.g.T, nh);
+            const int r = as_conv_gemm_f32(&o.g, o.s);
+            if (r != AS_OK) { fail(r, o); return; }
+            ++head[lone];
+        }
+    }
+}
 
 // Fork / join of independent branches over the plan's side streams: every branch first waits for the calling stream, the
 // calling stream then waits for every branch (hipGraph capture records them as parallel nodes).
@@ -683,8 +832,28 @@ struct Fork {
     hipStream_t main;
     int n, first;
     bool on_side;
+    bool defer = false, root = false;      // recorded form (serial plans with `merge`): branch i = queue qs[i] of the Ctx's Sched
+    int q0 = -1;
+    std::vector<int> qs;
     Fork(Ctx& c_, int n_, int first_) : c(c_), main(c_.s), n(n_), first(first_), on_side(c_.go() && !c_.p.serial)
     {
+        defer = c.go() && c.p.serial && c.p.merge;
+        if (defer) {
+            if (!c.sched) {
+                c.sched = std::make_shared<Sched>();
+                c.cur_q = c.sched->new_queue();                        // what the calling stream does from here on
+                root = true;
+            }
+            q0 = c.cur_q;
+            for (int i = 0; i < n; ++i) {
+                const int qi = c.sched->new_queue();
+                qs.push_back(qi);
+                c.cur_q = qi;
+                c.push(2).deps.push_back({q0, c.sched->q[q0].size()}); // a branch starts after what the calling stream has recorded so far
+            }
+            c.cur_q = q0;
+            return;
+        }
         if (!on_side) return;
         hipEvent_t e = c.p.event();
         if (!e || hipEventRecord(e, main) != hipSuccess) { c.fail((int)hipErrorUnknown); return; }
@@ -693,16 +862,53 @@ struct Fork {
             if (!st || hipStreamWaitEvent(st, e, 0) != hipSuccess) { c.fail((int)hipErrorUnknown); return; }
         }
     }
-    void branch(int i) { c.s = on_side ? c.p.stream(first + i) : main; }
-    void back() { c.s = main; }            // continue on the calling stream while the branches run; join() later
+    void branch(int i)
+    {
+        if (defer) { c.cur_q = qs[i]; return; }
+        c.s = on_side ? c.p.stream(first + i) : main;
+    }
+    void back()                            // continue on the calling stream while the branches run; join() later
+    {
+        if (defer) { c.cur_q = q0; return; }
+        c.s = main;
+    }
     void wait_main(int i)                  // branch i continues only after what the calling stream has enqueued so far
     {
+        if (defer) {
+            const int keep = c.cur_q;
+            c.cur_q = qs[i];
+            c.push(2).deps.push_back({q0, c.sched->q[q0].size()});
+            c.cur_q = keep;
+            return;
+        }
         if (!on_side) return;
         hipEvent_t e = c.p.event();
         if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(c.p.stream(first + i), e, 0) != hipSuccess) c.fail((int)hipErrorUnknown);
     }
+    void after(int i, std::initializer_list<int> js)   // (recorded form only) branch i goes on after everything branches js hold so far
+    {
+        if (!defer) return;
+        const int keep = c.cur_q;
+        c.cur_q = qs[i];
+        Op& o = c.push(2);
+        for (int j : js) o.deps.push_back({qs[j], c.sched->q[qs[j]].size()});
+        c.cur_q = keep;
+    }
     void join()
     {
+        if (defer) {
+            c.cur_q = q0;
+            Op& o = c.push(2);
+            for (int qi : qs) o.deps.push_back({qi, c.sched->q[qi].size()});
+            if (root) {
+                std::shared_ptr<Sched> S = c.sched;
+                c.sched.reset();
+                c.cur_q = -1;
+                play(c, *S);
+                S->q.clear();
+            }
+            return;
+        }
         c.s = main;
         if (!on_side) return;
         for (int i = 0; i < n; ++i) {
@@ -764,7 +970,6 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
 {
     if (!w || !lay) { c.fail(AS_EINVAL); return; }
     if (w->T != taps.n || K > w->Kp || K <= w->Kp - 16 || w->K2 != o.K2 || (o.K2 && !o.in_image)) { c.fail(AS_EINVAL); return; }
-    const bool in_image = o.in_image;
     ConvGemmArgs a;
     memset(&a, 0, sizeof(a));
     a.Wh = w->wh; a.W = w->w32; a.X = X; a.Xh = xh; a.Y = Y; a.Yh = o.yh;
@@ -781,13 +986,26 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     for (int i = 0; i < taps.n; ++i) { a.dh[i] = taps.dh[i]; a.dw[i] = taps.dw[i]; }
     const bool pointwise = taps.n == 1 && taps.dh[0] == 0 && taps.dw[0] == 0;
     if (lay->N == 0) return;
+    // A plan that records its branches (serial + merge): every conv should be able to share a launch, so fp32 activations are split into
+    // their operand image by a launch of their own first (what as_conv_gemm_f32 would do inside the call), and the workspace holds the K
+    // slices a merged launch may cut the problem into.  Decided by the PLAN's flags, the same in every pass.
+    const bool rec = c.p.serial && c.p.merge;
+    bool in_image = o.in_image;
+    if (rec && !in_image && !(K == 1 && w->w32)) {
+        uint16_t* img = c.image(K, lay->N);
+        if (c.go()) RUN(c, as_split_f16x2_f32(X, ldx, K, a.N, a.in_act, a.in_slope, img, c.s));
+        a.X = nullptr;
+        a.Xh = img;
+        a.in_act = 0;
+        in_image = true;
+    }
     // pointers that are null only because this pass does not run kernels must not change the plan the library makes
     ConvGemmArgs q = a;
     q.X = in_image ? nullptr : reinterpret_cast<const float*>(16);
     q.Xh = in_image ? reinterpret_cast<const uint16_t*>(16) : nullptr;
     q.Yh = o.want_yh ? reinterpret_cast<uint16_t*>(16) : nullptr;
     q.Xh2 = o.K2 ? reinterpret_cast<const uint16_t*>(16) : nullptr;
-    const size_t wsb = as_conv_gemm_workspace_bytes(&q);
+    const size_t wsb = rec ? as_conv_gemm_multi_workspace_bytes(&q) : as_conv_gemm_workspace_bytes(&q);
     if (getenv("AS_DEBUG_ALLOC"))
         fprintf(stderr, "artspeech_hip: conv %s M%d N%d K%d T%d G%d img%d -> ws %zu (arena at %zu)\n", c.count ? "count" : (c.launch ? "run" : "replay"), a.M,
                 a.N, a.K, a.T, a.n_groups, (int)in_image, wsb, c.off);
@@ -797,6 +1015,13 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     if (o.N_in && !o.src_col) { c.fail(AS_EINVAL); return; }
     a.meta = o.N_in ? o.src_meta : (pointwise ? nullptr : c.meta(lay));
     a.src_col = o.src_col;
+    if (c.deferring() && !EXP_SKIP(as_conv_gemm_f32)) {                  // recorded: it may share its launch with other branches' convs
+        Op& op = c.push(1);
+        op.g = a;
+        op.what = "as_conv_gemm_f32";
+        op.line = __LINE__;
+        return;
+    }
     RUN(c, as_conv_gemm_f32(&a, c.s));
 }
 
@@ -1181,7 +1406,7 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
     const std::string dname = p + (one_d ? ".pool" : ".downsample_res.conv");
     uint16_t* r2h = c.image(cin, lay2->N);
     const float *dww = m.vec(dname + ".weight"), *dwb = m.vec(dname + ".bias");
-    as_prof_hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
+    c.hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
     RUN(c, as_dwconv_down_image_f32(r, lay->N, lay->d_off, lay->d_w, lay->H, lay2->d_off, lay2->d_w, lay2->H, dww, dwb, half ? 3 : 1, B, cin,
                                     lay2->max_cols(), 1, r2h, lay2->N, c.s));
     const bool has_sc = m.has(p + ".conv1x1.weight");
@@ -1196,7 +1421,7 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
         // conv1x1(avgpool(x)): a quarter of the columns -- as `cin` more channels of conv2's reduction (conv_fold), the merge
         // (x + r)/sqrt(2) in that launch's epilogue: the residual branch never exists on its own.
         uint16_t* xsh = c.image(cin, lay2->N);
-        as_prof_hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
+        c.hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
         if (X.stem_x)
             RUN(c, as_stem_pool_image_f32(X.stem_x, lay->d_off, lay->d_w, lay->H, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, X.stem_w->w32,
                                           X.stem_w->Kp, X.stem_b, X.stem_kh, B, cin, lay2->max_cols(), xsh, lay2->N, c.s));
@@ -1213,7 +1438,7 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
     } else {
         float* r3 = conv_h_new(c, w2, r2h, cin, lay2, taps, o2);
         out = c.f32((size_t)w2->M * N2);
-        as_prof_hint(0, 4.0 * cin * ((double)lay->N + (want_image ? 3.0 : 2.0) * lay2->N));
+        c.hint(0, 4.0 * cin * ((double)lay->N + (want_image ? 3.0 : 2.0) * lay2->N));
         if (want_image)
             RUN(c, as_avgpool_down_image_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, out, lay2->N, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, r3,
                                              lay2->N, B, cin, lay2->max_cols(), outh, lay2->N, 1, c.s));
@@ -1660,6 +1885,8 @@ void decoder(Ctx& c, float* x0, const Lay* lay2, const float* fne, int ldp, cons
 // ArtsSpeech.forward(step="test"), models.py:356-371
 // ------------------------------------------------------------------------------------------------------------------
 struct PhaseA {                   // what the first half leaves in workspace A for the second
+    FcOut fc;                     // (recording plans) the AdaIN fc GEMM of the predictors / decoder, run beside the encoders' last layers
+    bool has_fc = false;
     float *feat12 = nullptr, *style = nullptr, *a_en = nullptr, *t_en = nullptr, *duration = nullptr;
     int ld_en = 0;
     int32_t *dur_i = nullptr, *frame_off = nullptr;
@@ -1695,7 +1922,7 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     float* ds = c.f32((size_t)B * (m.cfg.style_dim / 4));
     const float* stats = m.vec("__stats24");
     if (c.go()) c.p.mark(0, c.s);
-    as_prof_hint(0, 4.0 * (n_mels + 11.0 + 12.0) * A.ref->N);
+    c.hint(0, 4.0 * (n_mels + 11.0 + 12.0) * A.ref->N);
     RUN(c, as_ref_features_f32(io->mel, io->ld_mel, n_mels, io->f0_raw, io->ema_raw, io->ld_ema, A.ref->N, stats, A.feat12, A.ref->N, c.s));
     const StyleIn si = style_inputs(c, A.feat12, A.ref->N, io->mel, io->ld_mel, A.ref);
     if (!si.l1) return A;
@@ -1713,17 +1940,38 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     // predictor's tail while the text / articulatory pair runs its last two layers.  (Every edge is calling stream <-> side stream:
     // side-to-side edges break hipGraph instantiation.)
     const bool early = getenv("AS_DUR_EARLY") != nullptr;               // experiment: dur_block from the start on its own stream (slower in a graph)
-    Fork f(c, early ? 3 : 2, 0);
+    // Serial plans that merge (as_plan_set_serial + as_plan_set_merge, the default of a serial plan): the branches are RECORDED (Fork, Op)
+    // and played out on the one stream with their ready conv GEMMs sharing launches -- queues cost nothing, so every tower is its own
+    // branch and dur_block starts with the others; the predictor's tail joins its queue once the duration encoder is done.  The order of
+    // the calls (hence of the workspace allocations) depends on the PLAN's flags only, never on the pass (count / prepare / run).
+    const bool rec = c.p.serial && c.p.merge;
+    Fork f(c, rec ? 5 : (early ? 3 : 2), 0);
     f.branch(0);
     gate(1);
     style_tower(c, 0, si, A.style);
     f.branch(1);
     gate(3);
-    for (int t = 1; t <= 3; ++t) style_tower(c, t, si, A.style);
-    if (early) {
+    if (rec) {
+        style_tower(c, 1, si, A.style);
         f.branch(2);
+        style_tower(c, 2, si, A.style);
+        f.branch(3);
         gate(2);
         duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
+        // every AdaIN fc layer of the predictors and the decoder (75 MB of weights streamed for 32 columns: bandwidth-bound) needs the
+        // Style vector only -- here it rides along with the encoders' compute-bound convs instead of opening the second half alone
+        f.after(4, {0, 1, 2});
+        f.branch(4);
+        gate(3);
+        A.fc = adain_fc_all(c, "style", style_norms(m), A.style, sd2, sd2, B);
+        A.has_fc = true;
+    } else {
+        for (int t = 1; t <= 3; ++t) style_tower(c, t, si, A.style);
+        if (early) {
+            f.branch(2);
+            gate(2);
+            duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
+        }
     }
     f.back();
     gate(0);
@@ -1732,15 +1980,18 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     rel_encoder_multi(c, path_encoders(), io->tokens, A.tok, &eo, [&](int g) {
         if (g != ENC_DUR) return;
         const bool l0 = c.launch;
-        if (early) {
-            f.wait_main(2);                                              // the duration encoder's result
+        if (rec) {
+            f.wait_main(3);                                              // the duration encoder's result
+            f.branch(3);
+        } else if (early) {
+            f.wait_main(2);
             f.branch(2);
         } else {
             f2.reset(new Fork(c, 1, 2));
             f2->branch(0);
         }
         gate(2);
-        if (!early) duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
+        if (!early && !rec) duration_style(c, A.feat12 ? A.feat12 + (size_t)2 * A.ref->N : nullptr, A.ref->N, A.ref, ds);
         A.duration = duration_tail(c, eo.y[ENC_DUR], ds, A.tok, io->duration);
         f.back();
         c.launch = l0;
@@ -1778,13 +2029,13 @@ void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_
     float* fne = c.f32((size_t)12 * std::max(N2, 1));                    // rows: F0, N, EMA[10] (what the three branches predict)
     float* x0 = c.f32((size_t)(C + 128) * std::max(N2, 1));
     // every AdaIN fc layer of the predictors and the decoder (~75 MB of weights): one GEMM on the style vectors
-    const FcOut fc = adain_fc_all(c, "style", style_norms(m), A.style, 2 * m.cfg.style_dim, 2 * m.cfg.style_dim, B);
+    const FcOut fc = A.has_fc ? A.fc : adain_fc_all(c, "style", style_norms(m), A.style, 2 * m.cfg.style_dim, 2 * m.cfg.style_dim, B);
     // T_en @ pred_aln_trg is a column gather (models.py:367-368)
-    as_prof_hint(0, 4.0 * C * ((double)A.tok->N + N1));
+    c.hint(0, 4.0 * C * ((double)A.tok->N + N1));
     RUN(c, as_expand_f32(A.a_en, A.ld_en, C, tof, N1, 1, a_ex, N1, c.s));
     arts_predictor(c, a_ex, N1, lay1, fc, fne, N2);
     if (c.go()) c.p.mark(3, c.s);
-    as_prof_hint(0, 4.0 * C * ((double)A.tok->N + N2));
+    c.hint(0, 4.0 * C * ((double)A.tok->N + N2));
     RUN(c, as_expand_f32(A.t_en, A.ld_en, C, tof, N1, 2, x0, N2, c.s));      // text encoding at the mel rate: nearest x2 (models.py:500)
     decoder(c, x0, lay2, fne, N2, fc, io->mel_out, io->ld_out);
     if (c.go()) c.p.mark(4, c.s);
@@ -2088,6 +2339,13 @@ extern "C" int as_plan_set_serial(as_plan* p, int on)
 {
     if (!p) return AS_EINVAL;
     p->serial = on != 0;
+    return AS_OK;
+}
+
+extern "C" int as_plan_set_merge(as_plan* p, int on)
+{
+    if (!p) return AS_EINVAL;
+    p->merge = on != 0;
     return AS_OK;
 }
 

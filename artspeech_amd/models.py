@@ -87,6 +87,10 @@ class Runtime:
     def set_serial(self, on):
         check(_lib.lib().as_plan_set_serial(self.plan, int(on)), "as_plan_set_serial")
 
+    def set_merge(self, on):
+        """serial plans: conv GEMMs of independent branches share launches (as_plan_set_merge; on by default)"""
+        check(_lib.lib().as_plan_set_merge(self.plan, int(on)), "as_plan_set_merge")
+
     def set_operand_mode(self, n_prod):
         """3 = f16x3 (fp32-accurate, default); 1 = plain fp16 operands (BASELINE config C2's 16-bit mode)"""
         check(_lib.lib().as_plan_set_operand_mode(self.plan, int(n_prod)), "as_plan_set_operand_mode")

@@ -296,7 +296,7 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     for i, (dh, dw) in enumerate(taps):
         a.dh[i], a.dw[i] = dh, dw
     L = _lib.lib()
-    nbytes = L.as_conv_gemm_workspace_bytes(ctypes.byref(a))
+    nbytes = (L.as_conv_gemm_multi_workspace_bytes if defer is not None else L.as_conv_gemm_workspace_bytes)(ctypes.byref(a))
     if nbytes:                                       # split-K partial slabs, the split image of X (caller-owned scratch)
         ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=(Y if Y is not None else yh).device)
         a.ws, a.ws_bytes = ws.data_ptr(), nbytes

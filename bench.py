@@ -589,7 +589,10 @@ def main():
             r2 = Runner(twin, gi)
             firsts.append(r2.step()["mel"].clone())
             lanes.append((r2, r2.capture(), torch.cuda.Stream()))
-        assert torch.equal(firsts[0], mel_first), "a step as one chain and the step with its branches on side streams differ"
+        # (a chain's conv GEMMs share launches across branches -- as_plan_set_merge -- and may then run on another tile shape than alone:
+        # the same arithmetic in another order of partial sums)
+        chain_vs_side = float((firsts[0] - mel_first).abs().max())
+        assert chain_vs_side <= 2e-5, f"a step as one chain and the step with its branches on side streams differ by {chain_vs_side}"
         it = [0]
 
         def run_lanes():

@@ -191,6 +191,10 @@ int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
 #define AS_MAX_MULTI 6
 int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_stream_t stream);
 int as_conv_gemm_multi_tile(const ConvGemmArgs* list_host, int n);
+/* workspace (ConvGemmArgs.ws) a problem wants when it may go into a multi-problem launch: a long reduction on a few tiles beside
+ * shorter ones is cut into K slices there (as many as ws_bytes holds fp32 [M][N] slabs for) so that it does not outlast the launch;
+ * >= as_conv_gemm_workspace_bytes */
+size_t as_conv_gemm_multi_workspace_bytes(const ConvGemmArgs* args_host);
 /* which kernel as_conv_gemm_f32 runs for these arguments (tests, tuning): *kind 0 = the direct Cin = 1 kernel, 1 = the tiled kernel
  * (*tile = 22 / 21 / 12 / 11 / 14 / 2: 128x128, 128x64, 64x128, 64x64, 64x256, 32x128); *slices = K slices */
 int as_conv_gemm_plan(const ConvGemmArgs* args_host, int32_t* kind, int32_t* tile, int32_t* slices);
@@ -461,9 +465,15 @@ int as_model_create(const void* blob_host, size_t blob_bytes, const as_model_cfg
 int as_model_destroy(as_model* m);
 int as_plan_create(const as_model* m, as_plan** out);
 int as_plan_destroy(as_plan* p);
-/* on = 1: the independent branches of a forward run back to back on the calling stream instead of on side streams
- * (per-kernel timing: a kernel's event-bracketed duration is then its own) */
+/* on = 1: the independent branches of a forward run on the calling stream instead of on side streams (one chain per batch: the
+ * arrangement as_lanes keeps several of in flight).  as_plan_set_merge (default on; it matters for serial plans only): the branches'
+ * launches are recorded first and played out in an order that lets conv GEMMs of independent branches -- the towers, the triple encoder,
+ * dur_block and the duration predictor's blocks: models.py:356-360, 417-424, 540-546 have no edge between them -- share launches
+ * (as_conv_gemm_multi_f32): on one stream a step costs the sum of its kernels' durations, and a small conv beside a large one costs next to
+ * nothing.  off: every branch whole, one after the other, one launch per conv.  Set both before asking for workspace sizes and do not
+ * change them between as_forward_test_begin and _finish (the order of the workspace allocations follows the flags). */
 int as_plan_set_serial(as_plan* p, int on);
+int as_plan_set_merge(as_plan* p, int on);
 /* on = 1: as_forward_test records phase marks (HIP events) on the calling stream; as_plan_phase_ms then returns the ms of the
  * last call's phases: [0] reference features + tower inputs, [1] the concurrent branches (encoders, towers, duration predictor),
  * [2] durations + AdaIN fc + articulatory predictors, [3] decoder.  Blocks until that call has finished. */

@@ -38,8 +38,10 @@ def test_two_batches_in_flight_are_bit_identical():
 
 def test_four_single_stream_batches_in_flight_are_bit_identical():
     """bench.py's default arrangement since the end of round 3: four batches in flight, each ONE chain on one stream (as_plan_set_serial:
-    the step's branches back to back).  A chain produces the bits of the step with its branches on side streams, and four of them
-    replayed side by side keep producing them."""
+    the step's branches on the one stream, their ready conv GEMMs sharing launches: as_plan_set_merge).  Without merging a chain produces
+    the bits of the step with its branches on side streams; with it (the default) a conv that shares a launch may run on another tile
+    shape -- same arithmetic, another order of the partial sums: within 1e-5 of the side-stream step -- and four chains replayed side by
+    side keep producing the bits of the chain run alone."""
     import bench
     from artspeech_amd import models, synth
     from artspeech_amd.weights import DEFAULT_STATS, load_distribution
@@ -52,11 +54,16 @@ def test_four_single_stream_batches_in_flight_are_bit_identical():
     lanes, wants = [], []
     for i in range(4):
         _, g = bench.make_inputs(dev, seed0=bench.DATA_SEED + 100 * i)
-        want = bench.Runner(net, g).step()["mel"].clone()          # branches on side streams, alone
+        side = bench.Runner(net, g).step()["mel"].clone()          # branches on side streams, alone
+        plain = net.replica()
+        plain.rt.set_serial(True)
+        plain.rt.set_merge(False)
+        assert torch.equal(bench.Runner(plain, g).step()["mel"], side), "a step as one unmerged chain differs from the step with its branches on side streams"
         twin = net.replica()
         twin.rt.set_serial(True)
         r = bench.Runner(twin, g)
-        assert torch.equal(r.step()["mel"], want), "a step as one chain differs from the step with its branches on side streams"
+        want = r.step()["mel"].clone()                             # the merged chain, alone
+        assert float((want - side).abs().max()) <= 1e-5
         lanes.append((r, r.capture(), torch.cuda.Stream()))
         wants.append(want)
     torch.cuda.synchronize()

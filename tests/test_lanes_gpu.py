@@ -7,6 +7,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _alone(net):
+    """as_forward_test run ALONE on a plan like a lane's (serial, merging): what a lane's results are held against bit for bit"""
+    twin = net.replica()
+    twin.rt.set_serial(True)
+    return twin
+
+
 def _net(dev):
     import bench
     from artspeech_amd import models, synth
@@ -23,12 +30,16 @@ def test_lanes_forced_durations_graph_replay_bitwise():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     net = _net(dev)
+    ref = _alone(net)
     n_lanes, rounds = 4, 4
     gs, wants = [], []
     for i in range(n_lanes):
         _, g = bench.make_inputs(dev, 8, 24, 60, 100, seed0=bench.DATA_SEED + 10 * i, vary=True)
         gs.append(g)
-        wants.append(net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
+        side = net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"], frames_hint=g["frames"])["mel"]
+        assert float((side - ref.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
+                                                frames_hint=g["frames"])["mel"]).abs().max()) <= 1e-5
+        wants.append(ref.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
                                         frames_hint=g["frames"])["mel"].clone())
     torch.cuda.synchronize()
     lanes = models.Lanes(net, n_lanes)
@@ -45,7 +56,7 @@ def test_lanes_forced_durations_graph_replay_bitwise():
             outs[i]["mel"].zero_()                            # the next round must write it again
     # another geometry on the same lanes (workspaces grow, graphs are dropped), then the first one again
     _, big = bench.make_inputs(dev, 12, 30, 80, 120, seed0=bench.DATA_SEED + 77, vary=True)
-    want_big = net.forward_packed(big["tok"], big["tok_lens"], big["mel"], big["f0"], big["ema"], big["ref_lens"], forced=big["forced"],
+    want_big = ref.forward_packed(big["tok"], big["tok_lens"], big["mel"], big["f0"], big["ema"], big["ref_lens"], forced=big["forced"],
                                   frames_hint=big["frames"])["mel"].clone()
     ob = None
     for r in range(4 * n_lanes):
@@ -67,7 +78,7 @@ def test_lanes_predicted_durations():
     torch.cuda.set_device(0)
     net = _net(dev)
     _, g = bench.make_inputs(dev, 6, 20, 50, 90, seed0=bench.DATA_SEED + 5, vary=True)
-    ref = net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"])          # predicted durations
+    ref = _alone(net).forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"])          # predicted durations
     frames = ref["frames"]
     lanes = models.Lanes(net, 2)
     cap = 2 * sum(frames)
@@ -103,12 +114,13 @@ def test_lanes_survive_layout_flushes_and_graph_eviction():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     net = _tiny_net(dev)
+    solo = _alone(net)
     host, _ = bench.make_inputs(None, 14, 20, 44, 96, seed0=bench.DATA_SEED + 300, vary=True)
     subsets = [c for k in (2, 3) for c in itertools.combinations(range(14), k)]     # 91 + 364 distinct ragged geometries
     n_lanes = 4
 
     def alone(g):
-        return net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
+        return solo.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
                                   frames_hint=g["frames"])["mel"].clone()
 
     def submit(lanes, g, out=None):
@@ -181,13 +193,14 @@ def test_lanes_clustered_lstm_soak():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     net = _net(dev)
+    solo = _alone(net)
     for n_utt, n_tok, m_half, rounds in ((1, 30, 75, 60), (8, 96, 200, 12)):
         gs, wants, outs = [], [], []
         for i in range(4):
             _, g = bench.make_inputs(dev, n_utt, n_tok, m_half, 150, seed0=bench.DATA_SEED + 900 + 10 * i, vary=n_utt > 1)
             gs.append(g)
-            wants.append(net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
-                                            frames_hint=g["frames"])["mel"].clone())
+            wants.append(solo.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
+                                             frames_hint=g["frames"])["mel"].clone())
             outs.append(None)
         torch.cuda.synchronize()
         lanes = models.Lanes(net, 4)

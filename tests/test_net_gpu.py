@@ -326,14 +326,19 @@ def test_c_abi_forward_on_full_goldens(cuda, golden_dir):
         L.as_model_destroy(model)
 
 
-def test_c3_full_config_ragged_batch_vs_oracle(cuda):
+@pytest.mark.parametrize("arrangement", ["side_streams", "merged_chain"])
+def test_c3_full_config_ragged_batch_vs_oracle(cuda, arrangement):
     """BASELINE config C3 at full size: 32 utterances of VARIED lengths through one as_forward_test call, every utterance against the
     oracle's batch-1 run of the same utterance (durations identical, mel within 1e-4).  Predicted durations (no forcing): the integer
-    path is part of the check."""
+    path is part of the check.  Both arrangements of the step: branches on side streams, and the one-stream chain whose independent
+    branches share conv-GEMM launches (as_plan_set_serial + as_plan_set_merge: what as_lanes and bench.py's lanes run)."""
     from oracle import acoustic
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     hd, di, seed = 512, 64, 3407
     net = get_model(hd, di, seed, cuda)
+    if arrangement == "merged_chain":
+        net = net.replica()
+        net.rt.set_serial(True)
     W = fold_state_dict(synth.synth_state_dict(hd, di, seed=seed))
     dist = load_distribution(DEFAULT_STATS)
     rng = np.random.default_rng(7)
@@ -360,7 +365,7 @@ def test_c3_full_config_ragged_batch_vs_oracle(cuda):
         worst = max(worst, d)
         assert d <= MEL_TOL, (b, d)
         assert out.shape[2] == M2 or float(out[b, :, M2:].abs().max()) == 0.0
-    print("C3 ragged batch of 32, full config: worst mel max-abs vs oracle", worst)
+    print(f"C3 ragged batch of 32, full config, {arrangement}: worst mel max-abs vs oracle", worst)
 
 
 def test_f16_operand_mode_error_is_reported(cuda, golden_dir):
