@@ -457,6 +457,10 @@ int as_conv_gemm_h3_launch(const ConvGemmArgs* const* a, const int* S, int n, in
 #endif
     case 2:                                                             // 32 x 128 (a wave owns 32 x 64): the vocoder's 32-channel stage, M <= 32
         if (a[0]->n_prod == 1) return AS_EINVAL;
+        {
+            static const bool ns3 = getenv("AS_TILE2_NS3") != nullptr;   // (tuning: the three-stage form)
+            if (!ns3) return launch_h3<1, 2, 2, 1, 2, 3, 1>(a, S, n, stream);
+        }
         return launch_h3<1, 2, 2, 1, 3, 3, 1>(a, S, n, stream);
     case 22: return launch_h3_tile<2, 2, 1>(a, S, n, stream);
     case 21: return launch_h3_tile<2, 1, 2>(a, S, n, stream);

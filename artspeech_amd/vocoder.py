@@ -152,6 +152,8 @@ class Generator:
             # LeakyReLU(x) as an operand image, once for the three residual stacks that start from x; inside a stack every conv hands its
             # LeakyReLU'd result to the next one as an image (ConvGemmArgs.Yh / yh_lrelu): no fp32 copy of conv1's output, no split passes
             xh = ops.split_act(x, lay, in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
+            # (the three stacks of a stage as ONE launch per step -- ops.conv_gemm_multi -- was measured: 18.2 ms per batch against 17.9 with
+            # a launch per conv; these grids hold thousands of tiles each, there is no tail worth filling)
             for j in range(nk):
                 y, yh = x, xh
                 blk = W[f"rb{i * nk + j}"]

@@ -162,6 +162,9 @@ def cpu_baseline(host, sd, n_utt):
                        f"{dt:.1f} s of CPU work, torch {torch.__version__} fp32"), outs
 
 
+FORWARD_CALLS = [0]      # eager as_forward_test calls of this process (a kernel trace of the run holds exactly these steps)
+
+
 class Runner:
     """one geometry of the forward, eager or as a replayed hipGraph"""
 
@@ -170,6 +173,7 @@ class Runner:
 
     def step(self):
         g = self.g
+        FORWARD_CALLS[0] += 1
         self.out = self.net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
                                            frames_hint=g["frames"], out=self.out)
         return self.out
@@ -338,7 +342,11 @@ def bench_config(net, dev, name, n_utt, n_tok, m_half, t_ref, steps, n_prod_mode
     res = {}
     if lanes:
         batches = [g] + [make_inputs(dev, n_utt, n_tok, m_half, t_ref, seed0=DATA_SEED + 1000 + 100 * i)[1] for i in range(1, lanes)]
-        firsts = [Runner(net, b).step()["mel"].clone() for b in batches]
+        chain = net.replica()                                  # a plan like a lane's (one chain, branches' conv GEMMs sharing launches), alone
+        chain.rt.set_serial(True)
+        firsts = [Runner(chain, b).step()["mel"].clone() for b in batches]
+        rc = Runner(chain, g)
+        res["ms_per_step_one_chain_alone"] = rc.timed(rc.capture(), steps, 3) / steps * 1e3
         nl = bench_native_lanes(net, batches, firsts, 4 * steps, 0)
         res["in_flight"] = dict(lanes=lanes, ms_per_step=nl["ms_per_step"], ms_per_utt=nl["ms_per_step"] / n_utt,
                                 frames_per_s=2 * sum(g["frames"]) / (nl["ms_per_step"] * 1e-3), results_bitwise_equal=nl["results_bitwise_equal"],
@@ -366,6 +374,133 @@ def bench_config(net, dev, name, n_utt, n_tok, m_half, t_ref, steps, n_prod_mode
             res["f16_operand_mode"] = d
     net.rt.set_operand_mode(3)
     res["workload"] = f"{name}: batch {n_utt}, {n_tok} tokens -> {2 * m_half} mel frames per utterance, T_ref {t_ref}, forced durations"
+    return res
+
+
+def class_profile(fn, reps=3):
+    """per-class (HIP events, bracket cost removed) kernel time / algorithmic flop / bytes / launches of fn(): the median of `reps` runs"""
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    o = bracket_overhead_ms()
+    n = len(CLASSES)
+    runs = []
+    for _ in range(reps):
+        L.as_prof_enable(1)
+        fn()
+        ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+        cnt = (ctypes.c_int32 * n)()
+        _lib.check(L.as_prof_collect(ms, fl, by, cnt, n), "as_prof_collect")
+        runs.append((list(ms), list(fl), list(by), list(cnt)))
+    L.as_prof_enable(0)
+    out = {}
+    for i in range(n):
+        if not runs[0][3][i]:
+            continue
+        order = sorted(range(reps), key=lambda k: runs[k][0][i])
+        ms_i, fl_i, by_i, cnt_i = (runs[order[reps // 2]][j][i] for j in range(4))
+        out[CLASSES[i]] = dict(ms=max(ms_i - cnt_i * o, 0.0), ms_bracketed=ms_i, launches=cnt_i, gflop=fl_i / 1e9, gbyte=by_i / 1e9)
+    return out
+
+
+def bench_surface(net, dev, reps=5):
+    """The test.py chain AROUND the path for the C3 batch (/root/reference/test.py:94-125): reference wave ->
+    log-mel front end -> JDCNet + EMA_Predictor -> the acoustic model (forced durations as in the headline) -> HiFi-GAN generator.
+    Per-stage device time (HIP events around the stage's eager launches, warm, median of `reps`), the chain's audio real-time factor, and
+    a roofline of the generator's convs (algorithmic flop of its launches / their kernel time / the f16x3 ceiling).  Outside the headline's
+    timed region; seeded synthetic weights for every module (none ship with the reference)."""
+    from artspeech_amd import ema as E
+    from artspeech_amd import frontend as FE
+    from artspeech_amd import jdc as J
+    from artspeech_amd import ops, synth
+    from artspeech_amd import vocoder as V
+    host, g = make_inputs(dev)
+    nb = len(g["ref_lens"])
+    waves = [0.1 * synth.hash_tensor(f"surface/wave/{b}", ((t - 1) * FE.HOP + 1,), 77, 1.0) for b, t in enumerate(g["ref_lens"])]
+    fe = FE.LogMel(device=dev)
+    jd = J.JDCNet(device=dev).load_state_dict(J.synth_jdc_state_dict(1, seed=3407))
+    em = E.EMA_Predictor(device=dev).load_state_dict(E.synth_ema_state_dict(seed=3407))
+    gen = V.Generator(None, device=dev).load_state_dict(V.synth_generator_state_dict(None, seed=3407))
+    state = {}
+
+    def s_front():
+        state["mel"], state["lay"] = fe.forward_packed(waves)
+
+    def s_jdc():
+        state["f0"] = jd.forward_packed(state["mel"], state["lay"])
+
+    def s_ema():
+        m = state["mel"][:, : state["lay"].N]
+        n_raw = torch.log(torch.exp(m * 4 - 4).norm(dim=0, keepdim=True)).contiguous()          # models.py:431, :655-660
+        state["ema"] = em.forward_packed(state["f0"], n_raw, state["mel"], state["lay"])
+
+    def s_acoustic():
+        N = state["lay"].N
+        state["ac"] = net.forward_packed(g["tok"], g["tok_lens"], state["mel"][:, :N].contiguous(), state["f0"][:, :N].contiguous(),
+                                         state["ema"][:, :N].contiguous(), g["ref_lens"], forced=g["forced"], frames_hint=g["frames"], out=state.get("ac"))
+
+    def s_vocoder():
+        lay2 = ops.layout([2 * f for f in g["frames"]], dev)
+        state["wav"], state["lay_w"] = gen.forward_packed(state["ac"]["mel"], lay2)
+
+    stages = [("frontend_wave_to_logmel", s_front), ("jdcnet_f0", s_jdc), ("ema_predictor", s_ema), ("acoustic_model", s_acoustic),
+              ("hifigan_generator", s_vocoder)]
+    for _, fn in stages:                                   # warm: weights prepared, layouts cached
+        fn()
+    torch.cuda.synchronize()
+    per = {k: [] for k, _ in stages}
+    whole = []
+    for _ in range(reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)]
+        ev[0].record()
+        for i, (_, fn) in enumerate(stages):
+            fn()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        for i, (k, _) in enumerate(stages):
+            per[k].append(ev[i].elapsed_time(ev[i + 1]))
+        whole.append(ev[0].elapsed_time(ev[-1]))
+    med = lambda v: sorted(v)[len(v) // 2]
+    samples = state["lay_w"].N
+    audio_s = samples / 24000.0
+    res = dict(workload=f"{nb} utterances x {g['ref_lens'][0]}-frame reference waves -> {2 * sum(g['frames'])} mel frames -> {samples} samples "
+                        f"({audio_s:.1f} s of 24 kHz audio)",
+               stage_ms={k: med(v) for k, v in per.items()}, chain_ms=med(whole), audio_seconds=audio_s, rtf=med(whole) * 1e-3 / audio_s,
+               x_realtime=audio_s / (med(whole) * 1e-3), finite=bool(torch.isfinite(state["wav"]).all()),
+               timing="eager launches of every stage (Python callers of the C ABI), HIP events between the stages, warm, median of %d" % reps)
+    # the generator on its own: graph-replayed time and the roofline of its convs
+    mel_v, lay2 = state["ac"]["mel"], ops.layout([2 * f for f in g["frames"]], dev)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        gen.forward_packed(mel_v, lay2)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=st):
+            gen.forward_packed(mel_v, lay2)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        graph.replay()
+    torch.cuda.synchronize()
+    voc_ms = (time.perf_counter() - t0) / 10 * 1e3
+    kc = class_profile(lambda: gen.forward_packed(mel_v, lay2))
+    k0 = kc["conv_gemm"]
+    tf = k0["gflop"] / k0["ms"]
+    res["vocoder"] = dict(ms_per_batch_graph_replay=voc_ms, samples_per_s=samples / (voc_ms * 1e-3), x_realtime=audio_s / (voc_ms * 1e-3),
+                          kernel_classes=kc,
+                          roofline=dict(bound="mfma", kernel="conv_gemm_h3_kernel on the generator's convs (<= 512 channels x up to 1.92 M columns, "
+                                                               "dilated k = 3 / 7 / 11; Vocoder/vocoder.py:75-125)",
+                                        achieved=tf, peak=PEAK_F16_MFMA_TFLOPS / 3, unit="TFLOP/s", frac=tf / (PEAK_F16_MFMA_TFLOPS / 3),
+                                        algorithmic_gflop_per_batch=k0["gflop"], gemm_ms_per_batch=k0["ms"], launches=k0["launches"],
+                                        algorithmic_gbyte_per_batch=k0["gbyte"], hbm_frac_if_bytes_bound=k0["gbyte"] / k0["ms"] / PEAK_HBM_TBS))
+    for name, fn in (("jdcnet", s_jdc), ("ema_predictor", s_ema)):
+        kc = class_profile(fn)
+        k0 = kc["conv_gemm"]
+        res[name] = dict(ms_per_batch=res["stage_ms"]["jdcnet_f0" if name == "jdcnet" else "ema_predictor"], kernel_classes=kc,
+                         gemm_tflops=k0["gflop"] / k0["ms"], gemm_frac_of_f16x3_peak=k0["gflop"] / k0["ms"] / (PEAK_F16_MFMA_TFLOPS / 3))
     return res
 
 
@@ -492,7 +627,8 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=96, help="utterances in the CPU-baseline sample, capped at ~20 s (0 = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-concurrency", action="store_true", help="run the independent branches back to back (profiling)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the MAS / C2 / C5 / transfer lines (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the MAS / C2 / C5 / transfer / surface lines (profiling runs)")
+    ap.add_argument("--surface-only", action="store_true", help="print only the `surface` object (the test.py chain around the path): profiling runs")
     ap.add_argument("--config", default="C3", choices=["C3", "C5", "C2"], help="workload of the timed region (profiling runs; the headline is C3)")
     ap.add_argument("--global-batch", type=int, default=0, help="C4: ONE ragged batch of this many utterances sharded over the ranks")
     ap.add_argument("--c4-dump", default=None, help="with --global-batch: .npz for the merged mel of three utterances (tests hold them against the oracle)")
@@ -534,6 +670,9 @@ def main():
     if args.no_concurrency:
         net.rt.set_serial(True)
     barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+    if args.surface_only:
+        print(json.dumps({"surface": bench_surface(net, dev)}), flush=True)
+        return
 
     c4, mine = None, None
     if args.global_batch:
@@ -568,6 +707,7 @@ def main():
     # Consecutive steps are independent batches: with two in flight (a second plan + workspaces on the same weights, its own stream) the
     # tail round of one batch's kernels is filled by the other batch's -- what a server does; the K timed steps alternate between them.
     # Every lane has its OWN batch (other seeds, same geometry) in its own buffers: nothing a lane reads is warm from the other's pass.
+    one_chain_ms, chain_vs_side = None, None
     n_fl = 1 if (args.no_graph or args.global_batch) else max(1, args.in_flight)
     in_flight_note = None
     lanes = [(runner, run, torch.cuda.Stream())]
@@ -593,6 +733,9 @@ def main():
         # the same arithmetic in another order of partial sums)
         chain_vs_side = float((firsts[0] - mel_first).abs().max())
         assert chain_vs_side <= 2e-5, f"a step as one chain and the step with its branches on side streams differ by {chain_vs_side}"
+        # one chain ALONE (the latency of a batch on a merging serial plan, beside single_ms: the same batch with its branches on side streams)
+        with torch.cuda.stream(lanes[0][2]):
+            one_chain_ms = lanes[0][0].timed(lanes[0][1], max(args.steps // 4, 5), 3, lambda: None) / max(args.steps // 4, 5) * 1e3
         it = [0]
 
         def run_lanes():
@@ -653,6 +796,21 @@ def main():
 
     sus_reg, sus_lds = mfma_sustained()
     ms_per_step = elapsed / args.steps * 1e3
+    # The roofline fractions are reported from the committed rocprofv3 kernel trace of THIS build when there is one
+    # (profiles/latest_trace_classes.json: sum of kernel durations per class and step, scripts/make_profiles.py) -- a trace counts a kernel's
+    # own duration, nothing of the brackets around it -- and from this run's HIP events otherwise; the event figures stay beside them.
+    trace_cls, trace_src = None, "no kernel trace of this build under profiles/ (HIP events of this run, bracket cost removed)"
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "latest_trace_classes.json")))
+        if tj.get("source_id") == source_id() and args.config == "C3" and not args.global_batch:
+            trace_cls, trace_src = tj["classes"], f"{tj['file']} ({tj['command']}; {tj['steps_in_trace']} steps in the trace)"
+    except Exception:
+        pass
+    gemm_tflops_ev = gemm_tflops
+    hbm_ms_ev = hbm_ms
+    if trace_cls:
+        gemm_tflops = k0["gflop_per_step"] / trace_cls["conv_gemm"]["ms_per_step"]
+        hbm_ms = sum(trace_cls[c]["ms_per_step"] for c in HBM_GROUP if c in trace_cls)
     value = frames_total * args.steps / elapsed
     line = {
         "metric": "mel frames/sec (whole job; per-GPU = value / n_gpus), acoustic-model inference path, batch 32 x 200-frame utterances",
@@ -664,6 +822,8 @@ def main():
                    "launch": "eager (C ABI as_forward_test)" if args.no_graph else "hipGraph replay of one as_forward_test call",
                    "in_flight": n_fl, "lane_streams": "branches on side streams" if (args.lane_branches or n_fl == 1) else "one chain per lane"},
         "ms_per_step_one_in_flight": single_ms,
+        "ms_per_step_one_chain_alone": one_chain_ms,
+        "chain_vs_side_streams_max_abs": chain_vs_side,
         "in_flight_note": in_flight_note,
         "rtf": (elapsed / args.steps) / (frames_total * FRAME_SEC),
         "x_realtime_per_gpu": (value / world) * FRAME_SEC,
@@ -671,6 +831,10 @@ def main():
                      "kernel": "conv_gemm_h3_kernel (implicit-GEMM conv, fp16 matrix cores, two-way split operands h + l, 3 products per fp32 "
                                "product, fp32 accumulate; both operands staged by LDS-DMA from producer-written images)",
                      "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s", "frac": gemm_tflops / gemm_peak,
+                     "time_source": trace_src,
+                     "achieved_by_events": gemm_tflops_ev, "frac_by_events": gemm_tflops_ev / gemm_peak,
+                     "gemm_ms_per_step_by_trace": trace_cls["conv_gemm"]["ms_per_step"] if trace_cls else None,
+                     "gemm_ms_per_step_by_events": k0["ms_per_step"],
                      "peak_basis": "dense fp16 MFMA 2516.6 TFLOP/s / 3 matrix-core products per fp32 product (achieved = algorithmic fp32 flop); "
                                    "round 1 ran six bf16 products per fp32 product (ceiling 419.4)",
                      # measured live on this device: a bare loop of the kernel's own MFMA pattern on random operands (no memory traffic, no
@@ -690,7 +854,11 @@ def main():
                                                     "(classes adain + layernorm + other of the event profiler)",
                          "achieved": hbm_gb / hbm_ms if hbm_ms else None, "peak": PEAK_HBM_TBS, "unit": "TB/s",
                          "frac": hbm_gb / hbm_ms / PEAK_HBM_TBS if hbm_ms else None,
-                         "algorithmic_gbyte_per_step": hbm_gb, "ms_per_step": hbm_ms},
+                         "algorithmic_gbyte_per_step": hbm_gb, "ms_per_step": hbm_ms, "time_source": trace_src,
+                         "ms_per_step_by_events": hbm_ms_ev, "frac_by_events": hbm_gb / hbm_ms_ev / PEAK_HBM_TBS if hbm_ms_ev else None,
+                         "launches_per_step": sum(kern[c]["launches_per_step"] for c in HBM_GROUP if c in kern)},
+        "launches_per_step": {c: kern[c]["launches_per_step"] for c in kern},
+        "forward_calls_in_process": None,
         "kernel_classes": kern,
         "phase_ms_eager": dict(zip(["features", "encoders_towers_duration", "predictors", "decoder"], [round(v, 3) for v in phase])),
     }
@@ -707,12 +875,17 @@ def main():
             "C2": bench_config(net, dev, "C2 (LJSpeech-like latency)", 1, 30, 75, 150, 50, n_prod_modes=(3, 1), lanes=4),
             "C5": bench_config(net, dev, "C5 (long form)", 8, 1024, 1024, 200, 10, lanes=4),
         }
+        try:
+            line["surface"] = bench_surface(net, dev)
+        except Exception as e:                          # (an extra: never costs the headline line)
+            line["surface"] = {"error": repr(e)[:300]}
     if rank == 0 and args.cpu_utts > 0 and not args.global_batch and args.config == "C3":
         cb, outs = cpu_baseline(host, sd, args.cpu_utts)
         line["cpu_baseline"] = cb
         fo = np.concatenate([[0], np.cumsum([2 * f for f in g["frames"]])])
         err = max(float((mel_first[:, fo[b]:fo[b + 1]].cpu() - outs[b]["mel"]).abs().max()) for b in range(min(len(outs), B)))
         line["parity_mel_max_abs_vs_oracle"] = err
+    line["forward_calls_in_process"] = FORWARD_CALLS[0] if args.no_graph else None      # (what a kernel trace of an eager run holds)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

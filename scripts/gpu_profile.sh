@@ -13,6 +13,12 @@ ARGS="--steps 10 --warmup 2 --no-graph --no-concurrency --cpu-utts 0 --no-extras
 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace -o bench --output-format csv -- python3 $R/bench.py $ARGS > $OUT/prof_trace.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_graph -o bench --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-utts 0 > $OUT/prof_graph.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_c5 -o bench --output-format csv -- python3 $R/bench.py --config C5 --no-extras --steps 5 --warmup 2 --no-graph --no-concurrency --cpu-utts 0 > $OUT/prof_c5.log 2>&1
+# the test.py chain around the path: the frozen extractors and the HiFi-GAN generator at the C3 batch, and the whole
+# chain (bench.py's `surface` object)
+rocprofv3 --kernel-trace --stats -d $OUT/prof_jdc -o bench --output-format csv -- python3 $R/scripts/jdc_bench.py > $OUT/prof_jdc.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_ema -o bench --output-format csv -- python3 $R/scripts/ema_bench.py > $OUT/prof_ema.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_vocoder -o bench --output-format csv -- python3 $R/scripts/vocoder_bench.py > $OUT/prof_vocoder.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_surface -o bench --output-format csv -- python3 $R/bench.py --surface-only > $OUT/prof_surface.log 2>&1
 PARGS="--steps 2 --warmup 1 --no-graph --no-concurrency --cpu-utts 0 --no-extras"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/prof_pmc_sq -o bench --output-format csv -- python3 $R/bench.py $PARGS > $OUT/prof_pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_pmc_fetch -o bench --output-format csv -- python3 $R/bench.py $PARGS > $OUT/prof_pmc_fetch.log 2>&1
@@ -28,6 +34,6 @@ for mode in weak c4; do
 done
 cd /tmp
 # the stats CSVs are small; the raw traces are not: keep only what make_profiles.py reads
-for d in prof_trace prof_graph prof_c5; do rm -f $OUT/$d/bench_kernel_trace.csv; done
+for d in prof_trace prof_graph prof_c5 prof_jdc prof_ema prof_vocoder prof_surface; do rm -f $OUT/$d/bench_kernel_trace.csv; done
 ls $OUT/prof_trace $OUT/prof_graph $OUT/prof_c5 $OUT/prof_pmc_sq | head -20
 for f in prof_trace prof_graph prof_c5 two_ranks_weak two_ranks_c4; do grep '^{' $OUT/$f.log | head -1 | cut -c1-400; done

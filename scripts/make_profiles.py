@@ -13,6 +13,16 @@ for name in ("prof_trace", "prof_graph", "prof_c5"):        # the JSON line each
         if ln.startswith("{"):
             open(f"{P}/{tag}_{name[5:]}_bench_line.json", "w").write(ln)
 
+tc = trace_classes(f"{P}/{tag}_kernel_stats.csv", f"{P}/{tag}_trace_bench_line.json", f"{P}/latest_trace_classes.json", tag)
+print("trace classes:", json.dumps(tc, indent=1) if tc else "no forward_calls_in_process in the bench line")
+for extra in ("jdc", "ema", "vocoder", "surface"):                          # the test.py chain around the path (scripts/gpu_profile.sh)
+    if os.path.exists(f"{G}/prof_{extra}/bench_kernel_stats.csv"):
+        shutil.copy(f"{G}/prof_{extra}/bench_kernel_stats.csv", f"{P}/{tag}_{extra}_kernel_stats.csv")
+if os.path.exists(f"{G}/prof_surface.log"):
+    for ln in open(f"{G}/prof_surface.log"):
+        if ln.startswith("{"):
+            open(f"{P}/{tag}_surface_bench_line.json", "w").write(ln)
+
 if os.path.exists(f"{G}/gemm_launches_events.csv"):
     shutil.copy(f"{G}/gemm_launches_events.csv", f"{P}/{tag}_gemm_launches_events.csv")
 for mode in ("weak", "c4"):                                  # the two-rank launches on the one-GPU box
@@ -23,6 +33,46 @@ for mode in ("weak", "c4"):                                  # the two-rank laun
 
 def short(n):
     return n.split('(')[0].replace('void ', '')[:60]
+
+
+def kernel_class(name):
+    """the event profiler's classes (bench.py CLASSES) from a kernel name of the trace; None = not part of the step (profiler helpers, copies)"""
+    n = short(name)
+    if n.startswith(("conv_gemm_h3_kernel", "conv_direct_cin1", "splitk_reduce_kernel")):
+        return "conv_gemm"
+    if n.startswith("adain"):
+        return "adain"
+    if n.startswith("channel_ln"):
+        return "layernorm"
+    if n.startswith(("relpos_attention", "xl_attention")):
+        return "attention"
+    if n.startswith(("bilstm", "lstm_step0")):
+        return "lstm"
+    if n.startswith("mas_"):
+        return "mas"
+    if "as_prof_" in n or n.startswith("__amd_rocclr") or n.startswith("make_meta"):
+        return None
+    return "other"
+
+
+def trace_classes(stats_csv, bench_line_json, out_json, tag):
+    """Sum of kernel-trace durations per class and PER STEP of the eager one-chain pass (prof_trace): what bench.py reports as the
+    trace-based roofline fractions (`roofline.frac`, `roofline_hbm.frac`) for the build whose source id it carries."""
+    line = json.load(open(bench_line_json))
+    steps = line.get("forward_calls_in_process")
+    if not steps:
+        return None
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(stats_csv)):
+        c = kernel_class(r["Name"])
+        if c:
+            agg[c][0] += float(r["TotalDurationNs"]) / 1e6
+            agg[c][1] += int(r["Calls"])
+    out = dict(source_id=source_id(), steps_in_trace=steps, file=f"profiles/{tag}_kernel_stats.csv",
+               command="rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-graph --no-concurrency --cpu-utts 0 --no-extras",
+               classes={c: dict(ms_per_step=v[0] / steps, launches_per_step=v[1] / steps) for c, v in agg.items()})
+    json.dump(out, open(out_json, "w"), indent=1)
+    return out
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); dur = collections.defaultdict(float); cnt = collections.Counter(); seen = set()
 for r in csv.DictReader(open(f"{G}/prof_pmc_sq/bench_counter_collection.csv")):
