@@ -13,16 +13,6 @@ for name in ("prof_trace", "prof_graph", "prof_c5"):        # the JSON line each
         if ln.startswith("{"):
             open(f"{P}/{tag}_{name[5:]}_bench_line.json", "w").write(ln)
 
-tc = trace_classes(f"{P}/{tag}_kernel_stats.csv", f"{P}/{tag}_trace_bench_line.json", f"{P}/latest_trace_classes.json", tag)
-print("trace classes:", json.dumps(tc, indent=1) if tc else "no forward_calls_in_process in the bench line")
-for extra in ("jdc", "ema", "vocoder", "surface"):                          # the test.py chain around the path (scripts/gpu_profile.sh)
-    if os.path.exists(f"{G}/prof_{extra}/bench_kernel_stats.csv"):
-        shutil.copy(f"{G}/prof_{extra}/bench_kernel_stats.csv", f"{P}/{tag}_{extra}_kernel_stats.csv")
-if os.path.exists(f"{G}/prof_surface.log"):
-    for ln in open(f"{G}/prof_surface.log"):
-        if ln.startswith("{"):
-            open(f"{P}/{tag}_surface_bench_line.json", "w").write(ln)
-
 if os.path.exists(f"{G}/gemm_launches_events.csv"):
     shutil.copy(f"{G}/gemm_launches_events.csv", f"{P}/{tag}_gemm_launches_events.csv")
 for mode in ("weak", "c4"):                                  # the two-rank launches on the one-GPU box
@@ -73,6 +63,17 @@ def trace_classes(stats_csv, bench_line_json, out_json, tag):
                classes={c: dict(ms_per_step=v[0] / steps, launches_per_step=v[1] / steps) for c, v in agg.items()})
     json.dump(out, open(out_json, "w"), indent=1)
     return out
+
+tc = trace_classes(f"{P}/{tag}_kernel_stats.csv", f"{P}/{tag}_trace_bench_line.json", f"{P}/latest_trace_classes.json", tag)
+print("trace classes:", json.dumps(tc, indent=1) if tc else "no forward_calls_in_process in the bench line")
+for extra in ("jdc", "ema", "vocoder", "surface"):                          # the test.py chain around the path (scripts/gpu_profile.sh)
+    if os.path.exists(f"{G}/prof_{extra}/bench_kernel_stats.csv"):
+        shutil.copy(f"{G}/prof_{extra}/bench_kernel_stats.csv", f"{P}/{tag}_{extra}_kernel_stats.csv")
+if os.path.exists(f"{G}/prof_surface.log"):
+    for ln in open(f"{G}/prof_surface.log"):
+        if ln.startswith("{"):
+            open(f"{P}/{tag}_surface_bench_line.json", "w").write(ln)
+
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); dur = collections.defaultdict(float); cnt = collections.Counter(); seen = set()
 for r in csv.DictReader(open(f"{G}/prof_pmc_sq/bench_counter_collection.csv")):
