@@ -132,6 +132,7 @@ _SIGNATURES.update({
     "as_adain_image_f32": (c_i, [ctypes.POINTER(AdainArgs), c_p]),
     "as_rows_image_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "as_project_cols_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
+    "as_pointwise_small_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
     "as_model_create": (c_i, [c_p, c_sz, ctypes.POINTER(ModelCfg), ctypes.POINTER(c_p)]),
     "as_model_destroy": (c_i, [c_p]),
     "as_plan_create": (c_i, [c_p, ctypes.POINTER(c_p)]),

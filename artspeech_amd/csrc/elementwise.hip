@@ -397,6 +397,54 @@ extern "C" int as_project_cols_f32(const float* x, int ldx, int K, int N, const 
     return AS_OK;
 }
 
+// A 1x1 convolution of a handful of input channels (K <= 16) into up to 128 output channels, written to up to TWO destinations, each as
+// fp32 rows and / or as rows of an operand image -- decoder.F0_conv / N_conv / EMA_conv (models.py:480-482, 503-505: 12 -> 128 channels,
+// block diagonal) whose result is concatenated into two tensors (x0 and the decode blocks' concat buffer).  On the matrix cores this was
+// two launches of a 16-deep k-block that is three quarters zeros, each behind a split pass of its own (2 x 20 us); here a thread owns 8
+// output channels of one column: K loads, 8 K FMAs in fp32, one 16-byte image row per part and destination.
+__global__ void __launch_bounds__(256)
+pointwise_small_kernel(const float* __restrict__ x, int ldx, int K, int N, const float* __restrict__ w, const float* __restrict__ bias, int M,
+                       float* y1, int ld1, u32x4_t* h1, float* y2, int ld2, u32x4_t* h2)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;       // column (j == N: the images' zero column); 8-row group
+    if (j > N) return;
+    float xv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xv[k] = (k < K && j < N) ? x[(size_t)k * ldx + j] : 0.f;
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int m = 8 * g + r, mm = m < M ? m : M - 1;
+        float acc = bias ? bias[mm] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < K) acc = __builtin_fmaf(w[(size_t)mm * K + k], xv[k], acc);
+        const bool ok = m < M && j < N;
+        v[r] = ok ? acc : 0.f;
+        if (ok && y1) y1[(size_t)m * ld1 + j] = acc;
+        if (ok && y2) y2[(size_t)m * ld2 + j] = acc;
+    }
+    u32x4_t h, l;
+    split2(v, h, l);
+    const size_t NX = (size_t)N + 1, at = ((size_t)(g >> 1) * 4 + (g & 1)) * NX + j;
+    if (h1) { h1[at] = h; h1[at + 2 * NX] = l; }
+    if (h2) { h2[at] = h; h2[at + 2 * NX] = l; }
+}
+
+extern "C" int as_pointwise_small_f32(const float* x, int ldx, int K, int N, const float* w, const float* bias, int M, float* y1, int ld1,
+                                      uint16_t* yh1, float* y2, int ld2, uint16_t* yh2, as_stream_t stream)
+{
+    if (!x || !w || K <= 0 || K > 16 || M <= 0 || N < 0 || ldx < N || (!y1 && !yh1 && !y2 && !yh2) || (y1 && ld1 < N) || (y2 && ld2 < N)) return AS_EINVAL;
+    if (((reinterpret_cast<uintptr_t>(yh1) | reinterpret_cast<uintptr_t>(yh2)) & 15) != 0) return AS_EINVAL;
+    if (N == 0) return AS_OK;
+    const int groups = (yh1 || yh2) ? 2 * as_kbx(M) : (M + 7) / 8;     // an image's rows beyond M (up to its 64-row block) are zeros
+    AsProfScope prof__(AS_FILE_CLS, 2.0 * M * K * (double)N, 4.0 * (K + 2.0 * M * ((y1 || yh1 ? 1 : 0) + (y2 || yh2 ? 1 : 0))) * (double)N, (hipStream_t)stream);
+    hipLaunchKernelGGL(pointwise_small_kernel, dim3(as_cdiv(N + 1, 256), groups), dim3(256), 0, (hipStream_t)stream, x, ldx, K, N, w, bias, M, y1, ld1,
+                       reinterpret_cast<u32x4_t*>(yh1), y2, ld2, reinterpret_cast<u32x4_t*>(yh2));
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K2: durations -> integer alignment -> gather          models.py:361-368
 // ---------------------------------------------------------------------------------------------------

@@ -369,7 +369,7 @@ struct as_model {
     }
     // decoder.F0_conv (1 -> 32), N_conv (1 -> 32), EMA_conv (10 -> 64) (models.py:480-482, 1x1, weight-norm) as ONE block-diagonal
     // 1x1 conv from the stacked [F0; N; EMA] rows (12) to the 128 channels the decoder concatenates (models.py:503-505)
-    const GemmW* fne(const float** bias_out) const
+    const GemmW* fne(const float** bias_out, const float** w32_out = nullptr) const
     {
         const std::string key = "FNE:decoder";
         auto it = gemm.find(key);
@@ -392,9 +392,14 @@ struct as_model {
             d.n = b.size();
             d.p = upload(b.data(), b.size());
             vecs[key] = d;
+            Vec d32;                                                     // the same matrix in fp32 [M][K] (as_pointwise_small_f32)
+            d32.n = w.size();
+            d32.p = upload(w.data(), w.size());
+            vecs[key + ":w32"] = d32;
             it = gemm.find(key);
         }
         *bias_out = vecs[key].p;
+        if (w32_out) *w32_out = vecs[key + ":w32"].p;
         return &it->second;
     }
 };
@@ -1823,17 +1828,14 @@ void decoder(Ctx& c, float* x0, const Lay* lay2, const float* fne, int ldp, cons
     uint16_t* cath = c.image(cat, N2);
     float* sc_tmp = c.f32((size_t)bott * Nn2);
     RUN(c, as_split_f16x2_f32(x0, N2, C, N2, 0, 0.f, x0h, c.s));         // text encoding part of x0's image
-    const float* fb = nullptr;
-    const GemmW* wf = m.fne(&fb);
+    const float *fb = nullptr, *w32 = nullptr;
+    const GemmW* wf = m.fne(&fb, &w32);
     if (!wf) { c.fail(AS_EINVAL); return; }
-    {   // F0_conv / N_conv / EMA_conv (models.py:503-505) as one block-diagonal 1x1 conv, once per consumer
-        ConvOpt q;
-        q.bias = fb;
-        q.want_yh = true;
-        q.yh = at_block(x0h, C / 16);
-        conv_x(c, wf, fne, ldp, wf->K, lay2, k1, x0 ? x0 + (size_t)C * N2 : nullptr, N2, q);
-        q.yh = at_block(cath, (bott + 64) / 16);
-        conv_x(c, wf, fne, ldp, wf->K, lay2, k1, catb ? catb + (size_t)(bott + 64) * N2 : nullptr, N2, q);
+    {   // F0_conv / N_conv / EMA_conv (models.py:503-505) as one block-diagonal 1x1 conv of 12 input rows, written where both consumers
+        // read it: rows C.. of x0 with their blocks of x0's image, rows bott + 64.. of the concat buffer with theirs (one launch)
+        if (wf->K > 16) { c.fail(AS_EINVAL); return; }
+        RUN(c, as_pointwise_small_f32(fne, ldp, wf->K, N2, w32, fb, wf->M, x0 + (size_t)C * N2, N2, at_block(x0h, C / 16),
+                                      catb + (size_t)(bott + 64) * N2, N2, at_block(cath, (bott + 64) / 16), c.s));
     }
     Act x;
     x.p = x0; x.C = C + 128; x.ld = N2; x.lay = lay2; x.h = x0h;

@@ -732,7 +732,7 @@ def main():
         # (a chain's conv GEMMs share launches across branches -- as_plan_set_merge -- and may then run on another tile shape than alone:
         # the same arithmetic in another order of partial sums)
         chain_vs_side = float((firsts[0] - mel_first).abs().max())
-        assert chain_vs_side <= 2e-5, f"a step as one chain and the step with its branches on side streams differ by {chain_vs_side}"
+        assert chain_vs_side <= 3e-5, f"a step as one chain and the step with its branches on side streams differ by {chain_vs_side}"
         # one chain ALONE (the latency of a batch on a merging serial plan, beside single_ms: the same batch with its branches on side streams)
         with torch.cuda.stream(lanes[0][2]):
             one_chain_ms = lanes[0][0].timed(lanes[0][1], max(args.steps // 4, 5), 3, lambda: None) / max(args.steps // 4, 5) * 1e3

@@ -287,6 +287,12 @@ int as_rows_image_f32(const float* x, int ldx, int K, int B, uint16_t* xh, as_st
  * BiLSTMs and duration_proj (models.py:565,619-621) -- bandwidth-bound, one column per thread. */
 int as_project_cols_f32(const float* x, int ldx, int K, int N, const float* w, const float* bias, int M, float* y, int ldy,
                         as_stream_t stream);
+/* Y[m][j] = bias[m] + sum_{k < K} W[m][k] X[k][j] for K <= 16 input channels (decoder.F0_conv / N_conv / EMA_conv as one block-diagonal
+ * 12 -> 128 1x1 conv, models.py:480-482,503-505), written to up to two destinations, each as fp32 rows (y1 / y2, or NULL) and / or as the
+ * rows of an operand image over N columns (yh1 / yh2: where the image's -- or a k-block-aligned part's -- first row group lives; rows
+ * past M up to the image's 64-row block and the zero column N are written as zeros).  w fp32 [M][K]. */
+int as_pointwise_small_f32(const float* x, int ldx, int K, int N, const float* w, const float* bias, int M, float* y1, int ld1,
+                           uint16_t* yh1, float* y2, int ld2, uint16_t* yh2, as_stream_t stream);
 /* y[b][m] = bias[m] + W[m][:] . x[b][:]       nn.Linear on per-utterance vectors (models.py:237,412-415,538) */
 int as_linear_rows_f32(const float* x, int ldx, const float* w, const float* bias, int B, int M, int K, float* y,
                        int ldy, as_stream_t stream);

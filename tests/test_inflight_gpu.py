@@ -40,7 +40,7 @@ def test_four_single_stream_batches_in_flight_are_bit_identical():
     """bench.py's default arrangement since the end of round 3: four batches in flight, each ONE chain on one stream (as_plan_set_serial:
     the step's branches on the one stream, their ready conv GEMMs sharing launches: as_plan_set_merge).  Without merging a chain produces
     the bits of the step with its branches on side streams; with it (the default) a conv that shares a launch may run on another tile
-    shape -- same arithmetic, another order of the partial sums: within 1e-5 of the side-stream step -- and four chains replayed side by
+    shape -- same arithmetic, another order of the partial sums: within 3e-5 of the side-stream step -- and four chains replayed side by
     side keep producing the bits of the chain run alone."""
     import bench
     from artspeech_amd import models, synth
@@ -63,7 +63,7 @@ def test_four_single_stream_batches_in_flight_are_bit_identical():
         twin.rt.set_serial(True)
         r = bench.Runner(twin, g)
         want = r.step()["mel"].clone()                             # the merged chain, alone
-        assert float((want - side).abs().max()) <= 1e-5
+        assert float((want - side).abs().max()) <= 3e-5        # (each is within ~1e-5 of the fp32 oracle: test_c3_full_config_ragged_batch_vs_oracle)
         lanes.append((r, r.capture(), torch.cuda.Stream()))
         wants.append(want)
     torch.cuda.synchronize()

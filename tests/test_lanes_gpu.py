@@ -38,7 +38,7 @@ def test_lanes_forced_durations_graph_replay_bitwise():
         gs.append(g)
         side = net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"], frames_hint=g["frames"])["mel"]
         assert float((side - ref.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
-                                                frames_hint=g["frames"])["mel"]).abs().max()) <= 1e-5
+                                                frames_hint=g["frames"])["mel"]).abs().max()) <= 3e-5
         wants.append(ref.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], forced=g["forced"],
                                         frames_hint=g["frames"])["mel"].clone())
     torch.cuda.synchronize()

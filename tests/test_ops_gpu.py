@@ -839,3 +839,40 @@ def test_conv_gemm_multi_rejects_what_it_cannot_merge(cuda):
     ops.conv_gemm_multi(d[1:])                                  # n == 1: the single launch
     with pytest.raises(ops._lib.HipLibraryError):
         ops.conv_gemm_multi(d[1:] * 7)                          # more than AS_MAX_MULTI
+
+
+@pytest.mark.parametrize("K,M,lens", [(12, 128, [200, 33, 1]), (3, 64, [77]), (16, 128, [400] * 4)])
+def test_pointwise_small(cuda, K, M, lens):
+    """as_pointwise_small_f32: decoder.F0_conv / N_conv / EMA_conv as one 12 -> 128 1x1 conv written to two destinations, fp32 rows and
+    operand-image rows (models.py:480-482,503-505) -- against torch in float64; the image parts are whole k-blocks inside larger images."""
+    import ctypes
+    g = torch.Generator().manual_seed(K * 31 + M)
+    lay = Layout(lens, cuda)
+    N = lay.N
+    w = torch.randn(M, K, generator=g)
+    b = torch.randn(M, generator=g)
+    x = torch.randn(K, N, generator=g)
+    want = (w.double() @ x.double() + b.double()[:, None]).float()
+    xd = x.to(cuda).contiguous()
+    C0 = 64                                                       # channels in front of the part inside the larger images
+    y1 = torch.full((C0 + M, N), 7.0, device=cuda)
+    y2 = torch.full((M + 32, N), 7.0, device=cuda)
+    img1 = ops.new_image(C0 + M, N, cuda)
+    img2 = ops.new_image(M, N, cuda)
+    img1.zero_()
+    blk_elems = 4 * (N + 1) * 8                                   # int16 elements of one k-block of an image over N columns
+    part1 = img1[(C0 // 16) * blk_elems:]
+    L = ops._lib.lib()
+    wd, bd = w.to(cuda).contiguous(), b.to(cuda)
+    ops.check(L.as_pointwise_small_f32(xd.data_ptr(), N, K, N, wd.data_ptr(), bd.data_ptr(), M, y1[C0:].data_ptr(), N, part1.data_ptr(),
+                                       y2.data_ptr(), N, img2.data_ptr(), ops.stream()), "as_pointwise_small_f32")
+    torch.cuda.synchronize()
+    assert float((y1[C0:].cpu() - want).abs().max()) <= 1e-5 and float((y2[:M].cpu() - want).abs().max()) <= 1e-5
+    assert bool((y1[:C0] == 7.0).all()) and bool((y2[M:] == 7.0).all())
+    ref_img = ops.split_act(y2[:M].contiguous(), lay)
+    assert torch.equal(img2[: ref_img.numel()], ref_img)
+    parts = image_parts(img1, C0 + M, N)
+    assert float(parts[:, :C0].abs().max()) == 0.0                                # the part in front is untouched
+    got = (parts[0] + parts[1])[C0:C0 + M, :N]
+    assert float((got.cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
+    assert float(parts[:, C0:, N].abs().max()) == 0.0                             # the zero column
