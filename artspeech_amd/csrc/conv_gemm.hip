@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <cstring>
 
 // Cin = 1 (the first conv of every style tower and of the decoder's F0 / energy inputs): 9 MACs per output on a
 // 16-deep matrix-core k-block would be 2 % useful work, and the op is bound by writing Y anyway (M x N x 4 bytes: 130 MB
@@ -176,6 +177,23 @@ splitk_reduce_kernel(const ConvGemmArgs a, int S)
     as_reduce_epilogue(a, S, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
 }
 
+// the same for the K-sliced problems of ONE multi-problem launch: blockIdx.x walks the problems' column blocks back to back (a launch
+// per problem was 3-5 launches of ~6 us behind every merged launch at batch 1)
+struct ReduceMulti {
+    int32_t n, pad_;
+    int32_t blk0[H3_MAXP + 2];           // first column block of problem i (blk0[n] = all)
+    int32_t S[H3_MAXP];
+    ConvGemmArgs a[H3_MAXP];
+};
+__global__ void __launch_bounds__(256)
+splitk_reduce_multi_kernel(const ReduceMulti rm)
+{
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < H3_MAXP; ++i) pi += (i < rm.n && (int)blockIdx.x >= rm.blk0[i]) ? 1 : 0;
+    as_reduce_epilogue(rm.a[pi], rm.S[pi], ((int)blockIdx.x - rm.blk0[pi]) * 256 + threadIdx.x, blockIdx.y);
+}
+
 // as_set_range_probe: every launch tests its accumulators for inf / NaN (what an operand beyond fp16's range turns into)
 static int g_range_probe = 0;
 extern "C" int as_set_range_probe(int on)
@@ -253,6 +271,11 @@ static int gemm_ksplit(int M, int N, int Kp, int T, int choice, int K2 = 0)
     else if (tiles < 64) {
         s = as_cdiv(192, tiles);
         if (s > 16) s = 16;
+    } else if (tiles <= 128 && nkt * wk >= 64) {
+        // 64 .. 128 workgroups, each alone on its CU: the k loop runs at the latency of its own staging (3 stages in flight per workgroup:
+        // M1024 N286 K512 T9 at batch 1, 80 tiles: 49 us = 0.4 TB/s of weights), so K slices that fill the 512 workgroup slots pay even
+        // with the reduction pass behind them
+        s = 512 / (int)tiles;
     }
     const int env_min = getenv("AS_GEMM_MINKT") ? atoi(getenv("AS_GEMM_MINKT")) : 0;   // tuning/experiments only
     const int min_kt = env_min > 0 ? env_min : 24 / wk;   // a slice keeps >= 384 k
@@ -545,11 +568,25 @@ extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_s
         AsProfScope prof__(AS_CLS_GEMM, flops, bytes, stream, tag);
         const int rc = as_conv_gemm_h3_launch(ptr, So, m, choice, stream);
         if (rc != AS_OK) return rc;
+        ReduceMulti rm;
+        memset(&rm, 0, sizeof(rm));
+        int rows_max = 0;
         for (int k = 0; k < m; ++k)
             if (So[k] > 1) {
-                const int rr = launch_reduce(*ptr[k], So[k], stream);
-                if (rr != AS_OK) return rr;
+                const ConvGemmArgs& a = *ptr[k];
+                rm.a[rm.n] = a;
+                rm.S[rm.n] = So[k];
+                rm.blk0[rm.n + 1] = rm.blk0[rm.n] + as_cdiv(a.N + 1, 256);
+                rows_max = std::max(rows_max, a.Yh ? std::max(16 * as_kbx(a.M), a.M) : a.M);
+                ++rm.n;
             }
+        if (rm.n == 1) {
+            const int rr = launch_reduce(rm.a[0], rm.S[0], stream);
+            if (rr != AS_OK) return rr;
+        } else if (rm.n > 1) {
+            hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(rm.blk0[rm.n], as_cdiv(rows_max, 8)), dim3(256), 0, stream, rm);
+            AS_CHECK_LAUNCH();
+        }
     }
     return AS_OK;
 }

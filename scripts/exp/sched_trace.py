@@ -12,10 +12,23 @@ model = models.build_model(models.Munch(hidden_dim=512, dim_in=64, style_dim=256
 models.load_checkpoint(model, None, {"net": {"ArtsSpeech": sd}})
 net = model.ArtsSpeech.replica()
 net.rt.set_serial(True)
-_, g = bench.make_inputs(dev)
+cfg = os.environ.get("CONFIG", "C3")
+_, g = bench.make_inputs(dev, 1, 30, 75, 150, seed0=bench.DATA_SEED + 1000) if cfg == "C2" else (
+    bench.make_inputs(dev, 8, 1024, 1024, 200, seed0=bench.DATA_SEED + 1000) if cfg == "C5" else bench.make_inputs(dev))
 r = bench.Runner(net, g)
 r.step()
 torch.cuda.synchronize()
+if os.environ.get("AS_PROF_CSV"):
+    import ctypes
+    from artspeech_amd import _lib
+    L = _lib.lib()
+    L.as_prof_enable(1)
+    r.step()
+    n = 7
+    ms, fl, by, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_int32 * n)()
+    L.as_prof_collect(ms, fl, by, cnt, n)
+    L.as_prof_enable(0)
+    print("per class ms", [round(v, 3) for v in ms], "launches", list(cnt), file=sys.stderr)
 print("---- second step", file=sys.stderr)
 r.step()
 torch.cuda.synchronize()
