@@ -2,6 +2,8 @@
 // All operate on the packed-frames layout ([C][N] fp32, utterances concatenated along columns;
 // col_off int32 [B+1] gives each utterance's column range).
 #include "common.h"
+#include <algorithm>
+#include <cstring>
 #include "artspeech_hip.h"
 #include "conv_gemm.h"
 #define AS_FILE_CLS AS_CLS_OTHER
@@ -707,17 +709,24 @@ extern "C" int as_bn_lrelu_maxpool_rows_f32(const float* x, int ldx, const int32
 // region and paid its own memory round trip (the 64-channel 509 440-column launch: 82 us for 200 MB).  Same summation order as before.
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));      // a pair of floats at any 4-byte address (odd row starts)
 template <int KH>
-__global__ void __launch_bounds__(256)
-dwconv_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off, const int* __restrict__ in_w, int Hin,
-                   float* __restrict__ y, int ldy, const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout,
-                   const float* __restrict__ w, const float* __restrict__ bias, int sh, int ph, int act, int C,
-                   u32x4_t* __restrict__ yh, int Nout)
+static __device__ __forceinline__ void dwconv_down_body(const AsDownArgs& a, int b, int g, int bx, int gxn)
 {
     __shared__ float ws[8][KH * 3 + 1];                                 // the eight channels' taps and bias
-    const int b = blockIdx.y, g = blockIdx.z, c0 = g * 8;
+    const float* __restrict__ x = a.x;
+    const int ldx = a.ldx, Hin = a.Hin, ldy = a.ldy, Hout = a.Hout, C = a.C, Nout = a.n_out, act = a.lrelu;
+    const int* __restrict__ in_off = a.in_off;
+    const int* __restrict__ in_w = a.in_w;
+    const int* __restrict__ out_off = a.out_off;
+    const int* __restrict__ out_w = a.out_w;
+    const float* __restrict__ w = a.w;
+    const float* __restrict__ bias = a.bias;
+    float* __restrict__ y = a.y;
+    u32x4_t* __restrict__ yh = reinterpret_cast<u32x4_t*>(a.yh);
+    const int sh = KH == 3 ? 2 : 1, ph = KH == 3 ? 1 : 0;
+    const int c0 = g * 8;
     const int Wi = in_w[b], Wo = out_w[b];
     const size_t NX = (size_t)Nout + 1, plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;
-    if (yh && b == 0 && blockIdx.x == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + Nout] = u32x4_t{0u, 0u, 0u, 0u};
+    if (yh && b == 0 && bx == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + Nout] = u32x4_t{0u, 0u, 0u, 0u};
     if (threadIdx.x < 8 * (KH * 3 + 1)) {
         const int r = threadIdx.x / (KH * 3 + 1), k = threadIdx.x % (KH * 3 + 1), c = c0 + r;
         ws[r][k] = c < C ? (k < KH * 3 ? w[(size_t)c * KH * 3 + k] : bias[c]) : 0.f;
@@ -728,7 +737,7 @@ dwconv_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__
     // 4-byte loads at a stride of two floats every instruction touched its lines half-used and the address path, not the memory, set
     // the pace: 2.5 TB/s); column 2 wo - 1 is the previous lane's second value -- the first lane of a wave fetches its own.  Rows of
     // one column (Wi = 1) and the last column of an odd row (no right neighbour) take the pair from one float earlier.
-    for (int i0 = blockIdx.x * blockDim.x; i0 < Hout * Wo; i0 += gridDim.x * blockDim.x) {      // (whole waves stay in the loop: shuffles)
+    for (int i0 = bx * 256; i0 < Hout * Wo; i0 += gxn * 256) {      // (whole waves stay in the loop: shuffles)
         const int i = i0 + threadIdx.x, ic = min(i, Hout * Wo - 1);
         const int ho = ic / Wo, wo = ic - ho * Wo;
         const bool has_r = 2 * wo + 1 < Wi;                              // the right neighbour exists
@@ -801,26 +810,17 @@ dwconv_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__
     }
 }
 
+static int down_one(const AsDownArgs& a, hipStream_t stream);
+
 static int dwconv_launch(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy, const int32_t* out_off,
                          const int32_t* out_w, int Hout, const float* w, const float* bias, int kh, int B, int C, int max_out, int lrelu,
                          uint16_t* yh, int Nout, hipStream_t stream)
 {
-    if (!x || (!y && !yh) || !in_off || !in_w || !out_off || !out_w || !w || !bias || (kh != 1 && kh != 3) || B < 0 || C <= 0) return AS_EINVAL;
-    if (yh && ((reinterpret_cast<uintptr_t>(yh) & 15) != 0 || Nout < 0)) return AS_EINVAL;
-    if (B == 0 || max_out <= 0) return AS_OK;
-    const int sh = kh == 3 ? 2 : 1, ph = kh == 3 ? 1 : 0;
-    int gx = as_cdiv(max_out, 256);
-    gx = gx > 32 ? 32 : gx;
-    const int groups = yh ? 2 * as_kbx(C) : as_cdiv(C, 8);
-    AsProfScope prof__(AS_FILE_CLS, 0, 0, stream);
-    if (kh == 3)
-        hipLaunchKernelGGL(dwconv_down_kernel<3>, dim3(gx, B, groups), dim3(256), 0, stream, x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout,
-                           w, bias, sh, ph, lrelu, C, reinterpret_cast<u32x4_t*>(yh), Nout);
-    else
-        hipLaunchKernelGGL(dwconv_down_kernel<1>, dim3(gx, B, groups), dim3(256), 0, stream, x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout,
-                           w, bias, sh, ph, lrelu, C, reinterpret_cast<u32x4_t*>(yh), Nout);
-    AS_CHECK_LAUNCH();
-    return AS_OK;
+    AsDownArgs a;
+    memset(&a, 0, sizeof(a));
+    a.kind = 0; a.x = x; a.ldx = ldx; a.in_off = in_off; a.in_w = in_w; a.Hin = Hin; a.y = y; a.ldy = ldy; a.out_off = out_off; a.out_w = out_w;
+    a.Hout = Hout; a.w = w; a.bias = bias; a.kh = kh; a.B = B; a.C = C; a.max_out = max_out; a.lrelu = lrelu; a.yh = yh; a.n_out = Nout;
+    return down_one(a, stream);
 }
 
 extern "C" int as_dwconv_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin,
@@ -842,17 +842,23 @@ extern "C" int as_dwconv_down_image_f32(const float* x, int ldx, const int32_t* 
 // DownSample (models.py:43-57) / ResBlk1d.downsample (:127-130): replicate the last column when W is odd,
 // then average pool (ph x 2); optionally  y = (pool(x) + res) / sqrt(2)  (the block's output, models.py:99-100).
 template <int PH>
-__global__ void __launch_bounds__(256)
-avgpool_down_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ in_off, const int* __restrict__ in_w, int Hin,
-                    float* __restrict__ y, int ldy, const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout,
-                    const float* __restrict__ res, int ldr, int C, u32x4_t* __restrict__ yh, int Nout, int yh_lrelu)
+static __device__ __forceinline__ void avgpool_down_body(const AsDownArgs& a, int b, int g, int bx, int gxn)
 {
-    // 8 consecutive channels per workgroup, one output position of all eight per thread (as dwconv_down_kernel)
-    const int b = blockIdx.y, g = blockIdx.z, c0 = g * 8;
+    // 8 consecutive channels per workgroup, one output position of all eight per thread (as dwconv_down_body)
+    const float* __restrict__ x = a.x;
+    const int ldx = a.ldx, ldy = a.ldy, Hout = a.Hout, C = a.C, Nout = a.n_out, yh_lrelu = a.lrelu, ldr = a.ldr;
+    const int* __restrict__ in_off = a.in_off;
+    const int* __restrict__ in_w = a.in_w;
+    const int* __restrict__ out_off = a.out_off;
+    const int* __restrict__ out_w = a.out_w;
+    const float* __restrict__ res = a.res;
+    float* __restrict__ y = a.y;
+    u32x4_t* __restrict__ yh = reinterpret_cast<u32x4_t*>(a.yh);
+    const int c0 = g * 8;
     const int Wi = in_w[b], Wo = out_w[b], ib = in_off[b], ob = out_off[b];
     const size_t NX = (size_t)Nout + 1, plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;
-    if (yh && b == 0 && blockIdx.x == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + Nout] = u32x4_t{0u, 0u, 0u, 0u};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
+    if (yh && b == 0 && bx == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + Nout] = u32x4_t{0u, 0u, 0u, 0u};
+    for (int i = bx * 256 + threadIdx.x; i < Hout * Wo; i += gxn * 256) {
         const int ho = i / Wo, wo = i - ho * Wo;
         // the pair (2 wo, 2 wo + 1) as one 8-byte load (whole cache lines per wave); the last column of an odd row stands for its
         // missing neighbour: there the pair is loaded one float earlier and its second value is used twice.  Every load of the
@@ -904,21 +910,11 @@ static int avgpool_launch(const float* x, int ldx, const int32_t* in_off, const 
                           const int32_t* out_w, int Hout, int pool_h, const float* res, int ldr, int B, int C, int max_out, uint16_t* yh, int Nout,
                           int yh_lrelu, hipStream_t stream)
 {
-    if (!x || (!y && !yh) || !in_off || !in_w || !out_off || !out_w || (pool_h != 1 && pool_h != 2) || B < 0 || C <= 0) return AS_EINVAL;
-    if (yh && ((reinterpret_cast<uintptr_t>(yh) & 15) != 0 || Nout < 0)) return AS_EINVAL;
-    if (B == 0 || max_out <= 0) return AS_OK;
-    int gx = as_cdiv(max_out, 256);
-    gx = gx > 32 ? 32 : gx;
-    const int groups = yh ? 2 * as_kbx(C) : as_cdiv(C, 8);
-    AsProfScope prof__(AS_FILE_CLS, 0, 0, stream);
-    if (pool_h == 2)
-        hipLaunchKernelGGL(avgpool_down_kernel<2>, dim3(gx, B, groups), dim3(256), 0, stream, x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout,
-                           res, ldr, C, reinterpret_cast<u32x4_t*>(yh), Nout, yh_lrelu);
-    else
-        hipLaunchKernelGGL(avgpool_down_kernel<1>, dim3(gx, B, groups), dim3(256), 0, stream, x, ldx, in_off, in_w, Hin, y, ldy, out_off, out_w, Hout,
-                           res, ldr, C, reinterpret_cast<u32x4_t*>(yh), Nout, yh_lrelu);
-    AS_CHECK_LAUNCH();
-    return AS_OK;
+    AsDownArgs a;
+    memset(&a, 0, sizeof(a));
+    a.kind = 1; a.x = x; a.ldx = ldx; a.in_off = in_off; a.in_w = in_w; a.Hin = Hin; a.y = y; a.ldy = ldy; a.out_off = out_off; a.out_w = out_w;
+    a.Hout = Hout; a.pool_h = pool_h; a.res = res; a.ldr = ldr; a.B = B; a.C = C; a.max_out = max_out; a.yh = yh; a.n_out = Nout; a.lrelu = yh_lrelu;
+    return down_one(a, stream);
 }
 
 extern "C" int as_avgpool_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin,
@@ -943,23 +939,29 @@ extern "C" int as_avgpool_down_image_f32(const float* x, int ldx, const int32_t*
 // back -- its only other consumer, the block's conv1, reads the LeakyReLU image the stem writes.  w = the stem's fp32 image [T][Kp][M]
 // (k = 0 rows), taps in taps_2d(3, 3) / taps_1d(3) order, zero padding; then DownSample's (pool_h x 2) average with the last column
 // replicated when W is odd, summed in avgpool_down_kernel's order.  Workgroup = 8 channels of one utterance, thread = one output position.
-__global__ void __launch_bounds__(256)
-stem_pool_image_kernel(const float* __restrict__ x, const int* __restrict__ in_off, const int* __restrict__ in_w, int Hin,
-                       const int* __restrict__ out_off, const int* __restrict__ out_w, int Hout, int ph, const float* __restrict__ w, int Kp,
-                       const float* __restrict__ bias, int KH, int C, u32x4_t* __restrict__ yh, int Nout)
+static __device__ __forceinline__ void stem_pool_image_body(const AsDownArgs& a, int b, int g, int bx, int gxn)
 {
     __shared__ float ws[8][10];                                         // the eight channels' taps and bias
-    const int b = blockIdx.y, g = blockIdx.z, c0 = g * 8;
+    const float* __restrict__ x = a.x;
+    const int Hin = a.Hin, Hout = a.Hout, ph = a.pool_h, Kp = a.Kp, KH = a.kh, C = a.C, Nout = a.n_out;
+    const int* __restrict__ in_off = a.in_off;
+    const int* __restrict__ in_w = a.in_w;
+    const int* __restrict__ out_off = a.out_off;
+    const int* __restrict__ out_w = a.out_w;
+    const float* __restrict__ w = a.w;
+    const float* __restrict__ bias = a.bias;
+    u32x4_t* __restrict__ yh = reinterpret_cast<u32x4_t*>(a.yh);
+    const int c0 = g * 8;
     const int Wi = in_w[b], Wo = out_w[b];
     const size_t NX = (size_t)Nout + 1, plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;
-    if (b == 0 && blockIdx.x == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + Nout] = u32x4_t{0u, 0u, 0u, 0u};
+    if (b == 0 && bx == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + Nout] = u32x4_t{0u, 0u, 0u, 0u};
     if (threadIdx.x < 80) {
         const int r = threadIdx.x / 10, k = threadIdx.x % 10, c = c0 + r;
         ws[r][k] = c < C ? (k < 9 ? (k < KH * 3 ? w[(size_t)k * Kp * C + c] : 0.f) : (bias ? bias[c] : 0.f)) : 0.f;
     }
     __syncthreads();
     const int ib = in_off[b], ob = out_off[b], pad = KH / 2;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wo; i += gridDim.x * blockDim.x) {
+    for (int i = bx * 256 + threadIdx.x; i < Hout * Wo; i += gxn * 256) {
         const int ho = i / Wo, wo = i - ho * Wo;
         float win[4][4];                                                // rows ho ph - pad .. + ph + KH - 2, columns 2 wo - 1 .. 2 wo + 2 (zero outside)
 #pragma unroll
@@ -1012,18 +1014,85 @@ extern "C" int as_stem_pool_image_f32(const float* x, const int32_t* in_off, con
                                       const int32_t* out_w, int Hout, int pool_h, const float* w, int Kp, const float* bias, int kh, int B, int C,
                                       int max_out, uint16_t* yh, int n_out, as_stream_t stream)
 {
-    if (!x || !in_off || !in_w || !out_off || !out_w || !w || !yh || (pool_h != 1 && pool_h != 2) || (kh != 1 && kh != 3) || B < 0 || C <= 0 ||
-        Kp <= 0 || n_out < 0 || (reinterpret_cast<uintptr_t>(yh) & 15) != 0)
-        return AS_EINVAL;
-    if (B == 0 || max_out <= 0) return AS_OK;
-    int gx = as_cdiv(max_out, 256);
-    gx = gx > 32 ? 32 : gx;
-    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(stem_pool_image_kernel, dim3(gx, B, 2 * as_kbx(C)), dim3(256), 0, (hipStream_t)stream, x, in_off, in_w, Hin, out_off, out_w,
-                       Hout, pool_h, w, Kp, bias, kh, C, reinterpret_cast<u32x4_t*>(yh), n_out);
+    AsDownArgs a;
+    memset(&a, 0, sizeof(a));
+    a.kind = 2; a.x = x; a.in_off = in_off; a.in_w = in_w; a.Hin = Hin; a.out_off = out_off; a.out_w = out_w; a.Hout = Hout; a.pool_h = pool_h;
+    a.w = w; a.Kp = Kp; a.bias = bias; a.kh = kh; a.B = B; a.C = C; a.max_out = max_out; a.yh = yh; a.n_out = n_out;
+    return down_one(a, (hipStream_t)stream);
+}
+
+// ONE launch for several of the tower down-sampling steps above (AsDownArgs: include/artspeech_hip.h): blockIdx.y walks the problems'
+// workgroups back to back (exactly the workgroups every problem needs: a common 3-D grid sized for the widest problem was three quarters empty workgroups and slower than the launches it replaced).
+// The four towers of the style path and dur_block (models.py:385-411, 530-535) are independent and march through their blocks in step,
+// so their LearnedDownSample / DownSample launches -- 7-20 us each at C3 sizes, all latency -- come in sets of four.
+#define DOWN_MAXP 6
+struct DownMulti {
+    int32_t n, pad_;
+    int32_t blk0[DOWN_MAXP + 2];         // first workgroup of problem i; its workgroups: (x of gx, utterance of B, 8-channel group of gz), x fastest
+    int32_t gx[DOWN_MAXP], gz[DOWN_MAXP];
+    AsDownArgs a[DOWN_MAXP];
+};
+// HEAVY: the instantiation that also holds the 3-row depthwise conv and the stem bodies (200+ registers per lane); a set without them
+// runs the light one (the 1-D / channel-preserving steps and the average pools: a quarter of the registers, four times the waves)
+template <bool HEAVY>
+__global__ void __launch_bounds__(256)
+down_multi_kernel(const DownMulti dm)
+{
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < DOWN_MAXP; ++i) pi += (i < dm.n && (int)blockIdx.x >= dm.blk0[i]) ? 1 : 0;
+    const AsDownArgs& a = dm.a[pi];
+    const int gxn = dm.gx[pi], local = (int)blockIdx.x - dm.blk0[pi];
+    const int bx = local % gxn, rest = local / gxn, b = rest % a.B, g = rest / a.B;
+    if (a.kind == 0) {
+        if (a.kh == 3) { if constexpr (HEAVY) dwconv_down_body<3>(a, b, g, bx, gxn); }
+        else dwconv_down_body<1>(a, b, g, bx, gxn);
+    } else if (a.kind == 1) {
+        if (a.pool_h == 2) avgpool_down_body<2>(a, b, g, bx, gxn);
+        else avgpool_down_body<1>(a, b, g, bx, gxn);
+    } else {
+        if constexpr (HEAVY) stem_pool_image_body(a, b, g, bx, gxn);
+    }
+}
+
+static int down_check(const AsDownArgs& a)
+{
+    if (!a.x || !a.in_off || !a.in_w || !a.out_off || !a.out_w || a.B < 0 || a.C <= 0) return AS_EINVAL;
+    if (a.yh && ((reinterpret_cast<uintptr_t>(a.yh) & 15) != 0 || a.n_out < 0)) return AS_EINVAL;
+    if (a.kind == 0) return ((!a.y && !a.yh) || !a.w || !a.bias || (a.kh != 1 && a.kh != 3)) ? AS_EINVAL : AS_OK;
+    if (a.kind == 1) return ((!a.y && !a.yh) || (a.pool_h != 1 && a.pool_h != 2)) ? AS_EINVAL : AS_OK;
+    if (a.kind == 2) return (!a.w || !a.yh || (a.pool_h != 1 && a.pool_h != 2) || (a.kh != 1 && a.kh != 3) || a.Kp <= 0) ? AS_EINVAL : AS_OK;
+    return AS_EINVAL;
+}
+
+extern "C" int as_down_multi_f32(const AsDownArgs* list_host, int n, as_stream_t stream_)
+{
+    static_assert(DOWN_MAXP == AS_MAX_MULTI, "header and kernel disagree");
+    if (!list_host || n < 1 || n > DOWN_MAXP) return AS_EINVAL;
+    DownMulti dm;
+    memset(&dm, 0, sizeof(dm));
+    bool heavy = false;
+    for (int i = 0; i < n; ++i) {
+        const AsDownArgs& a = list_host[i];
+        const int r = down_check(a);
+        if (r != AS_OK) return r;
+        if (a.B == 0 || a.max_out <= 0) continue;
+        heavy = heavy || a.kind == 2 || (a.kind == 0 && a.kh == 3);
+        dm.a[dm.n] = a;
+        dm.gx[dm.n] = std::min(32, as_cdiv(a.max_out, 256));
+        dm.gz[dm.n] = a.yh ? 2 * as_kbx(a.C) : as_cdiv(a.C, 8);
+        dm.blk0[dm.n + 1] = dm.blk0[dm.n] + dm.gx[dm.n] * a.B * dm.gz[dm.n];
+        ++dm.n;
+    }
+    if (dm.n == 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream_);
+    if (heavy) hipLaunchKernelGGL(down_multi_kernel<true>, dim3(dm.blk0[dm.n]), dim3(256), 0, (hipStream_t)stream_, dm);
+    else hipLaunchKernelGGL(down_multi_kernel<false>, dim3(dm.blk0[dm.n]), dim3(256), 0, (hipStream_t)stream_, dm);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
+
+static int down_one(const AsDownArgs& a, hipStream_t stream) { return as_down_multi_f32(&a, 1, stream); }
 
 // im2col for the valid KxK convs that close the 2-D towers (models.py:391,399,535), with the LeakyReLU that
 // precedes them (models.py:390,398,534) applied on the fly.  col[(c*K*K + a*K + d)][out_off[b] + ho*Wo + wo]

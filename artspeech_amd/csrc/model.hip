@@ -511,9 +511,11 @@ namespace {
 // fork / join edges, and hands conv GEMMs that are ready at the same time to ONE launch (as_conv_gemm_multi_f32): on one stream a step costs
 // the sum of its kernels' durations, and a 40-tile conv beside a 2 000-tile one costs next to nothing.
 struct Op {
-    int kind = 0;                                  // 0: a recorded launch, 1: a conv GEMM (as_conv_gemm_f32 arguments), 2: wait for other queues
+    int kind = 0;                                  // 0: a recorded launch, 1: a conv GEMM (as_conv_gemm_f32 arguments), 2: wait for other queues,
+                                                   // 3: a tower down-sampling step (as_down_multi_f32 arguments)
     std::function<int()> fn;
     ConvGemmArgs g;
+    AsDownArgs d;
     hipStream_t s = nullptr;
     double hint_f = 0, hint_b = 0;                 // as_prof_hint that goes with the launch
     std::vector<std::pair<int, size_t>> deps;      // kind 2: queue q has played >= n ops
@@ -773,7 +775,7 @@ static void play(Ctx& c, Sched& S)
                     const int r = o.fn();
                     if (r != AS_OK) { fail(r, o); break; }
                 } else {
-                    break;                                               // a conv GEMM: decided below, with the other queues' heads
+                    break;                                               // a conv GEMM / a down-sampling step: decided below, with the other queues' heads
                 }
                 ++head[qi];
                 progress = true;
@@ -781,7 +783,40 @@ static void play(Ctx& c, Sched& S)
         }
         if (c.rc) return;
         if (progress) continue;
-        // every live head is a GEMM or a wait
+        // every live head is a GEMM, a down-sampling step or a wait.  The towers' down-sampling steps that are ready together go out as one
+        // launch first (they are what the towers' next convs wait for)
+        {
+            AsDownArgs dl[AS_MAX_MULTI];
+            int dq[AS_MAX_MULTI], nd = 0;
+            double hf = 0, hb = 0;
+            for (int qi = 0; qi < nq && nd < AS_MAX_MULTI; ++qi)
+                if (head[qi] < S.q[qi].size() && S.q[qi][head[qi]].kind == 3) {
+                    const Op& o = S.q[qi][head[qi]];
+                    dl[nd] = o.d;
+                    dq[nd++] = qi;
+                    hf += o.hint_f;
+                    hb += o.hint_b;
+                }
+            if (nd > 0) {
+                if (hf > 0 || hb > 0) as_prof_hint(hf, hb);
+                if (trace) {
+                    fprintf(stderr, "  DOWN x%d:", nd);
+                    for (int i = 0; i < nd; ++i) fprintf(stderr, " q%d kind%d C%d |", dq[i], dl[i].kind, dl[i].C);
+                    fprintf(stderr, "\n");
+                }
+                const Op& o0 = S.q[dq[0]][head[dq[0]]];
+                const int r = no_merge ? AS_OK : as_down_multi_f32(dl, nd, o0.s);
+                if (no_merge)
+                    for (int i = 0; i < nd && !c.rc; ++i) {
+                        const int r1 = as_down_multi_f32(&dl[i], 1, o0.s);
+                        if (r1 != AS_OK) fail(r1, o0);
+                    }
+                if (r != AS_OK) { fail(r, o0); return; }
+                if (c.rc) return;
+                for (int i = 0; i < nd; ++i) ++head[dq[i]];
+                continue;
+            }
+        }
         int heads[64], nh = 0;
         bool live = false;
         for (int qi = 0; qi < nq; ++qi)
@@ -1388,6 +1423,29 @@ bool rel_encoder_multi(Ctx& c, const std::vector<EncSpec>& enc, const int32_t* t
 std::vector<EncSpec> path_encoders() { return {{"arts_encoder", 4}, {"text_encoder", 4}, {"durationPredictor.text_encoder", 2}}; }
 enum { ENC_ARTS = 0, ENC_TEXT = 1, ENC_DUR = 2 };
 
+// one down-sampling step of a tower (as_down_multi_f32): launched, or recorded so that the towers' steps share a launch
+void down(Ctx& c, const AsDownArgs& a, int line)
+{
+    if (!c.go()) return;
+    if (c.deferring()) {
+        Op& o = c.push(3);
+        o.d = a;
+        o.what = "as_down_multi_f32";
+        o.line = line;
+        return;
+    }
+    const int r = as_down_multi_f32(&a, 1, c.s);
+    if (r != AS_OK) c.fail(r, "as_down_multi_f32", line);
+}
+AsDownArgs down_args(int kind, const float* x, int ldx, const Lay* lay, const Lay* lay2, int C)
+{
+    AsDownArgs a;
+    memset(&a, 0, sizeof(a));
+    a.kind = kind; a.x = x; a.ldx = ldx; a.in_off = lay->d_off; a.in_w = lay->d_w; a.Hin = lay->H;
+    a.out_off = lay2->d_off; a.out_w = lay2->d_w; a.Hout = lay2->H; a.B = lay->B; a.C = C; a.max_out = lay2->max_cols(); a.n_out = lay2->N;
+    return a;
+}
+
 // ResBlk (models.py:79-100) / ResBlk1d(downsample=True) (models.py:127-156).  X.h, if set, is the operand image of
 // LeakyReLU(X) (what conv1 reads); the result carries the same for the next block when want_image.
 Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_d, bool want_image)
@@ -1397,7 +1455,7 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
     Act Y;
     const Lay* lay2 = c.halved(lay, half);
     if (!lay2) return Y;
-    const int cin = X.C, B = lay->B, N2 = std::max(lay2->N, 1);
+    const int cin = X.C, N2 = std::max(lay2->N, 1);
     const Taps taps = one_d ? taps_1d(3) : taps_2d(3, 3);
     ConvOpt o;
     o.bias = m.bias(p + ".conv1");
@@ -1412,8 +1470,11 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
     uint16_t* r2h = c.image(cin, lay2->N);
     const float *dww = m.vec(dname + ".weight"), *dwb = m.vec(dname + ".bias");
     c.hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
-    RUN(c, as_dwconv_down_image_f32(r, lay->N, lay->d_off, lay->d_w, lay->H, lay2->d_off, lay2->d_w, lay2->H, dww, dwb, half ? 3 : 1, B, cin,
-                                    lay2->max_cols(), 1, r2h, lay2->N, c.s));
+    {
+        AsDownArgs a = down_args(0, r, lay->N, lay, lay2, cin);
+        a.w = dww; a.bias = dwb; a.kh = half ? 3 : 1; a.lrelu = 1; a.yh = r2h;
+        down(c, a, __LINE__);
+    }
     const bool has_sc = m.has(p + ".conv1x1.weight");
     const GemmW* w2 = has_sc ? m.conv_fold({p + ".conv2"}, {p + ".conv1x1"}) : m.conv(p + ".conv2");
     if (!w2) { c.fail(AS_EINVAL); return Y; }
@@ -1427,12 +1488,15 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
         // (x + r)/sqrt(2) in that launch's epilogue: the residual branch never exists on its own.
         uint16_t* xsh = c.image(cin, lay2->N);
         c.hint(0, 4.0 * cin * ((double)lay->N + lay2->N));
-        if (X.stem_x)
-            RUN(c, as_stem_pool_image_f32(X.stem_x, lay->d_off, lay->d_w, lay->H, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, X.stem_w->w32,
-                                          X.stem_w->Kp, X.stem_b, X.stem_kh, B, cin, lay2->max_cols(), xsh, lay2->N, c.s));
-        else
-            RUN(c, as_avgpool_down_image_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, nullptr, 0, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1,
-                                             nullptr, 0, B, cin, lay2->max_cols(), xsh, lay2->N, 0, c.s));
+        if (X.stem_x) {
+            AsDownArgs a = down_args(2, X.stem_x, 0, lay, lay2, cin);
+            a.pool_h = half ? 2 : 1; a.w = X.stem_w->w32; a.Kp = X.stem_w->Kp; a.bias = X.stem_b; a.kh = X.stem_kh; a.yh = xsh;
+            down(c, a, __LINE__);
+        } else {
+            AsDownArgs a = down_args(1, X.p, X.ld, lay, lay2, cin);
+            a.pool_h = half ? 2 : 1; a.yh = xsh;
+            down(c, a, __LINE__);
+        }
         o2.x2h = xsh;
         o2.K2 = cin;
         o2.div_sqrt2 = true;
@@ -1444,12 +1508,12 @@ Act resblk_down(Ctx& c, const std::string& p, const Act& X, bool half, bool one_
         float* r3 = conv_h_new(c, w2, r2h, cin, lay2, taps, o2);
         out = c.f32((size_t)w2->M * N2);
         c.hint(0, 4.0 * cin * ((double)lay->N + (want_image ? 3.0 : 2.0) * lay2->N));
-        if (want_image)
-            RUN(c, as_avgpool_down_image_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, out, lay2->N, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, r3,
-                                             lay2->N, B, cin, lay2->max_cols(), outh, lay2->N, 1, c.s));
-        else
-            RUN(c, as_avgpool_down_f32(X.p, X.ld, lay->d_off, lay->d_w, lay->H, out, lay2->N, lay2->d_off, lay2->d_w, lay2->H, half ? 2 : 1, r3, lay2->N,
-                                       B, cin, lay2->max_cols(), c.s));
+        {
+            AsDownArgs a = down_args(1, X.p, X.ld, lay, lay2, cin);
+            a.y = out; a.ldy = lay2->N; a.pool_h = half ? 2 : 1; a.res = r3; a.ldr = lay2->N;
+            if (want_image) { a.yh = outh; a.lrelu = 1; }
+            down(c, a, __LINE__);
+        }
     }
     Y.p = out; Y.C = w2->M; Y.ld = lay2->N; Y.lay = lay2; Y.h = outh;
     return Y;

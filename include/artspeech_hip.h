@@ -348,6 +348,23 @@ int as_avgpool_down_image_f32(const float* x, int ldx, const int32_t* in_off, co
 int as_stem_pool_image_f32(const float* x, const int32_t* in_off, const int32_t* in_w, int Hin, const int32_t* out_off,
                            const int32_t* out_w, int Hout, int pool_h, const float* w, int Kp, const float* bias, int kh, int B, int C,
                            int max_out, uint16_t* yh, int n_out, as_stream_t stream);
+/* One launch for up to AS_MAX_MULTI of the down-sampling steps above (independent problems: the style towers and dur_block march through
+ * their ResBlks in step, models.py:385-411,530-535).  kind 0 = as_dwconv_down[_image]_f32 (w [C][kh*3], bias [C], lrelu = LeakyReLU on the
+ * result), 1 = as_avgpool_down[_image]_f32 (res / ldr optional, lrelu = the image holds LeakyReLU(y)), 2 = as_stem_pool_image_f32 (w = the
+ * stem's fp32 image [T][Kp][C], bias or NULL).  y (kinds 0, 1) and yh as there; the single entry points are this with n = 1. */
+typedef struct AsDownArgs {
+    int32_t kind;
+    const float* x; int32_t ldx;
+    const int32_t* in_off; const int32_t* in_w; int32_t Hin;
+    float* y; int32_t ldy;
+    const int32_t* out_off; const int32_t* out_w; int32_t Hout;
+    const float* w; const float* bias;
+    int32_t kh, pool_h, Kp;
+    const float* res; int32_t ldr;
+    int32_t B, C, max_out, lrelu;
+    uint16_t* yh; int32_t n_out;
+} AsDownArgs;
+int as_down_multi_f32(const AsDownArgs* list_host, int n, as_stream_t stream);
 int as_im2col_valid_image_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, const int32_t* out_off,
                               const int32_t* out_w, int K, int stride, int lrelu, int B, int C, uint16_t* yh, as_stream_t stream);
 int as_mean_pool_f32(const float* x, int ldx, const int32_t* col_off, int B, int C, int lrelu, float* y, int ldy,
