@@ -1624,7 +1624,7 @@ void tower1d(Ctx& c, const std::string& p, const float* X, int ldx, const Lay* l
 // modules
 // ------------------------------------------------------------------------------------------------------------------
 struct StyleIn {                  // the T-1 crop of the reference features and the towers' images (models.py:459-471)
-    float* crop = nullptr;        // [12 + n_mels][N1]: rows 0 n, 1 f0, 2..11 ema, 12.. mel
+    float* crop = nullptr;        // [2][N1]: rows 0 n, 1 f0
     const Lay *l1 = nullptr, *lm = nullptr, *le = nullptr;
     float *mel_img = nullptr, *ema_img = nullptr;
 };
@@ -1632,7 +1632,7 @@ struct StyleIn {                  // the T-1 crop of the reference features and 
 StyleIn style_inputs(Ctx& c, const float* feat12, int ldf, const float* mel, int ldm, const Lay* ref)
 {
     StyleIn s;
-    const int n_mels = c.m.cfg.n_mels, R = 12 + n_mels;
+    const int n_mels = c.m.cfg.n_mels;
     std::vector<int> w(ref->w);
     for (int& v : w) v = v > 0 ? v - 1 : 0;                               // start = randint(0, 1) = 0, length T - 1
     s.l1 = c.lay(w);
@@ -1640,14 +1640,14 @@ StyleIn style_inputs(Ctx& c, const float* feat12, int ldf, const float* mel, int
     s.le = c.lay(w, 10);
     if (!s.l1 || !s.lm || !s.le) return s;
     const int N1 = std::max(s.l1->N, 1);
-    s.crop = c.f32((size_t)R * N1);
-    RUN(c, as_crop_f32(feat12, ldf, ref->d_off, 0, s.crop, s.l1->N, s.l1->d_off, ref->B, 12, s.l1->max_cols(), c.s));
-    RUN(c, as_crop_f32(mel, ldm, ref->d_off, 0, s.crop ? s.crop + (size_t)12 * s.l1->N : nullptr, s.l1->N, s.l1->d_off, ref->B, n_mels,
-                       s.l1->max_cols(), c.s));
+    // the T - 1 window of the energy / F0 rows (the 1-D towers' input); the 2-D towers' images are cut straight out of the mel and the TV
+    // rows (as_rows_to_images_f32 takes the utterances' source offsets and the images' widths: no cropped copy of 90 rows in between)
+    s.crop = c.f32((size_t)2 * N1);
+    RUN(c, as_crop_f32(feat12, ldf, ref->d_off, 0, s.crop, s.l1->N, s.l1->d_off, ref->B, 2, s.l1->max_cols(), c.s));
     s.mel_img = c.f32((size_t)std::max(s.lm->N, 1));
     s.ema_img = c.f32((size_t)std::max(s.le->N, 1));
-    RUN(c, as_rows_to_images_f32(s.crop + (size_t)12 * s.l1->N, s.l1->N, s.l1->d_off, 0, n_mels, s.mel_img, s.lm->d_off, ref->B, s.l1->max_cols(), c.s));
-    RUN(c, as_rows_to_images_f32(s.crop + (size_t)2 * s.l1->N, s.l1->N, s.l1->d_off, 0, 10, s.ema_img, s.le->d_off, ref->B, s.l1->max_cols(), c.s));
+    RUN(c, as_rows_to_images_f32(mel, ldm, ref->d_off, 0, n_mels, s.mel_img, s.lm->d_off, ref->B, s.l1->max_cols(), c.s));
+    RUN(c, as_rows_to_images_f32(feat12 + (size_t)2 * ldf, ldf, ref->d_off, 0, 10, s.ema_img, s.le->d_off, ref->B, s.l1->max_cols(), c.s));
     return s;
 }
 
@@ -2070,7 +2070,8 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     f.join();
     if (c.go()) c.p.mark(2, c.s);
     // round half even -> clamp(min = 1) (or the forced durations), per-utterance frame offsets (models.py:361-366)
-    RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, A.dur_i, A.frame_off, nullptr, 0, c.s));
+    // (with the frame counts given nobody reads this half's copy: the second half computes durations, offsets and the frame -> token map)
+    if (!batch->frames) RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, A.dur_i, A.frame_off, nullptr, 0, c.s));
     (void)C;
     return A;
 }
