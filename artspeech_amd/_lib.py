@@ -109,6 +109,15 @@ class AdainArgs(ctypes.Structure):
                 ("lrelu", ctypes.c_int32), ("yh", c_p), ("pool_w", c_p), ("pool_b", c_p), ("x_up", c_p), ("ld_up", ctypes.c_int32)]
 
 
+class DownArgs(ctypes.Structure):
+    """AsDownArgs (include/artspeech_hip.h): one tower down-sampling step of as_down_multi_f32"""
+    _fields_ = [("kind", ctypes.c_int32), ("x", c_p), ("ldx", ctypes.c_int32), ("in_off", c_p), ("in_w", c_p), ("Hin", ctypes.c_int32),
+                ("y", c_p), ("ldy", ctypes.c_int32), ("out_off", c_p), ("out_w", c_p), ("Hout", ctypes.c_int32), ("w", c_p), ("bias", c_p),
+                ("kh", ctypes.c_int32), ("pool_h", ctypes.c_int32), ("Kp", ctypes.c_int32), ("res", c_p), ("ldr", ctypes.c_int32),
+                ("B", ctypes.c_int32), ("C", ctypes.c_int32), ("max_out", ctypes.c_int32), ("lrelu", ctypes.c_int32), ("yh", c_p),
+                ("n_out", ctypes.c_int32)]
+
+
 class ModelCfg(ctypes.Structure):
     _fields_ = [("hidden_dim", ctypes.c_int32), ("dim_in", ctypes.c_int32), ("style_dim", ctypes.c_int32), ("n_mels", ctypes.c_int32),
                 ("n_token", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stats", ctypes.c_float * 24)]
@@ -130,6 +139,7 @@ AS_MOD_FORWARD_A, AS_MOD_FORWARD_B, AS_MOD_ENCODER, AS_MOD_STYLE, AS_MOD_DURATIO
 _pB, _pIO = ctypes.POINTER(Batch), ctypes.POINTER(ForwardIO)
 _SIGNATURES.update({
     "as_adain_image_f32": (c_i, [ctypes.POINTER(AdainArgs), c_p]),
+    "as_down_multi_f32": (c_i, [ctypes.POINTER(DownArgs), c_i, c_p]),
     "as_rows_image_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "as_project_cols_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "as_pointwise_small_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p]),

@@ -876,3 +876,69 @@ def test_pointwise_small(cuda, K, M, lens):
     got = (parts[0] + parts[1])[C0:C0 + M, :N]
     assert float((got.cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
     assert float(parts[:, C0:, N].abs().max()) == 0.0                             # the zero column
+
+
+def test_down_multi_equals_single_launches(cuda):
+    """as_down_multi_f32: the towers' down-sampling steps that are ready together as ONE launch (a 3-row depthwise conv of the mel
+    tower, a channel-preserving one of the TV tower, an average pool with the residual merge, a 1-D average pool, the stem + pool of a
+    first block) -- every output bitwise equal to the single entry points', which test_dwconv_down* / test_avgpool* / test_stem_pool*
+    hold against torch."""
+    import ctypes
+    from artspeech_amd._lib import DownArgs
+    g = torch.Generator().manual_seed(17)
+    L = ops._lib.lib()
+    probs = []
+
+    def lay_pair(widths, H, half):
+        lin = Layout(widths, cuda, H=H)
+        lout = Layout([(w + 1) // 2 for w in widths], cuda, H=H // 2 if half else H)
+        return lin, lout
+
+    def base(kind, X, lin, lout, C):
+        a = DownArgs()
+        a.kind, a.x, a.ldx = kind, X.data_ptr(), X.stride(0) if X.dim() > 1 else 0
+        a.in_off, a.in_w, a.Hin = lin.col_off.data_ptr(), lin.widths.data_ptr(), lin.H
+        a.out_off, a.out_w, a.Hout = lout.col_off.data_ptr(), lout.widths.data_ptr(), lout.H
+        a.B, a.C, a.max_out, a.n_out = lin.B, C, lout.max_cols, lout.N
+        return a
+
+    # 0: dwconv 3x3 s2 (mel tower), image only
+    lin, lout = lay_pair([25, 8, 13], 10, True)
+    X0 = torch.randn(20, lin.N, generator=g).to(cuda)
+    w0, b0 = torch.randn(20, 9, generator=g).to(cuda), torch.randn(20, generator=g).to(cuda)
+    a = base(0, X0, lin, lout, 20)
+    img0 = ops.new_image(20, lout.N, cuda)
+    a.w, a.bias, a.kh, a.lrelu, a.yh = w0.data_ptr(), b0.data_ptr(), 3, 1, img0.data_ptr()
+    probs.append(a)
+    # 1: dwconv 1x3 s(1,2) (TV tower), fp32 + no image
+    lin1, lout1 = lay_pair([199, 66], 10, False)
+    X1 = torch.randn(64, lin1.N, generator=g).to(cuda)
+    w1, b1 = torch.randn(64, 3, generator=g).to(cuda), torch.randn(64, generator=g).to(cuda)
+    y1 = lout1.new(64)
+    a = base(0, X1, lin1, lout1, 64)
+    a.w, a.bias, a.kh, a.lrelu, a.y, a.ldy = w1.data_ptr(), b1.data_ptr(), 1, 0, y1.data_ptr(), y1.stride(0)
+    probs.append(a)
+    # 2: avgpool 2x2 + residual merge, fp32 + LeakyReLU image
+    r2 = torch.randn(20, lout.N, generator=g).to(cuda)
+    y2, img2 = lout.new(20), ops.new_image(20, lout.N, cuda)
+    a = base(1, X0, lin, lout, 20)
+    a.pool_h, a.res, a.ldr, a.y, a.ldy, a.yh, a.lrelu = 2, r2.data_ptr(), r2.stride(0), y2.data_ptr(), y2.stride(0), img2.data_ptr(), 1
+    probs.append(a)
+    # 3: 1-D avgpool, image only
+    lin3, lout3 = lay_pair([199, 7, 66], 1, False)
+    X3 = torch.randn(130, lin3.N, generator=g).to(cuda)
+    img3 = ops.new_image(130, lout3.N, cuda)
+    a = base(1, X3, lin3, lout3, 130)
+    a.pool_h, a.yh = 1, img3.data_ptr()
+    probs.append(a)
+    arr = (DownArgs * len(probs))(*probs)
+    ops.check(L.as_down_multi_f32(arr, len(probs), ops.stream()), "as_down_multi_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(img0, ops.dwconv_down_image(X0, lin, lout, w0, b0, 3, True))
+    assert torch.equal(y1, ops.dwconv_down(X1, lin1, lout1.new(64), lout1, w1, b1, 1, False))
+    y2s = lout.new(20)
+    img2s = ops.avgpool_down_image(X0, lin, y2s, lout, 2, res=r2, yh_lrelu=True)
+    assert torch.equal(y2, y2s) and torch.equal(img2, img2s)
+    assert torch.equal(img3, ops.avgpool_down_image(X3, lin3, None, lout3, 1))
+    with pytest.raises(ops._lib.HipLibraryError):
+        ops.check(L.as_down_multi_f32(arr, 7, ops.stream()), "as_down_multi_f32")
