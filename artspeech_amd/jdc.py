@@ -96,6 +96,7 @@ class JDCNet:
         self.num_class, self.slope = num_class, float(leaky_relu_slope)
         self.device = _need_gpu(device if device is not None else "cuda")
         self.W = None
+        self._xchg = {}                                 # exchange buffers of the clustered recurrence, per batch size
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd, strict=False):
@@ -167,7 +168,12 @@ class JDCNet:
             H = Ho
         hout = H // 4
         f = ops.bn_lrelu_maxpool_rows(x, lay, H, 4, W["pool"][0], W["pool"][1], sl, lay.new(x.shape[0] * hout), to_channels=True)
-        h = bilstm(W["lstm"], "bilstm_classifier", f, lay)                                             # :127
+        # H = 256: the recurrence of an utterance split over a cluster of four workgroups that keep W_hh in registers (as_bilstm_cluster_f32;
+        # the single-workgroup kernel re-streams W_hh from L2 every step: 9.7 us per step, half of this module's time at 200 frames)
+        xchg = self._xchg.get(lay.B)
+        if xchg is None:
+            xchg = self._xchg[lay.B] = ops.bilstm_exchange_buffer(1, lay.B, dev)
+        h = bilstm(W["lstm"], "bilstm_classifier", f, lay, xchg=xchg)                                  # :127
         wt, b = W["cls"]
         return ops.conv_gemm(wt, h, lay, lay.new(wt.shape[2]), [(0, 0)], bias=b, act=ACT_ABS)         # :130, :137
 
