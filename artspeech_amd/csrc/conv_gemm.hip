@@ -541,7 +541,8 @@ extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_s
     for (int i = 0; i < m; ++i) {
         const ConvGemmArgs& a = norm[i];
         const int min_kt = std::max(1, 24 / wk);
-        int s = nkt[i] > 1.5 * share ? (int)ceil(nkt[i] / share) : 1;
+        static const double thr = getenv("AS_MULTI_SLICE_THR") ? atof(getenv("AS_MULTI_SLICE_THR")) : 1.5;   // (tuning)
+        int s = nkt[i] > thr * share ? (int)ceil(nkt[i] / share) : 1;
         s = std::min(std::min(s, 16), nkt[i] / min_kt);
         const size_t slab = (size_t)a.M * a.N * sizeof(float);
         if (s > 1 && (!a.ws || a.ws_bytes / slab < (size_t)s)) s = a.ws ? (int)std::min<size_t>(a.ws_bytes / slab, (size_t)s) : 1;
@@ -560,9 +561,10 @@ extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_s
         So[k] = S[order[k]];
         flops += gemm_flops(*ptr[k]);
         bytes += gemm_bytes(*ptr[k]);
-        char shape[64];
+        char shape[64], sl[8] = "";
         gemm_tag(*ptr[k], shape, sizeof(shape));
-        if (at < (int)sizeof(tag) - 1) at += snprintf(tag + at, sizeof(tag) - at, " %s%s", shape, k + 1 < m ? " |" : "");
+        if (So[k] > 1) snprintf(sl, sizeof(sl), " S%d", So[k]);
+        if (at < (int)sizeof(tag) - 1) at += snprintf(tag + at, sizeof(tag) - at, " %s%s%s", shape, sl, k + 1 < m ? " |" : "");
     }
     {
         AsProfScope prof__(AS_CLS_GEMM, flops, bytes, stream, tag);
