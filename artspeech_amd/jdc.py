@@ -120,8 +120,11 @@ class JDCNet:
         for i in range(3):
             p = f"res_block{i + 1}"
             s, t = _bn_affine(w, p + ".pre_conv.0")
-            W[p] = dict(pre=(s.to(dev), t.to(dev)), c0=conv(p + ".conv.0", p + ".conv.1"), c3=conv(p + ".conv.3"),
-                        sc=conv(p + ".conv1by1"))
+            # conv.3 with the block's 1x1 shortcut (conv1by1, no bias: model.py:180-181,186-187) as extra channels of its reduction
+            # (conv_gemm x2s / K2): one launch, the shortcut never exists as a tensor
+            k3 = w[p + ".conv.3.weight"].transpose(2, 3).contiguous()
+            ksc = w[p + ".conv1by1.weight"].reshape(k3.shape[0], -1).contiguous()
+            W[p] = dict(pre=(s.to(dev), t.to(dev)), c0=conv(p + ".conv.0", p + ".conv.1"), c3=(ops.prep_weight(k3, dev, sc=[ksc]), None))
         s, t = _bn_affine(w, "pool_block.0")
         W["pool"] = (s.to(dev), t.to(dev))
         W["lstm"] = Weights({k: v for k, v in w.items() if k.startswith("bilstm_classifier.")}, dev)
@@ -151,20 +154,25 @@ class JDCNet:
         l0 = img(H)
         x = ops.rows_to_images(mel_p, lay, 0, H, l0)                                                   # model.py:103 (transposed image)
         wt, b = W["c0"]
-        x = ops.conv_gemm(wt, x, l0, l0.new(wt.shape[2]), t33, bias=b, act=ACT_LRELU, act_slope=sl)    # conv_block :19-22
-        wt, _ = W["c3"]
-        x = ops.conv_gemm(wt, x, l0, l0.new(wt.shape[2]), t33)                                         # :23
+        # conv_block :19-22: the Cin = 1 conv (direct kernel) writes its BatchNorm-folded, LeakyReLU'd result only as the next conv's
+        # operand image (64 x 512 000 values at 32 x 200 frames: no fp32 copy, no split pass)
+        c0h = ops.new_image(wt.shape[2], l0.N, x.device)
+        ops.conv_gemm(wt, x, l0, None, t33, bias=b, act=ACT_LRELU, act_slope=sl, yh=c0h)
+        wt3, _ = W["c3"]
+        x = ops.conv_gemm(wt3, None, l0, l0.new(wt3.shape[2]), t33, xs=c0h, K=wt.shape[2])             # :23
         for i in range(3):                                                                             # ResBlock.forward :184-190
             blk = W[f"res_block{i + 1}"]
             Ho = H // 2
             lo = img(Ho)
             p = ops.bn_lrelu_maxpool_rows(x, lay, H, 2, blk["pre"][0], blk["pre"][1], sl, lo.new(x.shape[0]))
+            # p feeds conv.0 and the shortcut: split ONCE; conv.0 hands its (BatchNorm-folded, LeakyReLU'd) result to conv.3 as an operand
+            # image (no fp32 copy, no split pass); conv.3 sums the 1x1 shortcut of p in the same launch
+            ph = ops.split_act(p, lo)
             wt, b = blk["c0"]
-            a = ops.conv_gemm(wt, p, lo, lo.new(wt.shape[2]), t33, bias=b, act=ACT_LRELU, act_slope=sl)
-            wt, _ = blk["sc"]
-            sc = ops.conv_gemm(wt, p, lo, lo.new(wt.shape[2]), [(0, 0)])
-            wt, _ = blk["c3"]
-            x = ops.conv_gemm(wt, a, lo, lo.new(wt.shape[2]), t33, res=sc)
+            ah = ops.new_image(wt.shape[2], lo.N, p.device)
+            ops.conv_gemm(wt, None, lo, None, t33, bias=b, act=ACT_LRELU, act_slope=sl, xs=ph, K=p.shape[0], yh=ah)
+            wt3, _ = blk["c3"]
+            x = ops.conv_gemm(wt3, None, lo, lo.new(wt3.shape[2]), t33, xs=ah, K=wt.shape[2], x2s=ph, K2=p.shape[0])
             H = Ho
         hout = H // 4
         f = ops.bn_lrelu_maxpool_rows(x, lay, H, 4, W["pool"][0], W["pool"][1], sl, lay.new(x.shape[0] * hout), to_channels=True)

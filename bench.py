@@ -467,25 +467,33 @@ def bench_surface(net, dev, reps=5):
                stage_ms={k: med(v) for k, v in per.items()}, chain_ms=med(whole), audio_seconds=audio_s, rtf=med(whole) * 1e-3 / audio_s,
                x_realtime=audio_s / (med(whole) * 1e-3), finite=bool(torch.isfinite(state["wav"]).all()),
                timing="eager launches of every stage (Python callers of the C ABI), HIP events between the stages, warm, median of %d" % reps)
-    # the generator on its own: graph-replayed time and the roofline of its convs
-    mel_v, lay2 = state["ac"]["mel"], ops.layout([2 * f for f in g["frames"]], dev)
-    st = torch.cuda.Stream()
-    st.wait_stream(torch.cuda.current_stream())
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(st):
-        gen.forward_packed(mel_v, lay2)
+    # every stage as a replayed hipGraph: the device's time (called eagerly from Python, the extractors' 25-75 launches are host-paced)
+    def graph_ms(fn, n=10):
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=st):
+                fn()
         torch.cuda.synchronize()
-        with torch.cuda.graph(graph, stream=st):
-            gen.forward_packed(mel_v, lay2)
-    torch.cuda.synchronize()
-    for _ in range(2):
-        graph.replay()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        graph.replay()
-    torch.cuda.synchronize()
-    voc_ms = (time.perf_counter() - t0) / 10 * 1e3
+        for _ in range(2):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            graph.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    mel_v, lay2 = state["ac"]["mel"], ops.layout([2 * f for f in g["frames"]], dev)
+    gms = {"jdcnet_f0": graph_ms(s_jdc), "ema_predictor": graph_ms(s_ema), "acoustic_model": graph_ms(s_acoustic)}
+    voc_ms = graph_ms(lambda: gen.forward_packed(mel_v, lay2))
+    gms["hifigan_generator"] = voc_ms
+    res["stage_ms_graph_replay"] = gms
+    res["chain_ms_graph_replay"] = res["stage_ms"]["frontend_wave_to_logmel"] + sum(gms.values())
+    res["x_realtime_graph_replay"] = audio_s / (res["chain_ms_graph_replay"] * 1e-3)
     kc = class_profile(lambda: gen.forward_packed(mel_v, lay2))
     k0 = kc["conv_gemm"]
     tf = k0["gflop"] / k0["ms"]
