@@ -26,12 +26,26 @@
 #define DIRECT_TP 12                                       // weights per channel in LDS: T (<= 9 on the fast path) padded to 3 x 16 bytes
 // fast form (T <= 9): a thread owns FOUR consecutive columns (one 16-byte store per channel when Y allows), three
 // 16-byte LDS reads feed 4 x T FMAs
+// (several independent problems in one launch -- the stems of the mel tower, the TV tower and dur_block are ready together: blockIdx.x
+// walks the problems' column blocks back to back)
+#define DIRECT_MAXP 6
+struct DirectMulti {
+    int32_t n, pad_;
+    int32_t blk0[DIRECT_MAXP + 2];       // first workgroup of problem i; its workgroups: (column block of nx, channel-group share of ny), column block fastest
+    int32_t nx[DIRECT_MAXP], ny[DIRECT_MAXP];
+    ConvGemmArgs a[DIRECT_MAXP];
+};
 template <bool VEC>
 __global__ void __launch_bounds__(256)
-conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
+conv_direct_cin1_x4_kernel(const DirectMulti dm)
 {
     __shared__ __attribute__((aligned(16))) float ws[DIRECT_MAX_M * DIRECT_TP];   // [m][t]
     __shared__ float bs[DIRECT_MAX_M];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < DIRECT_MAXP; ++i) pi += (i < dm.n && (int)blockIdx.x >= dm.blk0[i]) ? 1 : 0;
+    const ConvGemmArgs& a = dm.a[pi];
+    const int local = (int)blockIdx.x - dm.blk0[pi], bx = local % dm.nx[pi], by = local / dm.nx[pi], nyp = dm.ny[pi];
     for (int i = threadIdx.x; i < a.M * DIRECT_TP; i += 256) {
         const int m = i / DIRECT_TP, t = i % DIRECT_TP;
         ws[i] = t < a.T ? a.W[(size_t)t * a.Kp * a.M + m] : 0.f;      // k = 0 rows of the [T][Kp][M] image
@@ -42,8 +56,8 @@ conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
     // store of the wave is then one contiguous run (256 bytes of x, 1 KB of an image row).  With four CONSECUTIVE columns per lane a
     // store instruction wrote 16 bytes every 64 -- 32 lines a quarter full instead of 8 full ones, and the texture path takes ~4 cycles
     // a line: the mel tower's first conv (130 MB of image) took 86 us.
-    const int j0 = (blockIdx.x * 256 + (threadIdx.x & ~63)) * 4 + (threadIdx.x & 63);
-    if ((blockIdx.x * 256 + (threadIdx.x & ~63)) * 4 >= a.N) return;   // (the whole wave)
+    const int j0 = (bx * 256 + (threadIdx.x & ~63)) * 4 + (threadIdx.x & 63);
+    if ((bx * 256 + (threadIdx.x & ~63)) * 4 >= a.N) return;   // (the whole wave)
     float x[4][9];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -69,10 +83,10 @@ conv_direct_cin1_x4_kernel(const ConvGemmArgs a)
     u32x4_t* yh = reinterpret_cast<u32x4_t*>(a.Yh);
     const size_t NX = (size_t)a.N + 1;
     const int groups = yh ? 2 * as_kbx(a.M) : (a.M + 7) / 8;
-    // blockIdx.y takes a share of the channel groups: few columns (the 1-D towers: 7 column blocks) would otherwise leave the chip to
+    // `by` (of the problem's ny) takes a share of the channel groups: few columns (the 1-D towers: 7 column blocks) would otherwise leave the chip to
     // 7 workgroups walking 64 channels each (47 us for 1.6 MB of output)
-    const int gpb = (groups + (int)gridDim.y - 1) / (int)gridDim.y, g_lo = blockIdx.y * gpb, g_hi = min(groups, g_lo + gpb);
-    if (yh && blockIdx.x == 0 && threadIdx.x == 0)
+    const int gpb = (groups + nyp - 1) / nyp, g_lo = by * gpb, g_hi = min(groups, g_lo + gpb);
+    if (yh && bx == 0 && threadIdx.x == 0)
         for (int g = g_lo; g < g_hi; ++g)
             for (int p = 0; p < 2; ++p) yh[((size_t)(g >> 1) * 4 + (g & 1) + 2 * p) * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};
     for (int g = g_lo; g < g_hi; ++g) {
@@ -400,6 +414,27 @@ static int launch_reduce(const ConvGemmArgs& a, int S, hipStream_t stream)
     return AS_OK;
 }
 
+// the fast direct form (T <= 9) for n problems
+static int launch_direct_x4(const ConvGemmArgs* a, int n, hipStream_t stream)
+{
+    DirectMulti dm;
+    memset(&dm, 0, sizeof(dm));
+    dm.n = n;
+    bool vec = true;
+    for (int i = 0; i < n; ++i) {
+        dm.a[i] = a[i];
+        const int nx = as_cdiv(a[i].N, 1024), groups = a[i].Yh ? 2 * as_kbx(a[i].M) : (a[i].M + 7) / 8;
+        dm.nx[i] = nx;
+        dm.ny[i] = std::max(1, std::min(groups, as_cdiv(1024, nx)));               // >= ~1024 workgroups when the channels allow it
+        dm.blk0[i + 1] = dm.blk0[i] + nx * dm.ny[i];
+        vec = vec && a[i].Y && (a[i].N & 3) == 0 && (a[i].ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a[i].Y) & 15) == 0;
+    }
+    if (vec) hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<true>, dim3(dm.blk0[n]), dim3(256), 0, stream, dm);
+    else hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<false>, dim3(dm.blk0[n]), dim3(256), 0, stream, dm);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
 extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -413,11 +448,8 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
         snprintf(tag, sizeof(tag), "M%d N%d K1 T%d direct", a.M, a.N, a.T);
         AsProfScope prof__(AS_CLS_GEMM, 2.0 * a.M * a.N * (double)a.T, 4.0 * ((double)a.T * a.M + a.N + (double)a.M * a.N), stream, tag);
         if (a.T <= 9) {
-            const bool vec = a.Y && (a.N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0;
-            const int nx = as_cdiv(a.N, 1024), groups = a.Yh ? 2 * as_kbx(a.M) : (a.M + 7) / 8;
-            const int ny = std::max(1, std::min(groups, as_cdiv(1024, nx)));        // >= ~1024 workgroups when the channels allow it
-            if (vec) hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<true>, dim3(nx, ny), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL(conv_direct_cin1_x4_kernel<false>, dim3(nx, ny), dim3(256), 0, stream, a);
+            const int rd = launch_direct_x4(&a, 1, stream);
+            if (rd != AS_OK) return rd;
         } else {
             hipLaunchKernelGGL(conv_direct_cin1_kernel, dim3(as_cdiv(a.N, 256)), dim3(256), 0, stream, a);
         }
@@ -511,17 +543,31 @@ extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_s
     static_assert(AS_MAX_MULTI == H3_MAXP, "header and kernel disagree");
     if (n == 1) return as_conv_gemm_f32(list_host, stream_);
     ConvGemmArgs norm[H3_MAXP];
-    int m = 0;
+    int m = 0, n_direct = 0;
     for (int i = 0; i < n; ++i) {
         const int r = conv_gemm_normalise(&list_host[i], norm[m]);
         if (r != AS_OK) return r;
         if (norm[m].N == 0) continue;                                    // nothing to do for this one
-        // in one launch only what the tiled kernel runs from operand images with the same arithmetic
-        if (direct_cin1(norm[m]) || !norm[m].Wh || !norm[m].Xh || norm[m].n_prod != norm[0].n_prod) return AS_EINVAL;
+        n_direct += direct_cin1(norm[m]) && norm[m].T <= 9 ? 1 : 0;
         ++m;
     }
     if (m == 0) return AS_OK;
     if (m == 1) return as_conv_gemm_f32(&norm[0], stream_);
+    if (n_direct == m) {                                                 // a set of Cin = 1 stems: the direct kernel, one launch
+        static_assert(DIRECT_MAXP == H3_MAXP, "one list length");
+        double fl = 0, by = 0;
+        for (int i = 0; i < m; ++i) {
+            fl += 2.0 * norm[i].M * norm[i].N * (double)norm[i].T;
+            by += 4.0 * ((double)norm[i].T * norm[i].M + norm[i].N + (double)norm[i].M * norm[i].N);
+        }
+        char tag[64];
+        snprintf(tag, sizeof(tag), "multi%d direct: M%d N%d K1 T%d | ...", m, norm[0].M, norm[0].N, norm[0].T);
+        AsProfScope prof__(AS_CLS_GEMM, fl, by, stream, tag);
+        return launch_direct_x4(norm, m, stream);
+    }
+    // otherwise, in one launch only what the tiled kernel runs from operand images with the same arithmetic
+    for (int i = 0; i < m; ++i)
+        if (direct_cin1(norm[i]) || !norm[i].Wh || !norm[i].Xh || norm[i].n_prod != norm[0].n_prod) return AS_EINVAL;
     const int choice = multi_tile_choice(norm, m);
     int bm, bn;
     tile_dims(choice, &bm, &bn);

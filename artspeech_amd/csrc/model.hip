@@ -746,6 +746,11 @@ static bool gemm_mergeable(const ConvGemmArgs& g)
     int32_t kind = 0, tile = 0, slices = 0;
     return as_conv_gemm_plan(&g, &kind, &tile, &slices) == AS_OK && kind == 1;
 }
+static bool gemm_direct(const ConvGemmArgs& g)           // the Cin = 1 direct kernel's fast form
+{
+    int32_t kind = 1, tile = 0, slices = 0;
+    return g.N > 0 && g.T <= 9 && as_conv_gemm_plan(&g, &kind, &tile, &slices) == AS_OK && kind == 0;
+}
 static bool gemm_tall(int M) { return M > 64 && (M % 128 == 0 || M % 128 > 64 || M >= 512); }   // (a 128-row tile is not half empty: conv_gemm.hip)
 
 static void play(Ctx& c, Sched& S)
@@ -831,6 +836,11 @@ static void play(Ctx& c, Sched& S)
         int pick[AS_MAX_MULTI], np = 0, lone = -1;
         for (int i = 0; i < nh && lone < 0; ++i)
             if (no_merge || !gemm_mergeable(S.q[heads[i]][head[heads[i]]].g)) lone = heads[i];
+        if (lone >= 0 && !no_merge && gemm_direct(S.q[lone][head[lone]].g)) {        // the towers' Cin = 1 stems that are ready together: one direct launch
+            for (int i = 0; i < nh && np < AS_MAX_MULTI; ++i)
+                if (gemm_direct(S.q[heads[i]][head[heads[i]]].g)) pick[np++] = heads[i];
+            if (np < 2) np = 0;
+        }
         if (lone < 0) {
             double work[2] = {0, 0};
             for (int i = 0; i < nh; ++i) {
