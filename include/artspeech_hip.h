@@ -184,8 +184,9 @@ int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
  * tiles first, so a problem that would own the chip alone at a fraction of its width -- the 40-tile convs of the duration predictor beside
  * the encoders' 240-tile ones, the small towers beside the mel tower: branches of ArtsSpeech.forward with no edge between them,
  * models.py:356-360, 417-424, 540-546 -- costs what it adds to the busiest CU, not a launch of its own.  Every problem as in
- * as_conv_gemm_f32 (own epilogue, groups, second operand, source positions), with these limits: operand images only (Xh given), no
- * Cin = 1 direct launches, one n_prod; 1 <= n <= AS_MAX_MULTI.  One tile shape serves the set (the cost model of the single launch on the
+ * as_conv_gemm_f32 (own epilogue, groups, second operand, source positions), with these limits: operand images only (Xh given) and one
+ * n_prod -- or a set made ONLY of Cin = 1 convs of <= 9 taps (the towers' stems: the direct kernel, one launch for the set); 1 <= n <=
+ * AS_MAX_MULTI.  One tile shape serves the set (the cost model of the single launch on the
  * summed tile count: as_conv_gemm_multi_tile says which), so a problem's result can differ in the last bits from its single launch where
  * that one would have split K inside the workgroup -- same arithmetic, other order of the partial sums.  n == 1 is as_conv_gemm_f32. */
 #define AS_MAX_MULTI 6

@@ -942,3 +942,37 @@ def test_down_multi_equals_single_launches(cuda):
     assert torch.equal(img3, ops.avgpool_down_image(X3, lin3, None, lout3, 1))
     with pytest.raises(ops._lib.HipLibraryError):
         ops.check(L.as_down_multi_f32(arr, 7, ops.stream()), "as_down_multi_f32")
+
+
+def test_conv_gemm_multi_direct_stems(cuda):
+    """as_conv_gemm_multi_f32 on a set of Cin = 1 stem convs (the towers' first convs: the direct kernel): one launch, every output --
+    fp32 rows and the LeakyReLU operand image -- bitwise equal to the single launches; a set that mixes direct and tiled problems is
+    refused."""
+    g = torch.Generator().manual_seed(23)
+    specs = [(64, 3, 80, [199, 66, 150]), (64, 3, 10, [199, 7]), (48, 1, 1, [300, 5, 64])]      # (Cout, kh, H, widths): 2-D 3x3 / 1-D k3
+    deferred, outs, singles = [], [], []
+    for cout, kh, H, widths in specs:
+        lay = Layout(widths, cuda, H=H)
+        w = torch.randn(cout, 1, kh, 3, generator=g) if kh > 1 else torch.randn(cout, 1, 3, generator=g)
+        b = torch.randn(cout, generator=g).to(cuda)
+        x = torch.randn(1, lay.N, generator=g).to(cuda)
+        taps = taps_2d(3, 3) if kh > 1 else taps_1d(3)
+        wt = ops.prep_weight(w, cuda)
+        y, yh = lay.new(cout), ops.new_image(cout, lay.N, cuda)
+        ops.conv_gemm(wt, x, lay, y, taps, bias=b, yh=yh, yh_lrelu=True, defer=deferred)
+        y1, yh1 = lay.new(cout), ops.new_image(cout, lay.N, cuda)
+        plan = {}
+        ops.conv_gemm(wt, x, lay, y1, taps, bias=b, yh=yh1, yh_lrelu=True, plan_out=plan)
+        assert plan["kind"] == 0
+        outs.append((y, yh))
+        singles.append((y1, yh1))
+    ops.conv_gemm_multi(deferred)
+    torch.cuda.synchronize()
+    for (y, yh), (y1, yh1) in zip(outs, singles):
+        assert torch.equal(y, y1) and torch.equal(yh, yh1)
+    lay = Layout([50], cuda)
+    x = torch.randn(32, 50, generator=g).to(cuda)
+    ops.conv_gemm(ops.prep_weight(torch.randn(64, 32, 3, generator=g), cuda), None, lay, lay.new(64), taps_1d(3), xs=ops.split_act(x, lay), K=32,
+                  defer=deferred)
+    with pytest.raises(ops._lib.HipLibraryError):
+        ops.conv_gemm_multi(deferred[-2:])
