@@ -1188,8 +1188,6 @@ struct BlkOpt {
     int ldo = 0;
     bool want_yh = false;              // also write the output as an operand image
     uint16_t* yh = nullptr;            // (where; null with want_yh: from the workspace)
-    float* sc_tmp = nullptr;           // learned-shortcut result when `out` aliases rows of X (decoder: in-place on the concat buffer)
-    bool yh_over_x = false;            // `yh` is X's own image (the same blocks): the shortcut cannot be read by the launch that overwrites it
 };
 
 Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
@@ -1199,9 +1197,9 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
     const int G = (int)o.names.size();
     auto sfx = [&](const char* s) { std::vector<std::string> v(o.names); for (auto& n : v) n += s; return v; };
     const bool has_sc = m.has(o.names[0] + ".conv1x1.weight");
-    // A learned shortcut whose input exists as an operand image is summed by conv2's launch (K2 more channels of its reduction)
-    // -- unless that launch writes its result image over the very image it would read (the decoder's in-place blocks).
-    const bool fold = has_sc && X.h && !o.upsample && !o.yh_over_x;
+    // A learned shortcut whose input exists as an operand image is summed by conv2's launch (K2 more channels of its reduction).
+    // (The decoder's in-place blocks give that launch another image to write than the one it reads: decoder().)
+    const bool fold = has_sc && X.h && !o.upsample;                     // (`yh`, if given, must not be the image X.h: that launch reads it)
     const GemmW *w1 = m.conv_stack(sfx(".conv1")), *w2 = fold ? m.conv_fold(sfx(".conv2"), sfx(".conv1x1")) : m.conv_stack(sfx(".conv2"));
     if (!w1 || !w2 || !X.lay) { c.fail(AS_EINVAL); return Y; }
     const int din = X.C, dout = w1->M;
@@ -1235,8 +1233,8 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
     if (has_sc && !fold) {                                              // learned shortcut (models.py:185-186), no bias
         ConvOpt q;
         q.group_cols = gc2;
-        float* dst = o.sc_tmp ? o.sc_tmp : out;
-        const int ldd = o.sc_tmp ? N2 : ldo;
+        float* dst = out;
+        const int ldd = ldo;
         const GemmW* wsc = m.conv_stack(sfx(".conv1x1"));
         if (X.h && !o.upsample) conv_h(c, wsc, X.h, din, lay2, k1, dst, ldd, q);
         else conv_x(c, wsc, sc, ldsc, din, lay2, k1, dst, ldd, q);
@@ -1885,9 +1883,10 @@ void copy_rows(Ctx& c, float* dst, int ldd, const float* src, int lds, int rows,
 
 // Decoder.forward (models.py:497-517).  x0 [C + 128][N2]: rows 0..C-1 already hold the up-sampled text encoding (models.py:500);
 // fne [12][ldp] = F0, N, EMA; mel [n_mels][ldo].
-// One concat buffer: the decode blocks write their result over the rows they were computed from (their learned shortcut goes to
-// a scratch tensor first), so cat([x, asr_res, F0, N, EMA]) (models.py:510) never copies anything; the operand image of the
-// concatenation is the concatenation of the parts' images (k-blocks are the image's outer axis), each written by its producer.
+// One concat buffer: the decode blocks write their fp32 result over the rows they were computed from, so cat([x, asr_res, F0, N, EMA])
+// (models.py:510) never copies anything; the operand image of the concatenation is the concatenation of the parts' images (k-blocks are
+// the image's outer axis), each written by its producer -- kept twice, because a block's conv2 launch reads the block's input image
+// (the folded shortcut) while it writes the result image.
 void decoder(Ctx& c, float* x0, const Lay* lay2, const float* fne, int ldp, const FcOut& fc, float* mel, int ldo)
 {
     const as_model& m = c.m;
@@ -1900,7 +1899,10 @@ void decoder(Ctx& c, float* x0, const Lay* lay2, const float* fne, int ldp, cons
     uint16_t* x0h = c.image(C + 128, N2);                               // image of x0 = [text encoding | F0 N EMA convs]
     float* catb = c.f32((size_t)cat * Nn2);                             // [x (2C) | asr_res (64) | F0 N EMA convs (128)]
     uint16_t* cath = c.image(cat, N2);
-    float* sc_tmp = c.f32((size_t)bott * Nn2);
+    // a second image of the concat buffer: decode.0 / decode.1 write their result image over the channels they were computed from, and
+    // their learned shortcut (K2 = 1216 more channels of conv2's reduction) reads the block's input image in that same launch -- so the
+    // two blocks ping-pong between two images; the 192 persistent channels (asr_res, F0 / N / EMA convs) are copied across once
+    uint16_t* cath2 = c.image(cat, N2);
     RUN(c, as_split_f16x2_f32(x0, N2, C, N2, 0, 0.f, x0h, c.s));         // text encoding part of x0's image
     const float *fb = nullptr, *w32 = nullptr;
     const GemmW* wf = m.fne(&fb, &w32);
@@ -1929,19 +1931,23 @@ void decoder(Ctx& c, float* x0, const Lay* lay2, const float* fne, int ldp, cons
         q.yh = at_block(cath, bott / 16);
         conv_h(c, m.conv(p + ".asr_res.0"), x0h, C, lay2, k1, catb ? catb + (size_t)bott * N2 : nullptr, N2, q);
     }
+    if (c.go() && hipMemcpyAsync(at_block(cath2, bott / 16), at_block(cath, bott / 16), (size_t)((cat - bott) / 16) * blk_bytes,
+                                 hipMemcpyDeviceToDevice, c.s) != hipSuccess)
+        c.fail((int)hipErrorUnknown);
     Act xc;
     xc.p = catb; xc.C = cat; xc.ld = N2; xc.lay = lay2; xc.h = cath;
-    for (int i = 0; i < 2; ++i) {                                       // decode.0, decode.1: 1216 -> 1024, in place on the concat buffer
+    for (int i = 0; i < 2; ++i) {                                       // decode.0, decode.1: 1216 -> 1024, fp32 in place on the concat buffer
         BlkOpt o;
         o.names = {p + ".decode." + std::to_string(i)};
         o.n1 = fc.norm(o.names[0] + ".norm1");
         o.n2 = fc.norm(o.names[0] + ".norm2");
         o.out = catb; o.ldo = N2;
-        o.want_yh = true; o.yh = cath;
-        o.sc_tmp = sc_tmp;
-        o.yh_over_x = true;
+        o.want_yh = true;
+        o.yh = i == 0 ? cath2 : cath;                                   // (the image the block does NOT read)
+        xc.h = i == 0 ? cath : cath2;
         adain_resblk1d(c, xc, o);
     }
+    xc.h = cath;
     Act y;
     for (int i = 2; i <= 5; ++i) {
         BlkOpt o;
