@@ -495,13 +495,19 @@ static int multi_tile_choice(const ConvGemmArgs* a, int n)
 {
     const char* env = getenv("AS_GEMM_TILE");           // tuning/experiments only
     if (env && atoi(env) > 0) return atoi(env);
-    bool all_tall = true, all_short = true, small_k = false, all_32 = true;
+    // 128-row tiles when the problems that can fill them carry (nearly) all of the set's work: a 64-channel conv that rides along -- the
+    // decoder's asr_res beside a predictor block -- leaves the lower half of its few tiles empty, which costs less than a launch of its own
+    bool all_short = true, small_k = false, all_32 = true;
+    double work = 0, tall_work = 0;
     for (int i = 0; i < n; ++i) {
-        all_tall = all_tall && multi_tall(a[i].M);
+        const double wi = (double)a[i].M * a[i].N * ((double)a[i].K * a[i].T + a[i].K2);
+        work += wi;
+        if (multi_tall(a[i].M)) tall_work += wi;
         all_short = all_short && a[i].M <= 64;
         all_32 = all_32 && a[i].M <= 32;
         small_k = small_k || a[i].Kp <= 32;
     }
+    const bool all_tall = tall_work >= 0.9 * work;
     if (all_32 && a[0].n_prod == 3) return 2;             // (as the single launch: a 64-row tile would be half empty)
     static const int choices[5] = {22, 21, 12, 11, 14};
     static const double t1[5] = {1.0, 0.78, 0.78, 0.59, 1.3};   // (64 x 256 from M64 N509440 K64 T9: 139 us against 167 with 64 x 128)

@@ -848,9 +848,11 @@ static void play(Ctx& c, Sched& S)
                 work[gemm_tall(g.M) ? 1 : 0] += (double)g.M * g.N * ((double)g.K * g.T + g.K2);
             }
             const int cls = work[1] >= work[0] ? 1 : 0;
+            // (a 64-channel conv may ride with a set of 128-row problems when it is a small part of the work: as_conv_gemm_multi_tile)
+            const bool ride = cls == 1 && work[0] <= 0.1 * work[1];
             for (int i = 0; i < nh && np < AS_MAX_MULTI; ++i) {
                 const ConvGemmArgs& g = S.q[heads[i]][head[heads[i]]].g;
-                if ((gemm_tall(g.M) ? 1 : 0) == cls && (np == 0 || g.n_prod == S.q[pick[0]][head[pick[0]]].g.n_prod)) pick[np++] = heads[i];
+                if (((gemm_tall(g.M) ? 1 : 0) == cls || ride) && (np == 0 || g.n_prod == S.q[pick[0]][head[pick[0]]].g.n_prod)) pick[np++] = heads[i];
             }
             if (np < 2) lone = pick[0];
         }
@@ -1887,23 +1889,49 @@ void copy_rows(Ctx& c, float* dst, int ldd, const float* src, int lds, int rows,
 // (models.py:510) never copies anything; the operand image of the concatenation is the concatenation of the parts' images (k-blocks are
 // the image's outer axis), each written by its producer -- kept twice, because a block's conv2 launch reads the block's input image
 // (the folded shortcut) while it writes the result image.
-void decoder(Ctx& c, float* x0, const Lay* lay2, const float* fne, int ldp, const FcOut& fc, float* mel, int ldo)
+struct DecPre {                   // the decoder's buffers and the part of it that needs nothing from the predictors
+    uint16_t *x0h = nullptr, *cath = nullptr, *cath2 = nullptr;
+    float* catb = nullptr;
+    bool ok = false;
+};
+// x0 rows 0..C-1 = the up-sampled text encoding: its operand image and asr_res (models.py:507) -- independent of ArtsPredictor, so a
+// recording plan runs them beside it (forward_b)
+DecPre decoder_pre(Ctx& c, float* x0, const Lay* lay2)
 {
     const as_model& m = c.m;
     const std::string p = "decoder";
+    DecPre d;
     const int C = m.cfg.hidden_dim, N2 = lay2->N, Nn2 = std::max(N2, 1), bott = 2 * C, cat = bott + 64 + 128;
+    const size_t blk_bytes = (size_t)4 * (N2 + 1) * 16;
+    if (C % 64 || (C + 128) % 64) { c.fail(AS_EINVAL); return d; }      // parts must start on the image's 4-block granularity
+    d.x0h = c.image(C + 128, N2);                                       // image of x0 = [text encoding | F0 N EMA convs]
+    d.catb = c.f32((size_t)cat * Nn2);                                  // [x (2C) | asr_res (64) | F0 N EMA convs (128)]
+    d.cath = c.image(cat, N2);
+    d.cath2 = c.image(cat, N2);                                         // (see decoder(): the in-place blocks ping-pong between two images)
+    RUN(c, as_split_f16x2_f32(x0, N2, C, N2, 0, 0.f, d.x0h, c.s));      // text encoding part of x0's image
+    ConvOpt q;
+    q.bias = m.bias(p + ".asr_res.0");
+    q.want_yh = true;
+    q.yh = d.cath ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d.cath) + (size_t)(bott / 16) * blk_bytes) : nullptr;
+    conv_h(c, m.conv(p + ".asr_res.0"), d.x0h, C, lay2, taps_1d(1), d.catb ? d.catb + (size_t)bott * N2 : nullptr, N2, q);
+    d.ok = c.rc == 0;
+    return d;
+}
+
+void decoder(Ctx& c, const DecPre& dp, float* x0, const Lay* lay2, const float* fne, int ldp, const FcOut& fc, float* mel, int ldo)
+{
+    const as_model& m = c.m;
+    const std::string p = "decoder";
+    const int C = m.cfg.hidden_dim, N2 = lay2->N, bott = 2 * C, cat = bott + 64 + 128;
     const Taps k1 = taps_1d(1);
     const size_t blk_bytes = (size_t)4 * (N2 + 1) * 16;                 // one k-block of an image over N2 columns
     auto at_block = [&](uint16_t* img, int kb) { return img ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(img) + (size_t)kb * blk_bytes) : nullptr; };
-    if (C % 64 || (C + 128) % 64) { c.fail(AS_EINVAL); return; }        // parts must start on the image's 4-block granularity
-    uint16_t* x0h = c.image(C + 128, N2);                               // image of x0 = [text encoding | F0 N EMA convs]
-    float* catb = c.f32((size_t)cat * Nn2);                             // [x (2C) | asr_res (64) | F0 N EMA convs (128)]
-    uint16_t* cath = c.image(cat, N2);
-    // a second image of the concat buffer: decode.0 / decode.1 write their result image over the channels they were computed from, and
-    // their learned shortcut (K2 = 1216 more channels of conv2's reduction) reads the block's input image in that same launch -- so the
-    // two blocks ping-pong between two images; the 192 persistent channels (asr_res, F0 / N / EMA convs) are copied across once
-    uint16_t* cath2 = c.image(cat, N2);
-    RUN(c, as_split_f16x2_f32(x0, N2, C, N2, 0, 0.f, x0h, c.s));         // text encoding part of x0's image
+    if (!dp.ok) { c.fail(AS_EINVAL); return; }
+    uint16_t *x0h = dp.x0h, *cath = dp.cath, *cath2 = dp.cath2;
+    float* catb = dp.catb;
+    // (cath2: a second image of the concat buffer.  decode.0 / decode.1 write their result image over the channels they were computed from,
+    // and their learned shortcut -- K2 = 1216 more channels of conv2's reduction -- reads the block's input image in that same launch: the
+    // two blocks ping-pong between two images; the 192 persistent channels (asr_res, F0 / N / EMA convs) are copied across once)
     const float *fb = nullptr, *w32 = nullptr;
     const GemmW* wf = m.fne(&fb, &w32);
     if (!wf) { c.fail(AS_EINVAL); return; }
@@ -1923,13 +1951,6 @@ void decoder(Ctx& c, float* x0, const Lay* lay2, const float* fne, int ldp, cons
         o.out = catb; o.ldo = N2;
         o.want_yh = true; o.yh = cath;
         adain_resblk1d(c, x, o);
-    }
-    {   // asr_res (models.py:507): 1x1 conv of the up-sampled text encoding = the first C channels of x0's image
-        ConvOpt q;
-        q.bias = m.bias(p + ".asr_res.0");
-        q.want_yh = true;
-        q.yh = at_block(cath, bott / 16);
-        conv_h(c, m.conv(p + ".asr_res.0"), x0h, C, lay2, k1, catb ? catb + (size_t)bott * N2 : nullptr, N2, q);
     }
     if (c.go() && hipMemcpyAsync(at_block(cath2, bott / 16), at_block(cath, bott / 16), (size_t)((cat - bott) / 16) * blk_bytes,
                                  hipMemcpyDeviceToDevice, c.s) != hipSuccess)
@@ -2113,14 +2134,33 @@ void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_
     float* x0 = c.f32((size_t)(C + 128) * std::max(N2, 1));
     // every AdaIN fc layer of the predictors and the decoder (~75 MB of weights): one GEMM on the style vectors
     const FcOut fc = A.has_fc ? A.fc : adain_fc_all(c, "style", style_norms(m), A.style, 2 * m.cfg.style_dim, 2 * m.cfg.style_dim, B);
-    // T_en @ pred_aln_trg is a column gather (models.py:367-368)
-    c.hint(0, 4.0 * C * ((double)A.tok->N + N1));
-    RUN(c, as_expand_f32(A.a_en, A.ld_en, C, tof, N1, 1, a_ex, N1, c.s));
-    arts_predictor(c, a_ex, N1, lay1, fc, fne, N2);
+    // T_en @ pred_aln_trg is a column gather (models.py:367-368); the text encoding at the mel rate is nearest x2 of it (models.py:500).
+    // What the decoder can do before the predictors are done -- x0's text part, its image, asr_res -- a recording plan runs BESIDE them
+    // (one more queue: the 64-channel asr_res conv then rides in a predictor launch).
+    const bool rec = c.p.serial && c.p.merge;
+    DecPre dp;
+    {
+        std::unique_ptr<Fork> f;
+        if (rec) {
+            f.reset(new Fork(c, 1, 0));
+            f->branch(0);
+            c.hint(0, 4.0 * C * ((double)A.tok->N + N2));
+            RUN(c, as_expand_f32(A.t_en, A.ld_en, C, tof, N1, 2, x0, N2, c.s));
+            dp = decoder_pre(c, x0, lay2);
+            f->back();
+        }
+        c.hint(0, 4.0 * C * ((double)A.tok->N + N1));
+        RUN(c, as_expand_f32(A.a_en, A.ld_en, C, tof, N1, 1, a_ex, N1, c.s));
+        arts_predictor(c, a_ex, N1, lay1, fc, fne, N2);
+        if (f) f->join();
+    }
     if (c.go()) c.p.mark(3, c.s);
-    c.hint(0, 4.0 * C * ((double)A.tok->N + N2));
-    RUN(c, as_expand_f32(A.t_en, A.ld_en, C, tof, N1, 2, x0, N2, c.s));      // text encoding at the mel rate: nearest x2 (models.py:500)
-    decoder(c, x0, lay2, fne, N2, fc, io->mel_out, io->ld_out);
+    if (!rec) {
+        c.hint(0, 4.0 * C * ((double)A.tok->N + N2));
+        RUN(c, as_expand_f32(A.t_en, A.ld_en, C, tof, N1, 2, x0, N2, c.s));
+        dp = decoder_pre(c, x0, lay2);
+    }
+    decoder(c, dp, x0, lay2, fne, N2, fc, io->mel_out, io->ld_out);
     if (c.go()) c.p.mark(4, c.s);
     if (c.go()) {
         if (io->F0) copy_rows(c, io->F0, io->ld_pred, fne, N2, 1, N2);
@@ -2539,7 +2579,7 @@ size_t count_module(const as_model* m, as_plan* p, int module, const as_batch* b
         float* x0 = c.f32((size_t)(C + 128) * std::max(lay2->N, 1));
         float* fne = c.f32((size_t)12 * std::max(lay2->N, 1));
         const FcOut fc = adain_fc_all(c, "style", style_norms(*m), nullptr, 2 * m->cfg.style_dim, 2 * m->cfg.style_dim, B);
-        decoder(c, x0, lay2, fne, lay2->N, fc, nullptr, lay2->N);
+        decoder(c, decoder_pre(c, x0, lay2), x0, lay2, fne, lay2->N, fc, nullptr, lay2->N);
         break;
     }
     default: return 0;
@@ -2699,7 +2739,7 @@ try {                                                                    // noth
     copy_rows(c, fne + (size_t)2 * lay2->N, lay2->N, EMA, ldp, 10, lay2->N);
     const int sd2 = 2 * m->cfg.style_dim;
     const FcOut fc = adain_fc_all(c, "style", style_norms(*m), style, sd2, sd2, batch->B);
-    decoder(c, x0, lay2, fne, lay2->N, fc, mel, ldo);
+    decoder(c, decoder_pre(c, x0, lay2), x0, lay2, fne, lay2->N, fc, mel, ldo);
     return k.done();
 } catch (const std::bad_alloc&) {
     return (int)hipErrorOutOfMemory;
