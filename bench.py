@@ -364,6 +364,11 @@ def bench_config(net, dev, name, n_utt, n_tok, m_half, t_ref, steps, n_prod_mode
         d = dict(ms_per_step=el / steps * 1e3, ms_per_utt=el / steps * 1e3 / n_utt, frames_per_s=frames * steps / el,
                  x_realtime=frames * steps / el * FRAME_SEC, gemm_tflops=tf, gemm_frac_of_peak=tf / peak,
                  gemm_gflop_per_step=kern["conv_gemm"]["gflop_per_step"],
+                 launches_per_step={c: kern[c]["launches_per_step"] for c in kern}, launches=sum(kern[c]["launches_per_step"] for c in kern),
+                 # the conv GEMMs' algorithmic bytes per step (at batch 1: the weights, 4 bytes each) over the step's time against the HBM peak:
+                 # what a batch-1 step is bound by if it were bound by any unit (it is bound by its count of dependent launches)
+                 gemm_algorithmic_gbyte_per_step=kern["conv_gemm"]["gbyte_per_step"],
+                 weight_stream_frac_of_hbm=kern["conv_gemm"]["gbyte_per_step"] / (el / steps * 1e3) / PEAK_HBM_TBS,
                  attention_ms_per_step=kern.get("attention", {}).get("ms_per_step"), lstm_ms_per_step=kern.get("lstm", {}).get("ms_per_step"))
         if n_prod == 3:
             ref_mel = mel
