@@ -413,6 +413,25 @@ def mean3(A, B, C3, n, Y):
     return Y
 
 
+def respair(X, lay, w1, b1, w2, b2, k, dil, slope, Y=None, add=None):
+    """One residual step of ResBlock1 (Vocoder/vocoder.py:35-42) as one launch: Y = X + conv2(lrelu(conv1(lrelu(X)))), conv1 with
+    dilation `dil`, both with k taps; X [C][N] fp32 with C = 32 or 64, w1 / w2 = prep_weight of the [C][C][k] weights.
+    add = (A, B): Y = ((A + B) + Y) / 3 (the mean of a stage's three stacks).  Y must not be X."""
+    C = X.shape[0]
+    if Y is None:
+        Y = lay.new(C)
+    a = _lib.ResPairArgs()
+    a.x, a.ldx, a.y, a.ldy = _p(X), _ld(X), _p(Y), _ld(Y)
+    a.w1, a.w2, a.b1, a.b2 = _p(w1.wh), _p(w2.wh), _p(b1), _p(b2)
+    a.scale1, a.scale2 = 1.0 / w1.scale, 1.0 / w2.scale
+    a.C, a.N, a.k, a.dil, a.slope = C, lay.N, int(k), int(dil), float(slope)
+    a.col_off, a.B, a.max_w = _p(lay.col_off), lay.B, lay.max_cols
+    if add is not None:
+        a.add1, a.add2, a.ld_add, a.out_div = _p(add[0]), _p(add[1]), _ld(add[0]), 3.0
+    check(_lib.lib().as_respair_f32(ctypes.byref(a), stream()), "as_respair_f32")
+    return Y
+
+
 def dwconv_down(X, lin, Y, lout, w, bias, kh, lrelu):
     check(_lib.lib().as_dwconv_down_f32(_p(X), _ld(X), _p(lin.col_off), _p(lin.widths), lin.H, _p(Y), _ld(Y),
                                         _p(lout.col_off), _p(lout.widths), lout.H, _p(w), _p(bias), kh, lin.B,

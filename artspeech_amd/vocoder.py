@@ -10,6 +10,8 @@ Everything dense runs through the conv GEMM of the acoustic path (``ops.conv_gem
                          x[q-1], x[q], x[q+1] with a per-phase weight (zero where a phase does not use the tap)
 Activations stay in the packed-frames layout, so a ragged batch costs nothing and every utterance equals its B = 1 result.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -151,9 +153,23 @@ class Generator:
             outs = []
             # LeakyReLU(x) as an operand image, once for the three residual stacks that start from x; inside a stack every conv hands its
             # LeakyReLU'd result to the next one as an image (ConvGemmArgs.Yh / yh_lrelu): no fp32 copy of conv1's output, no split passes
-            xh = ops.split_act(x, lay, in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
             # (the three stacks of a stage as ONE launch per step -- ops.conv_gemm_multi -- was measured: 18.2 ms per batch against 17.9 with
             # a launch per conv; these grids hold thousands of tiles each, there is no tail worth filling)
+            fused = cout in (32, 64) and nk == 3 and os.environ.get("AS_VOC_FUSED", "1") != "0"
+            if fused:
+                # 32 / 64 channels: a residual step is ONE launch that keeps its column tile in LDS between the two convs (ops.respair):
+                # x in, y out -- no operand images in HBM at all; the stage's mean rides in the last step of the third stack
+                for j in range(nk):
+                    y = x
+                    blk = W[f"rb{i * nk + j}"]
+                    for n, (w1, b1, t1, w2, b2, t2) in enumerate(blk):
+                        last = j + 1 == nk and n + 1 == len(blk)
+                        y = ops.respair(y, lay, w1, b1, w2, b2, len(t1), t1[1][1] - t1[0][1] if len(t1) > 1 else 1, LRELU_SLOPE,
+                                        add=(outs[0], outs[1]) if last else None)
+                    outs.append(y)
+                x = outs[2]
+                continue
+            xh = ops.split_act(x, lay, in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
             for j in range(nk):
                 y, yh = x, xh
                 blk = W[f"rb{i * nk + j}"]

@@ -447,6 +447,26 @@ int as_interleave_phases_f32(const float* z, int ldz, const float* bias, int C, 
                              as_stream_t stream);
 /* y = (a + b + c) / 3 over [C][N]                                              vocoder.py:104-110 */
 int as_mean3_f32(const float* a, const float* b, const float* c, int ld, int C, int N, float* y, int ldy, as_stream_t stream);
+/* One residual step of ResBlock1 (vocoder.py:35-42) as ONE launch, for the stages with C = 32 or 64 channels:
+ *     y = x + conv2(lrelu(conv1(lrelu(x))))        conv1: k taps with dilation dil, conv2: k taps with dilation 1, zero padding per utterance
+ * x, y fp32 [C][N] (y != x: a workgroup reads its neighbours' columns of x); w1, w2 = the conv GEMM's weight images of the two
+ * [C][C][k] weights (as_prep_weight_f16x2_host, G = 1), scale1 / scale2 = 1 / their scales, b1 / b2 [C] or NULL; slope = LeakyReLU's;
+ * col_off int32 [B + 1] = the utterances' first columns (packed frames), max_w = the widest utterance; k odd <= 17, dil * (k / 2) <= 40.
+ * add1 / add2 (both or neither; [C][N], ld_add): y = ((add1 + add2) + y) / out_div -- the mean of the three stacks of a stage
+ * (vocoder.py:104-110) folded into the last step of the third.  Same f16x3 arithmetic as as_conv_gemm_f32; the tile's columns stay in
+ * LDS between the two convs (csrc/respair.hip). */
+typedef struct AsResPairArgs {
+    const float* x; int32_t ldx;
+    float* y; int32_t ldy;
+    const uint16_t* w1; const uint16_t* w2;
+    const float* b1; const float* b2;
+    float scale1, scale2;
+    int32_t C, N, k, dil;
+    float slope;
+    const int32_t* col_off; int32_t B, max_w;
+    const float* add1; const float* add2; int32_t ld_add; float out_div;
+} AsResPairArgs;
+int as_respair_f32(const AsResPairArgs* a, as_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Module-level entry points: the acoustic model behind an opaque handle.  A C / C++ host runs

@@ -45,5 +45,5 @@ if os.environ.get("PROFILE"):
     agg = collections.OrderedDict()
     for r in csv.reader(open("/tmp/voc_prof.csv")):
         a = agg.setdefault((r[0], r[1]), [0, 0.0, 0.0]); a[0] += 1; a[1] += float(r[2]); a[2] += float(r[3])
-    for (c, tag), (k, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
+    for (c, tag), (k, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TOP', 22))]:
         print(f"cls{c} {tag:44s} n={k:3d} {t:8.3f} ms  {f / t / 1e9 if t else 0:7.1f} TF/s")

@@ -976,3 +976,53 @@ def test_conv_gemm_multi_direct_stems(cuda):
                   defer=deferred)
     with pytest.raises(ops._lib.HipLibraryError):
         ops.conv_gemm_multi(deferred[-2:])
+
+
+@pytest.mark.parametrize("C,k,dil,lens", [(32, 3, 1, [700, 3, 241, 1]), (32, 7, 5, [500, 17]), (32, 11, 5, [960, 40, 240]), (32, 11, 3, [239]),
+                                          (64, 3, 3, [481, 5]), (64, 7, 1, [300, 300]), (64, 11, 5, [721, 26]), (64, 11, 1, [250])])
+def test_respair_equals_two_convs(cuda, C, k, dil, lens):
+    """One residual step of the vocoder's ResBlock1 as one launch (ops.respair) against fp32 torch and against the two conv GEMM launches
+    it replaces: ragged utterances (shorter than a halo, one column, exactly one tile, several tiles), every (k, dilation) of the config."""
+    g = torch.Generator().manual_seed(C + 13 * k + dil)
+    w1 = torch.randn(C, C, k, generator=g) * (0.6 / np.sqrt(C * k))
+    w2 = torch.randn(C, C, k, generator=g) * (0.6 / np.sqrt(C * k))
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    xs = [torch.randn(C, L, generator=g) for L in lens]
+
+    def step(x):
+        t = F.conv1d(F.leaky_relu(x[None], 0.1), w1, b1, padding=dil * (k // 2), dilation=dil)
+        return (F.conv1d(F.leaky_relu(t, 0.1), w2, b2, padding=k // 2) + x[None])[0]
+
+    want = packed([step(x) for x in xs])
+    lay = Layout(lens, cuda)
+    W1, W2 = ops.prep_weight(w1, cuda), ops.prep_weight(w2, cuda)
+    X = packed(xs).to(cuda)
+    y = ops.respair(X, lay, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1)
+    torch.cuda.synchronize()
+    d = float((y.cpu() - want).abs().max())
+    assert d <= 2e-6, d
+    # the two launches
+    t1 = [(0, dil * (t - k // 2)) for t in range(k)]
+    xh = ops.split_act(X, lay, in_act=ops.ACT_LRELU, in_slope=0.1)
+    xth = ops.new_image(C, lay.N, cuda)
+    ops.conv_gemm(W1, None, lay, None, t1, bias=b1.to(cuda), xs=xh, K=C, yh=xth, yh_lrelu=True, in_slope=0.1)
+    y2 = ops.conv_gemm(W2, None, lay, lay.new(C), taps_1d(k), bias=b2.to(cuda), res=X, xs=xth, K=C)
+    assert float((y - y2).abs().max()) <= 2e-6
+    # the stage's mean folded into the step
+    A, B = torch.randn(C, lay.N, generator=g), torch.randn(C, lay.N, generator=g)
+    y3 = ops.respair(X, lay, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1, add=(A.to(cuda), B.to(cuda)))
+    assert float((y3.cpu() - ((A + B) + y.cpu()) / 3.0).abs().max()) <= 5e-7
+
+
+def test_respair_rejects(cuda):
+    from artspeech_amd import _lib
+    lay = Layout([100], cuda)
+    w = ops.prep_weight(torch.randn(32, 32, 3), cuda)
+    X = torch.randn(32, 100, device=cuda)
+    with pytest.raises(_lib.HipLibraryError):
+        ops.respair(X, lay, w, None, w, None, 3, 1, 0.1, Y=X)                  # in place
+    w48 = ops.prep_weight(torch.randn(48, 48, 3), cuda)
+    with pytest.raises(_lib.HipLibraryError):
+        ops.respair(torch.randn(48, 100, device=cuda), lay, w48, None, w48, None, 3, 1, 0.1)
+    with pytest.raises(_lib.HipLibraryError):
+        ops.respair(X, lay, w, None, w, None, 4, 1, 0.1)                       # even k
