@@ -222,7 +222,8 @@ def lib():
 
 AS_EDEVICE = -3
 STATUS_NAMES = ("clustered LSTM hand-over timed out", "MAS band hand-over timed out", "token id outside [0, n_token)",
-                "non-finite accumulator (an operand beyond fp16's range, or a non-finite input)")
+                "non-finite accumulator (an operand beyond fp16's range, or a non-finite input)",
+                "an utterance wider than the column descriptors allow (AS_META_MAX_W)")
 
 
 def device_status(clear=False):

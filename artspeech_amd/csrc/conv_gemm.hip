@@ -65,7 +65,7 @@ conv_direct_cin1_x4_kernel(const DirectMulti dm)
         int h = 0, w = 0, H = 1, Wj = 0x7fffffff;
         if (a.meta && j < a.N) {
             const unsigned long long md = a.meta[j];
-            h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff), H = (int)((md >> 32) & 0xffff), Wj = (int)(md >> 48);
+            h = AS_META_h(md), w = AS_META_w(md), H = AS_META_H(md), Wj = AS_META_W(md);
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -153,7 +153,7 @@ conv_direct_cin1_kernel(const ConvGemmArgs a)
     int h = 0, w = 0, H = 1, Wj = 0x7fffffff;
     if (a.meta) {
         const unsigned long long md = a.meta[j];
-        h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff), H = (int)((md >> 32) & 0xffff), Wj = (int)(md >> 48);
+        h = AS_META_h(md), w = AS_META_w(md), H = AS_META_H(md), Wj = AS_META_W(md);
     }
     float x[AS_MAX_TAPS];
 #pragma unroll

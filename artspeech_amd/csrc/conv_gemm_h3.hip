@@ -138,9 +138,9 @@ conv_gemm_h3_kernel(const H3Multi mm)
     if (j < n_end) {
         if (a.meta) {
             const unsigned long long md = a.meta[j];
-            const int h = (int)(md & 0xffff), w = (int)((md >> 16) & 0xffff);
-            const int H = (int)((md >> 32) & 0xffff);
-            Wj = (int)(md >> 48);
+            const int h = AS_META_h(md), w = AS_META_w(md);
+            const int H = AS_META_H(md);
+            Wj = AS_META_W(md);
             for (int t = 0; t < a.T; ++t) {
                 const int byte = (int)(h3_tap_word(tp, t) >> ((t & 7) * 8)) & 0xff;
                 const int dh = tp.wide ? 0 : (byte >> 4) - 8, dw = tp.wide ? byte - 128 : (byte & 15) - 8;

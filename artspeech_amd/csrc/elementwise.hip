@@ -21,26 +21,30 @@ static __device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 
 // column descriptors
 // ---------------------------------------------------------------------------------------------------
 __global__ void make_meta_kernel(const int* __restrict__ widths, const int* __restrict__ col_off, int B, int H,
-                                 unsigned long long* __restrict__ meta)
+                                 unsigned long long* __restrict__ meta, unsigned* __restrict__ status)
 {
     const int b = blockIdx.y;
     const int W = widths[b];
     const int base = col_off[b];
+    if (W > AS_META_MAX_W) {                                 // (the field would wrap: every conv would see walls in the wrong places)
+        if (blockIdx.x == 0 && threadIdx.x == 0) as_status_raise(status, AS_STATUS_BAD_LAYOUT);
+        return;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
         const unsigned long long h = i / W, w = i - (i / W) * W;
-        meta[base + i] = h | (w << 16) | ((unsigned long long)H << 32) | ((unsigned long long)W << 48);
+        meta[base + i] = AS_META_PACK(h, w, H, W);
     }
 }
 
 extern "C" int as_make_meta(const int32_t* widths, const int32_t* col_off, int B, int H, int n_cols_max,
                             uint64_t* meta, as_stream_t stream)
 {
-    if (!widths || !col_off || !meta || B < 0 || H <= 0 || H > 65535) return AS_EINVAL;
+    if (!widths || !col_off || !meta || B < 0 || H <= 0 || H > AS_META_MAX_H) return AS_EINVAL;
     if (B == 0) return AS_OK;
     const int gx = n_cols_max > 0 ? as_cdiv(as_cdiv(n_cols_max, B > 0 ? B : 1), 256) : 1;
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(make_meta_kernel, dim3(gx < 1 ? 1 : (gx > 64 ? 64 : gx), B), dim3(256), 0, (hipStream_t)stream,
-                       widths, col_off, B, H, reinterpret_cast<unsigned long long*>(meta));
+                       widths, col_off, B, H, reinterpret_cast<unsigned long long*>(meta), as_status_words_device());
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

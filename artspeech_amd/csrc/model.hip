@@ -596,7 +596,7 @@ struct Ctx {
             L->off.resize(L->B + 1);
             L->off[0] = 0;
             for (int b = 0; b < L->B; ++b) {
-                if (widths[b] < 0 || widths[b] > 65535) { fail(AS_EINVAL); return nullptr; }
+                if (widths[b] < 0 || widths[b] > AS_META_MAX_W || H > AS_META_MAX_H) { fail(AS_EINVAL); return nullptr; }
                 L->off[b + 1] = L->off[b] + H * widths[b];
                 L->max_w = std::max(L->max_w, widths[b]);
             }
@@ -1587,7 +1587,7 @@ void tower2d(Ctx& c, const std::string& p, const float* X, const Lay* lay, const
                 for (int wo = 0; wo < lout->w[b]; ++wo, ++j) {
                     const int h = ho * last_stride, w = wo * last_stride;
                     t[j] = lin->off[b] + h * lin->w[b] + w;
-                    const uint64_t md = (uint64_t)h | ((uint64_t)w << 16) | ((uint64_t)lin->H << 32) | ((uint64_t)lin->w[b] << 48);
+                    const uint64_t md = AS_META_PACK(h, w, lin->H, lin->w[b]);
                     memcpy(&t[mo + 2 * (size_t)j], &md, 8);
                 }
         return t;

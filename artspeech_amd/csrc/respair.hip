@@ -21,20 +21,25 @@
 // the order of the fp32 partial sums inside a tap differs, so results agree to fp32 rounding, not bit for bit.
 #include "conv_gemm.h"
 #include <cstdio>
+#include <cstdlib>
 
 typedef __attribute__((address_space(3))) void rp_lds_void;
 
 namespace {
-constexpr int RP_MW = 256;       // conv1 columns of a workgroup
-constexpr int RP_OW = 240;       // output columns of a workgroup
 constexpr int RP_ML = 8;         // conv1's lead over the first output column ((k-1)/2 <= 8)
-constexpr int RP_MWP = 272;      // columns of the conv1 tile as conv2 addresses it: 255 + 8 + 8 < 272
 constexpr int RP_ABUF = 4096;    // one weight granule
 
-template <int C>
-__global__ void __launch_bounds__(256) respair_kernel(const AsResPairArgs a)
+// NW waves: 64 NW conv1 columns, 64 NW - 16 output columns per workgroup.  Four waves and two to four workgroups per CU wherever the tile
+// fits twice into the 160 KB of LDS; eight waves, one workgroup per CU (152 KB) for 64 channels with a halo over 19 columns (k = 11, d = 5:
+// as four waves alone on a CU that step took 879 us against 540 for d = 1, 3)
+template <int C, int NW>
+__global__ void __launch_bounds__(64 * NW) respair_kernel(const AsResPairArgs a)
 {
     constexpr int KB = C / 16, MB = C / 32, PL = KB * 4;
+    constexpr int NT = 64 * NW;
+    constexpr int RP_MW = 64 * NW;                                       // conv1 columns of a workgroup
+    constexpr int RP_OW = RP_MW - 16;                                    // output columns of a workgroup
+    constexpr int RP_MWP = RP_MW + 16;                                   // columns of the conv1 tile as conv2 addresses it: MW - 1 + 8 + 8 < MWP
     constexpr int GPT = C == 32 ? 1 : KB;                               // weight granules per tap
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const abuf = smem;
@@ -59,8 +64,9 @@ __global__ void __launch_bounds__(256) respair_kernel(const AsResPairArgs a)
 #if __HIP_DEVICE_COMPILE__
         const int g = gg < G ? gg : gg - G;
         const int soff = C == 32 ? g * (int)TAPB : g * RP_ABUF;          // (C = 64: a tap is exactly four granules)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(gg < G ? rsW1 : rsW2, (rp_lds_void*)(abuf + (gg & 1) * RP_ABUF + wave * 1024), 16,
-                                                 (unsigned)tid * 16u, soff, 0, 0);
+        if (NW == 4 || wave < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(gg < G ? rsW1 : rsW2, (rp_lds_void*)(abuf + (gg & 1) * RP_ABUF + wave * 1024), 16,
+                                                     (unsigned)tid * 16u, soff, 0, 0);
 #endif
     };
     dma(0);
@@ -71,7 +77,7 @@ __global__ void __launch_bounds__(256) respair_kernel(const AsResPairArgs a)
     {
         const int total = (C / 8) * XW;
 #pragma unroll 2
-        for (int it = tid; it < total; it += 256) {
+        for (int it = tid; it < total; it += NT) {
             const int g = it / XW, c = it - g * XW;
             const int col = X0 + c;
             const unsigned off = (col >= n_lo && col < n_hi) ? (unsigned)(8 * g * a.ldx + col) * 4u : OOBH;
@@ -257,14 +263,19 @@ __global__ void __launch_bounds__(256) respair_kernel(const AsResPairArgs a)
 }
 
 template <int C>
+int lds_bytes(const AsResPairArgs& a, int nw)
+{
+    const int h1 = a.dil * (a.k / 2), mw = 64 * nw;
+    const int cols = mw + 2 * h1 > mw + 16 ? mw + 2 * h1 : mw + 16;
+    return 2 * RP_ABUF + (C / 16) * 4 * cols * 16;
+}
+
+template <int C, int NW>
 int launch(const AsResPairArgs& a, hipStream_t stream)
 {
-    const int h1 = a.dil * (a.k / 2);
-    const int cols = RP_MW + 2 * h1 > RP_MWP ? RP_MW + 2 * h1 : RP_MWP;
-    const int lds = 2 * RP_ABUF + (C / 16) * 4 * cols * 16;
-    AS_LDS_OPT_IN(respair_kernel<C>, 160 * 1024);
-    const int tiles = as_cdiv(a.max_w, RP_OW);
-    hipLaunchKernelGGL(respair_kernel<C>, dim3((unsigned)((tiles + 7) & ~7), (unsigned)a.B), dim3(256), lds, stream, a);
+    AS_LDS_OPT_IN((respair_kernel<C, NW>), 160 * 1024);
+    const int tiles = as_cdiv(a.max_w, 64 * NW - 16);
+    hipLaunchKernelGGL((respair_kernel<C, NW>), dim3((unsigned)((tiles + 7) & ~7), (unsigned)a.B), dim3(64 * NW), lds_bytes<C>(a, NW), stream, a);
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
@@ -287,5 +298,8 @@ extern "C" int as_respair_f32(const AsResPairArgs* ap, as_stream_t stream_)
     char tag[96];
     snprintf(tag, sizeof(tag), "respair C%d N%d k%d d%d%s", a.C, a.N, a.k, a.dil, a.add1 ? " mean3" : "");
     AsProfScope prof__(AS_CLS_GEMM, 2.0 * 2.0 * a.C * (double)a.C * a.k * (double)a.N, 8.0 * a.C * (double)a.N, stream, tag);
-    return a.C == 32 ? launch<32>(a, stream) : launch<64>(a, stream);
+    if (a.C == 32) return launch<32, 4>(a, stream);
+    int nw = lds_bytes<64>(a, 4) <= 80 * 1024 ? 4 : 8;                   // twice into the LDS, or one wide workgroup
+    if (const char* e = getenv("AS_RESPAIR_NW")) nw = atoi(e) == 8 ? 8 : (atoi(e) == 4 ? 4 : nw);
+    return nw == 4 ? launch<64, 4>(a, stream) : launch<64, 8>(a, stream);
 }

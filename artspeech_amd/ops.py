@@ -10,6 +10,7 @@ from . import _lib
 from ._lib import check, ptr, stream
 
 AS_MAX_TAPS = _lib.AS_MAX_TAPS
+META_MAX_H, META_MAX_W = 1023, 4194303      # include/artspeech_hip.h AS_META_MAX_H / AS_META_MAX_W
 KTILE = 16                      # the GEMM k-tile (BK in csrc/conv_gemm.hip): weights are zero-padded to it
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_ABS, ACT_SWISH = 0, 1, 2, 3, 4, 5
 
@@ -51,6 +52,9 @@ class Layout:
         self.widths_host = [int(w) for w in widths]
         self.B = len(self.widths_host)
         self.H = int(H)
+        if self.H > META_MAX_H or any(w > META_MAX_W for w in self.widths_host):
+            raise ValueError(f"an utterance of more than {META_MAX_W} columns (or {META_MAX_H} rows) does not fit the column descriptors "
+                             "(include/artspeech_hip.h AS_META_PACK): split it")
         off = [0]
         for w in self.widths_host:
             off.append(off[-1] + self.H * w)
@@ -182,7 +186,7 @@ def prep_weight(w, device=None, stack=None, sc=None):
 
 def strided_source(lay_in, lay_out, stride, device):
     """(src_col int32 [N_out], src_meta int64 [N_out]) of a valid conv with taps (a, d) >= 0 from lay_in to lay_out: output (ho, wo)
-    of utterance b reads input position (ho * stride + a, wo * stride + d); descriptor = h | w << 16 | H << 32 | W << 48 of the INPUT."""
+    of utterance b reads input position (ho * stride + a, wo * stride + d); descriptor = AS_META_PACK(h, w, H, W) of the INPUT."""
     cols, metas = [], []
     for b in range(lay_out.B):
         Wi, Wo = lay_in.widths_host[b], lay_out.widths_host[b]
@@ -190,7 +194,7 @@ def strided_source(lay_in, lay_out, stride, device):
             for wo in range(Wo):
                 h, w = ho * stride, wo * stride
                 cols.append(lay_in.off_host[b] + h * Wi + w)
-                metas.append(h | (w << 16) | (lay_in.H << 32) | (Wi << 48))
+                metas.append(h | (lay_in.H << 10) | (w << 20) | (Wi << 42))               # AS_META_PACK
     return torch.tensor(cols, dtype=torch.int32, device=device), torch.tensor(metas, dtype=torch.int64, device=device)
 
 

@@ -37,11 +37,13 @@ int as_abi_version(void);
  *   bit AS_STATUS_BAD_TOKEN     a token id outside [0, n_token) reached the embedding (it was clamped)
  *   bit AS_STATUS_F16_RANGE     a conv GEMM produced a non-finite accumulator: an operand beyond fp16's range, |x| > 65504, or a
  *                               non-finite input (debug probe, as_set_range_probe)
+ *   bit AS_STATUS_BAD_LAYOUT    an utterance wider than AS_META_MAX_W columns reached as_make_meta (its descriptors are void)
  * as_device_status returns the bits raised on the current HIP device since the last clear (0 = healthy) without synchronising; it is
  * final for work whose stream has been synchronised.  The module-level entry points (as_*_forward, as_forward_test*) return
  * AS_EDEVICE while any bit is set: results computed since it was raised are invalid; clear it to go on. */
 #define AS_EDEVICE (-3)
-enum { AS_STATUS_LSTM_TIMEOUT = 0, AS_STATUS_MAS_TIMEOUT = 1, AS_STATUS_BAD_TOKEN = 2, AS_STATUS_F16_RANGE = 3, AS_STATUS_KINDS = 4 };
+enum { AS_STATUS_LSTM_TIMEOUT = 0, AS_STATUS_MAS_TIMEOUT = 1, AS_STATUS_BAD_TOKEN = 2, AS_STATUS_F16_RANGE = 3, AS_STATUS_BAD_LAYOUT = 4,
+       AS_STATUS_KINDS = 5 };
 int as_device_status(int clear);
 /* test hook: raise `kind` from a kernel on `stream`, exactly as a failing kernel would */
 int as_device_status_raise_for_test(int kind, as_stream_t stream);
@@ -98,11 +100,21 @@ int as_softmax_mas_f32(const float* feat, const int32_t* t_x, const int32_t* t_y
 /* ---------------------------------------------------------------------------------------------
  * Packed-frames layout (DESIGN.md "Data layout").  An activation is fp32 [C][N] (row stride ld >= N)
  * with every utterance of the batch concatenated along the contiguous column axis, no padding.
- * Column j carries a descriptor  h | w<<16 | H<<32 | W<<48  (uint16 fields): its (row, column)
- * inside its own utterance's H x W image (H = 1, w = frame index for 1-D sequences).
+ * Column j carries a descriptor  h | H<<10 | w<<20 | W<<42  (AS_META_PACK: 10-bit rows, 22-bit columns): its (row, column)
+ * inside its own utterance's H x W image (H = 1, w = frame index for 1-D sequences); H <= AS_META_MAX_H (mel bins),
+ * W <= AS_META_MAX_W (the vocoder's last stage has 300 columns per mel frame: 174 s of audio per utterance).
  * as_make_meta builds the descriptors from per-utterance widths (int32 [B], device) for a common
- * height H; col_off int32 [B+1] are the utterances' first columns (exclusive prefix sums of H*W_b).
+ * height H; col_off int32 [B+1] are the utterances' first columns (exclusive prefix sums of H*W_b).  A width beyond
+ * AS_META_MAX_W raises AS_STATUS_BAD_LAYOUT on the device (the widths are device data).
  * ------------------------------------------------------------------------------------------- */
+#define AS_META_MAX_H 1023
+#define AS_META_MAX_W 4194303
+#define AS_META_PACK(h, w, H, W) \
+    ((uint64_t)(h) | ((uint64_t)(H) << 10) | ((uint64_t)(w) << 20) | ((uint64_t)(W) << 42))
+#define AS_META_h(md) ((int)((md) & 1023u))
+#define AS_META_H(md) ((int)(((md) >> 10) & 1023u))
+#define AS_META_w(md) ((int)(((md) >> 20) & 4194303u))
+#define AS_META_W(md) ((int)((md) >> 42))
 int as_make_meta(const int32_t* widths, const int32_t* col_off, int B, int H, int n_cols_max,
                  uint64_t* meta, as_stream_t stream);
 

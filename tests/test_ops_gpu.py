@@ -980,7 +980,7 @@ def test_conv_gemm_multi_direct_stems(cuda):
 
 @pytest.mark.parametrize("C,k,dil,lens", [(32, 3, 1, [700, 3, 241, 1]), (32, 7, 5, [500, 17]), (32, 11, 5, [960, 40, 240]), (32, 11, 3, [239]),
                                           (64, 3, 3, [481, 5]), (64, 7, 1, [300, 300]), (64, 11, 5, [721, 26]), (64, 11, 1, [250])])
-def test_respair_equals_two_convs(cuda, C, k, dil, lens):
+def test_respair_equals_two_convs(cuda, monkeypatch, C, k, dil, lens):
     """One residual step of the vocoder's ResBlock1 as one launch (ops.respair) against fp32 torch and against the two conv GEMM launches
     it replaces: ragged utterances (shorter than a halo, one column, exactly one tile, several tiles), every (k, dilation) of the config."""
     g = torch.Generator().manual_seed(C + 13 * k + dil)
@@ -1008,6 +1008,12 @@ def test_respair_equals_two_convs(cuda, C, k, dil, lens):
     ops.conv_gemm(W1, None, lay, None, t1, bias=b1.to(cuda), xs=xh, K=C, yh=xth, yh_lrelu=True, in_slope=0.1)
     y2 = ops.conv_gemm(W2, None, lay, lay.new(C), taps_1d(k), bias=b2.to(cuda), res=X, xs=xth, K=C)
     assert float((y - y2).abs().max()) <= 2e-6
+    if C == 64:                                                              # both workgroup widths (the library picks by LDS footprint)
+        for nw in ("4", "8"):
+            monkeypatch.setenv("AS_RESPAIR_NW", nw)
+            yn = ops.respair(X, lay, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1)
+            assert float((yn.cpu() - want).abs().max()) <= 2e-6, nw
+        monkeypatch.delenv("AS_RESPAIR_NW")
     # the stage's mean folded into the step
     A, B = torch.randn(C, lay.N, generator=g), torch.randn(C, lay.N, generator=g)
     y3 = ops.respair(X, lay, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1, add=(A.to(cuda), B.to(cuda)))
@@ -1026,3 +1032,16 @@ def test_respair_rejects(cuda):
         ops.respair(torch.randn(48, 100, device=cuda), lay, w48, None, w48, None, 3, 1, 0.1)
     with pytest.raises(_lib.HipLibraryError):
         ops.respair(X, lay, w, None, w, None, 4, 1, 0.1)                       # even k
+
+
+def test_conv_walls_beyond_65535_columns(cuda):
+    """An utterance longer than 2^16 columns (218 mel frames at the vocoder's last stage): the column descriptors carry 22-bit
+    positions, so the conv's zero padding sits at the utterance's own ends and nowhere else."""
+    g = torch.Generator().manual_seed(5)
+    lens = [70001, 9, 131075]
+    w = torch.randn(16, 8, 7, generator=g) / np.sqrt(56)
+    xs = [torch.randn(8, L, generator=g) for L in lens]
+    want = packed([F.conv1d(x[None], w, padding=9, dilation=3)[0] for x in xs])
+    lay = Layout(lens, cuda)
+    y = ops.conv_gemm(ops.prep_weight(w, cuda), packed(xs).to(cuda), lay, lay.new(16), [(0, 3 * (t - 3)) for t in range(7)])
+    assert float((y.cpu() - want).abs().max()) <= 2e-6

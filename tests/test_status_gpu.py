@@ -16,7 +16,7 @@ from artspeech_amd.ops import Layout, taps_1d
 from test_net_gpu import get_model, raw_features
 
 pytestmark = pytest.mark.gpu
-LSTM_TIMEOUT, MAS_TIMEOUT, BAD_TOKEN, F16_RANGE = range(4)
+LSTM_TIMEOUT, MAS_TIMEOUT, BAD_TOKEN, F16_RANGE, BAD_LAYOUT = range(5)
 
 
 @pytest.fixture(autouse=True)
@@ -187,3 +187,17 @@ def test_output_reuse_follows_the_frame_count(cuda, golden_dir):
     assert out3["mel"].data_ptr() == out2["mel"].data_ptr()
     torch.cuda.synchronize()
     assert bool(torch.isfinite(out3["mel"]).all())
+
+
+def test_utterance_wider_than_the_descriptors(cuda):
+    """Column descriptors hold 22-bit columns (AS_META_PACK): the Python layout refuses a wider utterance; the C entry point, whose
+    widths are device data, raises AS_STATUS_BAD_LAYOUT from the kernel."""
+    with pytest.raises(ValueError):
+        Layout([ops.META_MAX_W + 1], cuda)
+    L = _lib.lib()
+    widths = torch.tensor([ops.META_MAX_W + 1, 7], dtype=torch.int32, device=cuda)
+    off = torch.tensor([0, ops.META_MAX_W + 1, ops.META_MAX_W + 8], dtype=torch.int32, device=cuda)
+    meta = torch.zeros(ops.META_MAX_W + 8, dtype=torch.int64, device=cuda)
+    assert L.as_make_meta(ops._p(widths), ops._p(off), 2, 1, int(off[-1]), ops._p(meta), ops.stream()) == 0
+    torch.cuda.synchronize()
+    assert L.as_device_status(1) == 1 << BAD_LAYOUT

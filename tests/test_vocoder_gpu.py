@@ -74,3 +74,25 @@ def test_pipeline_mel_to_wav(cuda, golden_dir):
     solo = tts.synthesis_wav(ph[1], mels[1], features=feats[1])
     assert solo.shape == (300 * frames[1],)
     assert float((solo - wav[1, : solo.shape[0]]).abs().max()) <= 1e-5
+
+
+def test_long_utterance_matches_oracle(cuda):
+    """230 mel frames = 69 000 samples: past 2^16 columns at the last stage (the column descriptors carry 22-bit positions), several
+    column tiles of the fused residual steps per utterance, beside a short utterance in the same batch.  Against the CPU restatement
+    of the reference's Generator (oracle/vocoder.py, pinned by tests/test_oracle_vocoder.py)."""
+    from artspeech_amd.synth import hash_tensor
+    from artspeech_amd.weights import fold_state_dict
+    from oracle import vocoder as OV
+    h = dict(V.DEFAULT_H)
+    sd = V.synth_generator_state_dict(h, seed=3407)
+    Wf = {k: v.float() for k, v in fold_state_dict(sd).items()}
+    lens = [230, 9]
+    mel = torch.zeros(2, 80, max(lens))
+    for b, t in enumerate(lens):
+        mel[b, :, :t] = torch.from_numpy(hash_tensor("voc/long%d" % b, (80, t), 77, 1.0))
+    wav = gen(512, cuda)(mel, lengths=lens).cpu()
+    for b, t in enumerate(lens):
+        want = OV.generator(Wf, h, mel[b, :, :t])
+        d = float((wav[b, 0, : 300 * t] - want).abs().max())
+        print("frames", t, "wav max-abs", d)
+        assert d <= TOL, (t, d)
