@@ -56,3 +56,72 @@ extern "C" int as_mean3_f32(const float* a, const float* b, const float* c, int 
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
+
+// conv_post (vocoder.py:97, 111-113): wav = tanh(conv1d(LeakyReLU(x, 0.01), w [1][C][k]) + b), zero padding per utterance.  ONE output row:
+// as a conv GEMM launch this was a 32-row matrix-core tile computing one useful row behind a split pass over the whole input (336 us at
+// 32 channels x 1.92 M samples); as plain fp32 FMAs it is a read of x (245 MB).  A wave owns 256 consecutive columns, a lane the columns
+// lane + 64 p: every load of a wave is one contiguous 256-byte run, and the k-fold re-read of a column comes from the CU's cache.
+template <int K>
+__global__ void __launch_bounds__(256) conv_post_kernel(const float* __restrict__ x, int ldx, int C, int N, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float slope, int tanh_out,
+                                                        const unsigned long long* __restrict__ meta, float* __restrict__ y)
+{
+    constexpr int HALF = K / 2;
+    const int j0 = (blockIdx.x * 256 + (threadIdx.x & ~63)) * 4 + (threadIdx.x & 63);
+    if ((blockIdx.x * 256 + (threadIdx.x & ~63)) * 4 >= N) return;      // (the whole wave)
+    // taps that stay inside the column's own utterance
+    unsigned ok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int j = j0 + 64 * p;
+        ok[p] = 0;
+        if (j < N) {
+            const unsigned long long md = meta[j];
+            const int wj = AS_META_w(md), Wj = AS_META_W(md);
+#pragma unroll
+            for (int t = 0; t < K; ++t) ok[p] |= ((unsigned)(wj + t - HALF) < (unsigned)Wj ? 1u : 0u) << t;
+        }
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+        const float* xr = x + (size_t)c * ldx;
+        float wt[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) wt[t] = w[c * K + t];               // (uniform: scalar loads)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int j = j0 + 64 * p;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const bool in = (ok[p] >> t) & 1u;
+                float v = in ? xr[j + t - HALF] : 0.f;
+                v = v > 0.f ? v : slope * v;
+                acc[p] = __builtin_fmaf(wt[t], v, acc[p]);
+            }
+        }
+    }
+    const float b = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int j = j0 + 64 * p;
+        if (j < N) {
+            const float v = acc[p] + b;
+            y[j] = tanh_out ? tanhf(v) : v;
+        }
+    }
+}
+
+extern "C" int as_conv_post_f32(const float* x, int ldx, int C, int N, const float* w, const float* bias, int k, float in_slope,
+                                int tanh_out, const uint64_t* meta, float* y, as_stream_t stream)
+{
+    if (!x || !w || !meta || !y || C <= 0 || N < 0 || ldx < N || (k != 3 && k != 5 && k != 7)) return AS_EINVAL;
+    if (N == 0) return AS_OK;
+    AsProfScope prof__(AS_CLS_GEMM, 2.0 * C * k * (double)N, 4.0 * (C + 1.0) * N, (hipStream_t)stream, "conv_post");
+    const dim3 grid(as_cdiv(N, 1024)), block(256);
+    const unsigned long long* md = reinterpret_cast<const unsigned long long*>(meta);
+    if (k == 3) hipLaunchKernelGGL(conv_post_kernel<3>, grid, block, 0, (hipStream_t)stream, x, ldx, C, N, w, bias, in_slope, tanh_out, md, y);
+    else if (k == 5) hipLaunchKernelGGL(conv_post_kernel<5>, grid, block, 0, (hipStream_t)stream, x, ldx, C, N, w, bias, in_slope, tanh_out, md, y);
+    else hipLaunchKernelGGL(conv_post_kernel<7>, grid, block, 0, (hipStream_t)stream, x, ldx, C, N, w, bias, in_slope, tanh_out, md, y);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}

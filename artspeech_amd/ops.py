@@ -417,6 +417,14 @@ def mean3(A, B, C3, n, Y):
     return Y
 
 
+def conv_post(X, lay, w, bias, in_slope, tanh_out=True):
+    """y [1][N] = tanh(conv1d(LeakyReLU(X [C][N], in_slope), w fp32 [C][k]) + bias): the vocoder's last conv (vocoder.py:111-113)."""
+    Y = lay.new(1)
+    check(_lib.lib().as_conv_post_f32(_p(X), _ld(X), X.shape[0], lay.N, _p(w), _p(bias), w.shape[1], float(in_slope), int(tanh_out),
+                                      _p(lay.meta), _p(Y), stream()), "as_conv_post_f32")
+    return Y
+
+
 def respair(X, lay, w1, b1, w2, b2, k, dil, slope, Y=None, add=None):
     """One residual step of ResBlock1 (Vocoder/vocoder.py:35-42) as one launch: Y = X + conv2(lrelu(conv1(lrelu(X)))), conv1 with
     dilation `dil`, both with k taps; X [C][N] fp32 with C = 32 or 64, w1 / w2 = prep_weight of the [C][C][k] weights.

@@ -99,6 +99,8 @@ class Generator:
         dev, h, W = self.device, self.h, {}
         W["pre"] = (ops.prep_weight(w["conv_pre.weight"], dev), w["conv_pre.bias"].to(dev))
         W["post"] = (ops.prep_weight(w["conv_post.weight"], dev), w["conv_post.bias"].to(dev))
+        wp = w["conv_post.weight"]                                           # [1][C][7]: one output row -- plain FMAs (ops.conv_post)
+        W["post32"] = wp[0].float().contiguous().to(dev) if wp.shape[0] == 1 and wp.shape[2] in (3, 5, 7) else None
         for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
             if k != 2 * u:
                 raise NotImplementedError("ConvTranspose1d with k != 2 * stride")
@@ -185,7 +187,10 @@ class Generator:
                 raise NotImplementedError("three residual stacks per stage (Vocoder/config.json)")
             x = ops.mean3(outs[0], outs[1], outs[2], lay.N, lay.new(cout))
         wt, b = W["post"]
-        wav = ops.conv_gemm(wt, x, lay, lay.new(1), taps_1d(7), bias=b, in_act=ACT_LRELU, in_slope=0.01, act=ACT_TANH)
+        if W["post32"] is not None and os.environ.get("AS_VOC_FUSED", "1") != "0":
+            wav = ops.conv_post(x, lay, W["post32"], b, 0.01)
+        else:
+            wav = ops.conv_gemm(wt, x, lay, lay.new(1), taps_1d(7), bias=b, in_act=ACT_LRELU, in_slope=0.01, act=ACT_TANH)
         return wav, lay
 
     @torch.no_grad()

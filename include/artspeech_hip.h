@@ -459,6 +459,10 @@ int as_interleave_phases_f32(const float* z, int ldz, const float* bias, int C, 
                              as_stream_t stream);
 /* y = (a + b + c) / 3 over [C][N]                                              vocoder.py:104-110 */
 int as_mean3_f32(const float* a, const float* b, const float* c, int ld, int C, int N, float* y, int ldy, as_stream_t stream);
+/* conv_post (vocoder.py:97, 111-113): y [N] = act(conv1d(LeakyReLU(x [C][N], in_slope), w fp32 [C][k]) + bias[0]) with ONE output channel,
+ * zero padding per utterance (meta = the layout's column descriptors), act = tanh when tanh_out; k = 3, 5 or 7.  Plain fp32 FMAs: a read of x. */
+int as_conv_post_f32(const float* x, int ldx, int C, int N, const float* w, const float* bias, int k, float in_slope, int tanh_out,
+                     const uint64_t* meta, float* y, as_stream_t stream);
 /* One residual step of ResBlock1 (vocoder.py:35-42) as ONE launch, for the stages with C = 32 or 64 channels:
  *     y = x + conv2(lrelu(conv1(lrelu(x))))        conv1: k taps with dilation dil, conv2: k taps with dilation 1, zero padding per utterance
  * x, y fp32 [C][N] (y != x: a workgroup reads its neighbours' columns of x); w1, w2 = the conv GEMM's weight images of the two

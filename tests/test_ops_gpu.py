@@ -1045,3 +1045,16 @@ def test_conv_walls_beyond_65535_columns(cuda):
     lay = Layout(lens, cuda)
     y = ops.conv_gemm(ops.prep_weight(w, cuda), packed(xs).to(cuda), lay, lay.new(16), [(0, 3 * (t - 3)) for t in range(7)])
     assert float((y.cpu() - want).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("C,k,lens", [(32, 7, [1500, 2, 1, 64, 700]), (2, 7, [300, 301]), (32, 3, [5])])
+def test_conv_post(cuda, C, k, lens):
+    """The vocoder's one-row last conv as plain fp32 FMAs (ops.conv_post) against torch."""
+    g = torch.Generator().manual_seed(C + k)
+    w = torch.randn(1, C, k, generator=g) / np.sqrt(C * k)
+    b = torch.randn(1, generator=g) * 0.1
+    xs = [torch.randn(C, L, generator=g) for L in lens]
+    want = packed([torch.tanh(F.conv1d(F.leaky_relu(x[None], 0.01), w, b, padding=k // 2))[0] for x in xs])
+    lay = Layout(lens, cuda)
+    y = ops.conv_post(packed(xs).to(cuda), lay, w[0].contiguous().to(cuda), b.to(cuda), 0.01)
+    assert float((y.cpu() - want).abs().max()) <= 1e-6
