@@ -221,7 +221,9 @@ __global__ void __launch_bounds__(64 * NW) respair_kernel(const AsResPairArgs a)
     }
     {
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.b2), 0, a.b2 ? C * 4 : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)C * a.ldy * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y ? (int)((unsigned)C * a.ldy * 4u) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(
+            a.yh, 0, a.yh ? (int)(4u * 4u * ((unsigned)a.N + 1u) * 16u) : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.add1), 0, a.add1 ? (int)((unsigned)C * a.ld_add * 4u) : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(
@@ -249,13 +251,56 @@ __global__ void __launch_bounds__(64 * NW) respair_kernel(const AsResPairArgs a)
                         q[e] = buf_load1(rsQ, po + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.ld_add) * 4u, 0);
                     }
                 }
+                float v[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float x = __builtin_fmaf(acc[m][cb][e], a.scale2, bv[e]);
                     x += r[e];
                     if (a.add1) x = ((p[e] + q[e]) + x) / a.out_div;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rsY,
-                                                          yo + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.ldy) * 4u, 0, 0);
+                    v[e] = x;
+                }
+                if (a.y) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rsY,
+                                                              yo + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.ldy) * 4u, 0, 0);
+                }
+                if (a.yh) {                                              // LeakyReLU(y) as the next conv's operand image (conv_gemm.h yh_store_tile)
+                    const unsigned NXy = (unsigned)a.N + 1u;
+                    const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        float t[8];
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            float x0 = v[8 * pr + rr], x1 = v[8 * pr + 4 + rr];
+                            x0 = x0 > 0.f ? x0 : a.yh_slope * x0;
+                            x1 = x1 > 0.f ? x1 : a.yh_slope * x1;
+                            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(x1));
+                            t[rr] = x0;
+                            t[4 + rr] = x1;
+                        }
+                        u32x4_t h, l;
+                        split2(t, h, l);
+                        const int g = m * 4 + 2 * pr + lk;
+                        const unsigned pl = (unsigned)((g >> 1) * 4 + (g & 1));
+                        const unsigned off = ok ? (pl * NXy + (unsigned)col) * 16u : OOBH;
+                        __builtin_amdgcn_raw_buffer_store_b128(h, rsH, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(l, rsH, off + 2u * NXy * 16u, 0, 0);
+                        if (C == 32) {                                   // k-blocks 2, 3 of the image (as_kbx(32) = 4) are zero rows
+                            __builtin_amdgcn_raw_buffer_store_b128(z, rsH, off + 8u * NXy * 16u, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(z, rsH, off + 10u * NXy * 16u, 0, 0);
+                        }
+                        if (ok && col == 0) {                            // the zero column N, once per (group, part)
+                            const unsigned offz = (pl * NXy + (unsigned)a.N) * 16u;
+                            __builtin_amdgcn_raw_buffer_store_b128(z, rsH, offz, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(z, rsH, offz + 2u * NXy * 16u, 0, 0);
+                            if (C == 32) {
+                                __builtin_amdgcn_raw_buffer_store_b128(z, rsH, offz + 8u * NXy * 16u, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(z, rsH, offz + 10u * NXy * 16u, 0, 0);
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -286,14 +331,15 @@ extern "C" int as_respair_f32(const AsResPairArgs* ap, as_stream_t stream_)
     if (!ap) return AS_EINVAL;
     const AsResPairArgs& a = *ap;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!a.x || !a.y || a.x == a.y || !a.w1 || !a.w2 || !a.col_off) return AS_EINVAL;
+    if (!a.x || (!a.y && !a.yh) || a.x == a.y || !a.w1 || !a.w2 || !a.col_off) return AS_EINVAL;
+    if (a.yh && ((reinterpret_cast<uintptr_t>(a.yh) & 15) != 0 || 256.0 * ((double)a.N + 1.0) >= 2147483648.0)) return AS_EINVAL;
     if (a.C != 32 && a.C != 64) return AS_EINVAL;
     if (a.k < 1 || !(a.k & 1) || a.k / 2 > RP_ML || a.dil < 1 || a.dil * (a.k / 2) > 40) return AS_EINVAL;
-    if (a.B <= 0 || a.B > 65535 || a.N < 0 || a.max_w < 0 || a.ldx < a.N || a.ldy < a.N) return AS_EINVAL;
+    if (a.B <= 0 || a.B > 65535 || a.N < 0 || a.max_w < 0 || a.ldx < a.N || (a.y && a.ldy < a.N)) return AS_EINVAL;
     if ((a.add1 == nullptr) != (a.add2 == nullptr) || (a.add1 && (a.ld_add < a.N || !(a.out_div > 0.f)))) return AS_EINVAL;
     // 32-bit byte offsets inside every tensor (raw buffer accesses)
     const double lim = 2147483648.0;
-    if ((double)a.C * a.ldx * 4.0 >= lim || (double)a.C * a.ldy * 4.0 >= lim || (a.add1 && (double)a.C * a.ld_add * 4.0 >= lim)) return AS_EINVAL;
+    if ((double)a.C * a.ldx * 4.0 >= lim || (a.y && (double)a.C * a.ldy * 4.0 >= lim) || (a.add1 && (double)a.C * a.ld_add * 4.0 >= lim)) return AS_EINVAL;
     if (a.N == 0 || a.max_w == 0) return AS_OK;
     char tag[96];
     snprintf(tag, sizeof(tag), "respair C%d N%d k%d d%d%s", a.C, a.N, a.k, a.dil, a.add1 ? " mean3" : "");

@@ -1,7 +1,6 @@
 // Glue kernels of the HiFi-GAN generator (Vocoder/vocoder.py:75-125) -- SURVEY.md section 8(f) row N2; its
 // convolutions are the conv GEMM of the acoustic path (conv_gemm*.hip).
-#include "common.h"
-#include "artspeech_hip.h"
+#include "conv_gemm.h"
 #define AS_FILE_CLS AS_CLS_OTHER
 
 // ConvTranspose1d(k = 2u, stride u) runs as ONE 3-tap conv whose output rows are (phase r, channel m) (vocoder.py of
@@ -122,6 +121,53 @@ extern "C" int as_conv_post_f32(const float* x, int ldx, int C, int N, const flo
     if (k == 3) hipLaunchKernelGGL(conv_post_kernel<3>, grid, block, 0, (hipStream_t)stream, x, ldx, C, N, w, bias, in_slope, tanh_out, md, y);
     else if (k == 5) hipLaunchKernelGGL(conv_post_kernel<5>, grid, block, 0, (hipStream_t)stream, x, ldx, C, N, w, bias, in_slope, tanh_out, md, y);
     else hipLaunchKernelGGL(conv_post_kernel<7>, grid, block, 0, (hipStream_t)stream, x, ldx, C, N, w, bias, in_slope, tanh_out, md, y);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// LeakyReLU((a + b + c) / 3) as the operand image of the conv that follows (the next stage's ConvTranspose1d, vocoder.py:101-110): the
+// stage's mean is read by nothing else, so its fp32 copy and the split pass over it need not exist.  Thread geometry of split_f16x2_kernel.
+__global__ void __launch_bounds__(256)
+mean3_image_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int ld, int K, int N, float slope,
+                   u32x4_t* __restrict__ xh)
+{
+    const int wcol = (blockIdx.x * 256 + (threadIdx.x & ~63)) * 4;      // the wave's first column
+    const int col = wcol + (threadIdx.x & 63);
+    const int g = blockIdx.y;                                           // 8-row group: kb = g / 2, kh = g % 2
+    if (wcol > N) return;
+    const int bytes = (int)(((unsigned)(K - 1) * ld + N) * 4u);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c), 0, bytes, 0x00020000);
+    const size_t NX = (size_t)N + 1;
+    const size_t base = ((size_t)(g >> 1) * 4 + (g & 1)) * NX + col;    // plane p*2 + kh of k-block kb
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        if (col + 64 * cc > N) break;                                   // (column N itself is written: the zero column)
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = g * 8 + r;
+            const unsigned off = (k < K && col + 64 * cc < N) ? (unsigned)(k * ld + col + 64 * cc) * 4u : OOB;
+            const float e = ((buf_load1(ra, off, 0) + buf_load1(rb, off, 0)) + buf_load1(rc, off, 0)) / 3.0f;
+            t[r] = e > 0.f ? e : slope * e;
+        }
+        u32x4_t h, l;
+        split2(t, h, l);
+        xh[base + 64 * cc] = h;
+        xh[base + 64 * cc + 2 * NX] = l;
+    }
+}
+
+extern "C" int as_mean3_image_f32(const float* a, const float* b, const float* c, int ld, int C, int N, float slope, uint16_t* xh,
+                                  as_stream_t stream)
+{
+    if (!a || !b || !c || !xh || C <= 0 || N < 0 || ld < N || (reinterpret_cast<uintptr_t>(xh) & 15) != 0) return AS_EINVAL;
+    if ((double)C * ld * 4.0 >= 2147483648.0) return AS_EINVAL;         // 32-bit offsets in the buffer descriptors
+    if (N == 0) return AS_OK;
+    AsProfScope prof__(AS_FILE_CLS, 0, 16.0 * C * (double)N, (hipStream_t)stream);
+    hipLaunchKernelGGL(mean3_image_kernel, dim3(as_cdiv(N + 1, 1024), 2 * as_kbx(C)), dim3(256), 0, (hipStream_t)stream, a, b, c, ld, C, N,
+                       slope, reinterpret_cast<u32x4_t*>(xh));
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

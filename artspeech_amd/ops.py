@@ -425,15 +425,21 @@ def conv_post(X, lay, w, bias, in_slope, tanh_out=True):
     return Y
 
 
-def respair(X, lay, w1, b1, w2, b2, k, dil, slope, Y=None, add=None):
+def respair(X, lay, w1, b1, w2, b2, k, dil, slope, Y=None, add=None, image_slope=None):
     """One residual step of ResBlock1 (Vocoder/vocoder.py:35-42) as one launch: Y = X + conv2(lrelu(conv1(lrelu(X)))), conv1 with
     dilation `dil`, both with k taps; X [C][N] fp32 with C = 32 or 64, w1 / w2 = prep_weight of the [C][C][k] weights.
-    add = (A, B): Y = ((A + B) + Y) / 3 (the mean of a stage's three stacks).  Y must not be X."""
+    add = (A, B): Y = ((A + B) + Y) / 3 (the mean of a stage's three stacks).  Y must not be X.
+    image_slope: return LeakyReLU(Y, image_slope) as a split operand image (conv_gemm(..., xs=)) INSTEAD of the fp32 Y."""
     C = X.shape[0]
-    if Y is None:
-        Y = lay.new(C)
     a = _lib.ResPairArgs()
-    a.x, a.ldx, a.y, a.ldy = _p(X), _ld(X), _p(Y), _ld(Y)
+    if image_slope is not None:
+        yh = new_image(C, lay.N, X.device)
+        a.yh, a.yh_slope = _p(yh), float(image_slope)
+    else:
+        if Y is None:
+            Y = lay.new(C)
+        a.y, a.ldy = _p(Y), _ld(Y)
+    a.x, a.ldx = _p(X), _ld(X)
     a.w1, a.w2, a.b1, a.b2 = _p(w1.wh), _p(w2.wh), _p(b1), _p(b2)
     a.scale1, a.scale2 = 1.0 / w1.scale, 1.0 / w2.scale
     a.C, a.N, a.k, a.dil, a.slope = C, lay.N, int(k), int(dil), float(slope)
@@ -441,7 +447,14 @@ def respair(X, lay, w1, b1, w2, b2, k, dil, slope, Y=None, add=None):
     if add is not None:
         a.add1, a.add2, a.ld_add, a.out_div = _p(add[0]), _p(add[1]), _ld(add[0]), 3.0
     check(_lib.lib().as_respair_f32(ctypes.byref(a), stream()), "as_respair_f32")
-    return Y
+    return Y if image_slope is None else yh
+
+
+def mean3_image(A, B, C3, n, slope):
+    """LeakyReLU((A + B + C3) / 3, slope) as a split operand image (conv_gemm(..., xs=))"""
+    xh = new_image(A.shape[0], n, A.device)
+    check(_lib.lib().as_mean3_image_f32(_p(A), _p(B), _p(C3), _ld(A), A.shape[0], n, float(slope), _p(xh), stream()), "as_mean3_image_f32")
+    return xh
 
 
 def dwconv_down(X, lin, Y, lout, w, bias, kh, lrelu):

@@ -146,9 +146,15 @@ class Generator:
         wt, b = W["pre"]
         x = ops.conv_gemm(wt, mel_p, lay, lay.new(wt.shape[2]), taps_1d(7), bias=b)
         nk = len(h["resblock_kernel_sizes"])
-        for i in range(len(h["upsample_rates"])):
+        nst = len(h["upsample_rates"])
+        xi = None                                   # LeakyReLU(x) as an operand image, when the producer of x wrote that instead of x
+        for i in range(nst):
             wt, b, u, cout = W[f"ups{i}"]
-            z = ops.conv_gemm(wt, x, lay, lay.new(u * cout), taps_1d(3), in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
+            if xi is not None:
+                z = ops.conv_gemm(wt, None, lay, lay.new(u * cout), taps_1d(3), xs=xi, K=h["upsample_initial_channel"] // 2 ** i)
+                xi = None
+            else:
+                z = ops.conv_gemm(wt, x, lay, lay.new(u * cout), taps_1d(3), in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
             lay_up = lay.scaled(u)
             x = ops.interleave_phases(z, b, cout, u, lay.N, lay_up.new(cout))
             lay = lay_up
@@ -166,10 +172,15 @@ class Generator:
                     blk = W[f"rb{i * nk + j}"]
                     for n, (w1, b1, t1, w2, b2, t2) in enumerate(blk):
                         last = j + 1 == nk and n + 1 == len(blk)
+                        # (the stage's mean feeds only the next ConvTranspose1d: its last step writes LeakyReLU(mean) as that conv's image)
                         y = ops.respair(y, lay, w1, b1, w2, b2, len(t1), t1[1][1] - t1[0][1] if len(t1) > 1 else 1, LRELU_SLOPE,
-                                        add=(outs[0], outs[1]) if last else None)
+                                        add=(outs[0], outs[1]) if last else None,
+                                        image_slope=LRELU_SLOPE if last and i + 1 < nst else None)
                     outs.append(y)
-                x = outs[2]
+                if i + 1 < nst:
+                    x, xi = None, outs[2]
+                else:
+                    x = outs[2]
                 continue
             xh = ops.split_act(x, lay, in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
             for j in range(nk):
@@ -185,7 +196,10 @@ class Generator:
                 outs.append(y)
             if nk != 3:
                 raise NotImplementedError("three residual stacks per stage (Vocoder/config.json)")
-            x = ops.mean3(outs[0], outs[1], outs[2], lay.N, lay.new(cout))
+            if i + 1 < nst and os.environ.get("AS_VOC_FUSED", "1") != "0":
+                x, xi = None, ops.mean3_image(outs[0], outs[1], outs[2], lay.N, LRELU_SLOPE)
+            else:
+                x = ops.mean3(outs[0], outs[1], outs[2], lay.N, lay.new(cout))
         wt, b = W["post"]
         if W["post32"] is not None and os.environ.get("AS_VOC_FUSED", "1") != "0":
             wav = ops.conv_post(x, lay, W["post32"], b, 0.01)

@@ -459,6 +459,9 @@ int as_interleave_phases_f32(const float* z, int ldz, const float* bias, int C, 
                              as_stream_t stream);
 /* y = (a + b + c) / 3 over [C][N]                                              vocoder.py:104-110 */
 int as_mean3_f32(const float* a, const float* b, const float* c, int ld, int C, int N, float* y, int ldy, as_stream_t stream);
+/* LeakyReLU((a + b + c) / 3, slope) as the split operand image (as_split_f16x2_bytes(C, N) bytes) of the conv that follows -- the next
+ * stage's ConvTranspose1d (vocoder.py:101-110): the fp32 mean is read by nothing else. */
+int as_mean3_image_f32(const float* a, const float* b, const float* c, int ld, int C, int N, float slope, uint16_t* xh, as_stream_t stream);
 /* conv_post (vocoder.py:97, 111-113): y [N] = act(conv1d(LeakyReLU(x [C][N], in_slope), w fp32 [C][k]) + bias[0]) with ONE output channel,
  * zero padding per utterance (meta = the layout's column descriptors), act = tanh when tanh_out; k = 3, 5 or 7.  Plain fp32 FMAs: a read of x. */
 int as_conv_post_f32(const float* x, int ldx, int C, int N, const float* w, const float* bias, int k, float in_slope, int tanh_out,
@@ -469,7 +472,8 @@ int as_conv_post_f32(const float* x, int ldx, int C, int N, const float* w, cons
  * [C][C][k] weights (as_prep_weight_f16x2_host, G = 1), scale1 / scale2 = 1 / their scales, b1 / b2 [C] or NULL; slope = LeakyReLU's;
  * col_off int32 [B + 1] = the utterances' first columns (packed frames), max_w = the widest utterance; k odd <= 17, dil * (k / 2) <= 40.
  * add1 / add2 (both or neither; [C][N], ld_add): y = ((add1 + add2) + y) / out_div -- the mean of the three stacks of a stage
- * (vocoder.py:104-110) folded into the last step of the third.  Same f16x3 arithmetic as as_conv_gemm_f32; the tile's columns stay in
+ * (vocoder.py:104-110) folded into the last step of the third.  yh: the result also (or, with y NULL, only) as the split operand image
+ * of the next conv (as_split_f16x2_bytes(C, N) bytes; LeakyReLU(yh_slope) applied first).  Same f16x3 arithmetic as as_conv_gemm_f32; the tile's columns stay in
  * LDS between the two convs (csrc/respair.hip). */
 typedef struct AsResPairArgs {
     const float* x; int32_t ldx;
@@ -481,6 +485,7 @@ typedef struct AsResPairArgs {
     float slope;
     const int32_t* col_off; int32_t B, max_w;
     const float* add1; const float* add2; int32_t ld_add; float out_div;
+    uint16_t* yh; float yh_slope;       /* optional: LeakyReLU(y, yh_slope) as the operand image of the conv that follows (y may then be NULL) */
 } AsResPairArgs;
 int as_respair_f32(const AsResPairArgs* a, as_stream_t stream);
 

@@ -1014,6 +1014,13 @@ def test_respair_equals_two_convs(cuda, monkeypatch, C, k, dil, lens):
             yn = ops.respair(X, lay, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1)
             assert float((yn.cpu() - want).abs().max()) <= 2e-6, nw
         monkeypatch.delenv("AS_RESPAIR_NW")
+    # the result as the next conv's operand image instead of fp32
+    yi = ops.respair(X, lay, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1, image_slope=0.1)
+    parts = image_parts(yi.cpu(), C, lay.N)                                  # [2][KBx * 16][N + 1]
+    act = F.leaky_relu(y.cpu(), 0.1)
+    assert float((parts[0, :C, :-1] + parts[1, :C, :-1] - act).abs().max()) <= 1e-6
+    assert torch.equal(parts[0, :C, :-1], act.half().float())
+    assert (C == parts.shape[1] or float(parts[:, C:, :].abs().max()) == 0.0) and float(parts[:, :, -1].abs().max()) == 0.0
     # the stage's mean folded into the step
     A, B = torch.randn(C, lay.N, generator=g), torch.randn(C, lay.N, generator=g)
     y3 = ops.respair(X, lay, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1, add=(A.to(cuda), B.to(cuda)))
@@ -1058,3 +1065,14 @@ def test_conv_post(cuda, C, k, lens):
     lay = Layout(lens, cuda)
     y = ops.conv_post(packed(xs).to(cuda), lay, w[0].contiguous().to(cuda), b.to(cuda), 0.01)
     assert float((y.cpu() - want).abs().max()) <= 1e-6
+
+
+def test_mean3_image(cuda):
+    g = torch.Generator().manual_seed(3)
+    C, N = 40, 1500
+    A, B, Cc = (torch.randn(C, N, generator=g) for _ in range(3))
+    xh = ops.mean3_image(A.to(cuda), B.to(cuda), Cc.to(cuda), N, 0.1)
+    parts = image_parts(xh.cpu(), C, N)
+    want = F.leaky_relu(((A + B) + Cc) / 3.0, 0.1)
+    assert float((parts[0, :C, :-1] + parts[1, :C, :-1] - want).abs().max()) <= 1e-6
+    assert float(parts[:, C:, :].abs().max()) == 0.0 and float(parts[:, :, -1].abs().max()) == 0.0
