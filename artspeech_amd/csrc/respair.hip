@@ -61,7 +61,7 @@ constexpr int RP_ABUF = 4096;    // one weight granule
 // as four waves alone on a CU that step took 879 us against 540 for d = 1, 3)
 template <int C, int NW>
 // (C = 32: at most 128 registers, so that four workgroups share a CU -- 33-40 KB of LDS each; with three, 144 registers: 6-8 % slower)
-__global__ void __launch_bounds__(64 * NW, C == 32 ? 4 : 1) respair_kernel(const AsResPairArgs a)
+__global__ void __launch_bounds__(64 * NW, C == 32 && NW == 4 ? 4 : (C == 32 ? 2 : 1)) respair_kernel(const AsResPairArgs a)
 {
     constexpr int KB = C / 16, MB = C / 32, PL = KB * 4;
     constexpr int NT = 64 * NW;
@@ -419,8 +419,8 @@ extern "C" int as_respair_f32(const AsResPairArgs* ap, as_stream_t stream_)
     char tag[96];
     snprintf(tag, sizeof(tag), "respair C%d N%d k%d d%d%s", a.C, a.N, a.k, a.dil, a.add1 ? " mean3" : "");
     AsProfScope prof__(AS_CLS_GEMM, 2.0 * 2.0 * a.C * (double)a.C * a.k * (double)a.N, 8.0 * a.C * (double)a.N, stream, tag);
-    if (a.C == 32) return launch<32, 4>(a, stream);
-    int nw = lds_bytes<64>(a, 4) <= 80 * 1024 ? 4 : 8;                   // twice into the LDS, or one wide workgroup
+    int nw = a.C == 32 || lds_bytes<64>(a, 4) <= 80 * 1024 ? 4 : 8;      // C = 64: twice into the LDS, or one wide workgroup
     if (const char* e = getenv("AS_RESPAIR_NW")) nw = atoi(e) == 8 ? 8 : (atoi(e) == 4 ? 4 : nw);
+    if (a.C == 32) return nw == 4 ? launch<32, 4>(a, stream) : launch<32, 8>(a, stream);
     return nw == 4 ? launch<64, 4>(a, stream) : launch<64, 8>(a, stream);
 }
