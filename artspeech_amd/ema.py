@@ -16,6 +16,7 @@ larger batch (SURVEY.md N1 "batch-axis LSTM quirk"); here a batch is a stack of 
 reference is built but never called by forward.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -153,6 +154,11 @@ class EMA_Predictor:
                               wqkv=gemm(torch.cat([w[f"{at}.{n}_proj.linear.weight"] for n in ("query", "key", "value")], 0)),
                               bqkv=torch.cat([w[f"{at}.{n}_proj.linear.bias"] for n in ("query", "key", "value")], 0).to(dev),
                               wpos=gemm(w[at + ".pos_proj.linear.weight"]), u=vec(at + ".u_bias"), v=vec(at + ".v_bias"),
+                              # matrix-core attention (ops.xl_attention_image): the query rows twice, u_bias / v_bias folded into the bias
+                              wqkv4=gemm(torch.cat([w[f"{at}.{n}_proj.linear.weight"] for n in ("query", "query", "key", "value")], 0)),
+                              bqkv4=torch.cat([w[f"{at}.query_proj.linear.bias"] + w[at + ".u_bias"].reshape(-1),
+                                               w[f"{at}.query_proj.linear.bias"] + w[at + ".v_bias"].reshape(-1),
+                                               w[f"{at}.key_proj.linear.bias"], w[f"{at}.value_proj.linear.bias"]], 0).to(dev),
                               wo=gemm(w[at + ".out_proj.linear.weight"]), bo=vec(at + ".out_proj.linear.bias"))
             c = f"{q}.2.module.sequential"
             s, t = _bn_affine(w, c + ".5")
@@ -216,9 +222,15 @@ class EMA_Predictor:
             f = blk["ff1"]
             x = mm(f["w2"], mm(f["w1"], ln(f["ln"], x), bias=f["b1"], act=ACT_SWISH), bias=f["b2"], res=x)
             a = blk["att"]
-            qkv = mm(a["wqkv"], ln(a["ln"], x), bias=a["bqkv"])
-            pos = mm(a["wpos"], pos_in)
-            ctx = ops.xl_attention(qkv, D_MODEL, HEADS, pos, a["u"], a["v"], inv_scale, lay, lay.new(D_MODEL))
+            if os.environ.get("AS_XL_ATTENTION", "image") == "image":
+                qh, ph = ops.new_image(4 * D_MODEL, N, x.device), ops.new_image(D_MODEL, N, x.device)
+                qkv = mm(a["wqkv4"], ln(a["ln"], x), bias=a["bqkv4"], yh=qh)
+                ops.conv_gemm(a["wpos"], pos_in, lay, None, one, yh=ph)
+                ctx = ops.xl_attention_image(qkv, qh, ph, D_MODEL, HEADS, inv_scale, lay, lay.new(D_MODEL))
+            else:                                                                     # exact fp32 on the vector ALU
+                qkv = mm(a["wqkv"], ln(a["ln"], x), bias=a["bqkv"])
+                pos = mm(a["wpos"], pos_in)
+                ctx = ops.xl_attention(qkv, D_MODEL, HEADS, pos, a["u"], a["v"], inv_scale, lay, lay.new(D_MODEL))
             x = mm(a["wo"], ctx, bias=a["bo"], res=x)
             c = blk["conv"]
             g = ops.glu_dwconv_bn_swish(mm(c["w1"], ln(c["ln"], x), bias=c["b1"]), D_MODEL, c["dw"], c["bn"][0], c["bn"][1], lay,

@@ -562,6 +562,13 @@ def xl_attention(qkv, C, heads, pos, u_bias, v_bias, inv_scale, lay, out):
     return out
 
 
+def xl_attention_image(qkv4, qkv4_h, pos_h, C, heads, inv_scale, lay, out):
+    """as_xl_attention_image_f32: qkv4 fp32 [4C][N] = rows q + u, q + v, k, v and its operand image, pos_h = the image of pos [C][N]"""
+    check(_lib.lib().as_xl_attention_image_f32(_p(qkv4), _ld(qkv4), _p(qkv4_h), _p(pos_h), lay.N, C, heads, inv_scale, _p(lay.col_off), lay.B,
+                                               lay.max_w, _p(out), _ld(out), stream()), "as_xl_attention_image_f32")
+    return out
+
+
 def glu_dwconv_bn_swish(A, C, w, scale, shift, lay, Y):
     check(_lib.lib().as_glu_dwconv_bn_swish_f32(_p(A), _ld(A), C, _p(w), w.shape[1], _p(scale), _p(shift), _p(lay.col_off), lay.B,
                                                 _p(Y), _ld(Y), stream()), "as_glu_dwconv_bn_swish_f32")

@@ -1076,3 +1076,30 @@ def test_mean3_image(cuda):
     want = F.leaky_relu(((A + B) + Cc) / 3.0, 0.1)
     assert float((parts[0, :C, :-1] + parts[1, :C, :-1] - want).abs().max()) <= 1e-6
     assert float(parts[:, C:, :].abs().max()) == 0.0 and float(parts[:, :, -1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("lens", [[200, 31, 1], [32, 63, 2, 97], [333]])
+def test_xl_attention_image_equals_exact(cuda, lens):
+    """The Transformer-XL attention of the EMA predictor on the matrix cores (operand images in, f16x3 products) against the exact fp32
+    kernel: utterances shorter than / equal to / one past a wave's 31 queries, several key tiles, one frame."""
+    g = torch.Generator().manual_seed(sum(lens))
+    C, heads = 256, 4
+    lay = Layout(lens, cuda)
+    N = lay.N
+    x = torch.randn(C, N, generator=g)
+    wq, wk, wv, wp = (torch.randn(C, C, 1, generator=g) / 16 for _ in range(4))
+    bq, bk, bv = (torch.randn(C, generator=g) * 0.1 for _ in range(3))
+    u, v = torch.randn(heads, 64, generator=g) * 0.3, torch.randn(heads, 64, generator=g) * 0.3
+    pe = torch.randn(C, N, generator=g)
+    one = [(0, 0)]
+    X, PE = x.to(cuda), pe.to(cuda)
+    qkv = ops.conv_gemm(ops.prep_weight(torch.cat([wq, wk, wv], 0), cuda), X, lay, lay.new(3 * C), one, bias=torch.cat([bq, bk, bv]).to(cuda))
+    pos = ops.conv_gemm(ops.prep_weight(wp, cuda), PE, lay, lay.new(C), one)
+    want = ops.xl_attention(qkv, C, heads, pos, u.to(cuda), v.to(cuda), 1.0 / 16, lay, lay.new(C))
+    qh, ph = ops.new_image(4 * C, N, cuda), ops.new_image(C, N, cuda)
+    b4 = torch.cat([bq + u.reshape(-1), bq + v.reshape(-1), bk, bv]).to(cuda)
+    qkv4 = ops.conv_gemm(ops.prep_weight(torch.cat([wq, wq, wk, wv], 0), cuda), X, lay, lay.new(4 * C), one, bias=b4, yh=qh)
+    ops.conv_gemm(ops.prep_weight(wp, cuda), PE, lay, None, one, yh=ph)
+    got = ops.xl_attention_image(qkv4, qh, ph, C, heads, 1.0 / 16, lay, torch.full((C, N), float("nan"), device=cuda))
+    d = float((got - want).abs().max())
+    assert d <= 2e-5, d
