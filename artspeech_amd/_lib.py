@@ -149,7 +149,7 @@ _SIGNATURES.update({
     "as_adain_image_f32": (c_i, [ctypes.POINTER(AdainArgs), c_p]),
     "as_down_multi_f32": (c_i, [ctypes.POINTER(DownArgs), c_i, c_p]),
     "as_respair_f32": (c_i, [ctypes.POINTER(ResPairArgs), c_p]),
-    "as_xl_attention_image_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, ctypes.c_float, c_p, c_i, c_i, c_p, c_i, c_p]),
+    "as_xl_attention_image_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, ctypes.c_float, c_p, c_i, c_i, c_p, c_i, c_p, c_p]),
     "as_mean3_image_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, ctypes.c_float, c_p, c_p]),
     "as_conv_post_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, ctypes.c_float, c_i, c_p, c_p, c_p]),
     "as_rows_image_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),

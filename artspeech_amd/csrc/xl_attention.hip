@@ -33,8 +33,9 @@ struct XlArgs {
     int ld, C, N;
     float inv_scale;
     const int* col_off;
-    float* out;
+    float* out;             // fp32 [C][N], or NULL
     int ldo;
+    uint16_t* oh;           // the result as the operand image of the out-projection GEMM, or NULL
 };
 
 static __device__ __forceinline__ f16x8 ld_frag(__amdgpu_buffer_rsrc_t rs, unsigned off)
@@ -206,27 +207,58 @@ __global__ void __launch_bounds__(256) xl_attention_mfma_kernel(const XlArgs a)
             }
         }
     }
-    if (ii < 31 && i < T) {
-        const float inv = 1.0f / l;
+    const bool mine = ii < 31 && i < T;
+    const float inv = 1.0f / l;
+    if (a.out && mine) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 a.out[(size_t)(h * 64 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk) * a.ldo + o0 + i] = acc[rb][e] * inv;
     }
+    if (a.oh) {                                                          // 16-byte rows of 8 consecutive channels (conv_gemm.h yh_store_tile)
+        const __amdgpu_buffer_rsrc_t rsO =
+            __builtin_amdgcn_make_buffer_rsrc(a.oh, 0, (int)((unsigned)as_kbx(a.C) * 4u * NX * 16u), 0x00020000);
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float t[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x0 = acc[rb][8 * pr + r] * inv, x1 = acc[rb][8 * pr + 4 + r] * inv;
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(x1));
+                    t[r] = x0;
+                    t[4 + r] = x1;
+                }
+                u32x4_t hh, ll;
+                split2(t, hh, ll);
+                const int ch = h * 64 + rb * 32 + 16 * pr + 8 * lk;      // first of this lane's 8 channels
+                const unsigned pl = (unsigned)((ch >> 4) * 4 + ((ch >> 3) & 1));
+                const unsigned off = mine ? (pl * NX + (unsigned)(o0 + i)) * 16u : OOBH;
+                __builtin_amdgcn_raw_buffer_store_b128(hh, rsO, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ll, rsO, off + 2u * NX * 16u, 0, 0);
+                if (b == 0 && i == 0) {                                  // the image's zero column, once per (channel group, part)
+                    __builtin_amdgcn_raw_buffer_store_b128(z, rsO, (pl * NX + zc) * 16u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(z, rsO, ((pl + 2u) * NX + zc) * 16u, 0, 0);
+                }
+            }
+    }
 }
 }  // namespace
 
 extern "C" int as_xl_attention_image_f32(const float* qkv, int ld, const uint16_t* qkv_h, const uint16_t* pos_h, int n_total, int C, int heads,
-                                         float inv_scale, const int32_t* col_off, int B, int max_len, float* out, int ldo, as_stream_t stream)
+                                         float inv_scale, const int32_t* col_off, int B, int max_len, float* out, int ldo, uint16_t* out_h,
+                                         as_stream_t stream)
 {
-    if (!qkv || !qkv_h || !pos_h || !col_off || !out || C <= 0 || heads <= 0 || C != heads * 64 || B < 0 || B > 65535 || n_total < 0) return AS_EINVAL;
-    if (ld < n_total || ldo < n_total) return AS_EINVAL;
+    if (!qkv || !qkv_h || !pos_h || !col_off || (!out && !out_h) || C <= 0 || heads <= 0 || C != heads * 64 || B < 0 || B > 65535 || n_total < 0) return AS_EINVAL;
+    if (ld < n_total || (out && ldo < n_total) || (reinterpret_cast<uintptr_t>(out_h) & 15) != 0) return AS_EINVAL;
     if (16.0 * as_kbx(4 * C) * 4.0 * ((double)n_total + 1.0) >= 2147483648.0 || 16.0 * C * (double)ld >= 2147483648.0) return AS_EINVAL;
     if (B == 0 || max_len <= 0) return AS_OK;
     XlArgs a;
     a.qh = qkv_h; a.ph = pos_h; a.qkv = qkv; a.ld = ld; a.C = C; a.N = n_total; a.inv_scale = inv_scale;
-    a.col_off = col_off; a.out = out; a.ldo = ldo;
+    a.col_off = col_off; a.out = out; a.ldo = ldo; a.oh = out_h;
     AsProfScope prof__(AS_FILE_CLS, 2.0 * 4.0 * 64.0 * heads * (double)max_len * max_len * B, 0, (hipStream_t)stream, "xl_attention_image");
     const int waves = as_cdiv(max_len, 31);
     hipLaunchKernelGGL(xl_attention_mfma_kernel, dim3(as_cdiv(waves, 4), heads, B), dim3(256), 4 * 64 * 32 * sizeof(float), (hipStream_t)stream, a);

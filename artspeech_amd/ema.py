@@ -218,19 +218,65 @@ class EMA_Predictor:
         x = mm(W["enc1"][0], x82, bias=W["enc1"][1], act=ACT_RELU)                    # :75
         pos_in = self._pos_inputs(lay)
         inv_scale = 1.0 / math.sqrt(D_MODEL)                                          # attention.py:57: sqrt(d_model), not d_head
-        for blk in W["blocks"]:                                                       # :77-78, encoder.py:74-110
+        if os.environ.get("AS_XL_ATTENTION", "image") != "image":
+            return self._forward_exact(x, pos_in, inv_scale, lay)
+        # Activations travel between the GEMMs as operand images wherever their only reader is a GEMM: LayerNorm writes the image of the
+        # GEMM that follows it, the FFN's first GEMM (Swish) that of the second, the attention that of its out-projection -- 5 split
+        # passes per batch instead of 31.  pos = pos_proj(PE[frame index]) does not depend on the input: its image is made once per
+        # batch geometry and block.
+        img = lambda C: ops.new_image(C, N, x.device)
+        lns = lambda g, v: ops.channel_layernorm_split(v, lay, g[0], g[1], eps=1e-5)
+        gi = lambda wt, xs, K, Y=None, **kw: ops.conv_gemm(wt, None, lay, Y, one, xs=xs, K=K, **kw)
+
+        def ffn(f, v):
+            hh = gi(f["w1"], lns(f["ln"], v), D_MODEL, bias=f["b1"], act=ACT_SWISH, yh=img(4 * D_MODEL))
+            return gi(f["w2"], hh, 4 * D_MODEL, lay.new(D_MODEL), bias=f["b2"], res=v)
+
+        nb = len(W["blocks"])
+        for bi, blk in enumerate(W["blocks"]):                                        # :77-78, encoder.py:74-110
+            x = ffn(blk["ff1"], x)
+            a = blk["att"]
+            qh = img(4 * D_MODEL)
+            qkv = gi(a["wqkv4"], lns(a["ln"], x), D_MODEL, lay.new(4 * D_MODEL), bias=a["bqkv4"], yh=qh)
+            ctx = ops.xl_attention_image(qkv, qh, self._pos_image(lay, bi, a["wpos"], pos_in), D_MODEL, HEADS, inv_scale, lay, image=True)
+            x = gi(a["wo"], ctx, D_MODEL, lay.new(D_MODEL), bias=a["bo"], res=x)
+            c = blk["conv"]
+            g = ops.glu_dwconv_bn_swish(gi(c["w1"], lns(c["ln"], x), D_MODEL, lay.new(2 * D_MODEL), bias=c["b1"]), D_MODEL, c["dw"],
+                                        c["bn"][0], c["bn"][1], lay, lay.new(D_MODEL))
+            x = mm(c["w2"], g, bias=c["b2"], res=x)
+            x = ffn(blk["ff2"], x)
+            if bi + 1 < nb:
+                x = ln(blk["ln"], x)
+            else:                                                                     # the last LayerNorm feeds only decoder2's GEMM
+                gx = gi(W["lstm"][0], lns(blk["ln"], x), D_MODEL, lay.new(W["lstm"][0].shape[2]), bias=W["lstm"][1])
+        h = ops.lstm_step0(gx, D_MODEL, N, lay.new(2 * D_MODEL))                      # :79
+        d = ops.conv_gemm(W["d3a"][0], h, lay, None, one, bias=W["d3a"][1], act=ACT_RELU, yh=img(W["d3a"][0].shape[2]))   # :46-51
+        return gi(W["d3b"][0], d, W["d3a"][0].shape[2], lay.new(W["d3b"][0].shape[2]), bias=W["d3b"][1])                  # :53, :80
+
+    def _pos_image(self, lay, bi, wpos, pos_in):
+        """the operand image of pos_proj(PE[frame index]) of block bi for this batch geometry (input-independent: made once)"""
+        key = (tuple(int(v) for v in lay.widths_host), bi)
+        ph = self._pos_cache.get(key)
+        if ph is None:
+            ph = ops.new_image(D_MODEL, lay.N, pos_in.device)
+            ops.conv_gemm(wpos, pos_in, lay, None, [(0, 0)], yh=ph)
+            ops._settle(self.device)
+            self._pos_cache[key] = ph
+        return ph
+
+    def _forward_exact(self, x, pos_in, inv_scale, lay):
+        """the blocks with the exact fp32 attention kernel (AS_XL_ATTENTION=exact): fp32 activations between all launches"""
+        W, N = self.W, lay.N
+        one = [(0, 0)]
+        mm = lambda wt, v, **kw: ops.conv_gemm(wt, v, lay, lay.new(wt.shape[2]), one, **kw)
+        ln = lambda g, v: ops.channel_layernorm(v, N, g[0], g[1], lay.new(v.shape[0]), eps=1e-5)
+        for blk in W["blocks"]:
             f = blk["ff1"]
             x = mm(f["w2"], mm(f["w1"], ln(f["ln"], x), bias=f["b1"], act=ACT_SWISH), bias=f["b2"], res=x)
             a = blk["att"]
-            if os.environ.get("AS_XL_ATTENTION", "image") == "image":
-                qh, ph = ops.new_image(4 * D_MODEL, N, x.device), ops.new_image(D_MODEL, N, x.device)
-                qkv = mm(a["wqkv4"], ln(a["ln"], x), bias=a["bqkv4"], yh=qh)
-                ops.conv_gemm(a["wpos"], pos_in, lay, None, one, yh=ph)
-                ctx = ops.xl_attention_image(qkv, qh, ph, D_MODEL, HEADS, inv_scale, lay, lay.new(D_MODEL))
-            else:                                                                     # exact fp32 on the vector ALU
-                qkv = mm(a["wqkv"], ln(a["ln"], x), bias=a["bqkv"])
-                pos = mm(a["wpos"], pos_in)
-                ctx = ops.xl_attention(qkv, D_MODEL, HEADS, pos, a["u"], a["v"], inv_scale, lay, lay.new(D_MODEL))
+            qkv = mm(a["wqkv"], ln(a["ln"], x), bias=a["bqkv"])
+            pos = mm(a["wpos"], pos_in)
+            ctx = ops.xl_attention(qkv, D_MODEL, HEADS, pos, a["u"], a["v"], inv_scale, lay, lay.new(D_MODEL))
             x = mm(a["wo"], ctx, bias=a["bo"], res=x)
             c = blk["conv"]
             g = ops.glu_dwconv_bn_swish(mm(c["w1"], ln(c["ln"], x), bias=c["b1"]), D_MODEL, c["dw"], c["bn"][0], c["bn"][1], lay,

@@ -562,11 +562,14 @@ def xl_attention(qkv, C, heads, pos, u_bias, v_bias, inv_scale, lay, out):
     return out
 
 
-def xl_attention_image(qkv4, qkv4_h, pos_h, C, heads, inv_scale, lay, out):
-    """as_xl_attention_image_f32: qkv4 fp32 [4C][N] = rows q + u, q + v, k, v and its operand image, pos_h = the image of pos [C][N]"""
+def xl_attention_image(qkv4, qkv4_h, pos_h, C, heads, inv_scale, lay, out=None, image=False):
+    """as_xl_attention_image_f32: qkv4 fp32 [4C][N] = rows q + u, q + v, k, v and its operand image, pos_h = the image of pos [C][N].
+    image=True: the result as the operand image of the GEMM that follows (conv_gemm(..., xs=, K=C)) instead of fp32 `out`."""
+    oh = new_image(C, lay.N, qkv4.device) if image else None
     check(_lib.lib().as_xl_attention_image_f32(_p(qkv4), _ld(qkv4), _p(qkv4_h), _p(pos_h), lay.N, C, heads, inv_scale, _p(lay.col_off), lay.B,
-                                               lay.max_w, _p(out), _ld(out), stream()), "as_xl_attention_image_f32")
-    return out
+                                               lay.max_w, _p(out), _ld(out) if out is not None else 0, _p(oh), stream()),
+          "as_xl_attention_image_f32")
+    return oh if image else out
 
 
 def glu_dwconv_bn_swish(A, C, w, scale, shift, lay, Y):

@@ -410,10 +410,12 @@ int as_xl_attention_f32(const float* qkv, int ld, int C, int heads, const float*
                         as_stream_t stream);
 /* as_xl_attention_image_f32: the same attention on the matrix cores (csrc/xl_attention.hip), fed by the projection GEMMs' operand images.
  *   qkv fp32 [4C][N] (ld) and qkv_h its image (as_conv_gemm_f32 with Y and Yh): rows q + u_bias, q + v_bias, k, v -- the query weights
- *   stacked twice with the biases folded in; pos_h = the image of pos [C][N]; n_total = N (the images' column count); out [C][N].
+ *   stacked twice with the biases folded in; pos_h = the image of pos [C][N]; n_total = N (the images' column count); out fp32 [C][N]
+ *   and / or out_h = the result as the operand image of the out-projection GEMM (as_split_f16x2_bytes(C, N) bytes).
  *   f16x3 products (fp32-accurate); agrees with as_xl_attention_f32 to fp32 rounding. */
 int as_xl_attention_image_f32(const float* qkv, int ld, const uint16_t* qkv_h, const uint16_t* pos_h, int n_total, int C, int heads,
-                              float inv_scale, const int32_t* col_off, int B, int max_len, float* out, int ldo, as_stream_t stream);
+                              float inv_scale, const int32_t* col_off, int B, int max_len, float* out, int ldo, uint16_t* out_h,
+                              as_stream_t stream);
 int as_glu_dwconv_bn_swish_f32(const float* a, int lda, int C, const float* w, int k, const float* scale, const float* shift,
                                const int32_t* col_off, int B, float* y, int ldy, as_stream_t stream);
 int as_lstm_step0_f32(const float* gx, int ldg, int H, int N, float* h, int ldh, as_stream_t stream);

@@ -14,12 +14,31 @@ n.copy_(torch.from_numpy(synth.hash_tensor("ema/bench/n", (1, B * T), 1, 1.0)))
 for _ in range(3):
     out = net.forward_packed(f0, n, mel, lay)
 torch.cuda.synchronize()
+import time
 k = 20
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
+t0 = time.perf_counter()
 for _ in range(k):
     out = net.forward_packed(f0, n, mel, lay)
+host_ms = (time.perf_counter() - t0) / k * 1e3
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / k
-print(f"EMA_Predictor B={B} T={T}: {ms:.3f} ms per batch, {B * T / ms * 1e3:,.0f} frames/s, finite={bool(torch.isfinite(out).all())}")
+# the same launches as a hipGraph: what the device needs when the host is not in the way (eager, ~70 launches per batch are issued by
+# Python at 10-60 us each depending on the box's host load)
+s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+g = torch.cuda.CUDAGraph()
+with torch.cuda.stream(s):
+    net.forward_packed(f0, n, mel, lay); torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        out_g = net.forward_packed(f0, n, mel, lay)
+torch.cuda.synchronize()
+for _ in range(3): g.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(k): g.replay()
+torch.cuda.synchronize()
+gms = (time.perf_counter() - t0) / k * 1e3
+print(f"EMA_Predictor B={B} T={T}: {gms:.3f} ms per batch by graph replay ({B * T / gms * 1e3:,.0f} frames/s), {ms:.3f} eager "
+      f"(host issues a batch in {host_ms:.3f} ms), finite={bool(torch.isfinite(out).all())}, graph == eager: {bool(torch.equal(out, out_g))}")

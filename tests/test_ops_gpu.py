@@ -1103,3 +1103,8 @@ def test_xl_attention_image_equals_exact(cuda, lens):
     got = ops.xl_attention_image(qkv4, qh, ph, C, heads, 1.0 / 16, lay, torch.full((C, N), float("nan"), device=cuda))
     d = float((got - want).abs().max())
     assert d <= 2e-5, d
+    # the result as the out-projection's operand image
+    oh = ops.xl_attention_image(qkv4, qh, ph, C, heads, 1.0 / 16, lay, image=True)
+    parts = image_parts(oh.cpu(), C, N)
+    assert float((parts[0, :C, :-1] + parts[1, :C, :-1] - got.cpu()).abs().max()) <= 1e-6
+    assert torch.equal(parts[0, :C, :-1], got.cpu().half().float()) and float(parts[:, :, -1].abs().max()) == 0.0
