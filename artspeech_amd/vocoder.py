@@ -163,7 +163,8 @@ class Generator:
             # LeakyReLU'd result to the next one as an image (ConvGemmArgs.Yh / yh_lrelu): no fp32 copy of conv1's output, no split passes
             # (the three stacks of a stage as ONE launch per step -- ops.conv_gemm_multi -- was measured: 18.2 ms per batch against 17.9 with
             # a launch per conv; these grids hold thousands of tiles each, there is no tail worth filling)
-            fused = cout in (32, 64) and nk == 3 and os.environ.get("AS_VOC_FUSED", "1") != "0"
+            # (as_respair_f32 addresses a tensor with 32-bit byte offsets: a batch beyond 2 GiB per tensor takes the conv GEMM launches)
+            fused = cout in (32, 64) and nk == 3 and os.environ.get("AS_VOC_FUSED", "1") != "0" and 4 * cout * (lay.N + 1) < 2 ** 31
             if fused:
                 # 32 / 64 channels: a residual step is ONE launch that keeps its column tile in LDS between the two convs (ops.respair):
                 # x in, y out -- no operand images in HBM at all; the stage's mean rides in the last step of the third stack
