@@ -123,7 +123,8 @@ class ResPairArgs(ctypes.Structure):
     _fields_ = [("x", c_p), ("ldx", ctypes.c_int32), ("y", c_p), ("ldy", ctypes.c_int32), ("w1", c_p), ("w2", c_p), ("b1", c_p), ("b2", c_p),
                 ("scale1", ctypes.c_float), ("scale2", ctypes.c_float), ("C", ctypes.c_int32), ("N", ctypes.c_int32), ("k", ctypes.c_int32),
                 ("dil", ctypes.c_int32), ("slope", ctypes.c_float), ("col_off", c_p), ("B", ctypes.c_int32), ("max_w", ctypes.c_int32),
-                ("add1", c_p), ("add2", c_p), ("ld_add", ctypes.c_int32), ("out_div", ctypes.c_float), ("yh", c_p), ("yh_slope", ctypes.c_float)]
+                ("add1", c_p), ("add2", c_p), ("ld_add", ctypes.c_int32), ("out_div", ctypes.c_float), ("yh", c_p), ("yh_slope", ctypes.c_float),
+                ("x_u", ctypes.c_int32), ("x_bias", c_p)]
 
 
 class ModelCfg(ctypes.Structure):

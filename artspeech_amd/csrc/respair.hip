@@ -115,8 +115,20 @@ __global__ void __launch_bounds__(64 * NW, C == 32 && NW == 4 ? 4 : (C == 32 ? 2
     };
 
     // 1. the x tile
+    // x_u >= 2: x is the ConvTranspose1d's phase-major output z [u C][N / u] (vocoder.py of this package: one 3-tap conv GEMM with
+    // u x C rows) and x[ch][col] = z[(col % u) C + ch][col / u] + x_bias[ch] -- as_interleave_phases_f32 folded into the six reads of
+    // a stage's input (fill and residual of the three stacks' first steps); consecutive lanes then read u runs of 64 / u floats.
+    const int xu = a.x_u >= 2 ? a.x_u : 1;
     const __amdgpu_buffer_rsrc_t rsX =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((unsigned)C * a.ldx * 4u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((unsigned)(xu * C) * a.ldx * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsXB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x_bias), 0, (a.x_u >= 2 && a.x_bias) ? C * 4 : 0, 0x00020000);
+    // byte offset of x[ch][col] (col inside the tensor)
+    auto x_off = [&](int ch, int col) {
+        if (xu == 1) return (unsigned)(ch * a.ldx + col) * 4u;
+        const int q = col / xu, r = col - q * xu;
+        return (unsigned)((r * C + ch) * a.ldx + q) * 4u;
+    };
     {
         // every load of a batch of six items (48 per thread) is in flight before the first is converted: the fill is one or two memory
         // round trips of the workgroup, not one per item
@@ -129,9 +141,14 @@ __global__ void __launch_bounds__(64 * NW, C == 32 && NW == 4 ? 4 : (C == 32 ? 2
                 const int it = it0 + i * NT;
                 const int g = it / XW, c = it - g * XW;
                 const int col = X0 + c;
-                const unsigned off = (it < total && col >= n_lo && col < n_hi) ? (unsigned)(8 * g * a.ldx + col) * 4u : OOBH;
+                const bool in = it < total && col >= n_lo && col < n_hi;
+                const unsigned off = in ? x_off(8 * g, col) : OOBH;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[i][e] = buf_load1(rsX, off + (unsigned)(e * a.ldx) * 4u, 0);
+                if (xu > 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[i][e] += buf_load1(rsXB, in ? (unsigned)(8 * g + e) * 4u : OOBH, 0);
+                }
             }
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
@@ -305,12 +322,16 @@ __global__ void __launch_bounds__(64 * NW, C == 32 && NW == 4 ? 4 : (C == 32 ? 2
                 const int oc = wave * 64 + cb * 32 + l31, col = t0 + oc;
                 const bool ok = oc < RP_OW && col < n_hi;
                 const int row0 = m * 32 + 4 * lk;
-                const unsigned xo = ok ? (unsigned)(row0 * a.ldx + col) * 4u : OOBH;
+                const unsigned xo = ok ? x_off(row0, col) : OOBH;
                 const unsigned yo = ok ? (unsigned)(row0 * a.ldy + col) * 4u : OOBH;
                 const unsigned po = ok ? (unsigned)(row0 * a.ld_add + col) * 4u : OOBH;
                 float r[16], p[16], q[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) r[e] = buf_load1(rsX, xo + (unsigned)(((e & 3) + 8 * (e >> 2)) * a.ldx) * 4u, 0);
+                if (xu > 1) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) r[e] += buf_load1(rsXB, ok ? (unsigned)(row0 + (e & 3) + 8 * (e >> 2)) * 4u : OOBH, 0);
+                }
                 if (a.add1) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
@@ -410,11 +431,13 @@ extern "C" int as_respair_f32(const AsResPairArgs* ap, as_stream_t stream_)
     if (a.yh && ((reinterpret_cast<uintptr_t>(a.yh) & 15) != 0 || 256.0 * ((double)a.N + 1.0) >= 2147483648.0)) return AS_EINVAL;
     if (a.C != 32 && a.C != 64) return AS_EINVAL;
     if (a.k < 1 || !(a.k & 1) || a.k / 2 > RP_ML || a.dil < 1 || a.dil * (a.k / 2) > 40) return AS_EINVAL;
-    if (a.B <= 0 || a.B > 65535 || a.N < 0 || a.max_w < 0 || a.ldx < a.N || (a.y && a.ldy < a.N)) return AS_EINVAL;
+    const int xu = a.x_u >= 2 ? a.x_u : 1;
+    if (a.x_u < 0 || a.x_u == 1 || (long)a.ldx * xu < (long)a.N || (xu > 1 && a.N % xu != 0)) return AS_EINVAL;
+    if (a.B <= 0 || a.B > 65535 || a.N < 0 || a.max_w < 0 || (a.y && a.ldy < a.N)) return AS_EINVAL;
     if ((a.add1 == nullptr) != (a.add2 == nullptr) || (a.add1 && (a.ld_add < a.N || !(a.out_div > 0.f)))) return AS_EINVAL;
     // 32-bit byte offsets inside every tensor (raw buffer accesses)
     const double lim = 2147483648.0;
-    if ((double)a.C * a.ldx * 4.0 >= lim || (a.y && (double)a.C * a.ldy * 4.0 >= lim) || (a.add1 && (double)a.C * a.ld_add * 4.0 >= lim)) return AS_EINVAL;
+    if ((double)a.C * xu * a.ldx * 4.0 >= lim || (a.y && (double)a.C * a.ldy * 4.0 >= lim) || (a.add1 && (double)a.C * a.ld_add * 4.0 >= lim)) return AS_EINVAL;
     if (a.N == 0 || a.max_w == 0) return AS_OK;
     char tag[96];
     snprintf(tag, sizeof(tag), "respair C%d N%d k%d d%d%s", a.C, a.N, a.k, a.dil, a.add1 ? " mean3" : "");

@@ -429,9 +429,15 @@ def respair(X, lay, w1, b1, w2, b2, k, dil, slope, Y=None, add=None, image_slope
     """One residual step of ResBlock1 (Vocoder/vocoder.py:35-42) as one launch: Y = X + conv2(lrelu(conv1(lrelu(X)))), conv1 with
     dilation `dil`, both with k taps; X [C][N] fp32 with C = 32 or 64, w1 / w2 = prep_weight of the [C][C][k] weights.
     add = (A, B): Y = ((A + B) + Y) / 3 (the mean of a stage's three stacks).  Y must not be X.
-    image_slope: return LeakyReLU(Y, image_slope) as a split operand image (conv_gemm(..., xs=)) INSTEAD of the fp32 Y."""
-    C = X.shape[0]
+    image_slope: return LeakyReLU(Y, image_slope) as a split operand image (conv_gemm(..., xs=)) INSTEAD of the fp32 Y.
+    X may be (Z, bias, u): the phase-major output Z [u C][N / u] of the ConvTranspose1d-as-conv before interleave_phases, read in place."""
     a = _lib.ResPairArgs()
+    if isinstance(X, tuple):
+        X, xb, u = X
+        C = xb.shape[0]
+        a.x_u, a.x_bias = int(u), _p(xb)
+    else:
+        C = X.shape[0]
     if image_slope is not None:
         yh = new_image(C, lay.N, X.device)
         a.yh, a.yh_slope = _p(yh), float(image_slope)

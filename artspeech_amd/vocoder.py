@@ -156,15 +156,18 @@ class Generator:
             else:
                 z = ops.conv_gemm(wt, x, lay, lay.new(u * cout), taps_1d(3), in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
             lay_up = lay.scaled(u)
-            x = ops.interleave_phases(z, b, cout, u, lay.N, lay_up.new(cout))
+            # 32 / 64 channels: the residual steps are fused launches (below); they address a tensor with 32-bit byte offsets: a batch
+            # beyond 2 GiB per tensor takes the conv GEMM launches.  (They can read the conv's phase-major output in place -- the interleave
+            # as an address computation of their six reads, AS_VOC_FOLD=1 --: measured 14.30 ms per batch against 14.08 with the interleave
+            # kernel: the six strided reads cost more than the 0.28 ms the two passes take.)
+            fused = cout in (32, 64) and nk == 3 and os.environ.get("AS_VOC_FUSED", "1") != "0" and 4 * u * cout * (lay.N + 1) < 2 ** 31
+            x = (z, b, u) if fused and os.environ.get("AS_VOC_FOLD", "0") == "1" else ops.interleave_phases(z, b, cout, u, lay.N, lay_up.new(cout))
             lay = lay_up
             outs = []
             # LeakyReLU(x) as an operand image, once for the three residual stacks that start from x; inside a stack every conv hands its
             # LeakyReLU'd result to the next one as an image (ConvGemmArgs.Yh / yh_lrelu): no fp32 copy of conv1's output, no split passes
             # (the three stacks of a stage as ONE launch per step -- ops.conv_gemm_multi -- was measured: 18.2 ms per batch against 17.9 with
             # a launch per conv; these grids hold thousands of tiles each, there is no tail worth filling)
-            # (as_respair_f32 addresses a tensor with 32-bit byte offsets: a batch beyond 2 GiB per tensor takes the conv GEMM launches)
-            fused = cout in (32, 64) and nk == 3 and os.environ.get("AS_VOC_FUSED", "1") != "0" and 4 * cout * (lay.N + 1) < 2 ** 31
             if fused:
                 # 32 / 64 channels: a residual step is ONE launch that keeps its column tile in LDS between the two convs (ops.respair):
                 # x in, y out -- no operand images in HBM at all; the stage's mean rides in the last step of the third stack

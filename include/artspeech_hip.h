@@ -494,6 +494,8 @@ typedef struct AsResPairArgs {
     const int32_t* col_off; int32_t B, max_w;
     const float* add1; const float* add2; int32_t ld_add; float out_div;
     uint16_t* yh; float yh_slope;       /* optional: LeakyReLU(y, yh_slope) as the operand image of the conv that follows (y may then be NULL) */
+    int32_t x_u; const float* x_bias;   /* x_u >= 2: x is the phase-major ConvTranspose1d output z [x_u * C][N / x_u] (ldx its row stride) and
+                                         * x[ch][col] = z[(col % x_u) * C + ch][col / x_u] + x_bias[ch]: as_interleave_phases_f32 folded into the read */
 } AsResPairArgs;
 int as_respair_f32(const AsResPairArgs* a, as_stream_t stream);
 

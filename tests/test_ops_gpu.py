@@ -1014,6 +1014,16 @@ def test_respair_equals_two_convs(cuda, monkeypatch, C, k, dil, lens):
             yn = ops.respair(X, lay, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1)
             assert float((yn.cpu() - want).abs().max()) <= 2e-6, nw
         monkeypatch.delenv("AS_RESPAIR_NW")
+    # x given as the phase-major output of the up-sampling conv (interleave_phases folded into the read)
+    for u in (2, 3):
+        lens_in = [max(1, L // u) for L in lens]
+        lay_u = Layout([u * L for L in lens_in], cuda)
+        xb = torch.randn(C, generator=g) * 0.2
+        Z = torch.randn(u * C, sum(lens_in), generator=g)
+        xu = ops.interleave_phases(Z.to(cuda), xb.to(cuda), C, u, sum(lens_in), lay_u.new(C))
+        ya = ops.respair(xu, lay_u, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1)
+        yb = ops.respair((Z.to(cuda), xb.to(cuda), u), lay_u, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1)
+        assert torch.equal(ya, yb), u
     # the result as the next conv's operand image instead of fp32
     yi = ops.respair(X, lay, W1, b1.to(cuda), W2, b2.to(cuda), k, dil, 0.1, image_slope=0.1)
     parts = image_parts(yi.cpu(), C, lay.N)                                  # [2][KBx * 16][N + 1]
