@@ -1118,3 +1118,26 @@ def test_xl_attention_image_equals_exact(cuda, lens):
     parts = image_parts(oh.cpu(), C, N)
     assert float((parts[0, :C, :-1] + parts[1, :C, :-1] - got.cpu()).abs().max()) <= 1e-6
     assert torch.equal(parts[0, :C, :-1], got.cpu().half().float()) and float(parts[:, :, -1].abs().max()) == 0.0
+
+
+def test_respair_fuzz(cuda):
+    """Random shapes of the fused residual step against fp32 torch: every odd k the library accepts (1 .. 17), dilations up to the halo
+    limit, ragged batches around the tile widths (240 / 496 columns) and the halo."""
+    rng = np.random.default_rng(20261004)
+    g = torch.Generator().manual_seed(99)
+    for case in range(14):
+        C = int(rng.choice([32, 64]))
+        k = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 17]))
+        dil = int(rng.integers(1, max(2, min(6, 40 // max(k // 2, 1)) + 1)))
+        B = int(rng.integers(1, 5))
+        lens = [int(rng.choice([1, 2, 7, 239, 240, 241, 480, 495, 496, 497, int(rng.integers(1, 1300))])) for _ in range(B)]
+        w1 = torch.randn(C, C, k, generator=g) * (0.7 / np.sqrt(C * k))
+        w2 = torch.randn(C, C, k, generator=g) * (0.7 / np.sqrt(C * k))
+        b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+        xs = [torch.randn(C, L, generator=g) for L in lens]
+        want = packed([(F.conv1d(F.leaky_relu(F.conv1d(F.leaky_relu(x[None], 0.1), w1, b1, padding=dil * (k // 2), dilation=dil), 0.1),
+                                 w2, b2, padding=k // 2) + x[None])[0] for x in xs])
+        lay = Layout(lens, cuda)
+        y = ops.respair(packed(xs).to(cuda), lay, ops.prep_weight(w1, cuda), b1.to(cuda), ops.prep_weight(w2, cuda), b2.to(cuda), k, dil, 0.1)
+        d = float((y.cpu() - want).abs().max())
+        assert d <= 3e-6, (case, C, k, dil, lens, d)
