@@ -25,7 +25,12 @@
 // epilogue (HBM) and its convs (MFMA) follow each other, and two to four workgroups per CU overlap them only in part: k = 3 steps run
 // at 2.0-2.6 TB/s of x-in + y-out (the residual is read a second time, the halo columns twice), k = 11 ones at 260-320 TFLOP/s.
 // Tried, same times within 3 %: three weight buffers with the DMA two granules ahead and a vmcnt(1) wait before the barrier, fragments
-// double-buffered in registers, all loads of the fill in flight at once, staggering the first wave of workgroups.
+// double-buffered in registers, all loads of the fill in flight at once, staggering the first wave of workgroups.  Tried and SLOWER
+// (scripts/exp/records/respair_persistent.diff, results equal): one persistent eight-wave workgroup per CU that loads the next tile's
+// columns (and, at 32 channels, the residual) into registers while it multiplies the current one -- 237 / 307 / 375 us against 184 / 241 /
+// 309 at 32 channels (k = 3 / 7 / 11), 365 / 498 / 630 against 220 / 356 / 494 at 64: its loads do run under its MFMAs, but its conv1-to-conv2
+// hand-over, epilogue and tile commit no longer run under ANOTHER workgroup's MFMAs, and one workgroup's loads per CU are fewer bytes in
+// flight than four workgroups' (256 registers with 12 / 81 spills).
 #include "conv_gemm.h"
 #include <cstdio>
 #include <cstdlib>
