@@ -1088,7 +1088,7 @@ def test_mean3_image(cuda):
     assert float(parts[:, C:, :].abs().max()) == 0.0 and float(parts[:, :, -1].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("lens", [[200, 31, 1], [32, 63, 2, 97], [333]])
+@pytest.mark.parametrize("lens", [[200, 31, 1], [32, 63, 2, 97], [333], [2048, 5]])
 def test_xl_attention_image_equals_exact(cuda, lens):
     """The Transformer-XL attention of the EMA predictor on the matrix cores (operand images in, f16x3 products) against the exact fp32
     kernel: utterances shorter than / equal to / one past a wave's 31 queries, several key tiles, one frame."""
