@@ -87,7 +87,6 @@ _SIGNATURES.update({
     "as_glu_dwconv_bn_swish_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "as_lstm_step0_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "as_bn_lrelu_maxpool_rows_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
-    "as_bn_lrelu_maxpool_rows_image_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_i, c_p]),
     "as_avgpool_down_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "as_im2col_valid_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "as_dwconv_down_image_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),

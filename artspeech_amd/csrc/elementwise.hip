@@ -698,68 +698,6 @@ extern "C" int as_bn_lrelu_maxpool_rows_f32(const float* x, int ldx, const int32
     return AS_OK;
 }
 
-// The same pooling written ONLY as the operand image of the convs that read it (ResBlock.forward, model.py:184-190: the pooled
-// activations feed conv.0 and the 1x1 shortcut, both conv GEMMs): a thread owns 8 consecutive channels of one output pixel.
-__global__ void __launch_bounds__(256)
-bn_lrelu_maxpool_rows_image_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ tok_off, int H, int k, int C,
-                                   const float* __restrict__ scale, const float* __restrict__ shift, float slope,
-                                   u32x4_t* __restrict__ yh, int n_out)
-{
-    const int b = blockIdx.y, g = blockIdx.z;                           // 8-channel group: k-block g / 2, k-half g % 2
-    const int t0 = tok_off[b], Wb = tok_off[b + 1] - t0, Hout = H / k;
-    const size_t NX = (size_t)n_out + 1, plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;
-    if (b == 0 && blockIdx.x == 0 && threadIdx.x < 2) yh[plane + (size_t)threadIdx.x * 2 * NX + n_out] = u32x4_t{0u, 0u, 0u, 0u};
-    float sc[8], sh[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int c = 8 * g + r;
-        sc[r] = c < C ? scale[c] : 0.f;
-        sh[r] = c < C ? shift[c] : 0.f;
-    }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hout * Wb; i += gridDim.x * blockDim.x) {
-        const int ho = i / Wb, w = i - ho * Wb;
-        float m[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int c = 8 * g + r;
-            float best = -INFINITY;
-            if (c < C) {
-                const float* xr = x + (size_t)c * ldx + (size_t)H * t0;
-                for (int q = 0; q < k; ++q) {
-                    float v = xr[(size_t)(ho * k + q) * Wb + w] * sc[r] + sh[r];
-                    v = v > 0.f ? v : slope * v;
-                    best = fmaxf(best, v);
-                }
-            } else {
-                best = 0.f;
-            }
-            m[r] = best;
-        }
-        u32x4_t h, l;
-        split2(m, h, l);
-        const size_t col = (size_t)Hout * t0 + i;
-        yh[plane + col] = h;
-        yh[plane + 2 * NX + col] = l;
-    }
-}
-
-extern "C" int as_bn_lrelu_maxpool_rows_image_f32(const float* x, int ldx, const int32_t* tok_off, int B, int C, int H, int k,
-                                                  const float* scale, const float* shift, float slope, uint16_t* yh, int total_frames,
-                                                  as_stream_t stream)
-{
-    if (!x || !yh || !tok_off || !scale || !shift || B < 0 || C <= 0 || H <= 0 || k <= 0 || k > H) return AS_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(yh) & 15) != 0) return AS_EINVAL;
-    if (B == 0 || total_frames <= 0) return AS_OK;
-    AsProfScope prof__(AS_FILE_CLS, 0, 4.0 * C * (double)total_frames * (H + H / k), (hipStream_t)stream);
-    const int per_utt = as_cdiv((long)(H / k) * total_frames, B);
-    int gx = as_cdiv(per_utt, 256);
-    gx = gx < 1 ? 1 : gx > 64 ? 64 : gx;
-    hipLaunchKernelGGL(bn_lrelu_maxpool_rows_image_kernel, dim3(gx, B, 2 * as_kbx(C)), dim3(256), 0, (hipStream_t)stream, x, ldx, tok_off, H,
-                       k, C, scale, shift, slope, reinterpret_cast<u32x4_t*>(yh), (H / k) * total_frames);
-    AS_CHECK_LAUNCH();
-    return AS_OK;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Style-tower helpers (K10): learned / average 2x down-sampling, im2col for the valid 5x5 convs,
 // LeakyReLU + global average pool.  Images are [C][sum_b H*W_b] with per-utterance widths.

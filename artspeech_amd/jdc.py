@@ -164,16 +164,15 @@ class JDCNet:
             blk = W[f"res_block{i + 1}"]
             Ho = H // 2
             lo = img(Ho)
-            # the pooled activations p feed conv.0 and the shortcut, both conv GEMMs: the pooling kernel writes them only as the operand
-            # image (no fp32 copy, no split pass); conv.0 hands its (BatchNorm-folded, LeakyReLU'd) result to conv.3 as an image too;
-            # conv.3 sums the 1x1 shortcut of p in the same launch
-            cp = x.shape[0]
-            ph = ops.bn_lrelu_maxpool_rows_image(x, lay, H, 2, blk["pre"][0], blk["pre"][1], sl)
+            p = ops.bn_lrelu_maxpool_rows(x, lay, H, 2, blk["pre"][0], blk["pre"][1], sl, lo.new(x.shape[0]))
+            # p feeds conv.0 and the shortcut: split ONCE; conv.0 hands its (BatchNorm-folded, LeakyReLU'd) result to conv.3 as an operand
+            # image (no fp32 copy, no split pass); conv.3 sums the 1x1 shortcut of p in the same launch
+            ph = ops.split_act(p, lo)
             wt, b = blk["c0"]
-            ah = ops.new_image(wt.shape[2], lo.N, x.device)
-            ops.conv_gemm(wt, None, lo, None, t33, bias=b, act=ACT_LRELU, act_slope=sl, xs=ph, K=cp, yh=ah)
+            ah = ops.new_image(wt.shape[2], lo.N, p.device)
+            ops.conv_gemm(wt, None, lo, None, t33, bias=b, act=ACT_LRELU, act_slope=sl, xs=ph, K=p.shape[0], yh=ah)
             wt3, _ = blk["c3"]
-            x = ops.conv_gemm(wt3, None, lo, lo.new(wt3.shape[2]), t33, xs=ah, K=wt.shape[2], x2s=ph, K2=cp)
+            x = ops.conv_gemm(wt3, None, lo, lo.new(wt3.shape[2]), t33, xs=ah, K=wt.shape[2], x2s=ph, K2=p.shape[0])
             H = Ho
         hout = H // 4
         f = ops.bn_lrelu_maxpool_rows(x, lay, H, 4, W["pool"][0], W["pool"][1], sl, lay.new(x.shape[0] * hout), to_channels=True)

@@ -390,14 +390,6 @@ def crop(src, src_lay, start, dst, dst_lay):
     return dst
 
 
-def bn_lrelu_maxpool_rows_image(X, tok_lay, H, k, scale, shift, slope):
-    """as_bn_lrelu_maxpool_rows_image_f32: the pooled images only as a split operand image (conv_gemm(..., xs=, K=C))"""
-    xs = new_image(X.shape[0], (H // k) * tok_lay.N, X.device)
-    check(_lib.lib().as_bn_lrelu_maxpool_rows_image_f32(_p(X), _ld(X), _p(tok_lay.col_off), tok_lay.B, X.shape[0], H, k, _p(scale), _p(shift),
-                                                        slope, _p(xs), tok_lay.N, stream()), "as_bn_lrelu_maxpool_rows_image_f32")
-    return xs
-
-
 def bn_lrelu_maxpool_rows(X, tok_lay, H, k, scale, shift, slope, Y, to_channels=False):
     """BatchNorm(eval) -> LeakyReLU -> max over k consecutive image rows; X [C][H * frames] images of tok_lay's utterances."""
     check(_lib.lib().as_bn_lrelu_maxpool_rows_f32(_p(X), _ld(X), _p(tok_lay.col_off), tok_lay.B, X.shape[0], H, k, _p(scale), _p(shift),

@@ -339,10 +339,6 @@ int as_dwconv_down_f32(const float* x, int ldx, const int32_t* in_off, const int
 int as_bn_lrelu_maxpool_rows_f32(const float* x, int ldx, const int32_t* tok_off, int B, int C, int H, int k, const float* scale,
                                  const float* shift, float slope, float* y, int ldy, int to_channels, int total_frames,
                                  as_stream_t stream);
-/* the same (to_channels = 0) written only as the operand image of the convs that read it (ResBlock.forward, model.py:184-190):
- * yh = as_split_f16x2_bytes(C, (H / k) * total_frames) bytes */
-int as_bn_lrelu_maxpool_rows_image_f32(const float* x, int ldx, const int32_t* tok_off, int B, int C, int H, int k, const float* scale,
-                                       const float* shift, float slope, uint16_t* yh, int total_frames, as_stream_t stream);
 int as_avgpool_down_f32(const float* x, int ldx, const int32_t* in_off, const int32_t* in_w, int Hin, float* y, int ldy,
                         const int32_t* out_off, const int32_t* out_w, int Hout, int pool_h, const float* res, int ldr,
                         int B, int C, int max_out, as_stream_t stream);
