@@ -46,7 +46,7 @@ class ConvGemmArgs(ctypes.Structure):
                 ("dh", ctypes.c_int32 * AS_MAX_TAPS), ("dw", ctypes.c_int32 * AS_MAX_TAPS),
                 ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float), ("acc_scale", ctypes.c_float),
                 ("n_groups", ctypes.c_int32), ("group_cols", ctypes.c_int32), ("range_probe", ctypes.c_int32), ("status", ctypes.c_void_p),
-                ("Xh2", ctypes.c_void_p), ("K2", ctypes.c_int32), ("src_col", ctypes.c_void_p), ("N_in", ctypes.c_int32)]
+                ("Xh2", ctypes.c_void_p), ("K2", ctypes.c_int32), ("src_col", ctypes.c_void_p), ("N_in", ctypes.c_int32), ("ileave_u", ctypes.c_int32)]
 
 
 _SIGNATURES.update({

@@ -187,8 +187,8 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
         const_cast<float*>(a.bias ? a.bias + (size_t)grp * a.M : nullptr), 0, a.bias ? a.M * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.res), 0, a.res ? (int)((unsigned)a.M * a.ldr * 4u) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsY =
-        __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, a.Y ? (int)((unsigned)(TR ? a.N : a.M) * a.ldy * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+        a.Y, 0, a.Y ? (int)((unsigned)(TR ? a.N : (a.ileave_u > 1 ? a.M / a.ileave_u : a.M)) * a.ldy * 4u) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(
         a.Yh, 0, a.Yh ? (int)((unsigned)as_kbx(a.M) * 4u * ((unsigned)a.N + 1u) * 16u) : 0, 0x00020000);
     const float sc = a.acc_scale;
@@ -254,7 +254,11 @@ static __device__ __forceinline__ void epilogue_tiles(const ConvGemmArgs& a, con
                 }
             } else {
                 if (a.Y) {
-                    const unsigned off = col < n_end ? (unsigned)(row0 * a.ldy + col) * 4u : OOBH;
+                    unsigned off = col < n_end ? (unsigned)(row0 * a.ldy + col) * 4u : OOBH;
+                    if (a.ileave_u > 1) {                               // rows (phase r, channel m) -> Y[m][u col + r]; C % 32 == 0: one r per tile
+                        const int Cc = a.M / a.ileave_u, r = (row0 - 4 * lk) / Cc;
+                        off = (col < n_end && row0 - 4 * lk < a.M) ? (unsigned)((row0 - r * Cc) * a.ldy + a.ileave_u * col + r) * 4u : OOBH;
+                    }
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rsY,

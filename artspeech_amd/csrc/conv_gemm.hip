@@ -307,7 +307,7 @@ static GemmPlan gemm_plan(const ConvGemmArgs& a)
 {
     GemmPlan p = {};
     p.choice = gemm_tile_choice(a.M, a.N, a.n_prod ? a.n_prod : 3, a.Kp);
-    p.S = gemm_ksplit(a.M, a.N, a.Kp, a.T, p.choice, a.K2);
+    p.S = a.ileave_u > 1 ? 1 : gemm_ksplit(a.M, a.N, a.Kp, a.T, p.choice, a.K2);   // (the slab reduction writes plain rows)
     p.slab_bytes = p.S > 1 ? (size_t)p.S * a.M * a.N * sizeof(float) : 0;
     p.xh_bytes = a.Xh ? 0 : as_split_f16x2_bytes(a.K, a.N);
     return p;
@@ -315,7 +315,7 @@ static GemmPlan gemm_plan(const ConvGemmArgs& a)
 
 static bool direct_cin1(const ConvGemmArgs& a)
 {
-    return a.K == 1 && !a.K2 && a.W && a.X && (!a.Yh || a.T <= 9) && !a.res && !a.div_sqrt2 && !a.transpose_out && a.M <= DIRECT_MAX_M && a.n_groups <= 1 &&
+    return a.K == 1 && !a.K2 && a.W && a.X && (!a.Yh || a.T <= 9) && !a.res && !a.div_sqrt2 && !a.transpose_out && a.ileave_u <= 1 && a.M <= DIRECT_MAX_M && a.n_groups <= 1 &&
            !getenv("AS_GEMM_NO_DIRECT");
 }
 
@@ -381,6 +381,10 @@ static int conv_gemm_normalise(const ConvGemmArgs* args_host, ConvGemmArgs& norm
                                   (double)as_kbx(a.K2) * 64.0 * (a.N + 1.0) >= 2147483648.0)))
         return AS_EINVAL;                                                // the second operand comes as an image, beside an image
     if (a.src_col && (!a.Xh || !a.meta || a.K2 || a.N_in <= 0)) return AS_EINVAL;   // own input layout: an image, with the input positions
+    if (a.ileave_u < 0 || a.ileave_u == 1) return AS_EINVAL;
+    if (a.ileave_u > 1 && (a.M % a.ileave_u || (a.M / a.ileave_u) % 32 || !a.Y || a.Yh || a.res || a.transpose_out || a.n_groups > 1 ||
+                           (long)a.ldy < (long)a.ileave_u * a.N || (double)(a.M / a.ileave_u) * a.ldy * 4.0 >= 2147483648.0))
+        return AS_EINVAL;
     if (a.n_groups > 1 && (a.group_cols <= 0 || (long)a.group_cols * a.n_groups < a.N)) return AS_EINVAL;
     if ((a.X && a.ldx < a.N) || (a.Y && a.ldy < (a.transpose_out ? a.M : a.N)) || (a.res && (a.ldr < a.N || a.transpose_out)) ||
         (a.Yh && a.transpose_out))
@@ -573,7 +577,7 @@ extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_s
     }
     // otherwise, in one launch only what the tiled kernel runs from operand images with the same arithmetic
     for (int i = 0; i < m; ++i)
-        if (direct_cin1(norm[i]) || !norm[i].Wh || !norm[i].Xh || norm[i].n_prod != norm[0].n_prod) return AS_EINVAL;
+        if (direct_cin1(norm[i]) || !norm[i].Wh || !norm[i].Xh || norm[i].n_prod != norm[0].n_prod || norm[i].ileave_u > 1) return AS_EINVAL;
     const int choice = multi_tile_choice(norm, m);
     int bm, bn;
     tile_dims(choice, &bm, &bn);

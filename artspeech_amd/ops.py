@@ -261,7 +261,7 @@ def project_cols(X, N, w, bias, Y):
 
 def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, in_act=0, transpose_out=False,
               use_meta=True, in_slope=0.2, act_slope=0.2, xs=None, K=None, group_cols=0, yh=None, yh_lrelu=False, n_prod=None, plan_out=None,
-              x2s=None, K2=0, src_col=None, src_meta=None, N_in=0, defer=None):
+              x2s=None, K2=0, src_col=None, src_meta=None, N_in=0, defer=None, ileave=0):
     """Y = epi(sum_t Wt[t]^T X shifted by tap t).  defer: a list -- the call is not launched but appended to it (conv_gemm_multi
     launches the whole list as ONE kernel: as_conv_gemm_multi_f32).  Wt: prep_weight(...); X [K][*] fp32 or None with xs= (the split image of
     X: split_act / adain_split / channel_layernorm_split / another conv's yh=) and K=; Y [M][*] (or [N][*] transposed) or None
@@ -269,7 +269,8 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     sets (and bias [G][M]); columns [g * group_cols, (g+1) * group_cols) use set g.  x2s / K2: the split image of a second operand
     whose 1x1 conv (weights: prep_weight(..., sc=)) is summed into the same accumulators (needs xs=).  src_col / src_meta / N_in: a
     strided or valid conv -- `lay` is the OUTPUT layout, xs an image over N_in input columns, output column j reads input column
-    src_col[j] + dh * W_in + dw and src_meta[j] (strided_source) describes that input position."""
+    src_col[j] + dh * W_in + dw and src_meta[j] (strided_source) describes that input position.  ileave = u: the M = u C rows are
+    (phase, channel) and Y is [C][u N] with Y[m][u j + r] = row r C + m at column j (ConvGemmArgs.ileave_u; bias per row)."""
     T, Kp, M = Wt.shape
     if X is None:
         if xs is None or K is None:
@@ -295,6 +296,7 @@ def conv_gemm(Wt, X, lay, Y, taps, bias=None, res=None, act=0, div_sqrt2=False, 
     if src_col is not None:
         a.src_col, a.N_in, a.meta = _p(src_col), N_in, _p(src_meta)
     a.n_prod = n_prod if n_prod is not None else (1 if GEMM_IMPL == "h1" else 3)
+    a.ileave_u = int(ileave)
     a.in_slope, a.act_slope = in_slope, act_slope          # used as given (the acoustic path's LeakyReLU slope is 0.2)
     assert len(taps) == T
     for i, (dh, dw) in enumerate(taps):

@@ -114,6 +114,7 @@ class Generator:
                     dw = s - j
                     wc[r * cout:(r + 1) * cout, :, dw + 1] = wt[:, :, rr + u * j].t()
             W[f"ups{i}"] = (ops.prep_weight(wc, dev), w[f"ups.{i}.bias"].to(dev), u, cout)
+            W[f"ups{i}b"] = w[f"ups.{i}.bias"].repeat(u).to(dev)               # per row (phase, channel): the interleaved store adds it
         n = 0
         for i in range(len(h["upsample_rates"])):
             for k, dil in zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"]):
@@ -150,18 +151,26 @@ class Generator:
         xi = None                                   # LeakyReLU(x) as an operand image, when the producer of x wrote that instead of x
         for i in range(nst):
             wt, b, u, cout = W[f"ups{i}"]
+            lay_up = lay.scaled(u)
+            # ConvTranspose1d as one 3-tap conv with (phase, channel) rows: its epilogue stores the rows in time order (ileave) -- the
+            # interleave_phases pass over the stage's input is gone -- when the channels are a multiple of 32
+            il = cout % 32 == 0 and os.environ.get("AS_VOC_ILEAVE", "1") != "0"
+            out = lay_up.new(cout) if il else lay.new(u * cout)
+            kw = dict(bias=W[f"ups{i}b"], ileave=u) if il else {}
             if xi is not None:
-                z = ops.conv_gemm(wt, None, lay, lay.new(u * cout), taps_1d(3), xs=xi, K=h["upsample_initial_channel"] // 2 ** i)
+                z = ops.conv_gemm(wt, None, lay, out, taps_1d(3), xs=xi, K=h["upsample_initial_channel"] // 2 ** i, **kw)
                 xi = None
             else:
-                z = ops.conv_gemm(wt, x, lay, lay.new(u * cout), taps_1d(3), in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
-            lay_up = lay.scaled(u)
+                z = ops.conv_gemm(wt, x, lay, out, taps_1d(3), in_act=ACT_LRELU, in_slope=LRELU_SLOPE, **kw)
             # 32 / 64 channels: the residual steps are fused launches (below); they address a tensor with 32-bit byte offsets: a batch
             # beyond 2 GiB per tensor takes the conv GEMM launches.  (They can read the conv's phase-major output in place -- the interleave
             # as an address computation of their six reads, AS_VOC_FOLD=1 --: measured 14.30 ms per batch against 14.08 with the interleave
             # kernel: the six strided reads cost more than the 0.28 ms the two passes take.)
             fused = cout in (32, 64) and nk == 3 and os.environ.get("AS_VOC_FUSED", "1") != "0" and 4 * u * cout * (lay.N + 1) < 2 ** 31
-            x = (z, b, u) if fused and os.environ.get("AS_VOC_FOLD", "0") == "1" else ops.interleave_phases(z, b, cout, u, lay.N, lay_up.new(cout))
+            if il:
+                x = z
+            else:
+                x = (z, b, u) if fused and os.environ.get("AS_VOC_FOLD", "0") == "1" else ops.interleave_phases(z, b, cout, u, lay.N, lay_up.new(cout))
             lay = lay_up
             outs = []
             # LeakyReLU(x) as an operand image, once for the three residual stacks that start from x; inside a stack every conv hands its

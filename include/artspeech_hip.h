@@ -189,6 +189,11 @@ typedef struct ConvGemmArgs {
      * (+ its zero column).  src_col NULL: off (the input is laid out like the output).  Needs Xh and meta; not with Xh2. */
     const int32_t* src_col;
     int32_t N_in;
+    /* ileave_u >= 2: the M = ileave_u * C output rows are (phase r, channel m) -- row r C + m -- and Y is [C][ldy] with
+     * Y[m][ileave_u * j + r] = result[r C + m][j]: a ConvTranspose1d(k = 2u, stride u) written as ONE 3-tap conv leaves in time order
+     * (the interleave pass of as_interleave_phases_f32 folded into the store; the bias is given per ROW: the channel's, u times).
+     * C a multiple of 32, ldy >= ileave_u * N; Y only (no Yh, res, transpose_out, weight groups); never K-sliced. */
+    int32_t ileave_u;
 } ConvGemmArgs;
 #define AS_SLOPE_PATH 0.2f
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);

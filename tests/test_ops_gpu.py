@@ -1141,3 +1141,23 @@ def test_respair_fuzz(cuda):
         y = ops.respair(packed(xs).to(cuda), lay, ops.prep_weight(w1, cuda), b1.to(cuda), ops.prep_weight(w2, cuda), b2.to(cuda), k, dil, 0.1)
         d = float((y.cpu() - want).abs().max())
         assert d <= 3e-6, (case, C, k, dil, lens, d)
+
+
+@pytest.mark.parametrize("cin,cout,u,lens", [(64, 32, 2, [300, 7, 1]), (128, 64, 3, [100, 33]), (96, 128, 5, [40]), (48, 256, 10, [9, 20])])
+@pytest.mark.parametrize("tile", ["", "22", "21", "12", "14", "2"])
+def test_conv_gemm_interleaved_store(cuda, monkeypatch, cin, cout, u, lens, tile):
+    """ConvGemmArgs.ileave_u: the (phase, channel) rows of a ConvTranspose1d-as-conv stored in time order by the epilogue, against the
+    same conv followed by interleave_phases."""
+    if tile:
+        monkeypatch.setenv("AS_GEMM_TILE", tile)
+    g = torch.Generator().manual_seed(cin + cout + u)
+    w = torch.randn(u * cout, cin, 3, generator=g) / np.sqrt(3 * cin)
+    b = torch.randn(cout, generator=g)
+    lay = Layout(lens, cuda)
+    X = torch.randn(cin, lay.N, generator=g).to(cuda)
+    wt = ops.prep_weight(w, cuda)
+    z = ops.conv_gemm(wt, X, lay, lay.new(u * cout), taps_1d(3))
+    lay_up = lay.scaled(u)
+    want = ops.interleave_phases(z, b.to(cuda), cout, u, lay.N, lay_up.new(cout))
+    got = ops.conv_gemm(wt, X, lay, torch.full((cout, lay_up.N), float("nan"), device=cuda), taps_1d(3), bias=b.repeat(u).to(cuda), ileave=u)
+    assert float((got - want).abs().max()) <= 1e-6
