@@ -507,8 +507,9 @@ def bench_surface(net, dev, reps=5):
     tf = k0["gflop"] / k0["ms"]
     res["vocoder"] = dict(ms_per_batch_graph_replay=voc_ms, samples_per_s=samples / (voc_ms * 1e-3), x_realtime=audio_s / (voc_ms * 1e-3),
                           kernel_classes=kc,
-                          roofline=dict(bound="mfma", kernel="conv_gemm_h3_kernel on the generator's convs (<= 512 channels x up to 1.92 M columns, "
-                                                               "dilated k = 3 / 7 / 11; Vocoder/vocoder.py:75-125)",
+                          roofline=dict(bound="mfma", kernel="the generator's convs: conv_gemm_h3_kernel at 512-128 channels, respair_kernel (a residual step per "
+                                                               "launch) at 64 / 32 channels x up to 1.92 M columns, dilated k = 3 / 7 / 11, conv_post; "
+                                                               "Vocoder/vocoder.py:75-125",
                                         achieved=tf, peak=PEAK_F16_MFMA_TFLOPS / 3, unit="TFLOP/s", frac=tf / (PEAK_F16_MFMA_TFLOPS / 3),
                                         algorithmic_gflop_per_batch=k0["gflop"], gemm_ms_per_batch=k0["ms"], launches=k0["launches"],
                                         algorithmic_gbyte_per_batch=k0["gbyte"], hbm_frac_if_bytes_bound=k0["gbyte"] / k0["ms"] / PEAK_HBM_TBS))
