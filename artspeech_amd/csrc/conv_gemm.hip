@@ -366,7 +366,7 @@ static int conv_gemm_normalise(const ConvGemmArgs* args_host, ConvGemmArgs& norm
     if (!(fabsf(norm.in_slope) <= 3.0e38f) || !(fabsf(norm.act_slope) <= 3.0e38f)) return AS_EINVAL;   // slopes are used as given
     if (norm.acc_scale == 0.f) norm.acc_scale = 1.0f;
     norm.status = as_status_words_device();
-    norm.range_probe = g_range_probe;
+    norm.range_probe = (g_range_probe || args_host->range_probe == AS_PROBE_THIS) ? 1 : 0;
     if (norm.n_prod == 0) norm.n_prod = 3;
     if (norm.n_groups < 1) norm.n_groups = 1;
     // a 1x1 conv reads every column from itself: no tap can leave the utterance, so the kernels need not fetch the column descriptors

@@ -462,7 +462,7 @@ extern "C" int as_pointwise_small_f32(const float* x, int ldx, int K, int N, con
 __global__ void __launch_bounds__(1024)
 durations_kernel(const float* __restrict__ dur_f, const int* __restrict__ forced, const int* __restrict__ tok_off,
                  int B, int* __restrict__ dur_i, int* __restrict__ frame_off, int* __restrict__ tok_of_frame,
-                 int max_frames)
+                 int max_frames, unsigned* __restrict__ status)
 {
     __shared__ int sums[1024];
     const int ntok = tok_off[B];
@@ -473,8 +473,14 @@ durations_kernel(const float* __restrict__ dur_f, const int* __restrict__ forced
         int d;
         if (forced) d = forced[i];
         else {
-            const float r = rintf(dur_f[i]);               // ties to even, like torch.round
-            d = (int)(r < 1.f ? 1.f : r);
+            // (the reference's `int(pred_dur[i])` raises on NaN / inf, models.py:363-366: here the device status does -- the count
+            //  becomes 1 -- and an absurd finite value is held at 16 384 frames per token so that the sums stay inside an int: the caller's
+            //  AS_ENOSPC path meets it)
+            const float v = dur_f[i];
+            const bool fin = fabsf(v) <= 3.0e38f;
+            if (!fin) as_status_raise(status, AS_STATUS_F16_RANGE);
+            const float r = fin ? rintf(v) : 1.f;          // ties to even, like torch.round
+            d = (int)(r < 1.f ? 1.f : fminf(r, 16384.f));
         }
         dur_i[i] = d;
         local += d;
@@ -520,7 +526,7 @@ extern "C" int as_durations_f32(const float* dur_f32, const int32_t* forced_dur,
     if ((!dur_f32 && !forced_dur) || !tok_off || !dur_i32 || !frame_off || B < 0 || B > 1024) return AS_EINVAL;
     AsProfScope prof__(AS_FILE_CLS, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(durations_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dur_f32, forced_dur, tok_off, B,
-                       dur_i32, frame_off, tok_of_frame, max_frames);
+                       dur_i32, frame_off, tok_of_frame, max_frames, as_status_words_device());
     AS_CHECK_LAUNCH();
     return AS_OK;
 }

@@ -1014,6 +1014,7 @@ struct ConvOpt {
     const int32_t* src_col = nullptr;   // strided / valid conv: `lay` is the OUTPUT layout, the image has N_in columns, output column j
     const uint64_t* src_meta = nullptr; // reads input column src_col[j] (+ taps), src_meta[j] = that input position (ConvGemmArgs.src_col)
     int N_in = 0;
+    bool probe = false;           // this launch tests its accumulators for inf / NaN (AS_PROBE_THIS): the path's last conv, always on
 };
 
 // Y = epi(conv(W, X)); the input is fp32 X [K][ldx] (split by the library into the workspace) or the operand image xh
@@ -1035,6 +1036,7 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     a.n_groups = w->G; a.group_cols = o.group_cols;
     a.Xh2 = o.x2h; a.K2 = o.K2;
     a.N_in = o.N_in;
+    a.range_probe = o.probe ? AS_PROBE_THIS : 0;
     for (int i = 0; i < taps.n; ++i) { a.dh[i] = taps.dh[i]; a.dw[i] = taps.dw[i]; }
     const bool pointwise = taps.n == 1 && taps.dh[0] == 0 && taps.dw[0] == 0;
     if (lay->N == 0) return;
@@ -1981,6 +1983,7 @@ void decoder(Ctx& c, const DecPre& dp, float* x0, const Lay* lay2, const float* 
     }
     ConvOpt q;
     q.bias = m.bias(p + ".to_out.0");
+    q.probe = true;                                                     // a non-finite mel raises AS_STATUS_F16_RANGE (16 compares per tile of an 80-row conv)
     conv_h(c, m.conv(p + ".to_out.0"), y.h, y.C, lay2, k1, mel, ldo, q);
 }
 

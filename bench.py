@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: mel frames/s of the acoustic-model inference path (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher around it: the script starts its own N ranks as a
+                                                        child `python -m torch.distributed.run` BEFORE touching the GPU and relays rank 0's line)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -636,6 +637,27 @@ def c4_check(net, host, mel_mine, mine, world, rank, dev, dist, dump=None):
                 note="not bitwise: the GEMM's tile choice depends on a shard's total column count (bound 5e-5)")
 
 
+def self_launch(n):
+    """`python3 bench.py --gpus N` without a launcher around it: start `python -m torch.distributed.run --nproc-per-node N bench.py <the
+    same arguments>` as a child process (rendezvous on 127.0.0.1, a free port), pass rank 0's JSON line through, return the launcher's
+    exit code.  Called before anything in this process has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the pool's driver supports dmabuf IPC only)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for ln in p.stdout:                                      # rank 0 prints the one line; the launcher's own chatter goes to stderr
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -655,13 +677,17 @@ def main():
                     "lane in flight is one chain on one stream)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` on its own: this process has not touched the GPU (importing torch does not), so it starts the N
+        # ranks as a fresh CHILD process group and relays rank 0's line and the launcher's exit code (never an exec from here on)
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     dist = None
     if world > 1:                                       # the process group first, before anything touches the GPU
         import torch.distributed as dist

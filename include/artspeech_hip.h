@@ -36,7 +36,9 @@ int as_abi_version(void);
  *   bit AS_STATUS_MAS_TIMEOUT   a band of the alignment search gave up waiting for the band above it (as_mas_f32)
  *   bit AS_STATUS_BAD_TOKEN     a token id outside [0, n_token) reached the embedding (it was clamped)
  *   bit AS_STATUS_F16_RANGE     a conv GEMM produced a non-finite accumulator: an operand beyond fp16's range, |x| > 65504, or a
- *                               non-finite input (debug probe, as_set_range_probe)
+ *                               non-finite input (every launch under the debug probe as_set_range_probe; ALWAYS the last conv of
+ *                               as_forward_test / as_decoder_forward, `to_out`: inf / NaN anywhere upstream reaches it, so a
+ *                               non-finite mel is never handed back silently)
  *   bit AS_STATUS_BAD_LAYOUT    an utterance wider than AS_META_MAX_W columns reached as_make_meta (its descriptors are void)
  * as_device_status returns the bits raised on the current HIP device since the last clear (0 = healthy) without synchronising; it is
  * final for work whose stream has been synchronised.  The module-level entry points (as_*_forward, as_forward_test*) return
@@ -53,6 +55,7 @@ int as_device_status_raise_for_test(int kind, as_stream_t stream);
  * AS_STATUS_F16_RANGE for a non-finite one (AS_DEBUG=1 in the environment also prints the launch's shape).  Off by default: the
  * test costs 16 compares per accumulator tile. */
 int as_set_range_probe(int on);
+#define AS_PROBE_THIS 2
 
 /* Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg; no
  * reference counterpart).  Classes: 0 conv-GEMM, 1 AdaIN, 2 LayerNorm, 3 attention, 4 LSTM, 5 MAS, 6 other.
@@ -175,7 +178,9 @@ typedef struct ConvGemmArgs {
      * RelTransformerEnc.py; the F0 / energy / TV branches of ArtsPredictor, models.py:606-618): columns
      * [g * group_cols, (g+1) * group_cols) use weight set g.  n_groups <= 1: off. */
     int32_t n_groups, group_cols;
-    int32_t range_probe;       /* library-owned (as_conv_gemm_f32 overwrites both): as_set_range_probe's switch ... */
+    int32_t range_probe;       /* AS_PROBE_THIS (2) from the caller: THIS launch tests its accumulators whatever as_set_range_probe says
+                                * (as_forward_test's last conv: a non-finite mel always raises AS_STATUS_F16_RANGE); any other value is
+                                * overwritten with as_set_range_probe's switch ... */
     uint32_t* status;          /* ... and the device's status words (as_device_status) */
     /* A 1x1 convolution of a SECOND operand summed into the same accumulators before the epilogue -- a residual block's learned
      * shortcut (models.py:79-84,185-186: conv1x1, no bias) evaluated by the launch of the block's last conv, as K2 more channels

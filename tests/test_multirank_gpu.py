@@ -33,6 +33,22 @@ def launch(extra, timeout=900):
     return json.loads(lines[0])
 
 
+def test_bench_gpus_2_starts_its_own_ranks(cuda):
+    """`python3 bench.py --gpus 2` with NO launcher around it (the way the driver runs `--gpus 1`): the script itself starts the two
+    ranks as a fresh child process group before it touches the GPU and relays rank 0's single line and exit code."""
+    env = dict(os.environ, AS_BENCH_TEST_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-extras", "--cpu-utts", "0"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 6 and line["value"] > 0
+    assert line["config"]["global_batch"] == 64
+
+
 def test_two_ranks_weak_scaling_line(cuda):
     line = launch(["--steps", "6", "--warmup", "2", "--no-extras"])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 6

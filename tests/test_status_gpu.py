@@ -142,6 +142,46 @@ def test_range_probe_names_an_operand_beyond_fp16(cuda):
     assert L.as_device_status(1) == 1 << F16_RANGE
 
 
+def test_non_finite_mel_is_always_reported(cuda, golden_dir):
+    """The debug probe is OFF: the path's last conv (`to_out`) still tests its accumulators, and inf / NaN anywhere upstream reaches it --
+    an articulatory feature beyond fp16's range (the decoder's F0 / N / EMA convs and the towers read it), a NaN in the reference mel.
+    The bit is up once the stream is synchronised, the next call is refused, and after the clear the same call is healthy again.
+    (The reference's `int(pred_dur[i])` raises on a NaN duration, models.py:363-366: with predicted durations the duration kernel
+    raises the same bit before the frame counts are read back.)"""
+    L = _lib.lib()
+    net = get_model(64, 8, 3407, cuda)
+    g = np.load(sorted(glob.glob(os.path.join(golden_dir, "net_tiny_*.npz")))[0])
+    n = len(g["tokens"])
+    mel, f0_raw, ema_raw = raw_features(int(g["t_ref"]), int(g["seed"]))
+    tok = torch.from_numpy(g["tokens"]).to(cuda, torch.int32)
+    forced = torch.full((n,), 2, dtype=torch.int32, device=cuda)
+
+    def call(mel_, ema_, **kw):
+        return net.forward_packed(tok, [n], torch.from_numpy(mel_).to(cuda), torch.from_numpy(f0_raw).reshape(1, -1).to(cuda),
+                                  torch.from_numpy(ema_).to(cuda), [int(g["t_ref"])], **kw)["mel"].clone()
+    ref = call(mel, ema_raw, forced=forced, frames_hint=[2 * n])
+    torch.cuda.synchronize()
+    assert L.as_device_status(0) == 0 and bool(torch.isfinite(ref).all())
+    bad_mel = mel.copy()
+    bad_mel[3, 17] = np.nan
+    bad_ema = ema_raw.copy()
+    bad_ema[2, 5] = np.inf
+    for m_, e_ in ((bad_mel, ema_raw), (mel, bad_ema)):
+        out = call(m_, e_, forced=forced, frames_hint=[2 * n])
+        torch.cuda.synchronize()
+        assert not bool(torch.isfinite(out).all())
+        assert L.as_device_status(0) == 1 << F16_RANGE
+        with pytest.raises(_lib.HipLibraryError, match="kernel reported"):
+            call(mel, ema_raw, forced=forced, frames_hint=[2 * n])
+        assert L.as_device_status(1) == 1 << F16_RANGE
+        assert torch.equal(call(mel, ema_raw, forced=forced, frames_hint=[2 * n]), ref)
+    # predicted durations (the duration predictor is styled by the articulatory track, models.py:543-548): the call itself reads the
+    # frame counts back, and refuses
+    with pytest.raises(_lib.HipLibraryError, match="kernel reported"):
+        call(mel, bad_ema)
+    assert L.as_device_status(1) & (1 << F16_RANGE)
+
+
 def test_layout_cache_stays_bounded_and_valid(cuda):
     """more geometries than the cap through ONE plan: the cache is dropped between calls (never inside one), results stay those of a
     fresh plan, and the flush count says it happened"""
