@@ -29,6 +29,18 @@ def main():
     arrangements = [tuple(int(v) for v in a.split("x")) for a in os.environ.get("ARR", "1x4,2x1,2x2,4x1,4x2,2x3,8x1,1x1").split(",")]
     reps = int(os.environ.get("REPS", "40"))
     res = []
+    if os.environ.get("CLASSES"):
+        # per-class kernel time (HIP events, one chain) per 32 utterances at 32 k utterances per call: where does a wide call spend it?
+        for k in (int(v) for v in os.environ["CLASSES"].split(",")):
+            _, g = bench.make_inputs(dev, 32 * k)
+            twin = net.replica()
+            kern = bench.profile_classes(twin, bench.Runner(twin, g))
+            row = {c: round(v["ms_per_step"] / k, 4) for c, v in kern.items()}
+            row["gemm_tflops"] = round(kern["conv_gemm"]["gflop_per_step"] / kern["conv_gemm"]["ms_per_step"], 1)
+            row["launches"] = sum(v["launches_per_step"] for v in kern.values())
+            print("classes per 32 utt at", 32 * k, "per call:", row, flush=True)
+            del twin
+            torch.cuda.empty_cache()
     for k, c in arrangements:
         lanes = []
         for i in range(c):
