@@ -148,6 +148,7 @@ AS_MOD_FORWARD_A, AS_MOD_FORWARD_B, AS_MOD_ENCODER, AS_MOD_STYLE, AS_MOD_DURATIO
 _pB, _pIO = ctypes.POINTER(Batch), ctypes.POINTER(ForwardIO)
 _SIGNATURES.update({
     "as_adain_image_f32": (c_i, [ctypes.POINTER(AdainArgs), c_p]),
+    "as_conv_gemm_multi_post_f32": (c_i, [ctypes.POINTER(ConvGemmArgs), ctypes.POINTER(AdainArgs), ctypes.POINTER(ctypes.c_int32), c_i, c_p]),
     "as_down_multi_f32": (c_i, [ctypes.POINTER(DownArgs), c_i, c_p]),
     "as_respair_f32": (c_i, [ctypes.POINTER(ResPairArgs), c_p]),
     "as_xl_attention_image_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, ctypes.c_float, c_p, c_i, c_i, c_p, c_i, c_p, c_p]),

@@ -298,6 +298,28 @@ static __device__ __forceinline__ void slab_store(const ConvGemmArgs& a, const f
 // (deterministic whatever order the slices finished in); slab s = fp32 [M][N] at a.ws + s M N.  j == N with Yh: the image's zero
 // column.  One 16-byte row of the consumer's split image when Yh is wanted.  (A device function: scripts/exp/conv_gemm_sn.hip, the
 // small-N kernel that was measured and not shipped, ran the same code inside its own launch.)
+// the epilogue of ONE summed element (the K-sliced launches' reduction kernels: plain, and with the AdaIN behind it)
+// (LEAN: activations 0 .. 2 only -- tanh and swish expand to hundreds of instructions per use, and the fused reduction + AdaIN kernel
+// inlines this 8 x 4 times: 15 000 instructions, whose fetch alone took longer than the two launches the kernel replaces.  Explicit
+// roundings: the same bits in both forms whatever the compiler would contract.)
+template <bool LEAN = false>
+static __device__ __forceinline__ float as_reduce_value(const ConvGemmArgs& a, float x, float bias, float res)
+{
+    if (a.range_probe && !(fabsf(x) <= 3.0e38f)) as_status_raise(a.status, AS_STATUS_F16_RANGE);
+    x = __fmul_rn(x, a.acc_scale);
+    if (a.bias) x = __fadd_rn(x, bias);
+    if (a.res) x = __fadd_rn(x, res);
+    if (a.div_sqrt2) x = __fdiv_rn(x, 1.41421356237309504880f);
+    if (a.act == 1) x = x > 0.f ? x : 0.f;
+    else if (a.act == 2) x = x > 0.f ? x : __fmul_rn(a.act_slope, x);
+    else if (!LEAN) {
+        if (a.act == 3) x = tanhf(x);
+        else if (a.act == 4) x = fabsf(x);
+        else if (a.act == 5) x = x / (1.0f + expf(-x));
+    }
+    return x;
+}
+
 static __device__ __forceinline__ void as_reduce_epilogue(const ConvGemmArgs& a, int S, int j, int g)
 {
     if (j > a.N || (j == a.N && !a.Yh)) return;
@@ -350,17 +372,7 @@ static __device__ __forceinline__ void as_reduce_epilogue(const ConvGemmArgs& a,
         const int row = 8 * g + r;
         float x = 0.f;
         if (row < a.M && j < a.N) {
-            x = acc8[r];
-            if (a.range_probe && !(fabsf(x) <= 3.0e38f)) as_status_raise(a.status, AS_STATUS_F16_RANGE);
-            x *= a.acc_scale;
-            if (a.bias) x += bias8[r];
-            if (a.res) x += res8[r];
-            if (a.div_sqrt2) x = x / 1.41421356237309504880f;
-            if (a.act == 1) x = x > 0.f ? x : 0.f;
-            else if (a.act == 2) x = x > 0.f ? x : a.act_slope * x;
-            else if (a.act == 3) x = tanhf(x);
-            else if (a.act == 4) x = fabsf(x);
-            else if (a.act == 5) x = x / (1.0f + expf(-x));
+            x = as_reduce_value(a, acc8[r], bias8[r], res8[r]);
             if (a.Y) {
                 if (a.transpose_out) a.Y[(size_t)j * a.ldy + row] = x;
                 else a.Y[(size_t)row * a.ldy + j] = x;

@@ -208,6 +208,213 @@ splitk_reduce_multi_kernel(const ReduceMulti rm)
     as_reduce_epilogue(rm.a[pi], rm.S[pi], ((int)blockIdx.x - rm.blk0[pi]) * 256 + threadIdx.x, blockIdx.y);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Reduction of a K-sliced launch WITH the AdaIN1d (+ LeakyReLU) that reads its result (as_conv_gemm_multi_post_f32): at batch 1 every
+// conv of an AdainResBlk1d is cut into K slices, and the kernel that sums the slabs of 8 channels over an utterance of <= 256 columns
+// holds everything the instance norm's statistics need -- so it writes the NEXT conv's operand image itself (models.py:189-197: conv ->
+// norm -> actv -> conv; one dependent launch less per conv, ~7 us each in BASELINE config C2's chain of ~170).
+// The mapping is adain_image_kernel's (conv_gemm_h3.hip): a WAVE owns one 16-byte row group of the image -- 8 channels (k-block kb,
+// k-half kh) of one utterance --, lane = column (i = lane + 64 j, j < 4), values in registers from the slab loads to the last store; the
+// slabs are summed in the plain reduction's order (s ascending), the value epilogue is the plain one (as_reduce_value) and the statistics
+// are adain_image_kernel's, so the image is bit-identical to reduce -> AdaIN as two launches.
+// ----------------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float rp_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// NJ = register columns in use (utterance of <= 64 NJ columns): no condition inside the load loops
+template <int NJ>
+static __device__ __forceinline__ void reduce_adain_body(const ConvGemmArgs& a, int S, const AsAdainArgs& n, int kb, int kh, int u, int o0, int L)
+{
+    const int lane = threadIdx.x & 63;
+    const int M = a.M;
+    const size_t NX = (size_t)a.N + 1;
+    u32x4_t* xs = reinterpret_cast<u32x4_t*>(n.yh);
+    u32x4_t* yh = reinterpret_cast<u32x4_t*>(a.Yh);
+    const size_t plane = ((size_t)kb * 4 + kh) * NX;                    // h part; the l part two planes on
+    const int c0 = kb * 16 + kh * 8;
+    const int grp = a.n_groups > 1 ? o0 / a.group_cols : 0;             // (an utterance lies inside one weight group)
+    const size_t gbase = n.gb_off ? (size_t)n.gb_off[u] : (size_t)u * n.ldgb;
+    float g1[8], bt[8], bias8[8];
+    unsigned rowb[8];                                                    // byte offset of (row, first column) inside a slab
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int c = c0 + r < M ? c0 + r : M - 1;
+        g1[r] = 1.0f + n.gb[gbase + (size_t)c * n.gb_sc];
+        bt[r] = n.gb[gbase + (size_t)(M + c) * n.gb_sc];
+        bias8[r] = a.bias ? a.bias[(size_t)grp * M + c] : 0.f;
+        rowb[r] = (unsigned)(c * a.N + o0) * 4u;
+    }
+    int col[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) col[j] = min(lane + 64 * j, L - 1);
+    // the slabs through ONE buffer descriptor (S M N 4 bytes < 2 GiB: the host falls back otherwise): a load is one instruction -- the
+    // lane's (row, column) offset in a register, the slab's in a scalar -- instead of a 64-bit address computed per element
+    const unsigned slab_bytes = (unsigned)M * (unsigned)a.N * 4u;
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)((unsigned)S * slab_bytes), 0x00020000);
+    // the residual first (Y may alias it), then the slabs: four slabs' loads in flight at a time, none behind a branch; additions in the
+    // plain reduction's order s = 0 .. S-1
+    float res[8][NJ];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = c0 + r < M ? c0 + r : M - 1;
+            res[r][j] = a.res ? a.res[(size_t)c * a.ldr + o0 + col[j]] : 0.f;
+        }
+    float v[8][NJ];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[r][j] = 0.f;
+    constexpr int Q = 4;                                                 // slabs per trip: up to 128 loads of a lane in flight
+    int s = 0;
+    for (; s + Q <= S; s += Q) {
+        float t[Q][8][NJ];
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) t[q][r][j] = buf_load1(rsS, rowb[r] + (unsigned)col[j] * 4u, (int)((unsigned)(s + q) * slab_bytes));
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) v[r][j] += t[q][r][j];
+    }
+    for (; s < S; ++s) {
+        float t[8][NJ];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) t[r][j] = buf_load1(rsS, rowb[r] + (unsigned)col[j] * 4u, (int)((unsigned)s * slab_bytes));
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) v[r][j] += t[r][j];
+    }
+    // the conv's own epilogue; its outputs (fp32 rows, plain image) as the plain reduction writes them
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool in = c0 + r < M && lane + 64 * j < L;
+            const float x = in ? as_reduce_value<true>(a, v[r][j], bias8[r], res[r][j]) : 0.f;
+            v[r][j] = x;
+            if (in && a.Y) a.Y[(size_t)(c0 + r) * a.ldy + o0 + lane + 64 * j] = x;
+        }
+    if (yh) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int i = lane + 64 * j;
+            float t[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = (a.yh_lrelu && v[r][j] < 0.f) ? a.in_slope * v[r][j] : v[r][j];
+            u32x4_t h, l;
+            split2(t, h, l);
+            if (i < L) {
+                yh[plane + o0 + i] = h;
+                yh[plane + o0 + i + 2 * NX] = l;
+            }
+        }
+    }
+    // AdaIN over the utterance (adain_image_kernel's arithmetic: a lane adds its elements in ascending order, then the wave's butterfly)
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (lane + 64 * j < L) sacc += v[r][j];
+        mean[r] = rp_wave_sum(sacc) / (float)L;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float vacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (lane + 64 * j < L) { const float d = __fsub_rn(v[r][j], mean[r]); vacc = __fmaf_rn(d, d, vacc); }
+        rstd[r] = 1.0f / sqrtf(rp_wave_sum(vacc) / (float)L + 1e-5f);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = lane + 64 * j;
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t[r] = (c0 + r < M && i < L) ? as_adain_val(v[r][j], mean[r], rstd[r], g1[r], bt[r], n.lrelu) : 0.f;
+        u32x4_t h, l;
+        split2(t, h, l);
+        if (i < L) {
+            xs[plane + o0 + i] = h;
+            xs[plane + o0 + i + 2 * NX] = l;
+        }
+    }
+}
+
+// workgroup = ONE wave = one 16-byte row group (8 channels) of one utterance: `rg` = 2 kb + kh
+template <int NJ>
+static __device__ __forceinline__ void reduce_adain(const ConvGemmArgs& a, int S, const AsAdainArgs& n, int rg, int u)
+{
+    const int lane = threadIdx.x & 63;
+    const int kb = rg >> 1, kh = rg & 1;
+    const size_t NX = (size_t)a.N + 1;
+    const size_t plane = ((size_t)kb * 4 + kh) * NX;
+    if (u == 0 && lane == 0) {                                          // the zero columns
+        u32x4_t* xs = reinterpret_cast<u32x4_t*>(n.yh);
+        u32x4_t* yh = reinterpret_cast<u32x4_t*>(a.Yh);
+        xs[plane + a.N] = u32x4_t{0u, 0u, 0u, 0u};
+        xs[plane + 2 * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};
+        if (yh) {
+            yh[plane + a.N] = u32x4_t{0u, 0u, 0u, 0u};
+            yh[plane + 2 * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+    }
+    // (one utterance -- batch 1 -- owns every column: no dependent load of its offsets in front of the slab loads)
+    int o0 = 0, L = a.N;
+    if (n.U > 1) { o0 = n.col_off[u]; L = n.col_off[u + 1] - o0; }
+    if (L <= 0) return;
+    reduce_adain_body<NJ>(a, S, n, kb, kh, u, o0, L);                    // (L <= 64 NJ: the host picks the instantiation from the widest utterance)
+}
+
+// the K-sliced problems of ONE (multi-problem) launch: problem i either summed plainly (mode 0: a workgroup = 64 columns of one 8-row
+// group, as_reduce_epilogue) or summed + AdaIN'd (mode 1: a workgroup = one row group of one utterance); workgroups of ONE wave -- the
+// few dozen waves of such a launch then sit on as many CUs, each with a texture path of its own (with four waves to a workgroup the
+// launch took 21 us where reduce + AdaIN as two launches took 14) --, a 1-D grid of exactly the workgroups every problem needs
+struct ReducePost {
+    int32_t n, pad_;
+    int32_t blk0[H3_MAXP + 2];           // first workgroup of problem i (blk0[n] = all)
+    int32_t S[H3_MAXP], mode[H3_MAXP];
+    int32_t nxb[H3_MAXP];                // mode 0: column blocks; mode 1: row groups -- the fast index of the problem's workgroups
+    ConvGemmArgs a[H3_MAXP];
+    AsAdainArgs p[H3_MAXP];
+};
+template <int NJ>
+__global__ void __launch_bounds__(64)
+splitk_reduce_post_kernel(const ReducePost rm)
+{
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < H3_MAXP; ++i) pi += (i < rm.n && (int)blockIdx.x >= rm.blk0[i]) ? 1 : 0;
+    const int local = (int)blockIdx.x - rm.blk0[pi], nxb = rm.nxb[pi];
+    if (rm.mode[pi] == 0) as_reduce_epilogue(rm.a[pi], rm.S[pi], (local % nxb) * 64 + (int)threadIdx.x, local / nxb);
+    else reduce_adain<NJ>(rm.a[pi], rm.S[pi], rm.p[pi], local % nxb, local / nxb);
+}
+
+// ONE problem: its arguments directly in the kernel argument segment (every scalar load of the wave's head is issued at once; with the
+// problem list a wave first looks its problem up, then fetches that problem's fields: one more dependent round trip in a kernel that
+// consists of four)
+template <int NJ>
+__global__ void __launch_bounds__(64)
+splitk_reduce_adain_kernel(const ConvGemmArgs a, int S, const AsAdainArgs n, int nrg)
+{
+    reduce_adain<NJ>(a, S, n, (int)blockIdx.x % nrg, (int)blockIdx.x / nrg);
+}
+
 // as_set_range_probe: every launch tests its accumulators for inf / NaN (what an operand beyond fp16's range turns into)
 static int g_range_probe = 0;
 extern "C" int as_set_range_probe(int on)
@@ -439,14 +646,85 @@ static int launch_direct_x4(const ConvGemmArgs* a, int n, hipStream_t stream)
     return AS_OK;
 }
 
-extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream_)
+// the AdaIN that reads a conv's result (as_conv_gemm_multi_post_f32): its arguments completed from the conv's
+static bool post_wanted(const AsAdainArgs* post) { return post && post->yh; }
+static int post_normalise(const ConvGemmArgs& a, const AsAdainArgs& post_host, AsAdainArgs& n)
 {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    n = post_host;
+    if (!a.Y || a.transpose_out || a.ileave_u > 1 || !n.gb || !n.col_off || n.U <= 0 || n.gb_sc <= 0 || (!n.gb_off && n.ldgb <= 0) ||
+        (reinterpret_cast<uintptr_t>(n.yh) & 15) != 0)
+        return AS_EINVAL;
+    n.x = a.Y; n.ldx = a.ldy; n.C = a.M; n.N = a.N;
+    n.src_off = nullptr; n.pool_w = nullptr; n.pool_b = nullptr; n.x_up = nullptr; n.ld_up = 0;
+    return AS_OK;
+}
+// can the reduction kernel of this K-sliced problem write the AdaIN image itself?
+static bool post_fusable(const ConvGemmArgs& a, int max_w) { return max_w > 0 && max_w <= 256 && a.act <= 2 && (double)a.M * a.N * 4.0 * 16.0 < 2147483648.0 && !getenv("AS_NO_REDUCE_ADAIN"); }
+
+// one launch for the reductions of the K-sliced problems ptr[k] (So[k] > 1) of a launch; np[k] non-NULL: with the AdaIN behind it
+static int launch_reduce_post(const ConvGemmArgs* const* ptr, const int* So, const AsAdainArgs* const* np, const int* max_w, int m, hipStream_t stream)
+{
+    ReducePost rm;
+    memset(&rm, 0, sizeof(rm));
+    int mw = 1;
+    for (int k = 0; k < m; ++k)
+        if (So[k] > 1 && np[k]) mw = std::max(mw, max_w[k]);
+    const int nj = (mw + 63) / 64;                                       // register columns per lane (post_fusable: <= 4)
+    for (int k = 0; k < m; ++k)
+        if (So[k] > 1) {
+            const ConvGemmArgs& a = *ptr[k];
+            const int i = rm.n;
+            rm.a[i] = a;
+            rm.S[i] = So[k];
+            int blocks;
+            if (np[k]) {
+                rm.mode[i] = 1;
+                rm.p[i] = *np[k];
+                rm.nxb[i] = as_kbx(a.M) * 2;
+                blocks = rm.nxb[i] * np[k]->U;
+            } else {
+                const int rows = a.Yh ? std::max(16 * as_kbx(a.M), a.M) : a.M;
+                rm.nxb[i] = as_cdiv(a.N + 1, 64);
+                blocks = rm.nxb[i] * as_cdiv(rows, 8);
+            }
+            rm.blk0[i + 1] = rm.blk0[i] + blocks;
+            ++rm.n;
+        }
+    if (rm.n == 0) return AS_OK;
+    if (rm.n == 1 && rm.mode[0] == 1) {
+        const dim3 g1(rm.blk0[1]), b1(64);
+        if (nj == 1) hipLaunchKernelGGL(splitk_reduce_adain_kernel<1>, g1, b1, 0, stream, rm.a[0], rm.S[0], rm.p[0], rm.nxb[0]);
+        else if (nj == 2) hipLaunchKernelGGL(splitk_reduce_adain_kernel<2>, g1, b1, 0, stream, rm.a[0], rm.S[0], rm.p[0], rm.nxb[0]);
+        else if (nj == 3) hipLaunchKernelGGL(splitk_reduce_adain_kernel<3>, g1, b1, 0, stream, rm.a[0], rm.S[0], rm.p[0], rm.nxb[0]);
+        else hipLaunchKernelGGL(splitk_reduce_adain_kernel<4>, g1, b1, 0, stream, rm.a[0], rm.S[0], rm.p[0], rm.nxb[0]);
+        AS_CHECK_LAUNCH();
+        return AS_OK;
+    }
+    const dim3 gm(rm.blk0[rm.n]), bm(64);
+    if (nj == 1) hipLaunchKernelGGL(splitk_reduce_post_kernel<1>, gm, bm, 0, stream, rm);
+    else if (nj == 2) hipLaunchKernelGGL(splitk_reduce_post_kernel<2>, gm, bm, 0, stream, rm);
+    else if (nj == 3) hipLaunchKernelGGL(splitk_reduce_post_kernel<3>, gm, bm, 0, stream, rm);
+    else hipLaunchKernelGGL(splitk_reduce_post_kernel<4>, gm, bm, 0, stream, rm);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+static int conv_gemm_one(const ConvGemmArgs* args_host, const AsAdainArgs* post_host, int post_max_w, hipStream_t stream)
+{
     ConvGemmArgs norm;
     const int rn = conv_gemm_normalise(args_host, norm);
     if (rn != AS_OK) return rn;
     const ConvGemmArgs& a = norm;
     if (a.N == 0) return AS_OK;
+    AsAdainArgs post;
+    const bool want_post = post_wanted(post_host);
+    if (want_post) {
+        const int rp = post_normalise(a, *post_host, post);
+        if (rp != AS_OK) return rp;
+    }
+    bool post_done = false;
+    {
+    const int rc1 = [&]() -> int {
     if (direct_cin1(a)) {
         char tag[64];
         snprintf(tag, sizeof(tag), "M%d N%d K1 T%d direct", a.M, a.N, a.T);
@@ -485,8 +763,23 @@ extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t strea
     const ConvGemmArgs* one = &a;
     const int rc = as_conv_gemm_h3_launch(&one, &S, 1, plan.choice, stream);
     if (rc != AS_OK) return rc;
+    if (S > 1 && want_post && post_fusable(a, post_max_w)) {
+        const AsAdainArgs* np = &post;
+        post_done = true;
+        return launch_reduce_post(&one, &S, &np, &post_max_w, 1, stream);
+    }
     if (S > 1) return launch_reduce(a, S, stream);
     return AS_OK;
+    }();
+    if (rc1 != AS_OK) return rc1;
+    }
+    if (want_post && !post_done) return as_adain_image_f32(&post, stream);   // (its own profiling scope, behind the conv's)
+    return AS_OK;
+}
+
+extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream_)
+{
+    return conv_gemm_one(args_host, nullptr, 0, static_cast<hipStream_t>(stream_));
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -546,23 +839,43 @@ extern "C" int as_conv_gemm_multi_tile(const ConvGemmArgs* list_host, int n)
     return multi_tile_choice(norm, n);
 }
 
-extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_stream_t stream_)
+static int conv_gemm_multi(const ConvGemmArgs* list_host, const AsAdainArgs* post_host, const int32_t* post_max_w, int n, hipStream_t stream)
 {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!list_host || n < 1 || n > AS_MAX_MULTI) return AS_EINVAL;
+    if (!list_host || n < 1 || n > AS_MAX_MULTI || (post_host && !post_max_w)) return AS_EINVAL;
     static_assert(AS_MAX_MULTI == H3_MAXP, "header and kernel disagree");
-    if (n == 1) return as_conv_gemm_f32(list_host, stream_);
+    if (n == 1) return conv_gemm_one(list_host, post_host, post_host ? post_max_w[0] : 0, stream);
     ConvGemmArgs norm[H3_MAXP];
+    AsAdainArgs post[H3_MAXP];
+    bool has_post[H3_MAXP], post_done[H3_MAXP];
+    int pmw[H3_MAXP], src[H3_MAXP];
     int m = 0, n_direct = 0;
     for (int i = 0; i < n; ++i) {
         const int r = conv_gemm_normalise(&list_host[i], norm[m]);
         if (r != AS_OK) return r;
         if (norm[m].N == 0) continue;                                    // nothing to do for this one
         n_direct += direct_cin1(norm[m]) && norm[m].T <= 9 ? 1 : 0;
+        has_post[m] = post_host && post_wanted(&post_host[i]);
+        post_done[m] = false;
+        pmw[m] = has_post[m] ? post_max_w[i] : 0;
+        src[m] = i;
+        if (has_post[m]) {
+            const int rp = post_normalise(norm[m], post_host[i], post[m]);
+            if (rp != AS_OK) return rp;
+        }
         ++m;
     }
     if (m == 0) return AS_OK;
-    if (m == 1) return as_conv_gemm_f32(&norm[0], stream_);
+    if (m == 1) return conv_gemm_one(&list_host[src[0]], post_host ? &post_host[src[0]] : nullptr, pmw[0], stream);
+    bool any_post = false;
+    for (int i = 0; i < m; ++i) any_post = any_post || has_post[i];
+    auto finish_posts = [&]() -> int {                                   // the AdaINs no reduction kernel took along: one launch each, in list order
+        for (int i = 0; i < m; ++i)
+            if (has_post[i] && !post_done[i]) {
+                const int r = as_adain_image_f32(&post[i], stream);
+                if (r != AS_OK) return r;
+            }
+        return AS_OK;
+    };
     if (n_direct == m) {                                                 // a set of Cin = 1 stems: the direct kernel, one launch
         static_assert(DIRECT_MAXP == H3_MAXP, "one list length");
         double fl = 0, by = 0;
@@ -572,8 +885,12 @@ extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_s
         }
         char tag[64];
         snprintf(tag, sizeof(tag), "multi%d direct: M%d N%d K1 T%d | ...", m, norm[0].M, norm[0].N, norm[0].T);
-        AsProfScope prof__(AS_CLS_GEMM, fl, by, stream, tag);
-        return launch_direct_x4(norm, m, stream);
+        int rd;
+        {
+            AsProfScope prof__(AS_CLS_GEMM, fl, by, stream, tag);
+            rd = launch_direct_x4(norm, m, stream);
+        }
+        return rd != AS_OK ? rd : finish_posts();
     }
     // otherwise, in one launch only what the tiled kernel runs from operand images with the same arithmetic
     for (int i = 0; i < m; ++i)
@@ -626,10 +943,27 @@ extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_s
         AsProfScope prof__(AS_CLS_GEMM, flops, bytes, stream, tag);
         const int rc = as_conv_gemm_h3_launch(ptr, So, m, choice, stream);
         if (rc != AS_OK) return rc;
+        // K-sliced problems whose result is read through an AdaIN (few columns: the reduction holds a channel's whole time axis): the
+        // reduction launch writes the AdaIN image too
+        bool fused = false;
+        const AsAdainArgs* np[H3_MAXP];
+        for (int k = 0; k < m; ++k) {
+            const int i = order[k];
+            np[k] = (any_post && has_post[i] && So[k] > 1 && post_fusable(*ptr[k], pmw[i])) ? &post[i] : nullptr;
+            fused = fused || np[k];
+        }
+        if (fused) {
+            int mwo[H3_MAXP];
+            for (int k = 0; k < m; ++k) mwo[k] = pmw[order[k]];
+            const int rr = launch_reduce_post(ptr, So, np, mwo, m, stream);
+            if (rr != AS_OK) return rr;
+            for (int k = 0; k < m; ++k)
+                if (np[k]) post_done[order[k]] = true;
+        }
         ReduceMulti rm;
         memset(&rm, 0, sizeof(rm));
         int rows_max = 0;
-        for (int k = 0; k < m; ++k)
+        for (int k = 0; k < m && !fused; ++k)
             if (So[k] > 1) {
                 const ConvGemmArgs& a = *ptr[k];
                 rm.a[rm.n] = a;
@@ -646,5 +980,16 @@ extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_s
             AS_CHECK_LAUNCH();
         }
     }
-    return AS_OK;
+    return finish_posts();
+}
+
+extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_stream_t stream_)
+{
+    return conv_gemm_multi(list_host, nullptr, nullptr, n, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int as_conv_gemm_multi_post_f32(const ConvGemmArgs* list_host, const AsAdainArgs* post_host, const int32_t* post_max_w, int n,
+                                           as_stream_t stream_)
+{
+    return conv_gemm_multi(list_host, post_host, post_max_w, n, static_cast<hipStream_t>(stream_));
 }

@@ -674,7 +674,7 @@ adain_image_kernel(const AsAdainArgs a)
             float vacc = 0.f;
 #pragma unroll
             for (int j = 0; j < RV; ++j)
-                if (lane + 64 * j < L) { const float d = v[r][j] - mean[r]; vacc += d * d; }
+                if (lane + 64 * j < L) { const float d = __fsub_rn(v[r][j], mean[r]); vacc = __fmaf_rn(d, d, vacc); }   // (explicit: the same bits in every kernel that computes these statistics)
             rstd[r] = 1.0f / sqrtf(h3_wave_sum(vacc) / (float)L + 1e-5f);
         }
         if (UP && a.x_up) {
@@ -771,11 +771,11 @@ adain_image_kernel(const AsAdainArgs a)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { const float d = t[q][r] - mean[r]; acc[r] += d * d; }
+                for (int r = 0; r < 8; ++r) { const float d = __fsub_rn(t[q][r], mean[r]); acc[r] = __fmaf_rn(d, d, acc[r]); }
         }
         for (; i < L; i += 64)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { const float d = xr0[rowoff[r] + i] - mean[r]; acc[r] += d * d; }
+            for (int r = 0; r < 8; ++r) { const float d = __fsub_rn(xr0[rowoff[r] + i], mean[r]); acc[r] = __fmaf_rn(d, d, acc[r]); }
 #pragma unroll
         for (int r = 0; r < 8; ++r) rstd[r] = 1.0f / sqrtf(h3_wave_sum(acc[r]) / (float)L + 1e-5f);
     }

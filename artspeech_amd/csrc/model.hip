@@ -515,6 +515,8 @@ struct Op {
                                                    // 3: a tower down-sampling step (as_down_multi_f32 arguments)
     std::function<int()> fn;
     ConvGemmArgs g;
+    AsAdainArgs post;                              // kind 1: the AdaIN that reads the conv's result (post.yh NULL: none), as_conv_gemm_multi_post_f32
+    int post_max_w = 0;
     AsDownArgs d;
     hipStream_t s = nullptr;
     double hint_f = 0, hint_b = 0;                 // as_prof_hint that goes with the launch
@@ -858,19 +860,27 @@ static void play(Ctx& c, Sched& S)
         }
         if (np >= 2) {
             ConvGemmArgs list[AS_MAX_MULTI];
-            for (int i = 0; i < np; ++i) list[i] = S.q[pick[i]][head[pick[i]]].g;
+            AsAdainArgs posts[AS_MAX_MULTI];
+            int32_t pmw[AS_MAX_MULTI];
+            for (int i = 0; i < np; ++i) {
+                const Op& oi = S.q[pick[i]][head[pick[i]]];
+                list[i] = oi.g;
+                posts[i] = oi.post;
+                pmw[i] = oi.post_max_w;
+            }
             if (trace) {
                 fprintf(stderr, "  GEMM x%d:", np);
                 for (int i = 0; i < np; ++i) fprintf(stderr, " q%d M%d N%d K%d T%d |", pick[i], list[i].M, list[i].N, list[i].K, list[i].T);
                 fprintf(stderr, "\n");
             }
-            const int r = as_conv_gemm_multi_f32(list, np, S.q[pick[0]][head[pick[0]]].s);
+            const int r = as_conv_gemm_multi_post_f32(list, posts, pmw, np, S.q[pick[0]][head[pick[0]]].s);
             if (r != AS_OK) { fail(r, S.q[pick[0]][head[pick[0]]]); return; }
             for (int i = 0; i < np; ++i) ++head[pick[i]];
         } else {
             Op& o = S.q[lone][head[lone]];
             if (trace) fprintf(stderr, "  GEMM alone: q%d M%d N%d K%d T%d (%d heads)\n", lone, o.g.M, o.g.N, o.g.K, o.g.T, nh);
-            const int r = as_conv_gemm_f32(&o.g, o.s);
+            const int32_t mw1 = o.post_max_w;
+            const int r = as_conv_gemm_multi_post_f32(&o.g, &o.post, &mw1, 1, o.s);
             if (r != AS_OK) { fail(r, o); return; }
             ++head[lone];
         }
@@ -996,6 +1006,13 @@ Taps taps_2d(int kh, int kw)
     return t;
 }
 
+// gamma / beta of one AdaIN1d launch: AsAdainArgs addressing into the output of the fc GEMM ([rows][ldB], utterances as columns)
+struct Norm {
+    const float* gb = nullptr;
+    const int32_t* gb_off = nullptr;   // per-utterance offsets (grouped launches); NULL: utterance u at gb + u
+    int gb_sc = 0;                     // stride between channels = ldB
+};
+
 struct ConvOpt {
     const float* bias = nullptr;
     const float* res = nullptr;
@@ -1015,6 +1032,11 @@ struct ConvOpt {
     const uint64_t* src_meta = nullptr; // reads input column src_col[j] (+ taps), src_meta[j] = that input position (ConvGemmArgs.src_col)
     int N_in = 0;
     bool probe = false;           // this launch tests its accumulators for inf / NaN (AS_PROBE_THIS): the path's last conv, always on
+    // the AdaIN1d + LeakyReLU that reads this conv's result, written as the image post_yh by the same call (as_conv_gemm_multi_post_f32):
+    // in the launch's reduction kernel when the conv is cut into K slices and no utterance is wider than 256 columns, else a launch behind it
+    const Norm* post_n = nullptr;
+    const Lay* post_lay = nullptr;
+    uint16_t* post_yh = nullptr;
 };
 
 // Y = epi(conv(W, X)); the input is fp32 X [K][ldx] (split by the library into the workspace) or the operand image xh
@@ -1069,14 +1091,25 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     if (o.N_in && !o.src_col) { c.fail(AS_EINVAL); return; }
     a.meta = o.N_in ? o.src_meta : (pointwise ? nullptr : c.meta(lay));
     a.src_col = o.src_col;
+    AsAdainArgs post;
+    memset(&post, 0, sizeof(post));
+    int32_t post_mw = 0;
+    if (o.post_yh) {
+        if (!o.post_n || !o.post_lay || o.post_lay->N != lay->N || !Y) { c.fail(AS_EINVAL); return; }
+        post.gb = o.post_n->gb; post.gb_off = o.post_n->gb_off; post.ldgb = 1; post.gb_sc = o.post_n->gb_sc;
+        post.col_off = o.post_lay->d_off; post.U = o.post_lay->B; post.lrelu = 1; post.yh = o.post_yh;
+        post_mw = o.post_lay->max_w;
+    }
     if (c.deferring() && !EXP_SKIP(as_conv_gemm_f32)) {                  // recorded: it may share its launch with other branches' convs
         Op& op = c.push(1);
         op.g = a;
+        op.post = post;
+        op.post_max_w = post_mw;
         op.what = "as_conv_gemm_f32";
         op.line = __LINE__;
         return;
     }
-    RUN(c, as_conv_gemm_f32(&a, c.s));
+    RUN(c, as_conv_gemm_multi_post_f32(&a, &post, &post_mw, 1, c.s));
 }
 
 // fp32 input X [K][ldx]
@@ -1109,12 +1142,6 @@ float* conv_h_new(Ctx& c, const GemmW* w, const uint16_t* xh, int K, const Lay* 
 // ------------------------------------------------------------------------------------------------------------------
 // building blocks (the launch sequences of the reference's modules)
 // ------------------------------------------------------------------------------------------------------------------
-// gamma / beta of one AdaIN1d launch: AsAdainArgs addressing into the output of the fc GEMM ([rows][ldB], utterances as columns)
-struct Norm {
-    const float* gb = nullptr;
-    const int32_t* gb_off = nullptr;   // per-utterance offsets (grouped launches); NULL: utterance u at gb + u
-    int gb_sc = 0;                     // stride between channels = ldB
-};
 
 // Every AdaIN fc layer fed by `style` [B][lds] in one GEMM: gbT [Mtot][B] = W style^T + b (models.py:237).
 // Returns the output; row0 of a layer through FcAll::row0.
@@ -1171,6 +1198,9 @@ struct Act {                     // fp32 activation [C][ld] on a layout (+ optio
     int C = 0, ld = 0;
     const Lay* lay = nullptr;
     const uint16_t* h = nullptr;
+    // the operand image of LeakyReLU(AdaIN(p)) under the NEXT block's norm1, written by the launch that produced p (BlkOpt.next_n1): that
+    // block's first conv reads it and launches no AdaIN of its own
+    const uint16_t* pre = nullptr;
     // a tower stem's output that exists only as its LeakyReLU image h (p null): the one-channel input and the stem's fp32 weights,
     // from which the first block's shortcut is computed directly (as_stem_pool_image_f32)
     const float* stem_x = nullptr;
@@ -1192,6 +1222,8 @@ struct BlkOpt {
     int ldo = 0;
     bool want_yh = false;              // also write the output as an operand image
     uint16_t* yh = nullptr;            // (where; null with want_yh: from the workspace)
+    const Norm* next_n1 = nullptr;     // norm1 of the block that reads this block's output (same layout, no up-sampling): conv2's call also
+                                       // writes that block's conv1 operand (Act.pre) -- in its reduction kernel at batch-1 sizes
 };
 
 Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
@@ -1217,10 +1249,13 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
     if (!out) { out = c.f32((size_t)dout * Nn2); ldo = N2; }
     const Taps k3 = taps_1d(3), k1 = taps_1d(1);
     // norm1 -> LeakyReLU (-> depthwise ConvTranspose1d x2, models.py:172,195) exists only as conv1's operand image
-    uint16_t* xs = c.image(din, N2);
+    const bool have_pre = X.pre && !o.upsample;
+    uint16_t* xs = have_pre ? const_cast<uint16_t*>(X.pre) : c.image(din, N2);
     const float* sc = X.p;
     int ldsc = X.ld;
-    if (o.upsample) {
+    if (have_pre) {
+        // (the producer's call wrote it)
+    } else if (o.upsample) {
         float* up = c.f32((size_t)din * Nn2);                           // shortcut = nearest x2 (models.py:184,261-270)
         const float *pw = m.vec_stack(sfx(".pool.weight")), *pb = m.vec_stack(sfx(".pool.bias"));
         if (G > 1) { c.fail(AS_EINVAL); return Y; }                      // (grouped up-sampling blocks go through adain_image per group: see arts_predictor)
@@ -1230,10 +1265,13 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
     } else {
         adain_image(c, X.p, X.ld, din, o.n1, lay_in, nullptr, N2, xs);
     }
+    // norm2 -> LeakyReLU exists only as conv2's operand image, written by conv1's call (models.py:196-197)
+    uint16_t* xs2 = c.image(dout, N2);
     ConvOpt q1;
     q1.bias = m.bias_stack(sfx(".conv1"));
     q1.group_cols = gc2;
-    float* h1 = conv_h_new(c, w1, xs, din, lay2, k3, q1);
+    q1.post_n = &o.n2; q1.post_lay = lay2; q1.post_yh = xs2;
+    conv_h_new(c, w1, xs, din, lay2, k3, q1);
     if (has_sc && !fold) {                                              // learned shortcut (models.py:185-186), no bias
         ConvOpt q;
         q.group_cols = gc2;
@@ -1245,8 +1283,6 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
         sc = dst;
         ldsc = ldd;
     }
-    uint16_t* xs2 = c.image(dout, N2);
-    adain_image(c, h1, N2, dout, o.n2, lay2, nullptr, N2, xs2);
     ConvOpt q2;
     q2.bias = m.bias_stack(sfx(".conv2"));
     if (fold) {
@@ -1262,8 +1298,12 @@ Act adain_resblk1d(Ctx& c, const Act& X, BlkOpt o)
         q2.want_yh = true;
         q2.yh = o.yh ? o.yh : c.image(dout, N2);
     }
+    if (o.next_n1) {
+        q2.post_n = o.next_n1; q2.post_lay = lay2;
+        q2.post_yh = c.image(dout, N2);
+    }
     conv_h(c, w2, xs2, dout, lay2, k3, out, ldo, q2);
-    Y.p = out; Y.C = dout; Y.ld = ldo; Y.lay = lay2; Y.h = q2.yh;
+    Y.p = out; Y.C = dout; Y.ld = ldo; Y.lay = lay2; Y.h = q2.yh; Y.pre = q2.post_yh;
     return Y;
 }
 
@@ -1705,6 +1745,8 @@ float* duration_tail(Ctx& c, float* d, const float* ds, const Lay* tok, float* d
         o.n1 = fc.norm(o.names[0] + ".norm1");
         o.n2 = fc.norm(o.names[0] + ".norm2");
         o.want_yh = i == 2;                                             // the last block feeds the LSTM's input projection
+        const Norm nn = i < 2 ? fc.norm(p + ".duration." + std::to_string(i + 1) + ".norm1") : Norm();
+        if (i < 2) o.next_n1 = &nn;
         x = adain_resblk1d(c, x, o);
         if (!x.lay) return nullptr;
     }
@@ -1823,9 +1865,10 @@ void arts_predictor(Ctx& c, const float* a_en, int lda, const Lay* lay, const Fc
         ConvOpt q1;
         q1.bias = m.bias_stack(sfx(".conv1"));
         q1.group_cols = 2 * N1;
-        float* h1 = conv_h_new(c, w1, xs, C, layG2, taps_1d(3), q1);
         uint16_t* xs2 = c.image(w1->M, NG2);
-        adain_image(c, h1, NG2, w1->M, gnorm(0, ".norm2", w1->M), layG2, nullptr, NG2, xs2);
+        const Norm n2 = gnorm(0, ".norm2", w1->M);
+        q1.post_n = &n2; q1.post_lay = layG2; q1.post_yh = xs2;
+        conv_h_new(c, w1, xs, C, layG2, taps_1d(3), q1);
         ConvOpt q2;
         q2.bias = m.bias_stack(sfx(".conv2"));
         q2.res = up;
@@ -1834,8 +1877,10 @@ void arts_predictor(Ctx& c, const float* a_en, int lda, const Lay* lay, const Fc
         q2.group_cols = 2 * N1;
         q2.want_yh = true;                                              // block 1's learned shortcut reads the image
         q2.yh = c.image(w2->M, NG2);
+        const Norm nn = gnorm(1, ".norm1", w2->M);                       // block 1's norm1, by the same call
+        q2.post_n = &nn; q2.post_lay = layG2; q2.post_yh = c.image(w2->M, NG2);
         x.p = conv_h_new(c, w2, xs2, w1->M, layG2, taps_1d(3), q2);
-        x.C = w2->M; x.ld = NG2; x.lay = layG2; x.h = q2.yh;
+        x.C = w2->M; x.ld = NG2; x.lay = layG2; x.h = q2.yh; x.pre = q2.post_yh;
     }
     for (int blk = 1; blk <= 2; ++blk) {
         BlkOpt o;
@@ -1846,6 +1891,11 @@ void arts_predictor(Ctx& c, const float* a_en, int lda, const Lay* lay, const Fc
         o.n1 = gnorm(blk, ".norm1", x.C);
         o.n2 = gnorm(blk, ".norm2", w1->M);
         o.want_yh = true;
+        Norm nn;
+        if (blk == 1) {                                                  // block 2's norm1 by block 1's last call (conv1: din -> dout, conv2: dout -> dout)
+            nn = gnorm(2, ".norm1", w1->M);
+            o.next_n1 = &nn;
+        }
         x = adain_resblk1d(c, x, o);
         if (!x.lay) return;
     }
@@ -1978,6 +2028,8 @@ void decoder(Ctx& c, const DecPre& dp, float* x0, const Lay* lay2, const float* 
         o.n1 = fc.norm(o.names[0] + ".norm1");
         o.n2 = fc.norm(o.names[0] + ".norm2");
         o.want_yh = i == 5;                                             // to_out reads the image
+        const Norm nn = i < 5 ? fc.norm(p + ".decode." + std::to_string(i + 1) + ".norm1") : Norm();
+        if (i < 5) o.next_n1 = &nn;
         y = adain_resblk1d(c, i == 2 ? xc : y, o);
         if (!y.lay) return;
     }

@@ -327,6 +327,25 @@ def conv_gemm_multi(deferred, tile_out=None):
     check(L.as_conv_gemm_multi_f32(arr, n, stream()), "as_conv_gemm_multi_f32")
 
 
+def conv_gemm_multi_post(deferred, posts):
+    """as_conv_gemm_multi_post_f32: the deferred convs as one launch; posts[i] = None or (gb, gb_sc, lay, image[, gb_off]) -- the AdaIN1d +
+    LeakyReLU that reads conv i's result, written as `image` by the same call (by the launch's reduction kernel when it is K-sliced and no
+    utterance is wider than 256 columns)."""
+    n = len(deferred)
+    arr = (ConvGemmArgs * n)(*[d[0] for d in deferred])
+    pa = (_lib.AdainArgs * n)()
+    mw = (ctypes.c_int32 * n)()
+    for i, q in enumerate(posts):
+        if q is None:
+            continue
+        gb, gb_sc, lay, img = q[:4]
+        gb_off = q[4] if len(q) > 4 else None
+        pa[i].gb, pa[i].gb_off, pa[i].ldgb, pa[i].gb_sc = _p(gb), _p(gb_off), 1, gb_sc
+        pa[i].col_off, pa[i].U, pa[i].lrelu, pa[i].yh = _p(lay.col_off), lay.B, 1, _p(img)
+        mw[i] = max(lay.widths_host) if hasattr(lay, "widths_host") else int(lay.widths.max())
+    check(_lib.lib().as_conv_gemm_multi_post_f32(arr, pa, mw, n, stream()), "as_conv_gemm_multi_post_f32")
+
+
 def embed(tokens_i32, emb, scale, Y, group2=None, n_cols=None):
     """group2 = (emb2, n_split): token columns >= n_split look their rows up in the second table.  n_cols > tokens: the token list is
     read twice (columns [tokens, n_split) are filler, column n_split + j is token j again)."""

@@ -303,6 +303,18 @@ typedef struct AsAdainArgs {
     int32_t ld_up;
 } AsAdainArgs;
 int as_adain_image_f32(const AsAdainArgs* args_host, as_stream_t stream);
+/* as_conv_gemm_multi_f32 for convolutions whose RESULT is (also) read through an AdaIN1d + LeakyReLU -- conv1 -> norm2 -> actv -> conv2
+ * inside an AdainResBlk1d, conv2 -> the next block's norm1 (models.py:189-202) -- : problem i with post_host[i].yh != NULL also leaves
+ * the operand image post[i].yh = split(LeakyReLU?(AdaIN(y_i))) over the utterances post[i].col_off [post[i].U + 1] of its N columns,
+ * y_i = the conv's result after its own epilogue (post[i].x / ldx / C / N / src_off / pool_* are ignored: the input IS the conv's result,
+ * list[i].Y must be given, C = M; gb / gb_off / ldgb / gb_sc / lrelu as in as_adain_image_f32).  What it buys: a launch that is cut into
+ * K slices (few columns: batch 1, BASELINE config C2) ends in a reduction kernel that already holds a channel's whole time axis when no
+ * utterance is wider than 256 columns (post_max_w[i] = the widest utterance of problem i), so that kernel computes the statistics and
+ * writes the image itself -- conv -> reduce+AdaIN -> conv instead of conv -> reduce -> AdaIN -> conv, bit-identical to the separate
+ * launches.  Everywhere else the call is exactly as_conv_gemm_multi_f32 followed by as_adain_image_f32 on list[i].Y.
+ * post_host NULL: as_conv_gemm_multi_f32.  Not with transpose_out / ileave_u. */
+int as_conv_gemm_multi_post_f32(const ConvGemmArgs* list_host, const AsAdainArgs* post_host, const int32_t* post_max_w, int n,
+                                as_stream_t stream);
 /* x [B][ldx] (one K-vector per utterance) -> the split image of its transpose [K][B] (columns = utterances): the operand of
  * the GEMM that evaluates every AdaIN fc layer of the model at once (models.py:237). */
 int as_rows_image_f32(const float* x, int ldx, int K, int B, uint16_t* xh, as_stream_t stream);

@@ -826,6 +826,74 @@ def test_conv_gemm_multi(cuda, monkeypatch, impl, name, tile):
             assert float((y - y1).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("case", ["single", "multi", "grouped", "wide", "unsliced"])
+def test_conv_gemm_post_adain(cuda, monkeypatch, case):
+    """as_conv_gemm_multi_post_f32 (models.py:189-202: conv -> AdaIN -> LeakyReLU -> conv): the AdaIN image of a conv's result from the
+    same call.  At batch-1 sizes the launch is K-sliced and its reduction kernel writes the image (one dependent launch less) -- bitwise
+    what the conv followed by as_adain_image_f32 gives, fp32 rows and the plain image included; utterances wider than 256 columns and
+    unsliced launches take the two-launch route inside the call; with AS_NO_REDUCE_ADAIN every case does."""
+    import ctypes
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    if case == "single":
+        specs = [(1024, 1024, 3, [150], "plain")]
+    elif case == "multi":
+        specs = [(512, 512, 3, [30], "shortcut"), (256, 1024, 9, [90], "plain"), (512, 512, 3, [7, 30, 1], "plain")]
+    elif case == "grouped":
+        specs = [(256, 128, 3, [60, 41, 5] * 3, "grouped")]
+    elif case == "wide":
+        specs = [(512, 256, 3, [300, 20], "plain")]
+    else:
+        specs = [(64, 128, 3, [200] * 32, "plain")]
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("AS_NO_REDUCE_ADAIN", raising=False)
+        else:
+            monkeypatch.setenv("AS_NO_REDUCE_ADAIN", "1")
+        gg = torch.Generator().manual_seed(1234)
+        deferred, outs, wants, checks = _multi_problems(cuda, gg, specs)
+        posts, imgs, gbs = [], [], []
+        for (cin, cout, k, lens, fl), (a, keep) in zip(specs, deferred):
+            lay = keep[10]
+            gb = torch.randn(2 * cout, lay.B, generator=gg).to(cuda)            # [2C][U]: the fc GEMM's layout (gb_sc = U, utterance u at + u)
+            img = ops.new_image(cout, lay.N, cuda)
+            img.fill_(0x7e7e)
+            posts.append((gb, lay.B, lay, img))
+            imgs.append(img)
+            gbs.append(gb)
+        plans = []
+        for a, _ in deferred:
+            kk, tt, sl = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+            ops.check(ops._lib.lib().as_conv_gemm_plan(ctypes.byref(a), ctypes.byref(kk), ctypes.byref(tt), ctypes.byref(sl)), "as_conv_gemm_plan")
+            plans.append(sl.value)
+        ops.conv_gemm_multi_post(deferred, posts)
+        torch.cuda.synchronize()
+        return outs, wants, checks, imgs, gbs, [k[10] for _, k in deferred], plans
+    outs, wants, checks, imgs, gbs, lays, plans = run(True)
+    if case in ("single", "grouped", "wide"):
+        assert plans[0] > 1, plans                                                # (the case is about K-sliced launches)
+    if case == "unsliced":
+        assert plans[0] == 1
+    for (cin, cout, k, lens, fl), y, want in zip(specs, outs, wants):
+        assert float((y.double().cpu() - want).abs().max()) <= 3e-5
+    for yh, y, lay in checks:
+        assert torch.equal(yh, ops.split_act(y, lay))
+    # the image: AdaIN + LeakyReLU of the fp32 result by the stand-alone kernel, bit for bit
+    for y, img, gb, lay in zip(outs, imgs, gbs, lays):
+        ref = ops.adain_image(y, lay, gb, lay.B, lay.N)
+        torch.cuda.synchronize()
+        bad = (img[: ref.numel()] != ref).nonzero().flatten()
+        where = [(int(i) // (8 * (lay.N + 1)) // 4, int(i) // (8 * (lay.N + 1)) % 4, int(i) // 8 % (lay.N + 1), int(i) % 8) for i in bad[:6]]
+        assert bad.numel() == 0, (case, int(bad.numel()), "(k-block, plane, column, element):", where)
+    outs0, _, checks0, imgs0, _, _, _ = run(False)
+    for y, y0 in zip(outs, outs0):
+        assert torch.equal(y, y0)
+    for i, i0 in zip(imgs, imgs0):
+        assert torch.equal(i, i0)
+    for (yh, _, _), (yh0, _, _) in zip(checks, checks0):
+        assert torch.equal(yh, yh0)
+
+
 def test_conv_gemm_multi_rejects_what_it_cannot_merge(cuda):
     g = torch.Generator().manual_seed(1)
     lay = Layout([50, 20], cuda)
