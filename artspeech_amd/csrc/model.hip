@@ -523,6 +523,9 @@ struct Op {
     std::vector<std::pair<int, size_t>> deps;      // kind 2: queue q has played >= n ops
     const char* what = nullptr;
     int line = 0;
+    bool side = false;                             // kind 0: a long launch on a handful of workgroups (the duration predictor's recurrence over
+                                                   // hundreds of tokens): play() puts it on the plan's side stream and parks its queue, so that
+                                                   // the other queues' launches run beside it
 };
 struct Sched {
     std::vector<std::vector<Op>> q;
@@ -716,6 +719,8 @@ static bool exp_dup(const char* call)
 #define EXP_SKIP(call) false
 #define EXP_DUP(call) false
 #endif
+// (a recorded launch that play() moves to the plan's side stream: Op.side)
+static thread_local hipStream_t tl_stream_override = nullptr;
 // (recorded form: the closure copies what the call names -- argument structs and job arrays included -- and sees the stream as `c.s`)
 #define RUN(c, call)                                   \
     do {                                               \
@@ -725,7 +730,7 @@ static bool exp_dup(const char* call)
                 Op& o__ = (c).push(0);                 \
                 o__.what = #call; o__.line = __LINE__; \
                 o__.fn = [=]() -> int {                \
-                    struct { hipStream_t s; } c = {s__}; \
+                    struct { hipStream_t s; } c = {tl_stream_override ? tl_stream_override : s__}; \
                     (void)c;                           \
                     int r__ = (call);                  \
                     if (r__ == AS_OK && EXP_DUP(call)) r__ = (call); \
@@ -759,6 +764,20 @@ static void play(Ctx& c, Sched& S)
 {
     const int nq = (int)S.q.size();
     std::vector<size_t> head(nq, 0);
+    // a queue whose last launch went to the side stream (Op.side) is PARKED: its later ops wait until nothing else can go out, then the
+    // calling stream waits for the side stream's event and the queue moves on.  Dependencies see a parked queue one op back.
+    std::vector<hipEvent_t> parked(nq, nullptr);
+    const bool no_side = getenv("AS_NO_SIDE_LSTM") != nullptr;          // experiments / tests: everything on the one stream
+    auto unpark_all = [&]() -> bool {
+        bool any = false;
+        for (int qi = 0; qi < nq; ++qi)
+            if (parked[qi]) {
+                if (hipStreamWaitEvent(c.s, parked[qi], 0) != hipSuccess) c.fail((int)hipErrorUnknown, "unpark", __LINE__);
+                parked[qi] = nullptr;
+                any = true;
+            }
+        return any;
+    };
     auto fail = [&](int r, const Op& o) { c.fail(r, o.what, o.line); };
     static const bool no_merge = getenv("AS_NO_MERGE") != nullptr;    // experiments: the recorded order, one launch per conv
     static const bool trace = getenv("AS_DEBUG_SCHED") != nullptr;     // print what goes out, in order
@@ -770,15 +789,33 @@ static void play(Ctx& c, Sched& S)
     for (;;) {
         bool progress = false;
         for (int qi = 0; qi < nq && !c.rc; ++qi) {
-            while (head[qi] < S.q[qi].size()) {
+            while (head[qi] < S.q[qi].size() && !parked[qi]) {
                 Op& o = S.q[qi][head[qi]];
                 if (o.kind == 2) {
                     bool ok = true;
-                    for (auto& d : o.deps) ok = ok && head[d.first] >= d.second;
+                    for (auto& d : o.deps) ok = ok && head[d.first] - (parked[d.first] ? 1 : 0) >= d.second;
                     if (!ok) break;
                 } else if (o.kind == 0) {
                     if (o.hint_f > 0 || o.hint_b > 0) as_prof_hint(o.hint_f, o.hint_b);
-                    if (trace) fprintf(stderr, "  q%d  %.60s\n", qi, o.what ? o.what : "?");
+                    if (trace) fprintf(stderr, "  q%d  %.60s%s\n", qi, o.what ? o.what : "?", o.side && !no_side ? "  [side stream]" : "");
+                    if (o.side && !no_side) {
+                        // fork: the side stream continues from what the calling stream holds so far; join: when the queue is unparked
+                        hipStream_t ss = c.p.stream(0);
+                        hipEvent_t e1 = c.p.event(), e2 = c.p.event();
+                        if (!ss || !e1 || !e2 || hipEventRecord(e1, c.s) != hipSuccess || hipStreamWaitEvent(ss, e1, 0) != hipSuccess) {
+                            fail((int)hipErrorUnknown, o);
+                            break;
+                        }
+                        tl_stream_override = ss;
+                        const int r = o.fn();
+                        tl_stream_override = nullptr;
+                        if (r != AS_OK) { fail(r, o); break; }
+                        if (hipEventRecord(e2, ss) != hipSuccess) { fail((int)hipErrorUnknown, o); break; }
+                        parked[qi] = e2;
+                        ++head[qi];
+                        progress = true;
+                        break;
+                    }
                     const int r = o.fn();
                     if (r != AS_OK) { fail(r, o); break; }
                 } else {
@@ -797,7 +834,7 @@ static void play(Ctx& c, Sched& S)
             int dq[AS_MAX_MULTI], nd = 0;
             double hf = 0, hb = 0;
             for (int qi = 0; qi < nq && nd < AS_MAX_MULTI; ++qi)
-                if (head[qi] < S.q[qi].size() && S.q[qi][head[qi]].kind == 3) {
+                if (!parked[qi] && head[qi] < S.q[qi].size() && S.q[qi][head[qi]].kind == 3) {
                     const Op& o = S.q[qi][head[qi]];
                     dl[nd] = o.d;
                     dq[nd++] = qi;
@@ -829,10 +866,27 @@ static void play(Ctx& c, Sched& S)
         for (int qi = 0; qi < nq; ++qi)
             if (head[qi] < S.q[qi].size()) {
                 live = true;
-                if (S.q[qi][head[qi]].kind == 1 && nh < 64) heads[nh++] = qi;
+                if (!parked[qi] && S.q[qi][head[qi]].kind == 1 && nh < 64) heads[nh++] = qi;
             }
+        if (nh == 0 && unpark_all()) continue;                               // nothing else can go out: the parked queues move on
         if (!live) return;
         if (nh == 0) { c.fail(AS_EINVAL, "recorded queues wait for each other", __LINE__); return; }
+        // a queue with a side-stream launch still ahead of it goes FIRST and alone: its convs are what that launch waits for, and every
+        // conv of another queue that goes out before it is one that could have run beside it (the duration predictor's blocks before its
+        // recurrence; the encoders' last two layers then run while the recurrence does)
+        if (!no_side) {
+            int nu = 0, uh[64];
+            for (int i = 0; i < nh; ++i) {
+                const std::vector<Op>& Q = S.q[heads[i]];
+                bool urgent = false;
+                for (size_t k = head[heads[i]]; k < Q.size() && !urgent; ++k) urgent = Q[k].side;
+                if (urgent) uh[nu++] = heads[i];
+            }
+            if (nu > 0 && nu < nh) {
+                for (int i = 0; i < nu; ++i) heads[i] = uh[i];
+                nh = nu;
+            }
+        }
         // a head that cannot share a launch (fp32 input still to be split, the direct Cin = 1 kernel) goes out first and alone: its queue
         // moves on to heads that can.  Otherwise the set = the mergeable heads of the row class that holds the most work.
         int pick[AS_MAX_MULTI], np = 0, lone = -1;
@@ -1765,6 +1819,11 @@ float* duration_tail(Ctx& c, float* d, const float* ds, const Lay* tok, float* d
         size_t xb = 0;
         void* xchg = c.lstm_xchg(1, tok->B, &xb);
         RUN(c, as_bilstm_cluster_f32(&job, 1, tok->d_off, tok->B, H, tok->max_w, xchg, xb, c.s));
+        // hundreds of tokens: milliseconds on a few dozen workgroups (C5: 1.8 ms on 16) while the text / articulatory encoders' last two
+        // layers -- which do not depend on it (models.py:356-360) -- have the chip's worth of GEMMs to run: a recording plan puts the
+        // launch on its side stream (one fork / join pair of event edges: worth it only for a long launch)
+        static const int side_min = getenv("AS_SIDE_LSTM_MIN") ? atoi(getenv("AS_SIDE_LSTM_MIN")) : 200;
+        if (c.deferring() && c.go() && tok->max_w >= side_min && !c.sched->q[c.cur_q].empty()) c.sched->q[c.cur_q].back().side = true;
     }
     float* y = c.f32(Nn);
     if (dst) y = dst;

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from artspeech_amd import models, synth
+from artspeech_amd import _lib, models, synth
 from artspeech_amd.weights import DEFAULT_STATS, fold_state_dict, load_distribution
 
 pytestmark = pytest.mark.gpu
@@ -390,3 +390,46 @@ def test_f16_operand_mode_error_is_reported(cuda, golden_dir):
     print(f"C2 mel max-abs vs the reference: f16x3 {exact:.2e}, fp16 operands {coarse:.2e}")
     assert exact <= MEL_TOL and again == exact
     assert exact < coarse <= 5e-2
+
+
+def test_long_utterances_recurrence_beside_the_encoders(cuda, monkeypatch):
+    """A recording plan (one chain per batch: what as_lanes runs) with utterances of >= 200 tokens puts the duration predictor's recurrence
+    on the plan's side stream -- its blocks first, the text / articulatory encoders' last two layers beside it (models.py:356-360: they do
+    not depend on it).  Eagerly, as a replayed hipGraph, and with PREDICTED durations (where the recurrence's result is read back by
+    the call itself), against the chain without the fork."""
+    import bench
+    net = get_model(512, 64, 3407, cuda)
+    host, g = bench.make_inputs(cuda, 3, 260, 300, 120, vary=True, seed0=77)
+    assert max(g["tok_lens"]) >= 200
+
+    def run(side, graph):
+        if side:
+            monkeypatch.delenv("AS_NO_SIDE_LSTM", raising=False)
+        else:
+            monkeypatch.setenv("AS_NO_SIDE_LSTM", "1")
+        twin = net.replica()
+        twin.rt.set_serial(True)
+        r = bench.Runner(twin, g)
+        r.step()
+        if graph:
+            fn = r.capture()
+            for _ in range(3):
+                fn()
+        torch.cuda.synchronize()
+        forced = r.out["mel"].clone()
+        pred = twin.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], aux=True)
+        torch.cuda.synchronize()
+        return forced, pred["mel"].clone(), pred["duration"].clone()
+    base = run(False, False)
+    eager = run(True, False)
+    replay = run(True, True)
+    for a, b in zip(eager, replay):                                      # the fork survives capture: the replayed graph gives the eager bits
+        assert a.shape == b.shape and torch.equal(a, b)
+    # against the chain without the fork: the same arithmetic, but the duration predictor's convs now go out ahead of the encoders' instead
+    # of sharing their launches -- another tile, another order of partial sums (the bound of chain_vs_side_streams in bench.py)
+    assert float((base[0] - eager[0]).abs().max()) <= 3e-5
+    assert float((base[2] - eager[2]).abs().max()) <= 3e-5
+    if base[1].shape == eager[1].shape:                                  # (the same rounded durations)
+        assert float((base[1] - eager[1]).abs().max()) <= 3e-5
+    assert _lib.lib().as_device_status(0) == 0
+
