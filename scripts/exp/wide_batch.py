@@ -41,6 +41,22 @@ def main():
             print("classes per 32 utt at", 32 * k, "per call:", row, flush=True)
             del twin
             torch.cuda.empty_cache()
+    if os.environ.get("NATIVE"):
+        # the same arrangements through the library's own lanes (as_lanes: c streams created back to back -- consecutive HIP streams land on
+        # different hardware queues; two torch streams of a pool may share one, and then nothing of the two chains overlaps)
+        for k, c in arrangements:
+            batches = [bench.make_inputs(dev, 32 * k, seed0=bench.DATA_SEED + 100 * i)[1] for i in range(c)]
+            chain = net.replica()
+            chain.rt.set_serial(True)
+            firsts = [bench.Runner(chain, b).step()["mel"].clone() for b in batches]
+            best = None
+            for _ in range(2):
+                nl = bench.bench_native_lanes(net, batches, firsts, reps * c, 0)
+                best = nl["ms_per_step"] if best is None else min(best, nl["ms_per_step"])
+            print(dict(utt_per_call=32 * k, chains=c, ms_per_32_utt=round(best / k, 4), native_lanes=True, bitwise=nl["results_bitwise_equal"]), flush=True)
+            del chain, batches, firsts
+            torch.cuda.empty_cache()
+        return
     for k, c in arrangements:
         lanes = []
         for i in range(c):
