@@ -874,8 +874,11 @@ def main():
                      "kernel": "conv_gemm_h3_kernel (implicit-GEMM conv, fp16 matrix cores, two-way split operands h + l, 3 products per fp32 "
                                "product, fp32 accumulate; both operands staged by LDS-DMA from producer-written images)",
                      "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s", "frac": gemm_tflops / gemm_peak,
+                     # where `achieved` / `frac` come from: "committed_trace" = the rocprofv3 kernel trace of THIS build committed under
+                     # profiles/ (matched by the kernel sources' id; not measured by this run), "events_this_run" = HIP events of this run
+                     "frac_source": "committed_trace" if trace_cls else "events_this_run",
                      "time_source": trace_src,
-                     "achieved_by_events": gemm_tflops_ev, "frac_by_events": gemm_tflops_ev / gemm_peak,
+                     "achieved_by_events": gemm_tflops_ev, "frac_by_events": gemm_tflops_ev / gemm_peak,      # (always this run's)
                      "gemm_ms_per_step_by_trace": trace_cls["conv_gemm"]["ms_per_step"] if trace_cls else None,
                      "gemm_ms_per_step_by_events": k0["ms_per_step"],
                      "peak_basis": "dense fp16 MFMA 2516.6 TFLOP/s / 3 matrix-core products per fp32 product (achieved = algorithmic fp32 flop); "
@@ -897,6 +900,7 @@ def main():
                                                     "(classes adain + layernorm + other of the event profiler)",
                          "achieved": hbm_gb / hbm_ms if hbm_ms else None, "peak": PEAK_HBM_TBS, "unit": "TB/s",
                          "frac": hbm_gb / hbm_ms / PEAK_HBM_TBS if hbm_ms else None,
+                         "frac_source": "committed_trace" if trace_cls else "events_this_run",
                          "algorithmic_gbyte_per_step": hbm_gb, "ms_per_step": hbm_ms, "time_source": trace_src,
                          "ms_per_step_by_events": hbm_ms_ev, "frac_by_events": hbm_gb / hbm_ms_ev / PEAK_HBM_TBS if hbm_ms_ev else None,
                          "launches_per_step": sum(kern[c]["launches_per_step"] for c in HBM_GROUP if c in kern)},
