@@ -187,6 +187,9 @@ _SIGNATURES.update({
     "as_lanes_stream": (c_p, [c_p, c_i]),
     "as_lanes_submit": (c_i, [c_p, _pB, _pIO, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "as_lanes_wait": (c_i, [c_p, c_i]),
+    "as_lanes_set_coalesce": (c_i, [c_p, c_i]),
+    "as_lanes_flush": (c_i, [c_p]),
+    "as_lanes_merged_calls": (ctypes.c_int64, [c_p, c_i]),
     "as_lanes_set_graph_cap": (c_i, [c_p, c_i]),
     "as_lanes_set_layout_cap": (c_i, [c_p, c_i]),
     "as_lanes_reserve": (c_i, [c_p, c_sz, c_sz]),

@@ -40,7 +40,13 @@ struct Lane {
     std::unordered_map<std::string, hipGraphExec_t> graphs;      // key -> instantiated graph
     std::unordered_set<std::string> once;                         // pairs that ran once, on the eager plan (a bounded memory of candidates)
     std::unordered_set<std::string> met;                          // pairs the graph plan has met eagerly: captured at their next submit
-    int64_t n_drops = 0, n_launch = 0, n_eager = 0, n_capture = 0;
+    int64_t n_drops = 0, n_launch = 0, n_eager = 0, n_capture = 0, n_merged = 0;
+    // submissions waiting for their group (as_lanes_set_coalesce): host arrays copied, device pointers as given
+    struct Pending {
+        std::vector<int32_t> tok_lens, ref_lens, frames;
+        as_forward_io io;
+    };
+    std::vector<Pending> pend;
 };
 
 // the lane's stream is idle (lanes_submit synchronises it first): no graph is running, nothing reads the graph plan's tables
@@ -84,6 +90,7 @@ struct as_lanes {
     std::vector<void*> retired;                                   // outgrown workspaces: freed when every lane is idle
     int next = 0;
     size_t graph_cap = 256;
+    int coalesce = 1;                                             // submissions of adjacent buffers launched as ONE as_forward_test call
 };
 
 namespace {
@@ -212,9 +219,19 @@ extern "C" int as_lanes_stats(const as_lanes* q, int lane, int64_t* out6)
     return AS_OK;
 }
 
+static int flush_lane(as_lanes* q, int lane);
 extern "C" int as_lanes_wait(as_lanes* q, int lane)
 {
     if (!q || lane >= (int)q->lanes.size()) return AS_EINVAL;
+    try {                                                          // submissions still waiting for neighbours go out first
+        for (int i = 0; i < (int)q->lanes.size(); ++i)
+            if (lane < 0 || lane == i) {
+                const int rc = flush_lane(q, i);
+                if (rc != AS_OK) return rc;
+            }
+    } catch (...) {
+        return (int)hipErrorOutOfMemory;
+    }
     for (int i = 0; i < (int)q->lanes.size(); ++i)
         if (lane < 0 || lane == i)
             if (hipStreamSynchronize(q->lanes[i].stream) != hipSuccess) return (int)hipErrorUnknown;
@@ -222,12 +239,11 @@ extern "C" int as_lanes_wait(as_lanes* q, int lane)
     return as_device_status(0) ? AS_EDEVICE : AS_OK;
 }
 
-static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out)
+// one as_forward_test call on lane q->next (then the next lane's turn)
+static int lane_run(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out)
 {
-    if (!q || !batch || !io || batch->B <= 0 || !batch->tok_lens || !batch->ref_lens) return AS_EINVAL;
     const int lane = q->next;
     Lane& L = q->lanes[lane];
-    if (lane_out) *lane_out = lane;
     // the lane's previous batch has left its workspaces (and the caller's buffers of that lane)
     if (hipStreamSynchronize(L.stream) != hipSuccess) return (int)hipErrorUnknown;
     // (sizes come from the eager plan: a count pass adds host-side layout entries, which that plan may flush; the graph plan stays small)
@@ -320,6 +336,76 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
     return hipGraphLaunch(exec, L.stream) == hipSuccess ? AS_OK : (int)hipErrorUnknown;
 }
 
+// ---- coalescing (as_lanes_set_coalesce) ---------------------------------------------------------------------------------------------
+// Utterances are concatenated along the column axis of every tensor of the path, so two submissions whose buffers are ADJACENT views of
+// one block -- submission 2's tokens / reference features / output columns begin where submission 1's end, same leading dimensions --
+// ARE one batch: the lane holds a submission back until k such neighbours have arrived (or something else is submitted, or the lane is
+// flushed / waited for) and launches them as ONE as_forward_test call, with no copy.  What it buys: wider conv GEMM launches (fuller
+// rounds of the chip, the weights fetched once for k batches).  The reference processes one utterance at a time (models.py:361-362):
+// any grouping is legal, and every utterance still gets its batch-1 result (packed frames: no padding, no cross-utterance term).
+static bool plain_io(const as_forward_io* io)                     // only the mel is wanted: the optional outputs have no per-submission home in a merged call
+{
+    return !io->duration && !io->dur_i && !io->frame_off && !io->style && !io->feat12 && !io->t_en && !io->a_en && !io->F0 && !io->N && !io->EMA;
+}
+static bool adjacent(const Lane::Pending& p, const as_forward_io* io)
+{
+    long nt = 0, nr = 0, nf = 0;
+    for (int32_t v : p.tok_lens) nt += v;
+    for (int32_t v : p.ref_lens) nr += v;
+    for (int32_t v : p.frames) nf += v;
+    const as_forward_io& a = p.io;
+    return io->tokens == a.tokens + nt && io->mel == a.mel + nr && io->ld_mel == a.ld_mel && io->f0_raw == a.f0_raw + nr &&
+           io->ema_raw == a.ema_raw + nr && io->ld_ema == a.ld_ema &&
+           ((!io->forced_dur && !a.forced_dur) || (io->forced_dur && a.forced_dur && io->forced_dur == a.forced_dur + nt)) &&
+           io->mel_out == a.mel_out + 2 * nf && io->ld_out == a.ld_out;
+}
+// launch the pending group of lane q->next (if any) as one call
+static int flush_lane(as_lanes* q, int lane)
+{
+    Lane& L = q->lanes[lane];
+    if (L.pend.empty()) return AS_OK;
+    std::vector<int32_t> tl, rl, fr;
+    for (const Lane::Pending& p : L.pend) {
+        tl.insert(tl.end(), p.tok_lens.begin(), p.tok_lens.end());
+        rl.insert(rl.end(), p.ref_lens.begin(), p.ref_lens.end());
+        fr.insert(fr.end(), p.frames.begin(), p.frames.end());
+    }
+    as_batch b;
+    b.B = (int32_t)tl.size();
+    b.tok_lens = tl.data(); b.ref_lens = rl.data(); b.frames = fr.data();
+    const as_forward_io io = L.pend.front().io;
+    if (L.pend.size() > 1) ++L.n_merged;
+    L.pend.clear();
+    const int keep = q->next;
+    q->next = lane;
+    const int rc = lane_run(q, &b, &io, nullptr);
+    if (keep != lane) q->next = keep;                             // (a flush from as_lanes_wait does not change whose turn it is)
+    return rc;
+}
+
+static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out)
+{
+    if (!q || !batch || !io || batch->B <= 0 || !batch->tok_lens || !batch->ref_lens) return AS_EINVAL;
+    Lane& L = q->lanes[q->next];
+    const bool can_wait = q->coalesce > 1 && batch->frames && plain_io(io);
+    if (!L.pend.empty() && !(can_wait && adjacent(L.pend.back(), io))) {
+        const int rc = flush_lane(q, q->next);                    // not a neighbour of what waits here: that group goes out first (and the turn passes on)
+        if (rc != AS_OK) return rc;
+    }
+    if (lane_out) *lane_out = q->next;
+    if (!can_wait) return lane_run(q, batch, io, frames_host_out);
+    Lane& L2 = q->lanes[q->next];
+    Lane::Pending p;
+    p.tok_lens.assign(batch->tok_lens, batch->tok_lens + batch->B);
+    p.ref_lens.assign(batch->ref_lens, batch->ref_lens + batch->B);
+    p.frames.assign(batch->frames, batch->frames + batch->B);
+    p.io = *io;
+    L2.pend.push_back(std::move(p));
+    if (frames_host_out) memcpy(frames_host_out, batch->frames, sizeof(int32_t) * batch->B);
+    if ((int)L2.pend.size() >= q->coalesce) return flush_lane(q, q->next);
+    return AS_OK;
+}
+
 extern "C" int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out)
 {
     try {
@@ -327,4 +413,33 @@ extern "C" int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forw
     } catch (...) {
         return (int)hipErrorOutOfMemory;
     }
+}
+
+extern "C" int64_t as_lanes_merged_calls(const as_lanes* q, int lane)
+{
+    if (!q || lane < 0 || lane >= (int)q->lanes.size()) return -1;
+    return q->lanes[lane].n_merged;
+}
+
+extern "C" int as_lanes_flush(as_lanes* q)
+{
+    if (!q) return AS_EINVAL;
+    try {
+        for (int i = 0; i < (int)q->lanes.size(); ++i) {
+            const int rc = flush_lane(q, i);
+            if (rc != AS_OK) return rc;
+        }
+        return AS_OK;
+    } catch (...) {
+        return (int)hipErrorOutOfMemory;
+    }
+}
+
+extern "C" int as_lanes_set_coalesce(as_lanes* q, int k)
+{
+    if (!q || k < 1 || k > 16) return AS_EINVAL;
+    const int rc = as_lanes_flush(q);
+    if (rc != AS_OK) return rc;
+    q->coalesce = k;
+    return AS_OK;
 }

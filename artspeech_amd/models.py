@@ -426,6 +426,7 @@ class Lanes:
         check(_lib.lib().as_lanes_create(self.rt.model, n_lanes, ctypes.byref(self.h)), "as_lanes_create")
         self.n = n_lanes
         self._keep = [None] * n_lanes
+        self.coalesce = 1
 
     def close(self):
         if self.h:
@@ -438,9 +439,30 @@ class Lanes:
         except Exception:
             pass
 
+    def set_coalesce(self, k):
+        """as_lanes_set_coalesce: submissions whose tensors are adjacent column ranges of one block (views: `block[:, a:b]`) and that
+        bring their own `out["mel"]` view of one output block are launched k at a time as ONE call"""
+        check(_lib.lib().as_lanes_set_coalesce(self.h, int(k)), "as_lanes_set_coalesce")
+        self.coalesce = int(k)
+
+    def flush(self):
+        check(_lib.lib().as_lanes_flush(self.h), "as_lanes_flush")
+
+    def merged_calls(self, lane):
+        return int(_lib.lib().as_lanes_merged_calls(self.h, int(lane)))
+
     def submit(self, tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, forced=None, frames=None, out=None, capacity=None):
         """-> (lane, dict with the output tensors).  frames (per-utterance half-rate frame counts) known: graph-replayed from the second
-        submit of the same tensors on a lane; None: predicted durations, `capacity` = the mel frames the output buffer is made for."""
+        submit of the same tensors on a lane; None: predicted durations, `capacity` = the mel frames the output buffer is made for.
+        2-D tensors may be column ranges of a wider block (row stride = the block's width)."""
+        def _p(t):                                                  # (rows of a wider block: only the last axis has to be dense)
+            if t is None:
+                return None
+            if not t.is_cuda or t.device != dev:
+                raise _lib.HipLibraryError("expected a tensor on the model's GPU")
+            if t.stride(-1) != 1:
+                raise _lib.HipLibraryError("expected rows that are dense along the column axis")
+            return t.data_ptr()
         rt, L = self.rt, _lib.lib()
         dev = rt.device
         tok_lens, ref_lens = [int(v) for v in tok_lens], [int(v) for v in ref_lens]
@@ -454,16 +476,20 @@ class Lanes:
             n2 = 2 * sum(int(f) for f in frames) if frames is not None else int(capacity)
             if "mel" not in res:
                 res["mel"] = torch.empty((rt.cfg.n_mels, max(n2, 1)), dtype=torch.float32, device=dev)
+            if self.coalesce <= 1 and "dur_i" not in res:           # (a merged call has no per-submission home for them)
                 res["dur_i"] = torch.empty((max(Nt, 1),), dtype=torch.int32, device=dev)
                 res["frame_off"] = torch.empty((B + 1,), dtype=torch.int32, device=dev)
             io.mel_out, io.ld_out = _p(res["mel"]), res["mel"].stride(0)
-            io.dur_i, io.frame_off = _p(res["dur_i"]), _p(res["frame_off"])
+            if self.coalesce <= 1:
+                io.dur_i, io.frame_off = _p(res["dur_i"]), _p(res["frame_off"])
             ba = rt.batch(tok_lens=tok_lens, ref_lens=ref_lens, frames=frames)
             fr = (ctypes.c_int32 * B)()
             lane = ctypes.c_int32(-1)
             check(L.as_lanes_submit(self.h, ctypes.byref(ba), ctypes.byref(io), fr, ctypes.byref(lane)), "as_lanes_submit")
             res["frames"] = [int(v) for v in fr] if frames is None else [int(f) for f in frames]
-            self._keep[lane.value] = (ba, io, tok, mel_p, f0_p, ema_p, forced, res)
+            # (a lane's last group of submissions stays referenced: its launch may still be reading them)
+            prev = self._keep[lane.value] or []
+            self._keep[lane.value] = (prev + [(ba, io, tok, mel_p, f0_p, ema_p, forced, res)])[-2 * max(self.coalesce, 1):]
         return lane.value, res
 
     def wait(self, lane=-1):

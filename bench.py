@@ -138,6 +138,22 @@ def pack_inputs(host, idx, dev):
     return g
 
 
+def adjacent_submissions(g, per):
+    """a packed block g (pack_inputs) of k * per utterances as k submissions of `per` utterances whose tensors are ADJACENT column ranges of
+    the block -- what as_lanes_set_coalesce launches as one call, without a copy -- each with its own column range of one output block"""
+    n = len(g["frames"])
+    assert n % per == 0
+    mel_all = torch.empty((g["mel"].shape[0], 2 * sum(g["frames"])), dtype=torch.float32, device=g["mel"].device)
+    subs, t0, r0, f0 = [], 0, 0, 0
+    for i in range(0, n, per):
+        nt, nr, nf = sum(g["tok_lens"][i:i + per]), sum(g["ref_lens"][i:i + per]), sum(g["frames"][i:i + per])
+        subs.append(dict(tok=g["tok"][t0:t0 + nt], mel=g["mel"][:, r0:r0 + nr], f0=g["f0"][:, r0:r0 + nr], ema=g["ema"][:, r0:r0 + nr],
+                         forced=g["forced"][t0:t0 + nt], tok_lens=g["tok_lens"][i:i + per], ref_lens=g["ref_lens"][i:i + per],
+                         frames=g["frames"][i:i + per], out=dict(mel=mel_all[:, 2 * f0:2 * (f0 + nf)])))
+        t0, r0, f0 = t0 + nt, r0 + nr, f0 + nf
+    return subs, mel_all
+
+
 def cpu_baseline(host, sd, n_utt):
     """The oracle (CPU restatement of the reference, oracle/acoustic.py) on this box's host cores."""
     from artspeech_amd.weights import DEFAULT_STATS, fold_state_dict, load_distribution
@@ -612,6 +628,68 @@ def bench_native_lanes(net, batches, firsts, steps, warmup):
                 note="as_lanes_submit per batch: the library keeps the serial plans, streams, workspaces and hipGraphs")
 
 
+def merge_hosts(hosts):
+    """several make_inputs host dicts as one (utterances in order)"""
+    return {k: [v for h in hosts for v in h[k]] for k in hosts[0]}
+
+
+def bench_coalesced(net, hosts, k, n_lanes, steps, warmup, barrier=lambda: None):
+    """The K timed steps as K submissions of ONE 32-utterance batch each through the library's lanes with as_lanes_set_coalesce(k): a lane's k
+    consecutive batches live in adjacent column ranges of one block, so the lane launches them as ONE as_forward_test call over 32 k
+    utterances, without a copy (wider conv GEMM launches, one fetch of the weights for k batches; models.py:361-362 processes one utterance
+    at a time: any grouping is legal).  hosts: k * n_lanes make_inputs host dicts (one per batch).  Every batch's mel is compared with the
+    same batch run ALONE as one merged chain (not bitwise: k times the columns, another GEMM tile)."""
+    from artspeech_amd import models
+    dev = net.rt.device
+    per = len(hosts[0]["frames"])
+    chain = net.replica()
+    chain.rt.set_serial(True)
+    blocks, alone = [], []
+    for i in range(n_lanes):
+        hs = hosts[i * k:(i + 1) * k]
+        g = pack_inputs(merge_hosts(hs), list(range(per * k)), dev)
+        subs, mel_all = adjacent_submissions(g, per)
+        blocks.append((g, subs, mel_all))
+        for h in hs:
+            gj = pack_inputs(h, list(range(per)), dev)
+            alone.append(Runner(chain, gj).step()["mel"].clone())
+    torch.cuda.synchronize()
+    lanes = models.Lanes(net, n_lanes)
+    lanes.set_coalesce(k)
+    order = [sub for (_, subs, _) in blocks for sub in subs]
+
+    def submit(i):
+        sub = order[i % len(order)]
+        lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], forced=sub["forced"], frames=sub["frames"],
+                     out=sub["out"])
+    for i in range(max(warmup // len(order) + 1, 4) * len(order)):   # whole rounds: eager, eager (graph plan), captured, replayed
+        submit(i)
+    lanes.wait()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        submit(i)
+    lanes.wait()                                                  # (launches a group that is still short of its k)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    for i in range(steps, (steps // len(order) + 1) * len(order)):   # finish the round: every output block is of ONE launch generation
+        submit(i)
+    lanes.wait()
+    torch.cuda.synchronize()
+    worst = max(float((sub["out"]["mel"] - a).abs().max()) for sub, a in zip(order, alone))
+    merged = sum(lanes.merged_calls(i) for i in range(n_lanes))
+    st = lanes.stats(0)
+    first = order[0]["out"]["mel"].clone()
+    lanes.close()
+    return dict(elapsed_s=el, ms_per_step=el / steps * 1e3, coalesce=k, lanes=n_lanes, utterances_per_call=per * k, merged_calls=merged,
+                graph_launches_lane0=st["graph_launches"], max_abs_vs_each_batch_alone=worst, results_verified=bool(worst <= 3e-5),
+                note="as_lanes_submit per 32-utterance batch; a lane launches its k adjacent batches as one as_forward_test call"), first
+
+
 def c4_check(net, host, mel_mine, mine, world, rank, dev, dist, dump=None):
     """merge the ranks' shards on rank 0 and compare with rank 0 running the whole global batch alone; `dump`: an .npz that gets the
     merged mel of three utterances (shortest, median, longest) for the caller to hold against the oracle (tests/test_multirank_gpu.py)"""
@@ -673,6 +751,8 @@ def main():
     ap.add_argument("--c4-dump", default=None, help="with --global-batch: .npz for the merged mel of three utterances (tests hold them against the oracle)")
     ap.add_argument("--in-flight", type=int, default=4, help="batches in flight per GPU: consecutive steps are replayed on this many HIP streams "
                     "(each with its own plan and workspaces on the same weights); 1 = one step at a time (the step's latency)")
+    ap.add_argument("--coalesce", type=int, default=2, help="batches of 32 a lane of the library launches as ONE call (as_lanes_set_coalesce: "
+                    "adjacent buffers, no copy); with --in-flight F the library runs F / coalesce lanes.  1 = off")
     ap.add_argument("--lane-branches", action="store_true", help="lanes in flight keep their step's branches on side streams (default: a "
                     "lane in flight is one chain on one stream)")
     args = ap.parse_args()
@@ -796,6 +876,18 @@ def main():
             in_flight_note = "results of the batches in flight differed from the one-at-a-time result: in-flight timing discarded"
             n_fl = 1
             lanes = lanes[:1]
+    # The same K steps as K submissions through the LIBRARY's lanes with coalescing: a lane launches `--coalesce` adjacent batches of 32 as one
+    # call.  Every rank; the faster verified arrangement is the line's `value` (both are in the line).
+    coal, coal_first, elapsed_lanes32 = None, None, None
+    if n_fl > 1 and args.coalesce > 1 and args.config == "C3" and not args.global_batch and not args.no_graph and not args.lane_branches:
+        kc = args.coalesce
+        ncl = max(1, n_fl // kc)
+        hosts = [host] + [make_inputs(None, seed0=DATA_SEED + 100 * i)[0] for i in range(1, kc * ncl)]
+        coal, coal_first = bench_coalesced(net, hosts, kc, ncl, args.steps, args.warmup, barrier)
+        coal["adopted_as_value"] = bool(coal["results_verified"] and coal["elapsed_s"] < elapsed)
+        if coal["adopted_as_value"]:
+            elapsed_lanes32 = elapsed
+            elapsed = coal["elapsed_s"]
     native = None
     if n_fl > 1 and rank == 0 and not args.no_extras:
         native = bench_native_lanes(net, [r.g for r, _, _ in lanes], firsts, args.steps, args.warmup)
@@ -863,7 +955,13 @@ def main():
         "config": {"workload": workload, "global_batch": args.global_batch or len(g["frames"]) * world, "frames_per_step": frames_total,
                    "parallelism": f"batch-shard x{world}, no collectives",
                    "launch": "eager (C ABI as_forward_test)" if args.no_graph else "hipGraph replay of one as_forward_test call",
-                   "in_flight": n_fl, "lane_streams": "branches on side streams" if (args.lane_branches or n_fl == 1) else "one chain per lane"},
+                   "in_flight": n_fl, "lane_streams": "branches on side streams" if (args.lane_branches or n_fl == 1) else "one chain per lane",
+                   "arrangement": (f"coalesced {coal['coalesce']}x32: steps are submissions of ONE batch of 32 (as_lanes_submit); each of the "
+                                   f"library's {coal['lanes']} lanes launches {coal['coalesce']} adjacent batches as one as_forward_test call")
+                                  if (coal and coal["adopted_as_value"]) else
+                                  (f"{n_fl} batches of 32 in flight, one hipGraph replay of one as_forward_test call each" if n_fl > 1 else "one batch at a time")},
+        "ms_per_step_lanes_of_32": (elapsed_lanes32 / args.steps * 1e3) if elapsed_lanes32 else None,   # (the 4 x 32 arrangement, when `value` is the coalesced one's)
+        "coalesced": coal,
         "ms_per_step_one_in_flight": single_ms,
         "ms_per_step_one_chain_alone": one_chain_ms,
         "chain_vs_side_streams_max_abs": chain_vs_side,
@@ -932,6 +1030,9 @@ def main():
         fo = np.concatenate([[0], np.cumsum([2 * f for f in g["frames"]])])
         err = max(float((mel_first[:, fo[b]:fo[b + 1]].cpu() - outs[b]["mel"]).abs().max()) for b in range(min(len(outs), B)))
         line["parity_mel_max_abs_vs_oracle"] = err
+        if coal_first is not None:                       # the same batch as it came out of a coalesced call
+            line["parity_coalesced_mel_max_abs_vs_oracle"] = max(
+                float((coal_first[:, fo[b]:fo[b + 1]].cpu() - outs[b]["mel"]).abs().max()) for b in range(min(len(outs), B)))
     line["forward_calls_in_process"] = FORWARD_CALLS[0] if args.no_graph else None      # (what a kernel trace of an eager run holds)
     if rank == 0:
         print(json.dumps(line), flush=True)

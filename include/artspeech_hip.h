@@ -683,6 +683,18 @@ int as_lanes_next(const as_lanes* q);
 as_stream_t as_lanes_stream(const as_lanes* q, int lane);
 int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out);
 int as_lanes_wait(as_lanes* q, int lane);
+/* Coalescing (k > 1; 1 = off, the default).  Every tensor of the path concatenates the utterances along its column axis, so submissions
+ * whose buffers are ADJACENT views of one block -- the next one's tokens / mel / f0_raw / ema_raw / forced_dur / mel_out begin exactly where
+ * the previous one's end, with the same leading dimensions -- are one batch as they lie: a lane holds such a submission back (frames given,
+ * no optional outputs) until k neighbours have arrived and launches them as ONE as_forward_test call, without a copy (wider conv GEMM
+ * launches; one fetch of the weights for k batches).  A submission that is not the neighbour of what waits on its lane sends that group out
+ * first; as_lanes_wait and as_lanes_flush launch whatever waits.  With k > 1 a submit may therefore return before anything of it is
+ * enqueued, and the status of a group's launch is returned by the call that triggers it; the host arrays of as_batch are copied at
+ * submit, the rule about a lane's device buffers is unchanged.  The turn passes to the next lane when a group is launched.
+ * (models.py:361-362 processes one utterance at a time: any grouping is legal, and every utterance gets its batch-1 result.) */
+int as_lanes_set_coalesce(as_lanes* q, int k);
+int as_lanes_flush(as_lanes* q);
+int64_t as_lanes_merged_calls(const as_lanes* q, int lane);   /* as_forward_test calls of this lane that held more than one submission */
 /* tuning / tests: graphs a lane keeps (>= 1), and the layout cap of every lane's eager plan (as_plan_set_layout_cap) */
 int as_lanes_set_graph_cap(as_lanes* q, int max_graphs);
 int as_lanes_set_layout_cap(as_lanes* q, int max_layouts);

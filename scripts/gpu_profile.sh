@@ -3,6 +3,7 @@
 #   prof_trace    the C3 step, eager and with the concurrent branches run back to back: a kernel's duration is its own
 #   prof_graph    the command the driver times (hipGraph replay, branches on side streams), extras (MAS, C2, C5, transfers) included
 #   prof_c5       the long-form configuration
+#   prof_c2       batch 1 (one utterance, 150 frames), one merged chain, eager
 #   prof_pmc_*    counter passes (kernel trace only, one counter group per run)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -13,6 +14,7 @@ ARGS="--steps 10 --warmup 2 --no-graph --no-concurrency --cpu-utts 0 --no-extras
 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace -o bench --output-format csv -- python3 $R/bench.py $ARGS > $OUT/prof_trace.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_graph -o bench --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-utts 0 > $OUT/prof_graph.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_c5 -o bench --output-format csv -- python3 $R/bench.py --config C5 --no-extras --steps 5 --warmup 2 --no-graph --no-concurrency --cpu-utts 0 > $OUT/prof_c5.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_c2 -o bench --output-format csv -- python3 $R/bench.py --config C2 --no-extras --steps 20 --warmup 2 --no-graph --no-concurrency --cpu-utts 0 > $OUT/prof_c2.log 2>&1
 # the test.py chain around the path: the frozen extractors and the HiFi-GAN generator at the C3 batch, and the whole
 # chain (bench.py's `surface` object)
 rocprofv3 --kernel-trace --stats -d $OUT/prof_jdc -o bench --output-format csv -- python3 $R/scripts/jdc_bench.py > $OUT/prof_jdc.log 2>&1
@@ -34,6 +36,6 @@ for mode in weak c4; do
 done
 cd /tmp
 # the stats CSVs are small; the raw traces are not: keep only what make_profiles.py reads
-for d in prof_trace prof_graph prof_c5 prof_jdc prof_ema prof_vocoder prof_surface; do rm -f $OUT/$d/bench_kernel_trace.csv; done
+for d in prof_trace prof_graph prof_c5 prof_c2 prof_jdc prof_ema prof_vocoder prof_surface; do rm -f $OUT/$d/bench_kernel_trace.csv; done
 ls $OUT/prof_trace $OUT/prof_graph $OUT/prof_c5 $OUT/prof_pmc_sq | head -20
 for f in prof_trace prof_graph prof_c5 two_ranks_weak two_ranks_c4; do grep '^{' $OUT/$f.log | head -1 | cut -c1-400; done

@@ -8,7 +8,11 @@ os.makedirs(P, exist_ok=True)
 shutil.copy(f"{G}/prof_trace/bench_kernel_stats.csv", f"{P}/{tag}_kernel_stats.csv")
 shutil.copy(f"{G}/prof_graph/bench_kernel_stats.csv", f"{P}/{tag}_graph_kernel_stats.csv")
 shutil.copy(f"{G}/prof_c5/bench_kernel_stats.csv", f"{P}/{tag}_c5_kernel_stats.csv")
-for name in ("prof_trace", "prof_graph", "prof_c5"):        # the JSON line each profiled command printed
+if os.path.exists(f"{G}/prof_c2/bench_kernel_stats.csv"):
+    shutil.copy(f"{G}/prof_c2/bench_kernel_stats.csv", f"{P}/{tag}_c2_kernel_stats.csv")
+for name in ("prof_trace", "prof_graph", "prof_c5", "prof_c2"):        # the JSON line each profiled command printed
+    if not os.path.exists(f"{G}/{name}.log"):
+        continue
     for ln in open(f"{G}/{name}.log"):
         if ln.startswith("{"):
             open(f"{P}/{tag}_{name[5:]}_bench_line.json", "w").write(ln)
@@ -28,7 +32,7 @@ def short(n):
 def kernel_class(name):
     """the event profiler's classes (bench.py CLASSES) from a kernel name of the trace; None = not part of the step (profiler helpers, copies)"""
     n = short(name)
-    if n.startswith(("conv_gemm_h3_kernel", "conv_direct_cin1", "splitk_reduce_kernel")):
+    if n.startswith(("conv_gemm_h3_kernel", "conv_direct_cin1", "splitk_reduce")):     # (incl. the reductions that write an AdaIN image: one conv call)
         return "conv_gemm"
     if n.startswith("adain"):
         return "adain"

@@ -213,3 +213,113 @@ def test_lanes_clustered_lstm_soak():
                 for i in range(4):
                     assert torch.equal(outs[i]["mel"], wants[i]), (n_utt, r, i)
         lanes.close()
+
+
+def test_lanes_coalesce_adjacent_submissions():
+    """as_lanes_set_coalesce(2): submissions whose tensors are adjacent column ranges of one block go out two at a time as ONE
+    as_forward_test call (models.py:361-362 is per utterance: any grouping is legal).  Every submission's mel against the same 32 ragged
+    utterances run alone (not bitwise: twice the columns, another GEMM tile); the replayed graph of a group gives the bits of its eager
+    launches; a submission that is NOT a neighbour sends the waiting one out alone -- and then they are the bits of the alone run --;
+    as_lanes_wait launches what still waits."""
+    import bench
+    from artspeech_amd import _lib, models
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    net = _net(dev)
+    solo = _alone(net)
+    per, k, n_lanes = 16, 2, 2
+    blocks, wants = [], []
+    for i in range(n_lanes):
+        host, g = bench.make_inputs(dev, per * k, 30, 70, 120, seed0=bench.DATA_SEED + 40 * i, vary=True)
+        subs, mel_all = bench.adjacent_submissions(g, per)
+        blocks.append((g, subs, mel_all))
+        for j in range(k):
+            gj = bench.pack_inputs(host, list(range(j * per, (j + 1) * per)), dev)
+            wants.append(solo.forward_packed(gj["tok"], gj["tok_lens"], gj["mel"], gj["f0"], gj["ema"], gj["ref_lens"], forced=gj["forced"],
+                                             frames_hint=gj["frames"])["mel"].clone())
+    torch.cuda.synchronize()
+    lanes = models.Lanes(net, n_lanes)
+    lanes.set_coalesce(k)
+
+    def submit(sub):
+        lane, _ = lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], forced=sub["forced"],
+                               frames=sub["frames"], out=sub["out"])
+        return lane
+    first = None
+    for r in range(5):                                         # eager, eager (graph plan), captured, replayed, replayed
+        for i, (g, subs, mel_all) in enumerate(blocks):
+            mel_all.zero_()
+            assert [submit(sub) for sub in subs] == [i] * k    # a group fills ONE lane, then the turn passes on
+        lanes.wait()
+        got = [sub["out"]["mel"].clone() for (_, subs, _) in blocks for sub in subs]
+        for a, w in zip(got, wants):
+            assert a.shape == w.shape and float((a - w).abs().max()) <= 3e-5
+        if first is None:
+            first = got
+        else:
+            for a, b in zip(got, first):
+                assert torch.equal(a, b), r
+    assert all(lanes.merged_calls(i) == 5 for i in range(n_lanes))
+    assert lanes.stats(0)["graph_launches"] >= 2
+    # not neighbours: the first halves of the two blocks one after the other -- each goes out alone, with the bits of the alone run
+    for (_, subs, mel_all) in blocks:
+        mel_all.zero_()
+    la = submit(blocks[0][1][0])
+    lb = submit(blocks[1][1][0])                               # (sends the one that waits on lane `la` out first)
+    assert lb == (la + 1) % n_lanes
+    lanes.wait()                                               # launches the one still waiting
+    assert torch.equal(blocks[0][1][0]["out"]["mel"], wants[0]) and torch.equal(blocks[1][1][0]["out"]["mel"], wants[k])
+    assert all(lanes.merged_calls(i) == 5 for i in range(n_lanes))
+    # back to one submission per call
+    lanes.set_coalesce(1)
+    sub = blocks[0][1][1]
+    sub["out"]["mel"].zero_()
+    lane, o = lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], forced=sub["forced"],
+                           frames=sub["frames"], out=sub["out"])
+    lanes.wait(lane)
+    assert torch.equal(o["mel"], wants[1])
+    assert _lib.lib().as_device_status(0) == 0
+    lanes.close()
+
+
+def test_c3_coalesced_lanes_vs_oracle():
+    """BASELINE config C3 through the coalescing lanes: two ragged batches of 32 utterances, adjacent in one block, launched by as_lanes as
+    ONE as_forward_test call over 64 utterances (from its replayed hipGraph) -- every one of the 64 utterances against the oracle's batch-1
+    run of the same utterance with the same forced integer durations: 1e-4, the north-star bound."""
+    import os
+    import bench
+    from artspeech_amd import _lib, models, synth
+    from artspeech_amd.weights import DEFAULT_STATS, fold_state_dict, load_distribution
+    from oracle import acoustic
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    net = _net(dev)
+    host, g = bench.make_inputs(dev, 64, vary=True, seed0=bench.DATA_SEED + 555)
+    subs, mel_all = bench.adjacent_submissions(g, 32)
+    lanes = models.Lanes(net, 1)
+    lanes.set_coalesce(2)
+    for r in range(4):                                         # the last round is a graph replay
+        mel_all.zero_()
+        for sub in subs:
+            lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], forced=sub["forced"],
+                         frames=sub["frames"], out=sub["out"])
+        lanes.wait()
+    assert lanes.merged_calls(0) == 4 and lanes.stats(0)["graph_launches"] >= 2
+    W = fold_state_dict(synth.synth_state_dict(512, 64, seed=bench.WEIGHT_SEED))
+    dist = load_distribution(DEFAULT_STATS)
+    got = mel_all.cpu()
+    worst, o = 0.0, 0
+    for b in range(64):
+        ref = acoustic.forward_test(W, torch.from_numpy(host["tokens"][b]), torch.from_numpy(host["mel"][b]), torch.from_numpy(host["f0"][b]),
+                                    torch.from_numpy(host["ema"][b]), dist, forced_dur=host["forced"][b])["mel"]
+        n2 = 2 * host["frames"][b]
+        assert ref.shape[1] == n2
+        d = float((got[:, o:o + n2] - ref).abs().max())
+        worst = max(worst, d)
+        assert d <= 1e-4, (b, d)
+        o += n2
+    print("C3 coalesced 2 x 32 through as_lanes: worst mel max-abs vs oracle", worst)
+    assert _lib.lib().as_device_status(0) == 0
+    lanes.close()
+
