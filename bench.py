@@ -751,6 +751,8 @@ def main():
     ap.add_argument("--c4-dump", default=None, help="with --global-batch: .npz for the merged mel of three utterances (tests hold them against the oracle)")
     ap.add_argument("--in-flight", type=int, default=4, help="batches in flight per GPU: consecutive steps are replayed on this many HIP streams "
                     "(each with its own plan and workspaces on the same weights); 1 = one step at a time (the step's latency)")
+    ap.add_argument("--call-batches", type=int, default=1, help="profiling runs (C3): a step = ONE as_forward_test call over this many batches of 32 "
+                    "(what a coalescing lane launches: --call-batches 2 = the headline arrangement's call)")
     ap.add_argument("--coalesce", type=int, default=2, help="batches of 32 a lane of the library launches as ONE call (as_lanes_set_coalesce: "
                     "adjacent buffers, no copy); with --in-flight F the library runs F / coalesce lanes.  1 = off")
     ap.add_argument("--lane-branches", action="store_true", help="lanes in flight keep their step's branches on side streams (default: a "
@@ -813,6 +815,12 @@ def main():
         host, g = make_inputs(dev, 1, 30, 75, 150, seed0=DATA_SEED + 1000)
         frames_total = world * 2 * sum(host["frames"])
         workload = "C2: one utterance, 30 tokens -> 150 mel frames, T_ref=150 (profiling run)"
+    elif args.call_batches > 1:
+        host = merge_hosts([make_inputs(None, seed0=DATA_SEED + 100 * i)[0] for i in range(args.call_batches)])
+        g = pack_inputs(host, list(range(len(host["frames"]))), dev)
+        frames_total = world * 2 * sum(host["frames"])
+        workload = (f"C3 as a coalescing lane launches it: ONE call over {args.call_batches} batches of 32 utterances (40 tokens -> 200 mel frames each, "
+                    "T_ref=200), forced integer durations (profiling run: a step here is one such call)")
     else:
         host, g = make_inputs(dev)
         frames_total = world * 2 * sum(host["frames"])
@@ -831,7 +839,7 @@ def main():
     # tail round of one batch's kernels is filled by the other batch's -- what a server does; the K timed steps alternate between them.
     # Every lane has its OWN batch (other seeds, same geometry) in its own buffers: nothing a lane reads is warm from the other's pass.
     one_chain_ms, chain_vs_side = None, None
-    n_fl = 1 if (args.no_graph or args.global_batch) else max(1, args.in_flight)
+    n_fl = 1 if (args.no_graph or args.global_batch or args.call_batches > 1) else max(1, args.in_flight)
     in_flight_note = None
     lanes = [(runner, run, torch.cuda.Stream())]
     if n_fl > 1:
@@ -912,7 +920,13 @@ def main():
     # ---- phase times of one eager step with the branches concurrent (HIP events between the phases, on the calling stream)
     prunner = Runner(net, g)
     phase = [net.rt.phase_ms(prunner.step) for _ in range(3)][-1]
-    kern = profile_classes(net, Runner(net, g))
+    # the kernel classes AS THE TIMED REGION LAUNCHES THEM: with the coalesced arrangement adopted, one call over its 32 k utterances
+    per_call = args.call_batches
+    g_roof = g
+    if coal and coal["adopted_as_value"]:
+        per_call = coal["coalesce"]
+        g_roof = pack_inputs(merge_hosts(hosts[:per_call]), list(range(per_call * len(host["frames"]))), dev)
+    kern = profile_classes(net, Runner(net, g_roof))
     net.rt.set_serial(args.no_concurrency)
     gemm_tflops, gemm_peak = gemm_roofline(kern, 3)
     k0 = kern["conv_gemm"]
@@ -924,7 +938,7 @@ def main():
     traffic, traffic_src = None, "no PMC profile of this build (profiles/latest_pmc_traffic.json was taken from other kernel sources)"
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_traffic.json")))
-        if pj.get("source_id") == source_id():
+        if pj.get("source_id") == source_id() and pj.get("batches_per_call", 1) == per_call:
             traffic, traffic_src = pj["conv_gemm_hbm_bytes_per_launch"], pj["source"]
     except Exception:
         pass
@@ -937,15 +951,15 @@ def main():
     trace_cls, trace_src = None, "no kernel trace of this build under profiles/ (HIP events of this run, bracket cost removed)"
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "latest_trace_classes.json")))
-        if tj.get("source_id") == source_id() and args.config == "C3" and not args.global_batch:
+        if tj.get("source_id") == source_id() and args.config == "C3" and not args.global_batch and tj.get("batches_per_call", 1) == per_call:
             trace_cls, trace_src = tj["classes"], f"{tj['file']} ({tj['command']}; {tj['steps_in_trace']} steps in the trace)"
     except Exception:
         pass
     gemm_tflops_ev = gemm_tflops
     hbm_ms_ev = hbm_ms
-    if trace_cls:
-        gemm_tflops = k0["gflop_per_step"] / trace_cls["conv_gemm"]["ms_per_step"]
-        hbm_ms = sum(trace_cls[c]["ms_per_step"] for c in HBM_GROUP if c in trace_cls)
+    if trace_cls:                                                  # (both sides per CALL of per_call batches)
+        gemm_tflops = k0["gflop_per_step"] / trace_cls["conv_gemm"]["ms_per_call"]
+        hbm_ms = sum(trace_cls[c]["ms_per_call"] for c in HBM_GROUP if c in trace_cls)
     value = frames_total * args.steps / elapsed
     line = {
         "metric": "mel frames/sec (whole job; per-GPU = value / n_gpus), acoustic-model inference path, batch 32 x 200-frame utterances",
@@ -977,8 +991,10 @@ def main():
                      "frac_source": "committed_trace" if trace_cls else "events_this_run",
                      "time_source": trace_src,
                      "achieved_by_events": gemm_tflops_ev, "frac_by_events": gemm_tflops_ev / gemm_peak,      # (always this run's)
-                     "gemm_ms_per_step_by_trace": trace_cls["conv_gemm"]["ms_per_step"] if trace_cls else None,
-                     "gemm_ms_per_step_by_events": k0["ms_per_step"],
+                     # the launches the fraction is about: one as_forward_test call over `batches_per_call` batches of 32 (the timed region's)
+                     "batches_per_call": per_call, "utterances_per_call": len(g_roof["frames"]),
+                     "gemm_ms_per_step_by_trace": trace_cls["conv_gemm"]["ms_per_call"] / per_call if trace_cls else None,
+                     "gemm_ms_per_step_by_events": k0["ms_per_step"] / per_call,
                      "peak_basis": "dense fp16 MFMA 2516.6 TFLOP/s / 3 matrix-core products per fp32 product (achieved = algorithmic fp32 flop); "
                                    "round 1 ran six bf16 products per fp32 product (ceiling 419.4)",
                      # measured live on this device: a bare loop of the kernel's own MFMA pattern on random operands (no memory traffic, no
@@ -993,16 +1009,17 @@ def main():
                      "avg_launch_ms": k0["ms_per_step"] / max(k0["launches_per_step"], 1), "launches_per_step": k0["launches_per_step"],
                      "event_bracket_overhead_us": bracket_overhead_ms() * 1e3,
                      "achieved_with_bracket_overhead": k0["gflop_per_step"] / k0["ms_per_step_bracketed"],
-                     "algorithmic_gflop_per_step": k0["gflop_per_step"]},
+                     "algorithmic_gflop_per_step": k0["gflop_per_step"] / per_call},
         "roofline_hbm": {"bound": "hbm", "kernels": "AdaIN / LayerNorm operand-image writers, pooling, expansion, im2col, reference features "
                                                     "(classes adain + layernorm + other of the event profiler)",
                          "achieved": hbm_gb / hbm_ms if hbm_ms else None, "peak": PEAK_HBM_TBS, "unit": "TB/s",
                          "frac": hbm_gb / hbm_ms / PEAK_HBM_TBS if hbm_ms else None,
                          "frac_source": "committed_trace" if trace_cls else "events_this_run",
-                         "algorithmic_gbyte_per_step": hbm_gb, "ms_per_step": hbm_ms, "time_source": trace_src,
-                         "ms_per_step_by_events": hbm_ms_ev, "frac_by_events": hbm_gb / hbm_ms_ev / PEAK_HBM_TBS if hbm_ms_ev else None,
+                         "batches_per_call": per_call,
+                         "algorithmic_gbyte_per_step": hbm_gb / per_call, "ms_per_step": hbm_ms / per_call, "time_source": trace_src,
+                         "ms_per_step_by_events": hbm_ms_ev / per_call, "frac_by_events": hbm_gb / hbm_ms_ev / PEAK_HBM_TBS if hbm_ms_ev else None,
                          "launches_per_step": sum(kern[c]["launches_per_step"] for c in HBM_GROUP if c in kern)},
-        "launches_per_step": {c: kern[c]["launches_per_step"] for c in kern},
+        "launches_per_step": {c: kern[c]["launches_per_step"] for c in kern},       # (per call of `roofline.batches_per_call` batches, like kernel_classes)
         "forward_calls_in_process": None,
         "kernel_classes": kern,
         "phase_ms_eager": dict(zip(["features", "encoders_towers_duration", "predictors", "decoder"], [round(v, 3) for v in phase])),

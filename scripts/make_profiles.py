@@ -8,9 +8,11 @@ os.makedirs(P, exist_ok=True)
 shutil.copy(f"{G}/prof_trace/bench_kernel_stats.csv", f"{P}/{tag}_kernel_stats.csv")
 shutil.copy(f"{G}/prof_graph/bench_kernel_stats.csv", f"{P}/{tag}_graph_kernel_stats.csv")
 shutil.copy(f"{G}/prof_c5/bench_kernel_stats.csv", f"{P}/{tag}_c5_kernel_stats.csv")
+if os.path.exists(f"{G}/prof_trace32/bench_kernel_stats.csv"):
+    shutil.copy(f"{G}/prof_trace32/bench_kernel_stats.csv", f"{P}/{tag}_b32_kernel_stats.csv")
 if os.path.exists(f"{G}/prof_c2/bench_kernel_stats.csv"):
     shutil.copy(f"{G}/prof_c2/bench_kernel_stats.csv", f"{P}/{tag}_c2_kernel_stats.csv")
-for name in ("prof_trace", "prof_graph", "prof_c5", "prof_c2"):        # the JSON line each profiled command printed
+for name in ("prof_trace", "prof_trace32", "prof_graph", "prof_c5", "prof_c2"):        # the JSON line each profiled command printed
     if not os.path.exists(f"{G}/{name}.log"):
         continue
     for ln in open(f"{G}/{name}.log"):
@@ -62,9 +64,13 @@ def trace_classes(stats_csv, bench_line_json, out_json, tag):
         if c:
             agg[c][0] += float(r["TotalDurationNs"]) / 1e6
             agg[c][1] += int(r["Calls"])
-    out = dict(source_id=source_id(), steps_in_trace=steps, file=f"profiles/{tag}_kernel_stats.csv",
-               command="rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-graph --no-concurrency --cpu-utts 0 --no-extras",
-               classes={c: dict(ms_per_step=v[0] / steps, launches_per_step=v[1] / steps) for c, v in agg.items()})
+    import re
+    m = re.search(r"ONE call over (\d+) batches", line["config"]["workload"])
+    bpc = int(m.group(1)) if m else 1                                   # batches of 32 per traced call (bench.py --call-batches)
+    out = dict(source_id=source_id(), steps_in_trace=steps, batches_per_call=bpc, file=f"profiles/{tag}_kernel_stats.csv",
+               command="rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-graph --no-concurrency --cpu-utts 0 --no-extras"
+                       + (f" --call-batches {bpc}" if bpc > 1 else ""),
+               classes={c: dict(ms_per_call=v[0] / steps, ms_per_step=v[0] / steps / bpc, launches_per_call=v[1] / steps) for c, v in agg.items()})
     json.dump(out, open(out_json, "w"), indent=1)
     return out
 
@@ -115,7 +121,7 @@ json.dump(tr, open(f"{P}/{tag}_pmc_traffic.json", "w"), indent=1)
 # FETCH_SIZE / WRITE_SIZE are KiB; gfx950 reports half of a wide coalesced read stream (MI355X_MICROARCH.md "HBM") -> x2
 latest = dict(conv_gemm_hbm_bytes_per_launch=round((2 * gem_f + gem_w) / max(gem_n, 1)),
               conv_gemm_fetch_bytes_per_launch_x2=round(2 * gem_f / max(gem_n, 1)), conv_gemm_write_bytes_per_launch=round(gem_w / max(gem_n, 1)),
-              launches=gem_n, source_id=source_id(),
+              launches=gem_n, source_id=source_id(), batches_per_call=(tc or {}).get("batches_per_call", 1),
               source=f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (separate runs), "
                      "conv GEMM + split-K reduce kernels, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream)")
 json.dump(latest, open(f"{P}/latest_pmc_traffic.json", "w"), indent=1)
