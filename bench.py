@@ -913,7 +913,10 @@ def main():
             transfers["ms_per_step_including_transfers"] = transfers["elapsed_s"] / args.steps * 1e3
     if transfers:
         transfers["frames_per_s_including_transfers"] = frames_total * args.steps / transfers["elapsed_s"]
-        transfers["vs_resident_inputs"] = transfers["elapsed_s"] / elapsed
+        # (the copies are timed around the replays of 32-utterance graphs on the script's own streams: compared with THAT arrangement's
+        #  resident-input time, which is `elapsed` unless the coalesced lanes' figure became the line's value)
+        transfers["vs_resident_inputs"] = transfers["elapsed_s"] / (elapsed_lanes32 or elapsed)
+        transfers["arrangement"] = "batches of 32, one hipGraph replay each (ms_per_step_lanes_of_32)" if elapsed_lanes32 else "as the line's value"
     if args.global_batch:
         c4 = c4_check(net, host, runner.out["mel"], mine, world, rank, dev, dist, dump=args.c4_dump)
 
@@ -957,9 +960,14 @@ def main():
         pass
     gemm_tflops_ev = gemm_tflops
     hbm_ms_ev = hbm_ms
+    tc_ms = None
     if trace_cls:                                                  # (both sides per CALL of per_call batches)
-        gemm_tflops = k0["gflop_per_step"] / trace_cls["conv_gemm"]["ms_per_call"]
-        hbm_ms = sum(trace_cls[c]["ms_per_call"] for c in HBM_GROUP if c in trace_cls)
+        try:
+            tc_ms = lambda c: trace_cls[c].get("ms_per_call", trace_cls[c]["ms_per_step"] * per_call)   # (files of rounds 1-4: per step = per call)
+            gemm_tflops = k0["gflop_per_step"] / tc_ms("conv_gemm")
+            hbm_ms = sum(tc_ms(c) for c in HBM_GROUP if c in trace_cls)
+        except Exception:                                          # (a committed summary this script cannot read never costs the line)
+            trace_cls, trace_src, gemm_tflops, hbm_ms = None, "the committed kernel-trace summary is unreadable (HIP events of this run)", gemm_tflops_ev, hbm_ms_ev
     value = frames_total * args.steps / elapsed
     line = {
         "metric": "mel frames/sec (whole job; per-GPU = value / n_gpus), acoustic-model inference path, batch 32 x 200-frame utterances",
@@ -993,7 +1001,7 @@ def main():
                      "achieved_by_events": gemm_tflops_ev, "frac_by_events": gemm_tflops_ev / gemm_peak,      # (always this run's)
                      # the launches the fraction is about: one as_forward_test call over `batches_per_call` batches of 32 (the timed region's)
                      "batches_per_call": per_call, "utterances_per_call": len(g_roof["frames"]),
-                     "gemm_ms_per_step_by_trace": trace_cls["conv_gemm"]["ms_per_call"] / per_call if trace_cls else None,
+                     "gemm_ms_per_step_by_trace": tc_ms("conv_gemm") / per_call if trace_cls else None,
                      "gemm_ms_per_step_by_events": k0["ms_per_step"] / per_call,
                      "peak_basis": "dense fp16 MFMA 2516.6 TFLOP/s / 3 matrix-core products per fp32 product (achieved = algorithmic fp32 flop); "
                                    "round 1 ran six bf16 products per fp32 product (ceiling 419.4)",
