@@ -451,9 +451,11 @@ static int gemm_tile_choice(int M, int N, int n_prod, int Kp)
     // against 106, M512 N19200 105 against 96.  Inside the step the same launches take the same time with either tile (C3: 5.08 against
     // 5.10 ms of GEMM per step, C5: 8.78 against 8.70), so the default stays with the tiles that share a CU; -DAS_EXPERIMENTS builds
     // carry it (AS_GEMM_TILE=42 / AS_GEMM_USE42=1).
-    static const double t1[5] = {1.55, 1.0, 0.78, 0.78, 0.59};
+    double t1[5] = {1.55, 1.0, 0.78, 0.78, 0.59};
 #ifdef AS_EXPERIMENTS
     static const bool use42 = getenv("AS_GEMM_USE42") != nullptr;
+    static const double t42 = getenv("AS_GEMM_T42") ? atof(getenv("AS_GEMM_T42")) : 1.55;   // (tuning: the 256 x 128 tile's cost alone on a CU)
+    t1[0] = t42;
 #else
     constexpr bool use42 = false;
 #endif
