@@ -118,9 +118,16 @@ bool grow(as_lanes* q, void** p, size_t* have, size_t need)
 
 }  // namespace
 
+static int flush_lane(as_lanes* q, int lane);
 extern "C" int as_lanes_destroy(as_lanes* q)
 {
     if (!q) return AS_OK;
+    // submissions still waiting for neighbours were accepted: they go out before the lanes do (their status has nobody left to go to)
+    try {
+        for (int i = 0; i < (int)q->lanes.size(); ++i)
+            if (q->lanes[i].plan && q->lanes[i].gplan && q->lanes[i].stream) (void)flush_lane(q, i);
+    } catch (...) {
+    }
     for (Lane& L : q->lanes)
         if (L.stream) (void)hipStreamSynchronize(L.stream);
     for (Lane& L : q->lanes) {

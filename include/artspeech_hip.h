@@ -690,7 +690,11 @@ int as_lanes_wait(as_lanes* q, int lane);
  * launches; one fetch of the weights for k batches).  A submission that is not the neighbour of what waits on its lane sends that group out
  * first; as_lanes_wait and as_lanes_flush launch whatever waits.  With k > 1 a submit may therefore return before anything of it is
  * enqueued, and the status of a group's launch is returned by the call that triggers it; the host arrays of as_batch are copied at
- * submit, the rule about a lane's device buffers is unchanged.  The turn passes to the next lane when a group is launched.
+ * submit.  DEVICE BUFFERS with k > 1: a submission's buffers are read when its GROUP is launched, not when it is submitted, and entering
+ * the next submit of a lane no longer means the lane's previous work has finished (that submit may only be queued): refill or reuse a
+ * lane's buffers after as_lanes_wait(q, lane) -- or keep two blocks per lane and alternate.  Re-submitting the SAME unchanged buffers (a
+ * benchmark's replay) needs nothing: a group's launch first waits for the lane's previous group.  The turn passes to the next lane when
+ * a group is launched; as_lanes_destroy launches what still waits before it tears the lanes down.
  * (models.py:361-362 processes one utterance at a time: any grouping is legal, and every utterance gets its batch-1 result.) */
 int as_lanes_set_coalesce(as_lanes* q, int k);
 int as_lanes_flush(as_lanes* q);
