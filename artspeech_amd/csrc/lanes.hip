@@ -395,7 +395,10 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
     if (!q || !batch || !io || batch->B <= 0 || !batch->tok_lens || !batch->ref_lens) return AS_EINVAL;
     Lane& L = q->lanes[q->next];
     const bool can_wait = q->coalesce > 1 && batch->frames && plain_io(io);
-    if (!L.pend.empty() && !(can_wait && adjacent(L.pend.back(), io))) {
+    size_t waiting = 0;                                           // utterances of the group that waits here
+    for (const Lane::Pending& p : L.pend) waiting += p.tok_lens.size();
+    // (a call takes at most 1024 utterances: as_durations_f32's one-workgroup scan)
+    if (!L.pend.empty() && !(can_wait && adjacent(L.pend.back(), io) && waiting + (size_t)batch->B <= 1024)) {
         const int rc = flush_lane(q, q->next);                    // not a neighbour of what waits here: that group goes out first (and the turn passes on)
         if (rc != AS_OK) return rc;
     }
