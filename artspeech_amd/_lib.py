@@ -46,7 +46,8 @@ class ConvGemmArgs(ctypes.Structure):
                 ("dh", ctypes.c_int32 * AS_MAX_TAPS), ("dw", ctypes.c_int32 * AS_MAX_TAPS),
                 ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float), ("acc_scale", ctypes.c_float),
                 ("n_groups", ctypes.c_int32), ("group_cols", ctypes.c_int32), ("range_probe", ctypes.c_int32), ("status", ctypes.c_void_p),
-                ("Xh2", ctypes.c_void_p), ("K2", ctypes.c_int32), ("src_col", ctypes.c_void_p), ("N_in", ctypes.c_int32), ("ileave_u", ctypes.c_int32)]
+                ("Xh2", ctypes.c_void_p), ("K2", ctypes.c_int32), ("src_col", ctypes.c_void_p), ("N_in", ctypes.c_int32), ("ileave_u", ctypes.c_int32),
+                ("slab_tr", ctypes.c_int32)]
 
 
 _SIGNATURES.update({
@@ -103,6 +104,11 @@ _SIGNATURES.update({
 })
 
 
+class LnArgs(ctypes.Structure):
+    _fields_ = [("gamma", c_p), ("beta", c_p), ("gamma2", c_p), ("beta2", c_p), ("n_split", ctypes.c_int32), ("eps", ctypes.c_float),
+                ("relu", ctypes.c_int32), ("yh", c_p)]
+
+
 class AdainArgs(ctypes.Structure):
     _fields_ = [("x", c_p), ("ldx", ctypes.c_int32), ("C", ctypes.c_int32), ("gb", c_p), ("gb_off", c_p), ("ldgb", ctypes.c_int32),
                 ("gb_sc", ctypes.c_int32), ("col_off", c_p), ("src_off", c_p), ("U", ctypes.c_int32), ("N", ctypes.c_int32),
@@ -148,7 +154,8 @@ AS_MOD_FORWARD_A, AS_MOD_FORWARD_B, AS_MOD_ENCODER, AS_MOD_STYLE, AS_MOD_DURATIO
 _pB, _pIO = ctypes.POINTER(Batch), ctypes.POINTER(ForwardIO)
 _SIGNATURES.update({
     "as_adain_image_f32": (c_i, [ctypes.POINTER(AdainArgs), c_p]),
-    "as_conv_gemm_multi_post_f32": (c_i, [ctypes.POINTER(ConvGemmArgs), ctypes.POINTER(AdainArgs), ctypes.POINTER(ctypes.c_int32), c_i, c_p]),
+    "as_conv_gemm_multi_post_f32": (c_i, [ctypes.POINTER(ConvGemmArgs), ctypes.POINTER(AdainArgs), ctypes.POINTER(ctypes.c_int32),
+                                          ctypes.POINTER(LnArgs), c_i, c_p]),
     "as_down_multi_f32": (c_i, [ctypes.POINTER(DownArgs), c_i, c_p]),
     "as_respair_f32": (c_i, [ctypes.POINTER(ResPairArgs), c_p]),
     "as_xl_attention_image_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, ctypes.c_float, c_p, c_i, c_i, c_p, c_i, c_p, c_p]),

@@ -294,6 +294,32 @@ static __device__ __forceinline__ void slab_store(const ConvGemmArgs& a, const f
         }
 }
 
+// The same partial sums TIME-MAJOR: slab[col][row] (row stride M).  For a K-sliced conv whose reduction also computes the channel
+// LayerNorm of every column (as_conv_gemm_multi_post_f32, post_ln): a column's M channels then lie together, and the reduction's wave
+// = one column, lane = 8 consecutive channels, reads them as two 16-byte loads per slab.  A lane holds 4 consecutive rows per (e >> 2):
+// 16-byte stores (the four (e >> 2) groups and the two lane halves fill a column's 128-byte lines between them).
+template <int TM, int TN>
+static __device__ __forceinline__ void slab_store_tr(const ConvGemmArgs& a, const f32x16 (&acc)[TM][TN], __amdgpu_buffer_rsrc_t rs,
+                                                     int rbase, int cbase, int l31, int n_end)
+{
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int col = cbase + jn * 32 + l31;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = rbase + i * 32 + 8 * q;                  // rows row .. row + 3 (rbase carries the lane half's + 4)
+                float t0 = acc[i][jn][4 * q], t1 = acc[i][jn][4 * q + 1], t2 = acc[i][jn][4 * q + 2], t3 = acc[i][jn][4 * q + 3];
+                asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));     // (through VGPRs: see slab_store)
+                const f32x4 t = {t0, t1, t2, t3};
+                // M % 8 == 0 (host-checked for this form): a quad is inside the rows or outside as a whole
+                const unsigned off = (col < n_end && row < a.M) ? (unsigned)(col * a.M + row) * 4u : OOBH;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, t), rs, off, 0, 0);
+            }
+        }
+}
+
 // Split-K tail: y = epi(sum_s slab[s]) for the 8 rows 8 g .. 8 g + 7 of column j, slabs summed in the fixed order s = 0 .. S-1
 // (deterministic whatever order the slices finished in); slab s = fp32 [M][N] at a.ws + s M N.  j == N with Yh: the image's zero
 // column.  One 16-byte row of the consumer's split image when Yh is wanted.  (A device function: scripts/exp/conv_gemm_sn.hip, the
@@ -428,6 +454,7 @@ static __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, const f32
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<float*>(a.ws) + (size_t)slice * a.M * a.N, 0, (int)((unsigned)a.M * a.N * 4u), 0x00020000);
-    slab_store<TM, TN>(a, acc, rs, rbase, cbase, l31, n_end);
+    if (a.slab_tr) slab_store_tr<TM, TN>(a, acc, rs, rbase, cbase, l31, n_end);
+    else slab_store<TM, TN>(a, acc, rs, rbase, cbase, l31, n_end);
 }
 #endif

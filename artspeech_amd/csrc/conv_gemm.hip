@@ -381,6 +381,123 @@ static __device__ __forceinline__ void reduce_adain(const ConvGemmArgs& a, int S
     reduce_adain_body<NJ>(a, S, n, kb, kh, u, o0, L);                    // (L <= 64 NJ: the host picks the instantiation from the widest utterance)
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Reduction of a K-sliced launch WITH the channel LayerNorm (+ ReLU) that reads its result (as_conv_gemm_multi_post_f32, post_ln): the
+// encoders' conv -> residual add -> LayerNorm -> conv (RelTransformerEnc.py:72-87, 318-325) at batch-1 sizes.  The slices stored their
+// partial sums TIME-MAJOR (slab_store_tr), so a column's M <= 512 channels lie together: a WAVE owns one column, lane g its channels
+// 8 g .. 8 g + 7 -- one 16-byte row group of the image.  Slabs summed in the plain reduction's order, the plain value epilogue, and
+// channel_ln_split_kernel's statistics in ITS order of additions (a thread there sums groups g and g + 32, the 32 partial sums are
+// added in ascending order): the image is bit-identical to conv -> reduce -> as_channel_layernorm_split_f32.
+// ----------------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float rp_ln_total(float own, bool has)
+{
+    // sum_{q = 0 .. 31} partial[q], ascending, partial[q] in lane q (channel_ln_split_kernel: tot += red[q][col])
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) tot += __shfl(own, q);
+    (void)has;
+    return tot;
+}
+
+static __device__ __forceinline__ void reduce_ln(const ConvGemmArgs& a, int S, const AsLnArgs& n, int j)
+{
+    const int g = threadIdx.x & 63;
+    const int M = a.M, N = a.N;
+    const int groups = 2 * as_kbx(M);                                    // row groups of the image (zero beyond M)
+    const size_t NX = (size_t)N + 1;
+    u32x4_t* xs = reinterpret_cast<u32x4_t*>(n.yh);
+    const size_t plane = ((size_t)(g >> 1) * 4 + (g & 1)) * NX;
+    if (j == 0 && g < groups) {                                          // the zero column
+        xs[plane + N] = u32x4_t{0u, 0u, 0u, 0u};
+        xs[plane + 2 * NX + N] = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    const bool live = 8 * g < M;                                         // (M % 8 == 0: a lane's eight channels exist or do not)
+    const int c0 = live ? 8 * g : M - 8;
+    const int grp = a.n_groups > 1 ? j / a.group_cols : 0;
+    const int lg = n.gamma2 ? j / n.n_split : 0;
+    const float* gam = n.gamma + (ptrdiff_t)lg * (n.gamma2 - n.gamma) + c0;
+    const float* bet = n.beta + (ptrdiff_t)lg * (n.beta2 - n.beta) + c0;
+    // everything this lane loads, issued before the first use: gamma / beta / bias (16-byte loads), the residual's eight rows, the slabs
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam), g1 = *reinterpret_cast<const f32x4*>(gam + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bet), b1 = *reinterpret_cast<const f32x4*>(bet + 4);
+    f32x4 bi0 = {0.f, 0.f, 0.f, 0.f}, bi1 = bi0;
+    if (a.bias) {
+        bi0 = *reinterpret_cast<const f32x4*>(a.bias + (size_t)grp * M + c0);
+        bi1 = *reinterpret_cast<const f32x4*>(a.bias + (size_t)grp * M + c0 + 4);
+    }
+    float res[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) res[r] = a.res ? a.res[(size_t)(c0 + r) * a.ldr + j] : 0.f;
+    const float* slab = reinterpret_cast<const float*>(a.ws) + (size_t)j * M + c0;
+    const size_t total = (size_t)M * N;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        f32x4 t[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t[q][0] = *reinterpret_cast<const f32x4*>(slab + (size_t)(s + q) * total);
+            t[q][1] = *reinterpret_cast<const f32x4*>(slab + (size_t)(s + q) * total + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += t[q][r >> 2][r & 3];
+    }
+    for (; s < S; ++s) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(slab + (size_t)s * total), t1 = *reinterpret_cast<const f32x4*>(slab + (size_t)s * total + 4);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += r < 4 ? t0[r] : t1[r - 4];
+    }
+    const float bias8[8] = {bi0[0], bi0[1], bi0[2], bi0[3], bi1[0], bi1[1], bi1[2], bi1[3]};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float x = live ? as_reduce_value<true>(a, v[r], bias8[r], res[r]) : 0.f;
+        v[r] = x;
+        if (live && a.Y) a.Y[(size_t)(c0 + r) * a.ldy + j] = x;
+    }
+    // statistics over the M channels of the column, in channel_ln_split_kernel's order: lane p < 32 adds its group's eight values, then
+    // group p + 32's (the groups beyond: zeros there too), and the 32 partial sums are added in ascending order
+    float hi[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) hi[r] = __shfl_down(v[r], 32);
+    float sp = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sp += v[r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sp += hi[r];
+    const float mean = rp_ln_total(sp, true) / (float)M;
+    float q2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float d = __fsub_rn(v[r], mean);
+        if (8 * g + r < M) q2 = __fmaf_rn(d, d, q2);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float d = __fsub_rn(hi[r], mean);
+        if (8 * (g + 32) + r < M) q2 = __fmaf_rn(d, d, q2);
+    }
+    const float rs = 1.0f / sqrtf(rp_ln_total(q2, true) / (float)M + n.eps);
+    if (g >= groups) return;
+    const float gam8[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+    const float bet8[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    float t[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float o = 0.f;
+        if (live) {
+            o = __fmaf_rn(__fmul_rn(__fsub_rn(v[r], mean), rs), gam8[r], bet8[r]);
+            if (n.relu) o = o > 0.f ? o : 0.f;
+        }
+        t[r] = o;
+    }
+    u32x4_t h, l;
+    split2(t, h, l);
+    xs[plane + j] = h;
+    xs[plane + 2 * NX + j] = l;
+}
+
 // the K-sliced problems of ONE (multi-problem) launch: problem i either summed plainly (mode 0: a workgroup = 64 columns of one 8-row
 // group, as_reduce_epilogue) or summed + AdaIN'd (mode 1: a workgroup = one row group of one utterance); workgroups of ONE wave -- the
 // few dozen waves of such a launch then sit on as many CUs, each with a texture path of its own (with four waves to a workgroup the
@@ -392,6 +509,7 @@ struct ReducePost {
     int32_t nxb[H3_MAXP];                // mode 0: column blocks; mode 1: row groups -- the fast index of the problem's workgroups
     ConvGemmArgs a[H3_MAXP];
     AsAdainArgs p[H3_MAXP];
+    AsLnArgs l[H3_MAXP];                 // mode 2: + channel LayerNorm (a workgroup = one column; the slabs are time-major)
 };
 template <int NJ>
 __global__ void __launch_bounds__(64)
@@ -402,7 +520,14 @@ splitk_reduce_post_kernel(const ReducePost rm)
     for (int i = 1; i < H3_MAXP; ++i) pi += (i < rm.n && (int)blockIdx.x >= rm.blk0[i]) ? 1 : 0;
     const int local = (int)blockIdx.x - rm.blk0[pi], nxb = rm.nxb[pi];
     if (rm.mode[pi] == 0) as_reduce_epilogue(rm.a[pi], rm.S[pi], (local % nxb) * 64 + (int)threadIdx.x, local / nxb);
-    else reduce_adain<NJ>(rm.a[pi], rm.S[pi], rm.p[pi], local % nxb, local / nxb);
+    else if (rm.mode[pi] == 1) reduce_adain<NJ>(rm.a[pi], rm.S[pi], rm.p[pi], local % nxb, local / nxb);
+    else reduce_ln(rm.a[pi], rm.S[pi], rm.l[pi], local);
+}
+
+__global__ void __launch_bounds__(64)
+splitk_reduce_ln_kernel(const ConvGemmArgs a, int S, const AsLnArgs n)
+{
+    reduce_ln(a, S, n, (int)blockIdx.x);
 }
 
 // ONE problem: its arguments directly in the kernel argument segment (every scalar load of the wave's head is issued at once; with the
@@ -575,6 +700,7 @@ static int conv_gemm_normalise(const ConvGemmArgs* args_host, ConvGemmArgs& norm
     if (!(fabsf(norm.in_slope) <= 3.0e38f) || !(fabsf(norm.act_slope) <= 3.0e38f)) return AS_EINVAL;   // slopes are used as given
     if (norm.acc_scale == 0.f) norm.acc_scale = 1.0f;
     norm.status = as_status_words_device();
+    norm.slab_tr = 0;
     norm.range_probe = (g_range_probe || args_host->range_probe == AS_PROBE_THIS) ? 1 : 0;
     if (norm.n_prod == 0) norm.n_prod = 3;
     if (norm.n_groups < 1) norm.n_groups = 1;
@@ -660,11 +786,28 @@ static int post_normalise(const ConvGemmArgs& a, const AsAdainArgs& post_host, A
     n.src_off = nullptr; n.pool_w = nullptr; n.pool_b = nullptr; n.x_up = nullptr; n.ld_up = 0;
     return AS_OK;
 }
+static bool ln_wanted(const AsLnArgs* l) { return l && l->yh; }
+static int ln_check(const ConvGemmArgs& a, const AsLnArgs& n)
+{
+    if (!a.Y || a.transpose_out || a.ileave_u > 1 || !n.gamma || !n.beta || ((n.gamma2 == nullptr) != (n.beta2 == nullptr)) ||
+        (n.gamma2 && n.n_split <= 0) || (reinterpret_cast<uintptr_t>(n.yh) & 15) != 0 || !(n.eps >= 0.f))
+        return AS_EINVAL;
+    return AS_OK;
+}
+// can the reduction kernel of this K-sliced problem write the LayerNorm image itself?  (a wave per column, a lane per 8 channels; 16-byte loads)
+static bool ln_fusable(const ConvGemmArgs& a, const AsLnArgs& n)
+{
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const ptrdiff_t gs = n.gamma2 ? n.gamma2 - n.gamma : 0, bs = n.beta2 ? n.beta2 - n.beta : 0;
+    return a.M % 8 == 0 && a.M <= 512 && a.act <= 2 && !a.Yh && al16(n.gamma) && al16(n.beta) && gs % 4 == 0 && bs % 4 == 0 &&
+           (!a.bias || al16(a.bias)) && (double)a.M * a.N * 4.0 * 16.0 < 2147483648.0 && !getenv("AS_NO_REDUCE_LN");
+}
 // can the reduction kernel of this K-sliced problem write the AdaIN image itself?
 static bool post_fusable(const ConvGemmArgs& a, int max_w) { return max_w > 0 && max_w <= 256 && a.act <= 2 && (double)a.M * a.N * 4.0 * 16.0 < 2147483648.0 && !getenv("AS_NO_REDUCE_ADAIN"); }
 
 // one launch for the reductions of the K-sliced problems ptr[k] (So[k] > 1) of a launch; np[k] non-NULL: with the AdaIN behind it
-static int launch_reduce_post(const ConvGemmArgs* const* ptr, const int* So, const AsAdainArgs* const* np, const int* max_w, int m, hipStream_t stream)
+static int launch_reduce_post(const ConvGemmArgs* const* ptr, const int* So, const AsAdainArgs* const* np, const int* max_w,
+                              const AsLnArgs* const* nl, int m, hipStream_t stream)
 {
     ReducePost rm;
     memset(&rm, 0, sizeof(rm));
@@ -679,7 +822,12 @@ static int launch_reduce_post(const ConvGemmArgs* const* ptr, const int* So, con
             rm.a[i] = a;
             rm.S[i] = So[k];
             int blocks;
-            if (np[k]) {
+            if (nl && nl[k]) {
+                rm.mode[i] = 2;
+                rm.l[i] = *nl[k];
+                rm.nxb[i] = 1;
+                blocks = a.N;
+            } else if (np[k]) {
                 rm.mode[i] = 1;
                 rm.p[i] = *np[k];
                 rm.nxb[i] = as_kbx(a.M) * 2;
@@ -693,6 +841,11 @@ static int launch_reduce_post(const ConvGemmArgs* const* ptr, const int* So, con
             ++rm.n;
         }
     if (rm.n == 0) return AS_OK;
+    if (rm.n == 1 && rm.mode[0] == 2) {
+        hipLaunchKernelGGL(splitk_reduce_ln_kernel, dim3(rm.blk0[1]), dim3(64), 0, stream, rm.a[0], rm.S[0], rm.l[0]);
+        AS_CHECK_LAUNCH();
+        return AS_OK;
+    }
     if (rm.n == 1 && rm.mode[0] == 1) {
         const dim3 g1(rm.blk0[1]), b1(64);
         if (nj == 1) hipLaunchKernelGGL(splitk_reduce_adain_kernel<1>, g1, b1, 0, stream, rm.a[0], rm.S[0], rm.p[0], rm.nxb[0]);
@@ -711,7 +864,7 @@ static int launch_reduce_post(const ConvGemmArgs* const* ptr, const int* So, con
     return AS_OK;
 }
 
-static int conv_gemm_one(const ConvGemmArgs* args_host, const AsAdainArgs* post_host, int post_max_w, hipStream_t stream)
+static int conv_gemm_one(const ConvGemmArgs* args_host, const AsAdainArgs* post_host, int post_max_w, const AsLnArgs* ln_host, hipStream_t stream)
 {
     ConvGemmArgs norm;
     const int rn = conv_gemm_normalise(args_host, norm);
@@ -719,10 +872,15 @@ static int conv_gemm_one(const ConvGemmArgs* args_host, const AsAdainArgs* post_
     const ConvGemmArgs& a = norm;
     if (a.N == 0) return AS_OK;
     AsAdainArgs post;
-    const bool want_post = post_wanted(post_host);
+    const bool want_post = post_wanted(post_host), want_ln = ln_wanted(ln_host);
+    if (want_post && want_ln) return AS_EINVAL;
     if (want_post) {
         const int rp = post_normalise(a, *post_host, post);
         if (rp != AS_OK) return rp;
+    }
+    if (want_ln) {
+        const int rl = ln_check(a, *ln_host);
+        if (rl != AS_OK) return rl;
     }
     bool post_done = false;
     {
@@ -763,12 +921,20 @@ static int conv_gemm_one(const ConvGemmArgs* args_host, const AsAdainArgs* post_
         norm.Xh = xh;
     }
     const ConvGemmArgs* one = &a;
+    const bool fuse_ln = S > 1 && want_ln && ln_fusable(a, *ln_host);
+    norm.slab_tr = fuse_ln ? 1 : 0;                                     // (the slices store time-major for the reduction that normalises columns)
     const int rc = as_conv_gemm_h3_launch(&one, &S, 1, plan.choice, stream);
     if (rc != AS_OK) return rc;
+    if (fuse_ln) {
+        const AsAdainArgs* np = nullptr;
+        const AsLnArgs* nl = ln_host;
+        post_done = true;
+        return launch_reduce_post(&one, &S, &np, &post_max_w, &nl, 1, stream);
+    }
     if (S > 1 && want_post && post_fusable(a, post_max_w)) {
         const AsAdainArgs* np = &post;
         post_done = true;
-        return launch_reduce_post(&one, &S, &np, &post_max_w, 1, stream);
+        return launch_reduce_post(&one, &S, &np, &post_max_w, nullptr, 1, stream);
     }
     if (S > 1) return launch_reduce(a, S, stream);
     return AS_OK;
@@ -776,12 +942,15 @@ static int conv_gemm_one(const ConvGemmArgs* args_host, const AsAdainArgs* post_
     if (rc1 != AS_OK) return rc1;
     }
     if (want_post && !post_done) return as_adain_image_f32(&post, stream);   // (its own profiling scope, behind the conv's)
+    if (want_ln && !post_done)
+        return as_channel_layernorm_split_f32(a.Y, a.ldy, a.M, a.N, ln_host->gamma, ln_host->beta, ln_host->gamma2, ln_host->beta2, ln_host->n_split,
+                                              ln_host->eps, ln_host->relu, ln_host->yh, stream);
     return AS_OK;
 }
 
 extern "C" int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream_)
 {
-    return conv_gemm_one(args_host, nullptr, 0, static_cast<hipStream_t>(stream_));
+    return conv_gemm_one(args_host, nullptr, 0, nullptr, static_cast<hipStream_t>(stream_));
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -841,13 +1010,16 @@ extern "C" int as_conv_gemm_multi_tile(const ConvGemmArgs* list_host, int n)
     return multi_tile_choice(norm, n);
 }
 
-static int conv_gemm_multi(const ConvGemmArgs* list_host, const AsAdainArgs* post_host, const int32_t* post_max_w, int n, hipStream_t stream)
+static int conv_gemm_multi(const ConvGemmArgs* list_host, const AsAdainArgs* post_host, const int32_t* post_max_w, const AsLnArgs* ln_host, int n,
+                           hipStream_t stream)
 {
     if (!list_host || n < 1 || n > AS_MAX_MULTI || (post_host && !post_max_w)) return AS_EINVAL;
     static_assert(AS_MAX_MULTI == H3_MAXP, "header and kernel disagree");
-    if (n == 1) return conv_gemm_one(list_host, post_host, post_host ? post_max_w[0] : 0, stream);
+    if (n == 1) return conv_gemm_one(list_host, post_host, post_host ? post_max_w[0] : 0, ln_host, stream);
     ConvGemmArgs norm[H3_MAXP];
     AsAdainArgs post[H3_MAXP];
+    AsLnArgs lnp[H3_MAXP];
+    bool has_ln[H3_MAXP];
     bool has_post[H3_MAXP], post_done[H3_MAXP];
     int pmw[H3_MAXP], src[H3_MAXP];
     int m = 0, n_direct = 0;
@@ -857,6 +1029,13 @@ static int conv_gemm_multi(const ConvGemmArgs* list_host, const AsAdainArgs* pos
         if (norm[m].N == 0) continue;                                    // nothing to do for this one
         n_direct += direct_cin1(norm[m]) && norm[m].T <= 9 ? 1 : 0;
         has_post[m] = post_host && post_wanted(&post_host[i]);
+        has_ln[m] = ln_host && ln_wanted(&ln_host[i]);
+        if (has_post[m] && has_ln[m]) return AS_EINVAL;
+        if (has_ln[m]) {
+            lnp[m] = ln_host[i];
+            const int rl = ln_check(norm[m], lnp[m]);
+            if (rl != AS_OK) return rl;
+        }
         post_done[m] = false;
         pmw[m] = has_post[m] ? post_max_w[i] : 0;
         src[m] = i;
@@ -867,15 +1046,22 @@ static int conv_gemm_multi(const ConvGemmArgs* list_host, const AsAdainArgs* pos
         ++m;
     }
     if (m == 0) return AS_OK;
-    if (m == 1) return conv_gemm_one(&list_host[src[0]], post_host ? &post_host[src[0]] : nullptr, pmw[0], stream);
+    if (m == 1) return conv_gemm_one(&list_host[src[0]], post_host ? &post_host[src[0]] : nullptr, pmw[0], ln_host ? &ln_host[src[0]] : nullptr, stream);
     bool any_post = false;
-    for (int i = 0; i < m; ++i) any_post = any_post || has_post[i];
-    auto finish_posts = [&]() -> int {                                   // the AdaINs no reduction kernel took along: one launch each, in list order
-        for (int i = 0; i < m; ++i)
+    for (int i = 0; i < m; ++i) any_post = any_post || has_post[i] || has_ln[i];
+    auto finish_posts = [&]() -> int {                                   // the AdaINs / LayerNorms no reduction kernel took along: one launch each, in list order
+        for (int i = 0; i < m; ++i) {
             if (has_post[i] && !post_done[i]) {
                 const int r = as_adain_image_f32(&post[i], stream);
                 if (r != AS_OK) return r;
             }
+            if (has_ln[i] && !post_done[i]) {
+                const ConvGemmArgs& a = norm[i];
+                const int r = as_channel_layernorm_split_f32(a.Y, a.ldy, a.M, a.N, lnp[i].gamma, lnp[i].beta, lnp[i].gamma2, lnp[i].beta2,
+                                                             lnp[i].n_split, lnp[i].eps, lnp[i].relu, lnp[i].yh, stream);
+                if (r != AS_OK) return r;
+            }
+        }
         return AS_OK;
     };
     if (n_direct == m) {                                                 // a set of Cin = 1 stems: the direct kernel, one launch
@@ -941,13 +1127,22 @@ static int conv_gemm_multi(const ConvGemmArgs* list_host, const AsAdainArgs* pos
         if (So[k] > 1) snprintf(sl, sizeof(sl), " S%d", So[k]);
         if (at < (int)sizeof(tag) - 1) at += snprintf(tag + at, sizeof(tag) - at, " %s%s%s", shape, sl, k + 1 < m ? " |" : "");
     }
+    // K-sliced problems with a LayerNorm behind them store their slabs time-major (the reduction normalises whole columns)
+    const AsLnArgs* nl[H3_MAXP];
+    bool any_ln_fused = false;
+    for (int k = 0; k < m; ++k) {
+        const int i = order[k];
+        nl[k] = (has_ln[i] && So[k] > 1 && ln_fusable(norm[i], lnp[i])) ? &lnp[i] : nullptr;
+        norm[i].slab_tr = nl[k] ? 1 : 0;
+        any_ln_fused = any_ln_fused || nl[k];
+    }
     {
         AsProfScope prof__(AS_CLS_GEMM, flops, bytes, stream, tag);
         const int rc = as_conv_gemm_h3_launch(ptr, So, m, choice, stream);
         if (rc != AS_OK) return rc;
         // K-sliced problems whose result is read through an AdaIN (few columns: the reduction holds a channel's whole time axis): the
         // reduction launch writes the AdaIN image too
-        bool fused = false;
+        bool fused = any_ln_fused;
         const AsAdainArgs* np[H3_MAXP];
         for (int k = 0; k < m; ++k) {
             const int i = order[k];
@@ -957,10 +1152,10 @@ static int conv_gemm_multi(const ConvGemmArgs* list_host, const AsAdainArgs* pos
         if (fused) {
             int mwo[H3_MAXP];
             for (int k = 0; k < m; ++k) mwo[k] = pmw[order[k]];
-            const int rr = launch_reduce_post(ptr, So, np, mwo, m, stream);
+            const int rr = launch_reduce_post(ptr, So, np, mwo, nl, m, stream);
             if (rr != AS_OK) return rr;
             for (int k = 0; k < m; ++k)
-                if (np[k]) post_done[order[k]] = true;
+                if (np[k] || nl[k]) post_done[order[k]] = true;
         }
         ReduceMulti rm;
         memset(&rm, 0, sizeof(rm));
@@ -987,11 +1182,11 @@ static int conv_gemm_multi(const ConvGemmArgs* list_host, const AsAdainArgs* pos
 
 extern "C" int as_conv_gemm_multi_f32(const ConvGemmArgs* list_host, int n, as_stream_t stream_)
 {
-    return conv_gemm_multi(list_host, nullptr, nullptr, n, static_cast<hipStream_t>(stream_));
+    return conv_gemm_multi(list_host, nullptr, nullptr, nullptr, n, static_cast<hipStream_t>(stream_));
 }
 
-extern "C" int as_conv_gemm_multi_post_f32(const ConvGemmArgs* list_host, const AsAdainArgs* post_host, const int32_t* post_max_w, int n,
-                                           as_stream_t stream_)
+extern "C" int as_conv_gemm_multi_post_f32(const ConvGemmArgs* list_host, const AsAdainArgs* post_host, const int32_t* post_max_w,
+                                           const AsLnArgs* post_ln_host, int n, as_stream_t stream_)
 {
-    return conv_gemm_multi(list_host, post_host, post_max_w, n, static_cast<hipStream_t>(stream_));
+    return conv_gemm_multi(list_host, post_host, post_max_w, post_ln_host, n, static_cast<hipStream_t>(stream_));
 }

@@ -930,8 +930,8 @@ channel_ln_split_kernel(const float* __restrict__ x, int ldx, int C, int N, cons
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int c = 8 * (part + i * LNS_PARTS) + r;
-            const float d = v[i][r] - mean;
-            if (c < C) q2 += d * d;
+            const float d = __fsub_rn(v[i][r], mean);
+            if (c < C) q2 = __fmaf_rn(d, d, q2);                        // (explicit: the same bits in the reduction kernel that computes this LayerNorm, conv_gemm.hip)
         }
     red[part][col] = q2;
     __syncthreads();
@@ -959,7 +959,7 @@ channel_ln_split_kernel(const float* __restrict__ x, int ldx, int C, int N, cons
             const int c = 8 * g + r;
             float o = 0.f;
             if (c < C) {
-                o = (v[i][r] - mean) * rs * gamma[c] + beta[c];
+                o = __fmaf_rn(__fmul_rn(__fsub_rn(v[i][r], mean), rs), gamma[c], beta[c]);
                 if (relu) o = o > 0.f ? o : 0.f;
             }
             t[r] = o;

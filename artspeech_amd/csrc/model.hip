@@ -517,6 +517,7 @@ struct Op {
     ConvGemmArgs g;
     AsAdainArgs post;                              // kind 1: the AdaIN that reads the conv's result (post.yh NULL: none), as_conv_gemm_multi_post_f32
     int post_max_w = 0;
+    AsLnArgs post_ln;                              // kind 1: ... or the channel LayerNorm that does (post_ln.yh NULL: none)
     AsDownArgs d;
     hipStream_t s = nullptr;
     double hint_f = 0, hint_b = 0;                 // as_prof_hint that goes with the launch
@@ -915,11 +916,13 @@ static void play(Ctx& c, Sched& S)
         if (np >= 2) {
             ConvGemmArgs list[AS_MAX_MULTI];
             AsAdainArgs posts[AS_MAX_MULTI];
+            AsLnArgs lns[AS_MAX_MULTI];
             int32_t pmw[AS_MAX_MULTI];
             for (int i = 0; i < np; ++i) {
                 const Op& oi = S.q[pick[i]][head[pick[i]]];
                 list[i] = oi.g;
                 posts[i] = oi.post;
+                lns[i] = oi.post_ln;
                 pmw[i] = oi.post_max_w;
             }
             if (trace) {
@@ -927,14 +930,14 @@ static void play(Ctx& c, Sched& S)
                 for (int i = 0; i < np; ++i) fprintf(stderr, " q%d M%d N%d K%d T%d |", pick[i], list[i].M, list[i].N, list[i].K, list[i].T);
                 fprintf(stderr, "\n");
             }
-            const int r = as_conv_gemm_multi_post_f32(list, posts, pmw, np, S.q[pick[0]][head[pick[0]]].s);
+            const int r = as_conv_gemm_multi_post_f32(list, posts, pmw, lns, np, S.q[pick[0]][head[pick[0]]].s);
             if (r != AS_OK) { fail(r, S.q[pick[0]][head[pick[0]]]); return; }
             for (int i = 0; i < np; ++i) ++head[pick[i]];
         } else {
             Op& o = S.q[lone][head[lone]];
             if (trace) fprintf(stderr, "  GEMM alone: q%d M%d N%d K%d T%d (%d heads)\n", lone, o.g.M, o.g.N, o.g.K, o.g.T, nh);
             const int32_t mw1 = o.post_max_w;
-            const int r = as_conv_gemm_multi_post_f32(&o.g, &o.post, &mw1, 1, o.s);
+            const int r = as_conv_gemm_multi_post_f32(&o.g, &o.post, &mw1, &o.post_ln, 1, o.s);
             if (r != AS_OK) { fail(r, o); return; }
             ++head[lone];
         }
@@ -1091,6 +1094,8 @@ struct ConvOpt {
     const Norm* post_n = nullptr;
     const Lay* post_lay = nullptr;
     uint16_t* post_yh = nullptr;
+    // ... or the channel LayerNorm (+ ReLU) that reads it (the encoders: conv -> residual add -> LayerNorm -> conv): ln.yh = the image to write
+    AsLnArgs ln = {nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0, nullptr};
 };
 
 // Y = epi(conv(W, X)); the input is fp32 X [K][ldx] (split by the library into the workspace) or the operand image xh
@@ -1154,16 +1159,19 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
         post.col_off = o.post_lay->d_off; post.U = o.post_lay->B; post.lrelu = 1; post.yh = o.post_yh;
         post_mw = o.post_lay->max_w;
     }
+    if (o.ln.yh && (o.post_yh || !Y)) { c.fail(AS_EINVAL); return; }
     if (c.deferring() && !EXP_SKIP(as_conv_gemm_f32)) {                  // recorded: it may share its launch with other branches' convs
         Op& op = c.push(1);
         op.g = a;
         op.post = post;
+        op.post_ln = o.ln;
         op.post_max_w = post_mw;
         op.what = "as_conv_gemm_f32";
         op.line = __LINE__;
         return;
     }
-    RUN(c, as_conv_gemm_multi_post_f32(&a, &post, &post_mw, 1, c.s));
+    const AsLnArgs ln1 = o.ln;
+    RUN(c, as_conv_gemm_multi_post_f32(&a, &post, &post_mw, &ln1, 1, c.s));
 }
 
 // fp32 input X [K][ldx]
@@ -1428,6 +1436,19 @@ bool rel_encoder_multi(Ctx& c, const std::vector<EncSpec>& enc, const int32_t* t
         if (N > 0) RUN(c, as_channel_layernorm_split_f32(xin, ld, C, N, g1, b1, g2, b2, gc, 1e-4f, relu, xs, c.s));
         return xs;
     };
+    // ... written by the call of the conv that PRODUCES xin (ConvOpt.ln; round 5): the conv -> residual add -> LayerNorm -> conv of
+    // RelTransformerEnc.py:72-87, 318-325 as conv(+ LayerNorm) -> conv.  At batch-1 sizes the producer's reduction kernel writes the image;
+    // elsewhere the library launches the LayerNorm behind the conv (what ln_image does, issued one call earlier).  Only where producer and
+    // consumer cover the same groups (the same columns).
+    auto ln_post = [&](ConvOpt& q, const std::string& ln, bool relu, int k) {
+        const int N = lays[k]->N;
+        uint16_t* xs = c.image(C, N);
+        const float *g2 = nullptr, *b2 = nullptr;
+        const float *g1 = stack2(ln + ".gamma", k, &g2), *b1 = stack2(ln + ".beta", k, &b2);
+        q.ln.gamma = g1; q.ln.beta = b1; q.ln.gamma2 = g2; q.ln.beta2 = b2; q.ln.n_split = gc; q.ln.eps = 1e-4f; q.ln.relu = relu ? 1 : 0;
+        q.ln.yh = N > 0 ? xs : nullptr;
+        return xs;
+    };
     auto cw = [&](const std::string& name, int k) { return m.conv_stack(names(name, k)); };
     auto cb = [&](const std::string& name, int k) { return m.bias_stack(names(name, k)); };
     auto opt = [&](const std::string& bias_of, int k) {
@@ -1438,20 +1459,26 @@ bool rel_encoder_multi(Ctx& c, const std::vector<EncSpec>& enc, const int32_t* t
     };
     const Taps k5 = taps_1d(5), k1 = taps_1d(1), k9 = taps_1d(9);
     float* h = c.f32((size_t)C * ld);
+    const std::string e = ".encoder";
+    uint16_t* xs_next = nullptr;                                               // the image of the NEXT LayerNorm, written by the conv call in front of it
     {                                                                          // ConvReluNorm, RelTransformerEnc.py:318-325
-        conv_x(c, cw(".pre.conv_layers.0", G), x, ld, C, lays[G], k5, h, ld, opt(".pre.conv_layers.0", G));
+        ConvOpt q0 = opt(".pre.conv_layers.0", G);
+        xs_next = ln_post(q0, ".pre.norm_layers.0", true, G);
+        conv_x(c, cw(".pre.conv_layers.0", G), x, ld, C, lays[G], k5, h, ld, q0);
         for (int i = 0; i < 3; ++i) {
-            uint16_t* xs = ln_image(h, ".pre.norm_layers." + std::to_string(i), true, G);
+            uint16_t* xs = xs_next;
             const std::string nxt = i < 2 ? ".pre.conv_layers." + std::to_string(i + 1) : std::string(".pre.proj");
             ConvOpt q = opt(nxt, G);
             if (i == 2) { q.res = x; q.ldr = ld; }
+            // (the proj conv's result is the encoder's input: layer 0's first LayerNorm reads it)
+            xs_next = i < 2 ? ln_post(q, ".pre.norm_layers." + std::to_string(i + 1), true, G)
+                            : (enc[0].layers > 0 ? ln_post(q, e + ".norm_layers_1.0", false, G) : nullptr);
             float* hn = c.f32((size_t)C * ld);
             conv_h(c, cw(nxt, G), xs, C, lays[G], i < 2 ? k5 : k1, hn, ld, q);
             h = hn;
         }
     }
     x = h;
-    const std::string e = ".encoder";
     // one encoder's result: its own last LayerNorm on its columns
     auto finish = [&](int g0, int g1) {                                        // encoders g0 .. g1 - 1 (they share the remaining depth)
         const int Nk = (g1 - g0 - 1) * gc + N1;                                // columns from group g0's first to group g1 - 1's last
@@ -1468,6 +1495,7 @@ bool rel_encoder_multi(Ctx& c, const std::vector<EncSpec>& enc, const int32_t* t
         for (int g = g0; g < g1; ++g) done(g);
     };
     int k = G;
+    int xs_k = G;                                                              // the groups xs_next covers
     for (int i = 0; i < enc[0].layers; ++i) {                                  // Encoder.forward, RelTransformerEnc.py:66-90
         int kn = 0;
         while (kn < G && enc[kn].layers > i) ++kn;                             // encoders that have a layer i
@@ -1487,7 +1515,11 @@ bool rel_encoder_multi(Ctx& c, const std::vector<EncSpec>& enc, const int32_t* t
             o.want_yh = true;
             o.yh = c.image(3 * C, N);
         }
-        float* qkv = conv_h_new(c, wqkv, ln_image(x, e + ".norm_layers_1." + std::to_string(i), false, k), C, lay, k1, o);
+        // norm_layers_1[i](x): written by the call that produced x (the proj conv / the previous layer's second FFN conv) when that call
+        // covered the same groups; otherwise (a shallower encoder has just left) by a launch of its own
+        uint16_t* xs1 = (xs_next && xs_k == k) ? xs_next : ln_image(x, e + ".norm_layers_1." + std::to_string(i), false, k);
+        xs_next = nullptr;
+        float* qkv = conv_h_new(c, wqkv, xs1, C, lay, k1, o);
         float* att = img ? nullptr : c.f32((size_t)C * std::max(N, 1));
         uint16_t* att_h = img ? c.image(C, N) : nullptr;
         const float *ek2 = nullptr, *ev2 = nullptr;
@@ -1500,6 +1532,7 @@ bool rel_encoder_multi(Ctx& c, const std::vector<EncSpec>& enc, const int32_t* t
         ConvOpt oo = opt(a + ".conv_o", k);
         oo.res = x;
         oo.ldr = ld;
+        uint16_t* xs2 = ln_post(oo, e + ".norm_layers_2." + std::to_string(i), false, k);   // norm_layers_2[i] of x + attention, by the o-projection's call
         float* xo = c.f32((size_t)C * ld);
         if (img) conv_h(c, cw(a + ".conv_o", k), att_h, C, lay, k1, xo, ld, oo);
         else conv_x(c, cw(a + ".conv_o", k), att, N, C, lay, k1, xo, ld, oo);
@@ -1513,10 +1546,16 @@ bool rel_encoder_multi(Ctx& c, const std::vector<EncSpec>& enc, const int32_t* t
         o1.act = ACT_RELU;
         o1.want_yh = true;
         o1.yh = yh;
-        conv_h(c, w1, ln_image(x, e + ".norm_layers_2." + std::to_string(i), false, k), C, lay, k9, nullptr, N, o1);
+        conv_h(c, w1, xs2, C, lay, k9, nullptr, N, o1);
         ConvOpt o2 = opt(f + ".conv_2", k);
         o2.res = x;
         o2.ldr = ld;
+        // the next layer's norm_layers_1 by this call, if the next layer covers the same groups
+        {
+            int kn2 = 0;
+            while (kn2 < G && enc[kn2].layers > i + 1) ++kn2;
+            if (i + 1 < enc[0].layers && kn2 == k) { xs_next = ln_post(o2, e + ".norm_layers_1." + std::to_string(i + 1), false, k); xs_k = k; }
+        }
         float* xf = c.f32((size_t)C * ld);
         conv_h(c, cw(f + ".conv_2", k), yh, w1->M, lay, k1, xf, ld, o2);
         x = xf;

@@ -327,15 +327,23 @@ def conv_gemm_multi(deferred, tile_out=None):
     check(L.as_conv_gemm_multi_f32(arr, n, stream()), "as_conv_gemm_multi_f32")
 
 
-def conv_gemm_multi_post(deferred, posts):
+def conv_gemm_multi_post(deferred, posts, lns=None):
     """as_conv_gemm_multi_post_f32: the deferred convs as one launch; posts[i] = None or (gb, gb_sc, lay, image[, gb_off]) -- the AdaIN1d +
     LeakyReLU that reads conv i's result, written as `image` by the same call (by the launch's reduction kernel when it is K-sliced and no
-    utterance is wider than 256 columns)."""
+    utterance is wider than 256 columns); lns[i] = None or (gamma, beta, image, relu[, gamma2, beta2, n_split]) -- the channel LayerNorm
+    (eps 1e-4) that does."""
     n = len(deferred)
     arr = (ConvGemmArgs * n)(*[d[0] for d in deferred])
     pa = (_lib.AdainArgs * n)()
+    la = (_lib.LnArgs * n)()
     mw = (ctypes.c_int32 * n)()
-    for i, q in enumerate(posts):
+    for i, q in enumerate(lns or []):
+        if q is None:
+            continue
+        la[i].gamma, la[i].beta, la[i].yh, la[i].relu, la[i].eps = _p(q[0]), _p(q[1]), _p(q[2]), int(q[3]), 1e-4
+        if len(q) > 4:
+            la[i].gamma2, la[i].beta2, la[i].n_split = _p(q[4]), _p(q[5]), int(q[6])
+    for i, q in enumerate(posts or [None] * n):
         if q is None:
             continue
         gb, gb_sc, lay, img = q[:4]
@@ -343,7 +351,7 @@ def conv_gemm_multi_post(deferred, posts):
         pa[i].gb, pa[i].gb_off, pa[i].ldgb, pa[i].gb_sc = _p(gb), _p(gb_off), 1, gb_sc
         pa[i].col_off, pa[i].U, pa[i].lrelu, pa[i].yh = _p(lay.col_off), lay.B, 1, _p(img)
         mw[i] = max(lay.widths_host) if hasattr(lay, "widths_host") else int(lay.widths.max())
-    check(_lib.lib().as_conv_gemm_multi_post_f32(arr, pa, mw, n, stream()), "as_conv_gemm_multi_post_f32")
+    check(_lib.lib().as_conv_gemm_multi_post_f32(arr, pa, mw, la, n, stream()), "as_conv_gemm_multi_post_f32")
 
 
 def embed(tokens_i32, emb, scale, Y, group2=None, n_cols=None):

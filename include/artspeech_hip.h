@@ -199,6 +199,8 @@ typedef struct ConvGemmArgs {
      * (the interleave pass of as_interleave_phases_f32 folded into the store; the bias is given per ROW: the channel's, u times).
      * C a multiple of 32, ldy >= ileave_u * N; Y only (no Yh, res, transpose_out, weight groups); never K-sliced. */
     int32_t ileave_u;
+    int32_t slab_tr;           /* library-owned (overwritten): the K slices' partial sums are stored time-major for a reduction that also
+                                * computes the channel LayerNorm behind the conv (as_conv_gemm_multi_post_f32) */
 } ConvGemmArgs;
 #define AS_SLOPE_PATH 0.2f
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
@@ -312,9 +314,22 @@ int as_adain_image_f32(const AsAdainArgs* args_host, as_stream_t stream);
  * utterance is wider than 256 columns (post_max_w[i] = the widest utterance of problem i), so that kernel computes the statistics and
  * writes the image itself -- conv -> reduce+AdaIN -> conv instead of conv -> reduce -> AdaIN -> conv, bit-identical to the separate
  * launches.  Everywhere else the call is exactly as_conv_gemm_multi_f32 followed by as_adain_image_f32 on list[i].Y.
- * post_host NULL: as_conv_gemm_multi_f32.  Not with transpose_out / ileave_u. */
-int as_conv_gemm_multi_post_f32(const ConvGemmArgs* list_host, const AsAdainArgs* post_host, const int32_t* post_max_w, int n,
-                                as_stream_t stream);
+ * post_host NULL: as_conv_gemm_multi_f32.  Not with transpose_out / ileave_u.
+ * The same for a conv whose result is read through a channel LayerNorm (+ ReLU) -- the encoders' conv -> residual add -> LayerNorm -> conv
+ * (RelTransformerEnc.py:72-87, 318-325): problem i with post_ln_host[i].yh != NULL also leaves the operand image
+ * yh = split(ReLU?(LayerNorm(y_i))) (as_channel_layernorm_split_f32's arithmetic and parameter addressing: column group g = column /
+ * n_split takes gamma + g (gamma2 - gamma), NULL second set = one set).  K-sliced launches of <= 512 output channels (a multiple of 8)
+ * store their partial sums time-major and the reduction kernel -- a wave per column -- writes the image itself; everywhere else the call
+ * is the conv followed by as_channel_layernorm_split_f32 on list[i].Y.  post_ln_host NULL: none.  A problem has at most one of the two. */
+typedef struct AsLnArgs {
+    const float *gamma, *beta, *gamma2, *beta2;   /* [C] per set */
+    int32_t n_split;
+    float eps;
+    int32_t relu;
+    uint16_t* yh;                                  /* the split image [KBx(M)][4][N+1][8], or NULL: no LayerNorm behind this conv */
+} AsLnArgs;
+int as_conv_gemm_multi_post_f32(const ConvGemmArgs* list_host, const AsAdainArgs* post_host, const int32_t* post_max_w,
+                                const AsLnArgs* post_ln_host, int n, as_stream_t stream);
 /* x [B][ldx] (one K-vector per utterance) -> the split image of its transpose [K][B] (columns = utterances): the operand of
  * the GEMM that evaluates every AdaIN fc layer of the model at once (models.py:237). */
 int as_rows_image_f32(const float* x, int ldx, int K, int B, uint16_t* xh, as_stream_t stream);

@@ -894,6 +894,75 @@ def test_conv_gemm_post_adain(cuda, monkeypatch, case):
         assert torch.equal(yh, yh0)
 
 
+@pytest.mark.parametrize("case", ["single", "multi", "grouped", "wide_m", "unsliced"])
+def test_conv_gemm_post_layernorm(cuda, monkeypatch, case):
+    """as_conv_gemm_multi_post_f32 with a channel LayerNorm behind the conv (RelTransformerEnc.py:72-87, 318-325: conv -> residual add ->
+    LayerNorm -> conv).  K-sliced launches of <= 512 channels store their partial sums time-major and the reduction kernel -- a wave per
+    column -- writes the LayerNorm image: bitwise what the conv followed by as_channel_layernorm_split_f32 gives (fp32 rows included);
+    1 024 channels and unsliced launches take the two-launch route inside the call; with AS_NO_REDUCE_LN every case does."""
+    import ctypes
+    if case == "single":
+        specs = [(1024, 512, 1, [30, 30, 30], "plain")]
+    elif case == "multi":
+        specs = [(512, 512, 5, [90], "plain"), (1024, 512, 1, [7, 30, 1], "plain"), (256, 64, 3, [40], "shortcut_free")]
+    elif case == "grouped":
+        specs = [(512, 512, 5, [30, 11, 3] * 3, "grouped")]
+    elif case == "wide_m":
+        specs = [(512, 1024, 3, [90], "plain")]
+    else:
+        specs = [(64, 128, 3, [200] * 32, "plain")]
+    specs = [(a, b, c, d, "plain" if e == "shortcut_free" else e) for a, b, c, d, e in specs]
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("AS_NO_REDUCE_LN", raising=False)
+        else:
+            monkeypatch.setenv("AS_NO_REDUCE_LN", "1")
+        gg = torch.Generator().manual_seed(4321)
+        deferred, outs, wants, checks = _multi_problems(cuda, gg, specs)
+        lns, imgs, pars = [], [], []
+        for (cin, cout, k, lens, fl), (a, keep) in zip(specs, deferred):
+            lay = keep[10]
+            if fl == "grouped":                                                  # three parameter sets, one per column group
+                per = sum(lens[: len(lens) // 3])
+                gam, bet = torch.randn(3, cout, generator=gg).to(cuda), torch.randn(3, cout, generator=gg).to(cuda)
+                extra = (gam[1], bet[1], per)
+            else:
+                gam, bet = torch.randn(1, cout, generator=gg).to(cuda), torch.randn(1, cout, generator=gg).to(cuda)
+                extra = ()
+            img = ops.new_image(cout, lay.N, cuda)
+            img.fill_(0x7e7e)
+            lns.append((gam[0], bet[0], img, cin % 2 == 0) + extra)
+            imgs.append(img)
+            pars.append((gam, bet, extra))
+        plans = []
+        for a, _ in deferred:
+            kk, tt, sl = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+            ops.check(ops._lib.lib().as_conv_gemm_plan(ctypes.byref(a), ctypes.byref(kk), ctypes.byref(tt), ctypes.byref(sl)), "as_conv_gemm_plan")
+            plans.append(sl.value)
+        ops.conv_gemm_multi_post(deferred, None, lns)
+        torch.cuda.synchronize()
+        return outs, wants, imgs, pars, [k[10] for _, k in deferred], plans, lns
+    outs, wants, imgs, pars, lays, plans, lns = run(True)
+    if case in ("single", "grouped", "wide_m"):
+        assert plans[0] > 1, plans
+    if case == "unsliced":
+        assert plans[0] == 1
+    for (cin, cout, k, lens, fl), y, want in zip(specs, outs, wants):
+        assert float((y.double().cpu() - want).abs().max()) <= 3e-5
+    for y, img, (gam, bet, extra), lay, ln in zip(outs, imgs, pars, lays, lns):
+        ref = ops.channel_layernorm_split(y, lay, gam[0], bet[0], relu=ln[3], group2=(extra if extra else None))
+        torch.cuda.synchronize()
+        bad = (img[: ref.numel()] != ref).nonzero().flatten()
+        where = [(int(i) // (8 * (lay.N + 1)) // 4, int(i) // (8 * (lay.N + 1)) % 4, int(i) // 8 % (lay.N + 1), int(i) % 8) for i in bad[:6]]
+        assert bad.numel() == 0, (case, int(bad.numel()), "(k-block, plane, column, element):", where)
+    outs0, _, imgs0, _, _, _, _ = run(False)
+    for y, y0 in zip(outs, outs0):
+        assert torch.equal(y, y0)
+    for i, i0 in zip(imgs, imgs0):
+        assert torch.equal(i, i0)
+
+
 def test_conv_gemm_multi_rejects_what_it_cannot_merge(cuda):
     g = torch.Generator().manual_seed(1)
     lay = Layout([50, 20], cuda)
