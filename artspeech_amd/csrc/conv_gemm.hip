@@ -653,12 +653,23 @@ static bool direct_cin1(const ConvGemmArgs& a)
            !getenv("AS_GEMM_NO_DIRECT");
 }
 
+// A conv with an AdaIN / LayerNorm behind it (as_conv_gemm_multi_post_f32) whose output is tiny (batch-1 sizes: <= 1 MB) is cut into TWO K
+// slices even where the slicing rules would leave it whole: its reduction kernel then replaces the normalisation's launch (the slices
+// themselves cost nothing there: the launch is a few microseconds of latency either way).  The workspace always has room for it.
+static const size_t kPostSlabMax = (size_t)1 << 20;
+static bool post_slice_ok(const ConvGemmArgs& a)
+{
+    return a.Xh && a.ileave_u <= 1 && !a.transpose_out && (size_t)a.M * a.N * sizeof(float) <= kPostSlabMax &&
+           a.T * (a.Kp / 16) + as_cdiv(a.K2, 16) >= 8;
+}
+
 extern "C" size_t as_conv_gemm_workspace_bytes(const ConvGemmArgs* a)
 {
     if (!a || a->M <= 0 || a->N <= 0 || a->Kp <= 0 || a->T <= 0) return 0;
     if (direct_cin1(*a)) return 0;
     const GemmPlan p = gemm_plan(*a);
-    return p.xh_bytes ? align256(p.slab_bytes) + p.xh_bytes : p.slab_bytes;
+    const size_t slabs = std::max(p.slab_bytes, post_slice_ok(*a) ? 2 * (size_t)a->M * a->N * sizeof(float) : (size_t)0);
+    return p.xh_bytes ? align256(slabs) + p.xh_bytes : slabs;
 }
 
 // Room for the K slices a problem may be cut into inside a multi-problem launch (as_conv_gemm_multi_f32 takes no more slices than
@@ -907,7 +918,12 @@ static int conv_gemm_one(const ConvGemmArgs* args_host, const AsAdainArgs* post_
         plan.S = 1;                                        // no workspace: no K slices
         plan.slab_bytes = 0;
     }
-    const int S = plan.S;
+    // (see post_slice_ok: whatever AS_NO_REDUCE_* says -- the switch changes who normalises, never the conv's own arithmetic)
+    int S_ = plan.S;
+    if (S_ == 1 && post_slice_ok(a) && a.ws && a.ws_bytes >= 2 * (size_t)a.M * a.N * sizeof(float) &&
+        ((want_ln && a.M % 8 == 0 && a.M <= 512 && !a.Yh && a.act <= 2) || (want_post && post_max_w > 0 && post_max_w <= 256 && a.act <= 2)))
+        S_ = 2;
+    const int S = S_;
     char tag[96], shape[64];
     gemm_tag(a, shape, sizeof(shape));
     snprintf(tag, sizeof(tag), "%s tile%d S%d%s%s%s", shape, plan.choice, S, a.n_prod == 1 ? " h1" : "", a.Xh ? "" : " +split",
@@ -1108,6 +1124,10 @@ static int conv_gemm_multi(const ConvGemmArgs* list_host, const AsAdainArgs* pos
         const size_t slab = (size_t)a.M * a.N * sizeof(float);
         if (s > 1 && (!a.ws || a.ws_bytes / slab < (size_t)s)) s = a.ws ? (int)std::min<size_t>(a.ws_bytes / slab, (size_t)s) : 1;
         S[i] = s < 1 ? 1 : s;
+        // (post_slice_ok: a tiny conv with a normalisation behind it is always cut in two -- its reduction replaces the normalisation's launch)
+        if (S[i] == 1 && post_slice_ok(a) && a.ws && a.ws_bytes >= 2 * slab && nkt[i] >= 2 &&
+            ((has_ln[i] && a.M % 8 == 0 && a.M <= 512 && !a.Yh && a.act <= 2) || (has_post[i] && pmw[i] > 0 && pmw[i] <= 256 && a.act <= 2)))
+            S[i] = 2;
         len[i] = (double)nkt[i] / S[i];
         order[i] = i;
     }
