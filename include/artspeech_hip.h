@@ -320,7 +320,10 @@ int as_adain_image_f32(const AsAdainArgs* args_host, as_stream_t stream);
  * yh = split(ReLU?(LayerNorm(y_i))) (as_channel_layernorm_split_f32's arithmetic and parameter addressing: column group g = column /
  * n_split takes gamma + g (gamma2 - gamma), NULL second set = one set).  K-sliced launches of <= 512 output channels (a multiple of 8)
  * store their partial sums time-major and the reduction kernel -- a wave per column -- writes the image itself; everywhere else the call
- * is the conv followed by as_channel_layernorm_split_f32 on list[i].Y.  post_ln_host NULL: none.  A problem has at most one of the two. */
+ * is the conv followed by as_channel_layernorm_split_f32 on list[i].Y.  post_ln_host NULL: none.  A problem has at most one of the two.
+ * So that the fused form is the rule at batch 1, a conv with either normalisation behind it whose output is at most 1 MB is cut into two
+ * K slices even where the slicing rules would leave it whole (as_conv_gemm_workspace_bytes / _multi_workspace_bytes leave room for the two
+ * slabs of any such output): another order of two partial sums, the same arithmetic. */
 typedef struct AsLnArgs {
     const float *gamma, *beta, *gamma2, *beta2;   /* [C] per set */
     int32_t n_split;
