@@ -1,2 +1,2 @@
 #include "common.h"
-extern "C" int as_abi_version(void) { return 8; }
+extern "C" int as_abi_version(void) { return 7; }
