@@ -378,6 +378,10 @@ static __device__ __forceinline__ void reduce_adain(const ConvGemmArgs& a, int S
     int o0 = 0, L = a.N;
     if (n.U > 1) { o0 = n.col_off[u]; L = n.col_off[u + 1] - o0; }
     if (L <= 0) return;
+    if (L > 64 * NJ) {                                                   // the caller's post_max_w was not the widest utterance: say so, write nothing wrong silently
+        if (lane == 0) as_status_raise(a.status, AS_STATUS_BAD_LAYOUT);
+        return;
+    }
     reduce_adain_body<NJ>(a, S, n, kb, kh, u, o0, L);                    // (L <= 64 NJ: the host picks the instantiation from the widest utterance)
 }
 

@@ -350,7 +350,7 @@ def conv_gemm_multi_post(deferred, posts, lns=None):
         gb_off = q[4] if len(q) > 4 else None
         pa[i].gb, pa[i].gb_off, pa[i].ldgb, pa[i].gb_sc = _p(gb), _p(gb_off), 1, gb_sc
         pa[i].col_off, pa[i].U, pa[i].lrelu, pa[i].yh = _p(lay.col_off), lay.B, 1, _p(img)
-        mw[i] = max(lay.widths_host) if hasattr(lay, "widths_host") else int(lay.widths.max())
+        mw[i] = q[5] if len(q) > 5 else (max(lay.widths_host) if hasattr(lay, "widths_host") else int(lay.widths.max()))   # (q[5]: tests)
     check(_lib.lib().as_conv_gemm_multi_post_f32(arr, pa, mw, la, n, stream()), "as_conv_gemm_multi_post_f32")
 
 

@@ -39,7 +39,8 @@ int as_abi_version(void);
  *                               non-finite input (every launch under the debug probe as_set_range_probe; ALWAYS the last conv of
  *                               as_forward_test / as_decoder_forward, `to_out`: inf / NaN anywhere upstream reaches it, so a
  *                               non-finite mel is never handed back silently)
- *   bit AS_STATUS_BAD_LAYOUT    an utterance wider than AS_META_MAX_W columns reached as_make_meta (its descriptors are void)
+ *   bit AS_STATUS_BAD_LAYOUT    an utterance wider than AS_META_MAX_W columns reached as_make_meta (its descriptors are void), or an
+ *                               utterance wider than the post_max_w its caller named reached as_conv_gemm_multi_post_f32's reduction
  * as_device_status returns the bits raised on the current HIP device since the last clear (0 = healthy) without synchronising; it is
  * final for work whose stream has been synchronised.  The module-level entry points (as_*_forward, as_forward_test*) return
  * AS_EDEVICE while any bit is set: results computed since it was raised are invalid; clear it to go on. */

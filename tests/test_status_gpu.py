@@ -142,6 +142,24 @@ def test_range_probe_names_an_operand_beyond_fp16(cuda):
     assert L.as_device_status(1) == 1 << F16_RANGE
 
 
+def test_post_max_w_smaller_than_an_utterance_is_reported(cuda):
+    """as_conv_gemm_multi_post_f32: the reduction kernel that also writes the AdaIN image holds 64 NJ columns of an utterance, NJ chosen
+    from the caller's post_max_w; an utterance wider than that raises AS_STATUS_BAD_LAYOUT instead of dropping its last columns."""
+    L = _lib.lib()
+    lens, cin, cout = [150], 512, 512
+    g = torch.Generator().manual_seed(2)
+    lay = Layout(lens, cuda)
+    w = torch.randn(cout, cin, 3, generator=g) / 40
+    xs = ops.split_act(torch.randn(cin, lay.N, generator=g).to(cuda), lay)
+    gb = torch.randn(2 * cout, 1, generator=g).to(cuda)
+    for claimed, bad in ((150, False), (64, True)):
+        d = []
+        ops.conv_gemm(ops.prep_weight(w, cuda), None, lay, lay.new(cout), taps_1d(3), xs=xs, K=cin, defer=d)
+        ops.conv_gemm_multi_post(d, [(gb, 1, lay, ops.new_image(cout, lay.N, cuda), None, claimed)])
+        torch.cuda.synchronize()
+        assert L.as_device_status(1) == ((1 << BAD_LAYOUT) if bad else 0), claimed
+
+
 def test_non_finite_mel_is_always_reported(cuda, golden_dir):
     """The debug probe is OFF: the path's last conv (`to_out`) still tests its accumulators, and inf / NaN anywhere upstream reaches it --
     an articulatory feature beyond fp16's range (the decoder's F0 / N / EMA convs and the towers read it), a NaN in the reference mel.
