@@ -32,6 +32,7 @@ _SIGNATURES = {
 }
 
 AS_MAX_TAPS = 25
+AS_ABI_VERSION = 8          # include/artspeech_hip.h
 
 
 class ConvGemmArgs(ctypes.Structure):
@@ -150,6 +151,11 @@ class ForwardIO(ctypes.Structure):
                 ("F0", c_p), ("N", c_p), ("EMA", c_p), ("ld_pred", ctypes.c_int32)]
 
 
+class HostIO(ctypes.Structure):                 # as_host_io: HOST pointers (as_lanes_submit_host)
+    _fields_ = [("tokens", c_p), ("mel", c_p), ("ld_mel", ctypes.c_int32), ("f0_raw", c_p), ("ema_raw", c_p), ("ld_ema", ctypes.c_int32),
+                ("forced_dur", c_p), ("mel_out", c_p), ("ld_out", ctypes.c_int32)]
+
+
 AS_MOD_FORWARD_A, AS_MOD_FORWARD_B, AS_MOD_ENCODER, AS_MOD_STYLE, AS_MOD_DURATION, AS_MOD_ARTS, AS_MOD_DECODER = range(7)
 _pB, _pIO = ctypes.POINTER(Batch), ctypes.POINTER(ForwardIO)
 _SIGNATURES.update({
@@ -195,6 +201,9 @@ _SIGNATURES.update({
     "as_lanes_submit": (c_i, [c_p, _pB, _pIO, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "as_lanes_wait": (c_i, [c_p, c_i]),
     "as_lanes_set_coalesce": (c_i, [c_p, c_i]),
+    "as_lanes_set_debug": (c_i, [c_p, c_i]),
+    "as_lanes_submit_host": (c_i, [c_p, _pB, ctypes.POINTER(HostIO), ctypes.POINTER(ctypes.c_int32)]),
+    "as_model_get_cfg": (c_i, [c_p, c_p]),
     "as_lanes_flush": (c_i, [c_p]),
     "as_lanes_merged_calls": (ctypes.c_int64, [c_p, c_i]),
     "as_lanes_set_graph_cap": (c_i, [c_p, c_i]),
@@ -231,6 +240,9 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the header and the .so disagree
             fn.restype = res
             fn.argtypes = args
+        if handle.as_abi_version() != AS_ABI_VERSION and not os.environ.get("AS_LIB_PATH"):
+            raise HipLibraryError(f"{LIB_PATH} has ABI version {handle.as_abi_version()}, this binding is written for {AS_ABI_VERSION} "
+                                  "(include/artspeech_hip.h): rebuild with `python -m artspeech_amd._build`")
         _lib = handle
     return _lib
 
@@ -238,7 +250,8 @@ def lib():
 AS_EDEVICE = -3
 STATUS_NAMES = ("clustered LSTM hand-over timed out", "MAS band hand-over timed out", "token id outside [0, n_token)",
                 "non-finite accumulator (an operand beyond fp16's range, or a non-finite input)",
-                "an utterance wider than the column descriptors allow (AS_META_MAX_W)")
+                "a layout the kernels cannot serve: an utterance wider than the column descriptors (AS_META_MAX_W) or than its caller said, "
+                "or (as_lanes debug mode) device buffers that changed while their submission was waiting for its group")
 
 
 def device_status(clear=False):

@@ -124,7 +124,7 @@ static __device__ __forceinline__ float div_sqrt2f(float x)
 template <int ACT>
 static __device__ __forceinline__ float epi_act(float x, float slope)
 {
-    if (ACT == 1) x = x > 0.f ? x : 0.f;
+    if (ACT == 1) x = x < 0.f ? 0.f : x;                             // (NaN stays NaN, as torch.relu)
     if (ACT == 2) x = x > 0.f ? x : slope * x;
     if (ACT == 3) x = tanhf(x);
     if (ACT == 4) x = fabsf(x);
@@ -336,7 +336,7 @@ static __device__ __forceinline__ float as_reduce_value(const ConvGemmArgs& a, f
     if (a.bias) x = __fadd_rn(x, bias);
     if (a.res) x = __fadd_rn(x, res);
     if (a.div_sqrt2) x = __fdiv_rn(x, 1.41421356237309504880f);
-    if (a.act == 1) x = x > 0.f ? x : 0.f;
+    if (a.act == 1) x = x < 0.f ? 0.f : x;                      // (NaN stays NaN, as torch.relu: a non-finite value upstream reaches to_out)
     else if (a.act == 2) x = x > 0.f ? x : __fmul_rn(a.act_slope, x);
     else if (!LEAN) {
         if (a.act == 3) x = tanhf(x);

@@ -108,7 +108,7 @@ conv_direct_cin1_x4_kernel(const DirectMulti dm)
 #pragma unroll
                     for (int t = 0; t < 9; ++t) sum += wt[t] * x[c][t];
                     sum += bs[m];
-                    if (a.act == 1) sum = sum > 0.f ? sum : 0.f;
+                    if (a.act == 1) sum = sum < 0.f ? 0.f : sum;
                     else if (a.act == 2) sum = sum > 0.f ? sum : a.act_slope * sum;
                     else if (a.act == 3) sum = tanhf(sum);
                     else if (a.act == 4) sum = fabsf(sum);
@@ -174,7 +174,7 @@ conv_direct_cin1_kernel(const ConvGemmArgs a)
         for (int t = 0; t < AS_MAX_TAPS; ++t)
             if (t < a.T) s += ws[t * a.M + m] * x[t];
         s += bs[m];
-        if (a.act == 1) s = s > 0.f ? s : 0.f;
+        if (a.act == 1) s = s < 0.f ? 0.f : s;
         else if (a.act == 2) s = s > 0.f ? s : a.act_slope * s;
         else if (a.act == 3) s = tanhf(s);
         else if (a.act == 4) s = fabsf(s);
@@ -374,15 +374,19 @@ static __device__ __forceinline__ void reduce_adain(const ConvGemmArgs& a, int S
             yh[plane + 2 * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};
         }
     }
-    // (one utterance -- batch 1 -- owns every column: no dependent load of its offsets in front of the slab loads)
-    int o0 = 0, L = a.N;
+    // (one utterance -- batch 1 -- owns every column: no dependent load of its offsets in front of the slab loads; the offsets it was
+    // given are still read -- nothing waits for them until the end -- and an utterance that is NOT columns [0, N) is reported: the
+    // two-launch form, as_adain_image_f32, honours col_off, and the two must never differ silently)
+    int o0 = 0, L = a.N, c_lo = 0, c_hi = a.N;
     if (n.U > 1) { o0 = n.col_off[u]; L = n.col_off[u + 1] - o0; }
+    else if (n.col_off) { c_lo = n.col_off[0]; c_hi = n.col_off[1]; }
     if (L <= 0) return;
     if (L > 64 * NJ) {                                                   // the caller's post_max_w was not the widest utterance: say so, write nothing wrong silently
         if (lane == 0) as_status_raise(a.status, AS_STATUS_BAD_LAYOUT);
         return;
     }
     reduce_adain_body<NJ>(a, S, n, kb, kh, u, o0, L);                    // (L <= 64 NJ: the host picks the instantiation from the widest utterance)
+    if ((c_lo != 0 || c_hi != a.N) && lane == 0) as_status_raise(a.status, AS_STATUS_BAD_LAYOUT);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -492,7 +496,7 @@ static __device__ __forceinline__ void reduce_ln(const ConvGemmArgs& a, int S, c
         float o = 0.f;
         if (live) {
             o = __fmaf_rn(__fmul_rn(__fsub_rn(v[r], mean), rs), gam8[r], bet8[r]);
-            if (n.relu) o = o > 0.f ? o : 0.f;
+            if (n.relu) o = o < 0.f ? 0.f : o;
         }
         t[r] = o;
     }

@@ -960,7 +960,7 @@ channel_ln_split_kernel(const float* __restrict__ x, int ldx, int C, int N, cons
             float o = 0.f;
             if (c < C) {
                 o = __fmaf_rn(__fmul_rn(__fsub_rn(v[i][r], mean), rs), gamma[c], beta[c]);
-                if (relu) o = o > 0.f ? o : 0.f;
+                if (relu) o = o < 0.f ? 0.f : o;
             }
             t[r] = o;
         }

@@ -148,13 +148,13 @@ channel_ln_kernel(const float* __restrict__ x, int ldx, int C, int N, const floa
         const int c = part + i * LN_PARTS;
         if (c < C) {
             float o = (v[i] - mean) * rs * gamma[c] + beta[c];
-            if (relu) o = o > 0.f ? o : 0.f;
+            if (relu) o = o < 0.f ? 0.f : o;
             y[(size_t)c * ldy + j] = o;
         }
     }
     for (int c = part + LN_MAXV * LN_PARTS; c < C; c += LN_PARTS) {
         float o = (x[(size_t)c * ldx + j] - mean) * rs * gamma[c] + beta[c];
-        if (relu) o = o > 0.f ? o : 0.f;
+        if (relu) o = o < 0.f ? 0.f : o;
         y[(size_t)c * ldy + j] = o;
     }
 }

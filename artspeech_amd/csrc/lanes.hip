@@ -22,6 +22,8 @@
 #include "artspeech_hip.h"
 #include <algorithm>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -45,8 +47,22 @@ struct Lane {
     struct Pending {
         std::vector<int32_t> tok_lens, ref_lens, frames;
         as_forward_io io;
+        float* out_host = nullptr;                                // as_lanes_submit_host: where the submission's mel goes once its group is out
+        int32_t ld_out_host = 0;
+        unsigned long long sum = 0;                               // debug mode: checksum of the device inputs as they were at submit
     };
     std::vector<Pending> pend;
+    // as_lanes_submit_host: the lane's own device block -- the inputs of a group's submissions side by side (adjacent column ranges: one
+    // batch as they lie) and the group's output
+    struct Block {
+        void* dev = nullptr;
+        size_t bytes = 0;
+        int cap_tok = 0, cap_ref = 0, cap_out = 0;               // tokens / reference frames / mel frames (columns) the block holds
+        int used_tok = 0, used_ref = 0, used_out = 0;            // ... of which the group that is being filled has taken
+        int32_t *tokens = nullptr, *forced = nullptr;
+        float *f0 = nullptr, *ema = nullptr, *mel = nullptr, *out = nullptr;
+    } blk;
+    unsigned long long* dbg = nullptr;                            // debug mode: one device word for the checksum kernels
 };
 
 // the lane's stream is idle (lanes_submit synchronises it first): no graph is running, nothing reads the graph plan's tables
@@ -91,6 +107,8 @@ struct as_lanes {
     int next = 0;
     size_t graph_cap = 256;
     int coalesce = 1;                                             // submissions of adjacent buffers launched as ONE as_forward_test call
+    bool debug = false;                                           // as_lanes_set_debug / AS_DEBUG=1: a held-back submission's inputs are checksummed at submit and at its group's launch
+    as_model_cfg cfg;
 };
 
 namespace {
@@ -134,6 +152,8 @@ extern "C" int as_lanes_destroy(as_lanes* q)
         for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
         if (L.wa) (void)hipFree(L.wa);
         if (L.wb) (void)hipFree(L.wb);
+        if (L.blk.dev) (void)hipFree(L.blk.dev);
+        if (L.dbg) (void)hipFree(L.dbg);
         if (L.plan) as_plan_destroy(L.plan);
         if (L.gplan) as_plan_destroy(L.gplan);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -151,6 +171,9 @@ static int lanes_create(const as_model* m, int n_lanes, as_lanes** out)
     as_lanes* q = new (std::nothrow) as_lanes;
     if (!q) return (int)hipErrorOutOfMemory;
     q->m = m;
+    if (as_model_get_cfg(m, &q->cfg) != AS_OK) { delete q; return AS_EINVAL; }
+    const char* dbg = getenv("AS_DEBUG");
+    q->debug = dbg && *dbg && *dbg != '0';
     q->lanes.resize(n_lanes);
     for (Lane& L : q->lanes) {
         int rc = as_plan_create(m, &L.plan);
@@ -366,11 +389,71 @@ static bool adjacent(const Lane::Pending& p, const as_forward_io* io)
            ((!io->forced_dur && !a.forced_dur) || (io->forced_dur && a.forced_dur && io->forced_dur == a.forced_dur + nt)) &&
            io->mel_out == a.mel_out + 2 * nf && io->ld_out == a.ld_out;
 }
-// launch the pending group of lane q->next (if any) as one call
+
+// ---- debug mode (as_lanes_set_debug, AS_DEBUG=1) -------------------------------------------------------------------------------------
+// Under coalescing a submission's device buffers are read when its GROUP is launched, not when it is submitted: a caller that refills them
+// in between corrupts a batch without any sign.  Debug mode makes that loud: the inputs of a held-back submission (tokens, forced
+// durations, f0, the EMA and mel rows) are checksummed on the lane's stream when it is submitted -- the call then WAITS for that stream,
+// so the sum is of the data the caller handed over -- and again when the group goes out; a difference raises AS_STATUS_BAD_LAYOUT (the
+// group's launch returns AS_EDEVICE, as every entry point does while a bit is set).  Costs a stream synchronisation per submission.
+__global__ void __launch_bounds__(256)
+lanes_sum_kernel(const uint32_t* __restrict__ p, long n, long ld, unsigned long long salt, unsigned long long* __restrict__ out)
+{
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    const long r = blockIdx.y;
+    unsigned long long v = 0;
+    if (j < n) v = (unsigned long long)p[r * ld + j] * (2ull * (unsigned long long)(r * n + j) + 1ull + salt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);          // (a sum: the order of the additions does not matter)
+}
+
+void as_status_raise_host(int kind);                               // status.hip
+
+// checksum of a submission's device inputs as they are when the lane's stream gets here; blocks until it is known
+static int inputs_sum(as_lanes* q, Lane& L, const std::vector<int32_t>& tok_lens, const std::vector<int32_t>& ref_lens, const as_forward_io& io,
+                      unsigned long long* sum)
+{
+    if (!L.dbg && hipMalloc(reinterpret_cast<void**>(&L.dbg), sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipGetLastError();
+        return (int)hipErrorOutOfMemory;
+    }
+    long nt = 0, nr = 0;
+    for (int32_t v : tok_lens) nt += v;
+    for (int32_t v : ref_lens) nr += v;
+    AS_CHECK(hipMemsetAsync(L.dbg, 0, sizeof(unsigned long long), L.stream));
+    auto add = [&](const void* ptr, long n, long rows, long ld, unsigned long long salt) {
+        if (!ptr || n <= 0) return;
+        hipLaunchKernelGGL(lanes_sum_kernel, dim3(as_cdiv(n, 256), (unsigned)rows), dim3(256), 0, L.stream, static_cast<const uint32_t*>(ptr), n, ld, salt, L.dbg);
+    };
+    add(io.tokens, nt, 1, nt, 0x100000000ull);
+    add(io.forced_dur, nt, 1, nt, 0x200000000ull);
+    add(io.f0_raw, nr, 1, nr, 0x300000000ull);
+    add(io.ema_raw, nr, 10, io.ld_ema, 0x400000000ull);
+    add(io.mel, nr, q->cfg.n_mels, io.ld_mel, 0x500000000ull);
+    AS_CHECK_LAUNCH();
+    AS_CHECK(hipMemcpyAsync(sum, L.dbg, sizeof(unsigned long long), hipMemcpyDeviceToHost, L.stream));
+    AS_CHECK(hipStreamSynchronize(L.stream));
+    return AS_OK;
+}
+
+// launch the pending group of lane `lane` (if any) as one call
 static int flush_lane(as_lanes* q, int lane)
 {
     Lane& L = q->lanes[lane];
     if (L.pend.empty()) return AS_OK;
+    if (q->debug) {
+        for (const Lane::Pending& p : L.pend) {
+            unsigned long long now = 0;
+            const int rc = inputs_sum(q, L, p.tok_lens, p.ref_lens, p.io, &now);
+            if (rc != AS_OK) return rc;
+            if (now != p.sum) {
+                fprintf(stderr, "artspeech_hip: as_lanes (debug): the device buffers of a submission that was waiting for its group on lane %d "
+                                "changed between as_lanes_submit and the group's launch\n", lane);
+                as_status_raise_host(AS_STATUS_BAD_LAYOUT);
+            }
+        }
+    }
     std::vector<int32_t> tl, rl, fr;
     for (const Lane::Pending& p : L.pend) {
         tl.insert(tl.end(), p.tok_lens.begin(), p.tok_lens.end());
@@ -382,19 +465,36 @@ static int flush_lane(as_lanes* q, int lane)
     b.tok_lens = tl.data(); b.ref_lens = rl.data(); b.frames = fr.data();
     const as_forward_io io = L.pend.front().io;
     if (L.pend.size() > 1) ++L.n_merged;
+    // (host submissions: where each one's mel goes once the group's kernels are enqueued)
+    struct Out { float* host; int32_t ld; const float* dev; long cols; };
+    std::vector<Out> outs;
+    for (const Lane::Pending& p : L.pend)
+        if (p.out_host) {
+            long nf = 0;
+            for (int32_t v : p.frames) nf += v;
+            outs.push_back({p.out_host, p.ld_out_host, p.io.mel_out, 2 * nf});
+        }
     L.pend.clear();
+    L.blk.used_tok = L.blk.used_ref = L.blk.used_out = 0;         // (the block's next group starts at its first column: stream order keeps it behind this one)
     const int keep = q->next;
     q->next = lane;
     const int rc = lane_run(q, &b, &io, nullptr);
     if (keep != lane) q->next = keep;                             // (a flush from as_lanes_wait does not change whose turn it is)
-    return rc;
+    if (rc != AS_OK) return rc;
+    for (const Out& o : outs)
+        if (o.cols > 0)
+            AS_CHECK(hipMemcpy2DAsync(o.host, (size_t)o.ld * 4, o.dev, (size_t)io.ld_out * 4, (size_t)o.cols * 4, (size_t)q->cfg.n_mels,
+                                      hipMemcpyDeviceToHost, L.stream));
+    return AS_OK;
 }
 
-static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out)
+static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out,
+                        float* out_host = nullptr, int32_t ld_out_host = 0)
 {
     if (!q || !batch || !io || batch->B <= 0 || !batch->tok_lens || !batch->ref_lens) return AS_EINVAL;
     Lane& L = q->lanes[q->next];
-    const bool can_wait = q->coalesce > 1 && batch->frames && plain_io(io);
+    // (a host submission always joins the group of its lane's block -- a group of one when coalescing is off)
+    const bool can_wait = (q->coalesce > 1 || out_host) && batch->frames && plain_io(io);
     size_t waiting = 0;                                           // utterances of the group that waits here
     for (const Lane::Pending& p : L.pend) waiting += p.tok_lens.size();
     // (a call takes at most 1024 utterances: as_durations_f32's one-workgroup scan)
@@ -410,6 +510,12 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
     p.ref_lens.assign(batch->ref_lens, batch->ref_lens + batch->B);
     p.frames.assign(batch->frames, batch->frames + batch->B);
     p.io = *io;
+    p.out_host = out_host;
+    p.ld_out_host = ld_out_host;
+    if (q->debug && !out_host) {                                  // (a host submission's device buffers are the library's own)
+        const int rc = inputs_sum(q, L2, p.tok_lens, p.ref_lens, p.io, &p.sum);
+        if (rc != AS_OK) return rc;
+    }
     L2.pend.push_back(std::move(p));
     if (frames_host_out) memcpy(frames_host_out, batch->frames, sizeof(int32_t) * batch->B);
     if ((int)L2.pend.size() >= q->coalesce) return flush_lane(q, q->next);
@@ -420,6 +526,105 @@ extern "C" int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forw
 {
     try {
         return lanes_submit(q, batch, io, frames_host_out, lane_out);
+    } catch (...) {
+        return (int)hipErrorOutOfMemory;
+    }
+}
+
+// ---- host submissions (as_lanes_submit_host) -----------------------------------------------------------------------------------------
+// The reference's boundary hands over HOST arrays (test.py:96-113 moves tokens / mel to the device inside `synthesis`).  Here the lane owns
+// the device side: one block per lane that holds the inputs of a group's submissions as ADJACENT column ranges (so that the group is one
+// batch as it lies) and the group's output.  A submission's inputs are copied into the block's next free columns when it is submitted, the
+// group's launch follows the last of them, and every submission's mel goes back to its own host array behind the launch -- copies and
+// kernels all on the lane's stream, in that order, so the next group's copies into the same block queue up behind this group's kernels and
+// its device -> host copies by stream order alone (what as_lanes_set_coalesce's buffer rule asks of a caller that brings device buffers),
+// while the OTHER lanes' kernels run beside them.
+static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// the block holds a group of `k` submissions like this one (with some slack); a block that has to grow is replaced while the lane is idle
+static int block_fit(as_lanes* q, Lane& L, long nt, long nr, long nf2, int k)
+{
+    Lane::Block& b = L.blk;
+    if (b.dev && b.used_tok + nt <= b.cap_tok && b.used_ref + nr <= b.cap_ref && b.used_out + nf2 <= b.cap_out) return AS_OK;
+    if (!L.pend.empty()) return AS_ENOSPC;                        // (the caller sends the waiting group out first, then asks again)
+    const auto grow_to = [](long need, int k_) { return (int)std::min<long>((long)INT_MAX / 64, (need * k_ * 5 + 3) / 4 + 64); };
+    const int ct = std::max(b.cap_tok, grow_to(nt, k)), cr = std::max(b.cap_ref, grow_to(nr, k)), co = std::max(b.cap_out, grow_to(nf2, k));
+    const int n_mels = q->cfg.n_mels;
+    const size_t bytes = 2 * up256((size_t)ct * 4) + up256((size_t)cr * 4) + up256((size_t)10 * cr * 4) + up256((size_t)n_mels * cr * 4) +
+                         up256((size_t)n_mels * co * 4);
+    AS_CHECK(hipStreamSynchronize(L.stream));                     // the previous group has left the old block
+    drop_graphs(L);                                               // (its graphs hold the old block's addresses)
+    if (b.dev) q->retired.push_back(b.dev);                       // (not hipFree: it would stall the other lanes)
+    b = Lane::Block();
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return (int)hipErrorOutOfMemory;
+    }
+    char* c = static_cast<char*>(d);
+    b.dev = d; b.bytes = bytes; b.cap_tok = ct; b.cap_ref = cr; b.cap_out = co;
+    b.tokens = reinterpret_cast<int32_t*>(c); c += up256((size_t)ct * 4);
+    b.forced = reinterpret_cast<int32_t*>(c); c += up256((size_t)ct * 4);
+    b.f0 = reinterpret_cast<float*>(c); c += up256((size_t)cr * 4);
+    b.ema = reinterpret_cast<float*>(c); c += up256((size_t)10 * cr * 4);
+    b.mel = reinterpret_cast<float*>(c); c += up256((size_t)n_mels * cr * 4);
+    b.out = reinterpret_cast<float*>(c);
+    return AS_OK;
+}
+
+static int lanes_submit_host(as_lanes* q, const as_batch* batch, const as_host_io* h, int32_t* lane_out)
+{
+    if (!q || !batch || !h || batch->B <= 0 || !batch->tok_lens || !batch->ref_lens || !batch->frames) return AS_EINVAL;
+    if (!h->tokens || !h->mel || !h->f0_raw || !h->ema_raw || !h->mel_out) return AS_EINVAL;
+    long nt = 0, nr = 0, nf = 0;
+    for (int b = 0; b < batch->B; ++b) {
+        if (batch->tok_lens[b] < 0 || batch->ref_lens[b] < 0 || batch->frames[b] < 0) return AS_EINVAL;
+        nt += batch->tok_lens[b]; nr += batch->ref_lens[b]; nf += batch->frames[b];
+    }
+    if (h->ld_mel < nr || h->ld_ema < nr || h->ld_out < 2 * nf) return AS_EINVAL;
+    const int n_mels = q->cfg.n_mels;
+    for (int attempt = 0;; ++attempt) {
+        Lane& L = q->lanes[q->next];
+        // what waits on this lane came with device buffers of the caller's, or the block is full: that group goes out first
+        size_t waiting = 0;
+        for (const Lane::Pending& p : L.pend) waiting += p.tok_lens.size();
+        const bool foreign = !L.pend.empty() && (!L.pend.back().out_host || (L.pend.back().io.forced_dur != nullptr) != (h->forced_dur != nullptr) ||
+                                                 waiting + (size_t)batch->B > 1024);
+        int rc = foreign ? AS_ENOSPC : block_fit(q, L, nt, nr, 2 * nf, std::max(q->coalesce, 1));
+        if (rc == AS_ENOSPC && attempt <= (int)q->lanes.size()) {
+            rc = flush_lane(q, q->next);                          // (the turn passes on: the submission opens the next lane's group)
+            if (rc != AS_OK) return rc;
+            continue;
+        }
+        if (rc != AS_OK) return rc;
+        Lane::Block& b = L.blk;
+        hipStream_t s = L.stream;
+        AS_CHECK(hipMemcpyAsync(b.tokens + b.used_tok, h->tokens, (size_t)nt * 4, hipMemcpyHostToDevice, s));
+        if (h->forced_dur) AS_CHECK(hipMemcpyAsync(b.forced + b.used_tok, h->forced_dur, (size_t)nt * 4, hipMemcpyHostToDevice, s));
+        AS_CHECK(hipMemcpyAsync(b.f0 + b.used_ref, h->f0_raw, (size_t)nr * 4, hipMemcpyHostToDevice, s));
+        if (nr > 0) {
+            AS_CHECK(hipMemcpy2DAsync(b.ema + b.used_ref, (size_t)b.cap_ref * 4, h->ema_raw, (size_t)h->ld_ema * 4, (size_t)nr * 4, 10, hipMemcpyHostToDevice, s));
+            AS_CHECK(hipMemcpy2DAsync(b.mel + b.used_ref, (size_t)b.cap_ref * 4, h->mel, (size_t)h->ld_mel * 4, (size_t)nr * 4, (size_t)n_mels,
+                                      hipMemcpyHostToDevice, s));
+        }
+        as_forward_io io;
+        memset(&io, 0, sizeof(io));
+        io.tokens = b.tokens + b.used_tok;
+        io.mel = b.mel + b.used_ref; io.ld_mel = b.cap_ref;
+        io.f0_raw = b.f0 + b.used_ref;
+        io.ema_raw = b.ema + b.used_ref; io.ld_ema = b.cap_ref;
+        io.forced_dur = h->forced_dur ? b.forced + b.used_tok : nullptr;
+        io.mel_out = b.out + b.used_out; io.ld_out = b.cap_out;
+        // (a group mixes forced and predicted-from-known-frames submissions only if all or none bring forced durations: `adjacent` says no otherwise)
+        b.used_tok += (int)nt; b.used_ref += (int)nr; b.used_out += (int)(2 * nf);
+        return lanes_submit(q, batch, &io, nullptr, lane_out, h->mel_out, h->ld_out);
+    }
+}
+
+extern "C" int as_lanes_submit_host(as_lanes* q, const as_batch* batch, const as_host_io* io, int32_t* lane_out)
+{
+    try {
+        return lanes_submit_host(q, batch, io, lane_out);
     } catch (...) {
         return (int)hipErrorOutOfMemory;
     }
@@ -451,5 +656,14 @@ extern "C" int as_lanes_set_coalesce(as_lanes* q, int k)
     const int rc = as_lanes_flush(q);
     if (rc != AS_OK) return rc;
     q->coalesce = k;
+    return AS_OK;
+}
+
+extern "C" int as_lanes_set_debug(as_lanes* q, int on)
+{
+    if (!q) return AS_EINVAL;
+    const int rc = as_lanes_flush(q);                             // (what waits was submitted without a checksum)
+    if (rc != AS_OK) return rc;
+    q->debug = on != 0;
     return AS_OK;
 }

@@ -2590,6 +2590,13 @@ extern "C" int as_model_destroy(as_model* m)
     return AS_OK;
 }
 
+extern "C" int as_model_get_cfg(const as_model* m, as_model_cfg* out)
+{
+    if (!m || !out) return AS_EINVAL;
+    *out = m->cfg;
+    return AS_OK;
+}
+
 extern "C" int as_plan_create(const as_model* m, as_plan** out)
 {
     if (!m || !out) return AS_EINVAL;

@@ -80,6 +80,13 @@ extern "C" int as_device_status(int clear)
     return bits;
 }
 
+// a failure the HOST side of the library found (as_lanes' debug checks): the same sticky word a kernel would have written
+void as_status_raise_host(int kind)
+{
+    Slot* s = slot_of_current_device();
+    if (s && kind >= 0 && kind < AS_STATUS_KINDS) static_cast<volatile unsigned*>(s->host)[kind] = 1u;
+}
+
 // test hook: raises `kind` from a kernel, exactly as a failing kernel would
 __global__ void status_raise_kernel(unsigned* words, int kind) { as_status_raise(words, kind); }
 

@@ -476,11 +476,14 @@ class Lanes:
             n2 = 2 * sum(int(f) for f in frames) if frames is not None else int(capacity)
             if "mel" not in res:
                 res["mel"] = torch.empty((rt.cfg.n_mels, max(n2, 1)), dtype=torch.float32, device=dev)
-            if self.coalesce <= 1 and "dur_i" not in res:           # (a merged call has no per-submission home for them)
+            # a submission that a lane may hold back for its group (frames known, coalescing on) has no per-submission home for the
+            # optional outputs; every other one -- predicted durations above all, where frame_off is the only record of the split -- has
+            can_merge = self.coalesce > 1 and frames is not None
+            if not can_merge and "dur_i" not in res:
                 res["dur_i"] = torch.empty((max(Nt, 1),), dtype=torch.int32, device=dev)
                 res["frame_off"] = torch.empty((B + 1,), dtype=torch.int32, device=dev)
             io.mel_out, io.ld_out = _p(res["mel"]), res["mel"].stride(0)
-            if self.coalesce <= 1:
+            if not can_merge:
                 io.dur_i, io.frame_off = _p(res["dur_i"]), _p(res["frame_off"])
             ba = rt.batch(tok_lens=tok_lens, ref_lens=ref_lens, frames=frames)
             fr = (ctypes.c_int32 * B)()
@@ -491,6 +494,34 @@ class Lanes:
             prev = self._keep[lane.value] or []
             self._keep[lane.value] = (prev + [(ba, io, tok, mel_p, f0_p, ema_p, forced, res)])[-2 * max(self.coalesce, 1):]
         return lane.value, res
+
+    def set_debug(self, on=True):
+        """as_lanes_set_debug: the device inputs of a held-back submission are checksummed at submit and at its group's launch"""
+        check(_lib.lib().as_lanes_set_debug(self.h, int(bool(on))), "as_lanes_set_debug")
+
+    def submit_host(self, tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, forced, frames, out_mel):
+        """as_lanes_submit_host: HOST tensors in (pinned: `.pin_memory()`), the mel back into the host tensor `out_mel` [n_mels][>= 2 sum
+        frames]; the lane owns the device side (its block, the copies, the group's launch).  -> lane.  Keep the tensors alive and unchanged
+        until `wait(lane)`; `out_mel` is valid after it."""
+        def _h(t):
+            if t is None:
+                return None
+            if t.is_cuda or t.stride(-1) != 1:
+                raise _lib.HipLibraryError("expected a host tensor whose rows are dense")
+            return t.data_ptr()
+        tok_lens, ref_lens, frames = [int(v) for v in tok_lens], [int(v) for v in ref_lens], [int(v) for v in frames]
+        with torch.cuda.device(self.rt.device):
+            io = _lib.HostIO()
+            io.tokens, io.mel, io.ld_mel = _h(tok), _h(mel_p), mel_p.stride(0)
+            io.f0_raw, io.ema_raw, io.ld_ema = _h(f0_p), _h(ema_p), ema_p.stride(0)
+            io.forced_dur = _h(forced)
+            io.mel_out, io.ld_out = _h(out_mel), out_mel.stride(0)
+            ba = self.rt.batch(tok_lens=tok_lens, ref_lens=ref_lens, frames=frames)
+            lane = ctypes.c_int32(-1)
+            check(_lib.lib().as_lanes_submit_host(self.h, ctypes.byref(ba), ctypes.byref(io), ctypes.byref(lane)), "as_lanes_submit_host")
+            prev = self._keep[lane.value] or []
+            self._keep[lane.value] = (prev + [(ba, io, tok, mel_p, f0_p, ema_p, forced, out_mel)])[-2 * max(self.coalesce, 1):]
+        return lane.value
 
     def wait(self, lane=-1):
         check(_lib.lib().as_lanes_wait(self.h, lane), "as_lanes_wait")

@@ -25,7 +25,10 @@ extern "C" {
 
 typedef void* as_stream_t; /* hipStream_t */
 
-/* library/ABI version; bumped on any signature change */
+/* library/ABI version; bumped on any change of a signature or of a struct's layout (never held back for anything outside this header:
+ * bench.py's source id of the kernel sources leaves version.hip out).  as_abi_version() returns the AS_ABI_VERSION the library was built
+ * from: a caller compiled against another header must not go on (artspeech_amd/_lib.py refuses to). */
+#define AS_ABI_VERSION 8
 int as_abi_version(void);
 
 /* Device-side status.  The reference's operators cannot return silently stale results: nn.Embedding raises on an id >= n_token
@@ -37,10 +40,13 @@ int as_abi_version(void);
  *   bit AS_STATUS_BAD_TOKEN     a token id outside [0, n_token) reached the embedding (it was clamped)
  *   bit AS_STATUS_F16_RANGE     a conv GEMM produced a non-finite accumulator: an operand beyond fp16's range, |x| > 65504, or a
  *                               non-finite input (every launch under the debug probe as_set_range_probe; ALWAYS the last conv of
- *                               as_forward_test / as_decoder_forward, `to_out`: inf / NaN anywhere upstream reaches it, so a
- *                               non-finite mel is never handed back silently)
- *   bit AS_STATUS_BAD_LAYOUT    an utterance wider than AS_META_MAX_W columns reached as_make_meta (its descriptors are void), or an
- *                               utterance wider than the post_max_w its caller named reached as_conv_gemm_multi_post_f32's reduction
+ *                               as_forward_test / as_decoder_forward, `to_out`: inf / NaN anywhere upstream reaches it -- every
+ *                               ReLU of the library keeps a NaN, as torch.relu does -- so a non-finite mel is never handed back
+ *                               silently)
+ *   bit AS_STATUS_BAD_LAYOUT    an utterance wider than AS_META_MAX_W columns reached as_make_meta (its descriptors are void), an
+ *                               utterance wider than the post_max_w its caller named -- or, with one utterance, another column range
+ *                               than [0, N) -- reached as_conv_gemm_multi_post_f32's reduction, or (as_lanes_set_debug) the device
+ *                               buffers of a submission changed while it was waiting for its group
  * as_device_status returns the bits raised on the current HIP device since the last clear (0 = healthy) without synchronising; it is
  * final for work whose stream has been synchronised.  The module-level entry points (as_*_forward, as_forward_test*) return
  * AS_EDEVICE while any bit is set: results computed since it was raised are invalid; clear it to go on. */
@@ -315,7 +321,9 @@ int as_adain_image_f32(const AsAdainArgs* args_host, as_stream_t stream);
  * utterance is wider than 256 columns (post_max_w[i] = the widest utterance of problem i), so that kernel computes the statistics and
  * writes the image itself -- conv -> reduce+AdaIN -> conv instead of conv -> reduce -> AdaIN -> conv, bit-identical to the separate
  * launches.  Everywhere else the call is exactly as_conv_gemm_multi_f32 followed by as_adain_image_f32 on list[i].Y.
- * post_host NULL: as_conv_gemm_multi_f32.  Not with transpose_out / ileave_u.
+ * post_host NULL: as_conv_gemm_multi_f32.  Not with transpose_out / ileave_u.  With ONE utterance (post[i].U == 1) the fused reduction
+ * takes the utterance to be columns [0, N) without waiting for col_off; a col_off that says otherwise raises AS_STATUS_BAD_LAYOUT (the
+ * two-launch form honours it: the two never differ silently).
  * The same for a conv whose result is read through a channel LayerNorm (+ ReLU) -- the encoders' conv -> residual add -> LayerNorm -> conv
  * (RelTransformerEnc.py:72-87, 318-325): problem i with post_ln_host[i].yh != NULL also leaves the operand image
  * yh = split(ReLU?(LayerNorm(y_i))) (as_channel_layernorm_split_f32's arithmetic and parameter addressing: column group g = column /
@@ -579,6 +587,8 @@ typedef struct as_model_cfg {
  * weight out for the kernels and uploads it. */
 int as_model_create(const void* blob_host, size_t blob_bytes, const as_model_cfg* cfg, as_model** out);
 int as_model_destroy(as_model* m);
+/* the configuration the model was created with */
+int as_model_get_cfg(const as_model* m, as_model_cfg* out);
 int as_plan_create(const as_model* m, as_plan** out);
 int as_plan_destroy(as_plan* p);
 /* on = 1: the independent branches of a forward run on the calling stream instead of on side streams (one chain per batch: the
@@ -717,6 +727,31 @@ int as_lanes_wait(as_lanes* q, int lane);
  * (models.py:361-362 processes one utterance at a time: any grouping is legal, and every utterance gets its batch-1 result.) */
 int as_lanes_set_coalesce(as_lanes* q, int k);
 int as_lanes_flush(as_lanes* q);
+/* Debug mode (also switched on by AS_DEBUG=1 in the environment at as_lanes_create).  The buffer rule above is the caller's to keep, and a
+ * caller that breaks it corrupts a batch without a sign.  With debug on, the device inputs of a submission that is held back for its group
+ * (tokens, forced durations, f0, the EMA and mel rows) are checksummed when it is submitted -- the submit then WAITS for its lane's stream, so
+ * the sum is of what was handed over -- and again when the group is launched: a difference raises AS_STATUS_BAD_LAYOUT and the call that
+ * launches the group returns AS_EDEVICE.  One stream synchronisation per submission: not for production traffic. */
+int as_lanes_set_debug(as_lanes* q, int on);
+/* Host submissions: the boundary of the reference hands over HOST arrays (test.py:96-113 moves tokens / mel to the device inside
+ * `synthesis` and the mel back), and under coalescing the device-buffer rule above is easy to get wrong -- so the lane can own the device
+ * side.  as_lanes_submit_host copies the submission's inputs into the next free column range of the lane's own device block (one block per
+ * lane: a group's submissions lie side by side in it, i.e. they are adjacent as as_lanes_set_coalesce wants them, with no gather), launches
+ * the group when it is full (coalesce = 1: at once) and copies every submission's mel to ITS host array behind the launch -- copies and
+ * kernels on the lane's stream in exactly that order, so a block is refilled only behind the kernels and copies of the group that used
+ * it, by stream order, while the other lanes' kernels run beside the copies.  batch->frames must be given (forced durations, or known
+ * from an earlier pass).  Pointers are HOST pointers: pinned memory (hipHostMalloc) for copies that do not block the calling thread; the
+ * input arrays must stay unchanged and the output array is valid after as_lanes_wait(q, lane) (lane = *lane_out) has returned.  A
+ * submission that does not fit behind what waits on its lane's block (or follows a device submission there) sends that group out first. */
+typedef struct as_host_io {
+    const int32_t* tokens;                 /* [sum tok_lens] */
+    const float* mel; int32_t ld_mel;      /* [n_mels][ld_mel >= sum ref_lens] */
+    const float* f0_raw;                   /* [sum ref_lens] */
+    const float* ema_raw; int32_t ld_ema;  /* [10][ld_ema >= sum ref_lens] */
+    const int32_t* forced_dur;             /* optional [sum tok_lens] */
+    float* mel_out; int32_t ld_out;        /* [n_mels][ld_out >= 2 * sum frames] */
+} as_host_io;
+int as_lanes_submit_host(as_lanes* q, const as_batch* batch, const as_host_io* io, int32_t* lane_out);
 int64_t as_lanes_merged_calls(const as_lanes* q, int lane);   /* as_forward_test calls of this lane that held more than one submission */
 /* tuning / tests: graphs a lane keeps (>= 1), and the layout cap of every lane's eager plan (as_plan_set_layout_cap) */
 int as_lanes_set_graph_cap(as_lanes* q, int max_graphs);

@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     assert set(_lib._SIGNATURES) == set(declared())
     L = _lib.lib()                     # dlopen + resolve every symbol (torch is imported first by _lib)
-    assert L.as_abi_version() >= 1
+    hdr = open(os.path.join(ROOT, "include", "artspeech_hip.h")).read()
+    assert L.as_abi_version() == int(re.search(r"#define AS_ABI_VERSION (\d+)", hdr).group(1)) == _lib.AS_ABI_VERSION
     assert L.as_mas_workspace_bytes(2, 40, 100) > 0
     assert L.as_mas_workspace_bytes(2, 1 << 20, 100) == 0      # unsupported geometry -> 0, not a crash
 

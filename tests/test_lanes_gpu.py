@@ -1,6 +1,7 @@
 """GPU: as_lanes (csrc/lanes.hip) -- the throughput arrangement as a piece of the library: batches submitted round robin to N serial plans
 on their own streams (eager, captured, then graph-replayed) produce the bits of the same batches run one at a time through
 as_forward_test; predicted durations (frame counts read back, workspace re-sized on AS_ENOSPC) included."""
+import numpy as np
 import pytest
 import torch
 
@@ -54,6 +55,7 @@ def test_lanes_forced_durations_graph_replay_bitwise():
         for i in range(n_lanes):
             assert torch.equal(outs[i]["mel"], wants[i]), (r, i)
             outs[i]["mel"].zero_()                            # the next round must write it again
+            torch.cuda.synchronize()                          # (the memset ran on torch's stream, the lanes launch on their own: order them)
     # another geometry on the same lanes (workspaces grow, graphs are dropped), then the first one again
     _, big = bench.make_inputs(dev, 12, 30, 80, 120, seed0=bench.DATA_SEED + 77, vary=True)
     want_big = ref.forward_packed(big["tok"], big["tok_lens"], big["mel"], big["f0"], big["ema"], big["ref_lens"], forced=big["forced"],
@@ -146,6 +148,7 @@ def test_lanes_survive_layout_flushes_and_graph_eviction():
             h = hot[k * n_lanes + i]
             assert torch.equal(h["out"]["mel"], h["want"]), (k, i)
             h["out"]["mel"].zero_()
+            torch.cuda.synchronize()                          # (the memset ran on torch's stream, the lanes launch on their own: order them)
 
     # workspaces at their final size from the start (a workspace that moves drops the lane's graphs -- not what this test is after; and a
     # smaller batch can need MORE room than a larger one: split-K slabs exist only where the tile grid is small)
@@ -249,6 +252,7 @@ def test_lanes_coalesce_adjacent_submissions():
     for r in range(5):                                         # eager, eager (graph plan), captured, replayed, replayed
         for i, (g, subs, mel_all) in enumerate(blocks):
             mel_all.zero_()
+            torch.cuda.synchronize()                          # (the memset ran on torch's stream, the lanes launch on their own: order them)
             assert [submit(sub) for sub in subs] == [i] * k    # a group fills ONE lane, then the turn passes on
         lanes.wait()
         got = [sub["out"]["mel"].clone() for (_, subs, _) in blocks for sub in subs]
@@ -264,6 +268,7 @@ def test_lanes_coalesce_adjacent_submissions():
     # not neighbours: the first halves of the two blocks one after the other -- each goes out alone, with the bits of the alone run
     for (_, subs, mel_all) in blocks:
         mel_all.zero_()
+    torch.cuda.synchronize()                              # (torch's stream -> the lanes' streams)
     la = submit(blocks[0][1][0])
     lb = submit(blocks[1][1][0])                               # (sends the one that waits on lane `la` out first)
     assert lb == (la + 1) % n_lanes
@@ -274,6 +279,7 @@ def test_lanes_coalesce_adjacent_submissions():
     lanes.set_coalesce(1)
     sub = blocks[0][1][1]
     sub["out"]["mel"].zero_()
+    torch.cuda.synchronize()                          # (the memset ran on torch's stream, the lanes launch on their own: order them)
     lane, o = lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], forced=sub["forced"],
                            frames=sub["frames"], out=sub["out"])
     lanes.wait(lane)
@@ -301,6 +307,7 @@ def test_c3_coalesced_lanes_vs_oracle():
     lanes.set_coalesce(2)
     for r in range(4):                                         # the last round is a graph replay
         mel_all.zero_()
+        torch.cuda.synchronize()                          # (the memset ran on torch's stream, the lanes launch on their own: order them)
         for sub in subs:
             lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], forced=sub["forced"],
                          frames=sub["frames"], out=sub["out"])
@@ -323,3 +330,188 @@ def test_c3_coalesced_lanes_vs_oracle():
     assert _lib.lib().as_device_status(0) == 0
     lanes.close()
 
+
+
+def _sub_args(sub):
+    return (sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"])
+
+
+def test_lanes_debug_mode_reports_buffers_overwritten_while_pending():
+    """The buffer rule of as_lanes_set_coalesce (a held-back submission's device buffers are read when its GROUP is launched) is the
+    caller's to keep; as_lanes_set_debug makes a breach loud: the inputs are checksummed at submit and at the group's launch, a difference
+    raises AS_STATUS_BAD_LAYOUT and the launching call fails.  A clean round under debug mode gives the results of the plain lanes."""
+    import bench
+    from artspeech_amd import _lib, models
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    net = _net(dev)
+    solo = _alone(net)
+    host, g = bench.make_inputs(dev, 16, 24, 60, 100, seed0=bench.DATA_SEED + 901, vary=True)
+    subs, mel_all = bench.adjacent_submissions(g, 8)
+    wants = []
+    for j in range(2):
+        gj = bench.pack_inputs(host, list(range(8 * j, 8 * j + 8)), dev)
+        wants.append(solo.forward_packed(gj["tok"], gj["tok_lens"], gj["mel"], gj["f0"], gj["ema"], gj["ref_lens"], forced=gj["forced"],
+                                         frames_hint=gj["frames"])["mel"].clone())
+    torch.cuda.synchronize()
+    lanes = models.Lanes(net, 1)
+    lanes.set_coalesce(2)
+    lanes.set_debug(True)
+    # a clean round
+    for sub in subs:
+        lanes.submit(*_sub_args(sub), forced=sub["forced"], frames=sub["frames"], out=sub["out"])
+    lanes.wait()
+    for sub, w in zip(subs, wants):
+        assert float((sub["out"]["mel"] - w).abs().max()) <= 3e-5
+    assert _lib.lib().as_device_status(0) == 0
+    # the first submission's tokens are overwritten while it waits for its neighbour: the group's launch says so
+    lanes.submit(*_sub_args(subs[0]), forced=subs[0]["forced"], frames=subs[0]["frames"], out=subs[0]["out"])
+    keep = subs[0]["tok"].clone()
+    subs[0]["tok"].copy_(torch.flip(keep, dims=[0]))
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.HipLibraryError, match="as_device_status|kernel reported"):
+        lanes.submit(*_sub_args(subs[1]), forced=subs[1]["forced"], frames=subs[1]["frames"], out=subs[1]["out"])
+        lanes.wait()
+    assert _lib.lib().as_device_status(0) & (1 << 4)               # AS_STATUS_BAD_LAYOUT
+    assert _lib.lib().as_device_status(1) != 0                     # (clear)
+    subs[0]["tok"].copy_(keep)
+    torch.cuda.synchronize()
+    # ... and the same with a mel row (a strided 2-D input), caught at as_lanes_wait's flush
+    lanes.submit(*_sub_args(subs[0]), forced=subs[0]["forced"], frames=subs[0]["frames"], out=subs[0]["out"])
+    row = subs[0]["mel"][37].clone()
+    subs[0]["mel"][37].add_(1.0)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.HipLibraryError):
+        lanes.wait()
+    assert _lib.lib().as_device_status(1) & (1 << 4)
+    subs[0]["mel"][37].copy_(row)
+    torch.cuda.synchronize()
+    # healthy again
+    for sub in subs:
+        lanes.submit(*_sub_args(sub), forced=sub["forced"], frames=sub["frames"], out=sub["out"])
+    lanes.wait()
+    for sub, w in zip(subs, wants):
+        assert float((sub["out"]["mel"] - w).abs().max()) <= 3e-5
+    lanes.close()
+
+
+def test_lanes_failed_group_surfaces_at_wait_and_short_last_group():
+    """k = 3: two submissions and as_lanes_wait -- the short group goes out as one call of two; then a group whose tokens hold an id the
+    embedding cannot look up: its submits return (nothing is enqueued until the group is full), the failure of the group's kernels is what
+    as_lanes_wait returns (AS_EDEVICE, AS_STATUS_BAD_TOKEN), and after the clear the lanes serve again."""
+    import bench
+    from artspeech_amd import _lib, models
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    net = _net(dev)
+    solo = _alone(net)
+    host, g = bench.make_inputs(dev, 24, 24, 60, 100, seed0=bench.DATA_SEED + 902, vary=True)
+    subs, mel_all = bench.adjacent_submissions(g, 8)
+    wants = []
+    for j in range(3):
+        gj = bench.pack_inputs(host, list(range(8 * j, 8 * j + 8)), dev)
+        wants.append(solo.forward_packed(gj["tok"], gj["tok_lens"], gj["mel"], gj["f0"], gj["ema"], gj["ref_lens"], forced=gj["forced"],
+                                         frames_hint=gj["frames"])["mel"].clone())
+    torch.cuda.synchronize()
+    lanes = models.Lanes(net, 2)
+    lanes.set_coalesce(3)
+    for r in range(4):                                             # full groups of three: eager, eager, captured, replayed
+        for sub in subs:
+            lanes.submit(*_sub_args(sub), forced=sub["forced"], frames=sub["frames"], out=sub["out"])
+    lanes.wait()
+    for sub, w in zip(subs, wants):
+        assert float((sub["out"]["mel"] - w).abs().max()) <= 3e-5
+    merged0 = sum(lanes.merged_calls(i) for i in range(2))
+    assert merged0 == 4
+    mel_all.zero_()
+    torch.cuda.synchronize()
+    la = [lanes.submit(*_sub_args(sub), forced=sub["forced"], frames=sub["frames"], out=sub["out"])[0] for sub in subs[:2]]
+    assert la[0] == la[1]
+    assert float(mel_all.abs().max()) == 0.0                       # (held back: nothing has run)
+    lanes.wait()                                                   # the short group: ONE call over the two
+    assert sum(lanes.merged_calls(i) for i in range(2)) == merged0 + 1
+    for sub, w in zip(subs[:2], wants[:2]):
+        assert float((sub["out"]["mel"] - w).abs().max()) <= 3e-5
+    assert float(subs[2]["out"]["mel"].abs().max()) == 0.0
+    # a bad token inside the second submission of a group
+    keep = subs[1]["tok"].clone()
+    subs[1]["tok"][3] = 100000
+    torch.cuda.synchronize()
+    for sub in subs[:2]:
+        lanes.submit(*_sub_args(sub), forced=sub["forced"], frames=sub["frames"], out=sub["out"])   # (returns: the group is not out yet)
+    with pytest.raises(_lib.HipLibraryError):
+        lanes.submit(*_sub_args(subs[2]), forced=subs[2]["forced"], frames=subs[2]["frames"], out=subs[2]["out"])   # launches the group
+        lanes.wait()                                               # ... whose kernels raise the bit
+    assert _lib.lib().as_device_status(1) & (1 << 2)               # AS_STATUS_BAD_TOKEN; cleared
+    subs[1]["tok"].copy_(keep)
+    torch.cuda.synchronize()
+    for sub in subs:
+        lanes.submit(*_sub_args(sub), forced=sub["forced"], frames=sub["frames"], out=sub["out"])
+    lanes.wait()
+    for sub, w in zip(subs, wants):
+        assert float((sub["out"]["mel"] - w).abs().max()) <= 3e-5
+    lanes.close()
+
+
+def test_lanes_submit_host_blocks_refilled_behind_groups_in_flight():
+    """as_lanes_submit_host: host arrays in, host arrays out, the lane owns the device block.  Twelve DIFFERENT batches go through two
+    coalescing lanes back to back without a wait in between -- every lane's block is refilled (by the submit's copies) while the block's
+    previous group and the other lane's group are in flight; stream order on the lane's stream is all that keeps them apart -- and every
+    utterance of every batch is held against the same batch run alone from device buffers (<= 3e-5: a group is another GEMM tile).  Then
+    the same batches again (graphs by now): the bits of the first pass."""
+    import bench
+    from artspeech_amd import _lib, models
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    net = _net(dev)
+    solo = _alone(net)
+    n_b, per = 12, 8
+    pin = lambda a: torch.from_numpy(a).pin_memory()
+    batches, wants = [], []
+    for i in range(n_b):
+        # (three geometries in rotation: groups of equal geometry come back and are replayed from graphs; the lengths inside a batch vary)
+        host, g = bench.make_inputs(dev, per, 24, 60, 100, seed0=bench.DATA_SEED + 3000 + (i % 3), vary=True)
+        host2, _ = bench.make_inputs(None, per, 24, 60, 100, seed0=bench.DATA_SEED + 3000 + (i % 3), vary=True)
+        # same geometry, other values: the reference features and tokens of batch i
+        rng = np.random.default_rng(7000 + i)
+        for b in range(per):
+            host2["mel"][b] = (host["mel"][b] + 0.1 * rng.standard_normal(host["mel"][b].shape)).astype(np.float32)
+            host2["tokens"][b] = np.concatenate([[0], rng.integers(1, 178, size=len(host["tokens"][b]) - 2), [0]]).astype(host["tokens"][b].dtype)
+        gi = bench.pack_inputs(host2, list(range(per)), dev)
+        wants.append(solo.forward_packed(gi["tok"], gi["tok_lens"], gi["mel"], gi["f0"], gi["ema"], gi["ref_lens"], forced=gi["forced"],
+                                         frames_hint=gi["frames"])["mel"].cpu())
+        cat = lambda key, ax: np.ascontiguousarray(np.concatenate([host2[key][b] for b in range(per)], ax))
+        n2 = 2 * sum(host2["frames"])
+        batches.append(dict(tok=pin(cat("tokens", 0).astype(np.int32)), mel=pin(cat("mel", 1)), f0=pin(cat("f0", 1).reshape(-1)),
+                            ema=pin(cat("ema", 1)), forced=pin(cat("forced", 0).astype(np.int32)), tok_lens=host2["tok_lens"],
+                            ref_lens=host2["ref_lens"], frames=host2["frames"], out=torch.zeros((80, n2), dtype=torch.float32).pin_memory()))
+    torch.cuda.synchronize()
+    lanes = models.Lanes(net, 2)
+    lanes.set_coalesce(2)
+    first = None
+    for r in range(4):
+        for b in batches:
+            b["out"].zero_()
+        for b in batches:                                          # no wait in between: blocks are refilled behind groups in flight
+            lanes.submit_host(b["tok"], b["tok_lens"], b["mel"], b["f0"], b["ema"], b["ref_lens"], b["forced"], b["frames"], b["out"])
+        lanes.wait()
+        for i, (b, w) in enumerate(zip(batches, wants)):
+            assert b["out"].shape == w.shape
+            d = float((b["out"] - w).abs().max())
+            assert d <= 3e-5, (r, i, d)
+        if r == 2:
+            first = [b["out"].clone() for b in batches]
+        if r == 3:
+            for b, f in zip(batches, first):
+                assert torch.equal(b["out"], f)
+    assert sum(lanes.merged_calls(i) for i in range(2)) == 4 * n_b // 2
+    assert lanes.stats(0)["graph_launches"] >= 2
+    # a lone host submission with coalescing off: a group of one
+    lanes.set_coalesce(1)
+    b = batches[5]
+    b["out"].zero_()
+    lane = lanes.submit_host(b["tok"], b["tok_lens"], b["mel"], b["f0"], b["ema"], b["ref_lens"], b["forced"], b["frames"], b["out"])
+    lanes.wait(lane)
+    assert float((b["out"] - wants[5]).abs().max()) <= 3e-5
+    assert _lib.lib().as_device_status(0) == 0
+    lanes.close()
