@@ -61,7 +61,11 @@ struct Lane {
         int used_tok = 0, used_ref = 0, used_out = 0;            // ... of which the group that is being filled has taken
         int32_t *tokens = nullptr, *forced = nullptr;
         float *f0 = nullptr, *ema = nullptr, *mel = nullptr, *out = nullptr;
-    } blk;
+    } blk[2];                                                     // two, alternating from group to group: the next group's copies run under this group's kernels
+    int cur = 0;                                                  // the block the group that is being filled lives in
+    bool blk_used[2] = {false, false};                            // a group has gone out from it (ev_d2h[i] has been recorded)
+    hipStream_t h2d = nullptr, d2h = nullptr;                     // copy streams of the host submissions (created with the first one)
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
     unsigned long long* dbg = nullptr;                            // debug mode: one device word for the checksum kernels
 };
 
@@ -146,13 +150,23 @@ extern "C" int as_lanes_destroy(as_lanes* q)
             if (q->lanes[i].plan && q->lanes[i].gplan && q->lanes[i].stream) (void)flush_lane(q, i);
     } catch (...) {
     }
-    for (Lane& L : q->lanes)
+    for (Lane& L : q->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
+        if (L.h2d) (void)hipStreamSynchronize(L.h2d);
+        if (L.d2h) (void)hipStreamSynchronize(L.d2h);
+    }
     for (Lane& L : q->lanes) {
         for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
         if (L.wa) (void)hipFree(L.wa);
         if (L.wb) (void)hipFree(L.wb);
-        if (L.blk.dev) (void)hipFree(L.blk.dev);
+        for (int i = 0; i < 2; ++i) {
+            if (L.blk[i].dev) (void)hipFree(L.blk[i].dev);
+            if (L.ev_h2d[i]) (void)hipEventDestroy(L.ev_h2d[i]);
+            if (L.ev_comp[i]) (void)hipEventDestroy(L.ev_comp[i]);
+            if (L.ev_d2h[i]) (void)hipEventDestroy(L.ev_d2h[i]);
+        }
+        if (L.h2d) (void)hipStreamDestroy(L.h2d);
+        if (L.d2h) (void)hipStreamDestroy(L.d2h);
         if (L.dbg) (void)hipFree(L.dbg);
         if (L.plan) as_plan_destroy(L.plan);
         if (L.gplan) as_plan_destroy(L.gplan);
@@ -263,8 +277,12 @@ extern "C" int as_lanes_wait(as_lanes* q, int lane)
         return (int)hipErrorOutOfMemory;
     }
     for (int i = 0; i < (int)q->lanes.size(); ++i)
-        if (lane < 0 || lane == i)
+        if (lane < 0 || lane == i) {
             if (hipStreamSynchronize(q->lanes[i].stream) != hipSuccess) return (int)hipErrorUnknown;
+            // (host submissions: their mel is at home when the lane's device -> host stream has drained)
+            if (q->lanes[i].d2h && hipStreamSynchronize(q->lanes[i].d2h) != hipSuccess) return (int)hipErrorUnknown;
+            if (q->lanes[i].h2d && hipStreamSynchronize(q->lanes[i].h2d) != hipSuccess) return (int)hipErrorUnknown;
+        }
     if (lane < 0) free_retired(q);                                // every lane is idle: a free's device synchronisation costs nothing now
     return as_device_status(0) ? AS_EDEVICE : AS_OK;
 }
@@ -274,6 +292,9 @@ static int lane_run(as_lanes* q, const as_batch* batch, const as_forward_io* io,
 {
     const int lane = q->next;
     Lane& L = q->lanes[lane];
+    // a status bit is up: as_forward_test would refuse anyway -- but it must do so before the pair's state moves on (a refused call under
+    // capture would look up its layouts there, and a plan's first look-up of a geometry is an upload: not capturable)
+    if (as_device_status(0)) return AS_EDEVICE;
     // the lane's previous batch has left its workspaces (and the caller's buffers of that lane)
     if (hipStreamSynchronize(L.stream) != hipSuccess) return (int)hipErrorUnknown;
     // (sizes come from the eager plan: a count pass adds host-side layout entries, which that plan may flush; the graph plan stays small)
@@ -475,17 +496,31 @@ static int flush_lane(as_lanes* q, int lane)
             outs.push_back({p.out_host, p.ld_out_host, p.io.mel_out, 2 * nf});
         }
     L.pend.clear();
-    L.blk.used_tok = L.blk.used_ref = L.blk.used_out = 0;         // (the block's next group starts at its first column: stream order keeps it behind this one)
+    const bool host_group = !outs.empty();
+    const int bi = L.cur;
+    if (host_group) {                                             // the group's kernels start behind its host -> device copies
+        AS_CHECK(hipEventRecord(L.ev_h2d[bi], L.h2d));
+        AS_CHECK(hipStreamWaitEvent(L.stream, L.ev_h2d[bi], 0));
+        L.cur ^= 1;                                               // (the next group of this lane fills the other block)
+        L.blk_used[bi] = true;
+    }
     const int keep = q->next;
     q->next = lane;
     const int rc = lane_run(q, &b, &io, nullptr);
     if (keep != lane) q->next = keep;                             // (a flush from as_lanes_wait does not change whose turn it is)
-    if (rc != AS_OK) return rc;
-    for (const Out& o : outs)
-        if (o.cols > 0)
-            AS_CHECK(hipMemcpy2DAsync(o.host, (size_t)o.ld * 4, o.dev, (size_t)io.ld_out * 4, (size_t)o.cols * 4, (size_t)q->cfg.n_mels,
-                                      hipMemcpyDeviceToHost, L.stream));
-    return AS_OK;
+    if (host_group) {
+        // ... and every submission's mel goes home behind them, on the lane's device -> host stream: the lane's next group computes meanwhile.
+        // ev_d2h[bi] is what the block's NEXT group's copies wait for (recorded whatever happened: a block is never left without it)
+        hipError_t e = hipEventRecord(L.ev_comp[bi], L.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(L.d2h, L.ev_comp[bi], 0);
+        for (const Out& o : outs)
+            if (rc == AS_OK && e == hipSuccess && o.cols > 0)
+                e = hipMemcpy2DAsync(o.host, (size_t)o.ld * 4, o.dev, (size_t)io.ld_out * 4, (size_t)o.cols * 4, (size_t)q->cfg.n_mels,
+                                     hipMemcpyDeviceToHost, L.d2h);
+        const hipError_t e2 = hipEventRecord(L.ev_d2h[bi], L.d2h);
+        if (rc == AS_OK && (e != hipSuccess || e2 != hipSuccess)) return (int)(e != hipSuccess ? e : e2);
+    }
+    return rc;
 }
 
 static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out,
@@ -535,16 +570,28 @@ extern "C" int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forw
 // The reference's boundary hands over HOST arrays (test.py:96-113 moves tokens / mel to the device inside `synthesis`).  Here the lane owns
 // the device side: one block per lane that holds the inputs of a group's submissions as ADJACENT column ranges (so that the group is one
 // batch as it lies) and the group's output.  A submission's inputs are copied into the block's next free columns when it is submitted, the
-// group's launch follows the last of them, and every submission's mel goes back to its own host array behind the launch -- copies and
-// kernels all on the lane's stream, in that order, so the next group's copies into the same block queue up behind this group's kernels and
-// its device -> host copies by stream order alone (what as_lanes_set_coalesce's buffer rule asks of a caller that brings device buffers),
-// while the OTHER lanes' kernels run beside them.
+// group's launch follows the last of them, and every submission's mel goes back to its own host array behind the launch.  TWO blocks per
+// lane, alternating from group to group, and a copy stream for either direction: host -> device copies of group g + 1 (stream h2d) run
+// under the kernels of group g (the lane's stream), whose results leave on stream d2h under the kernels of group g + 1.  Edges, all events
+// between streams of ONE lane: kernels(g) wait for h2d(g); d2h(g) waits for kernels(g); h2d(g + 2) -- the same block -- waits for d2h(g).
+// (With copies and kernels on the one stream the copies of a lane cost it 0.17 ms per step of 3.69: measured first.)  This is the
+// buffer rule of as_lanes_set_coalesce kept by the library instead of the caller.
 static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 // the block holds a group of `k` submissions like this one (with some slack); a block that has to grow is replaced while the lane is idle
 static int block_fit(as_lanes* q, Lane& L, long nt, long nr, long nf2, int k)
 {
-    Lane::Block& b = L.blk;
+    if (!L.h2d) {                                                 // first host submission of this lane: its copy streams and events
+        if (hipStreamCreateWithFlags(&L.h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&L.d2h, hipStreamNonBlocking) != hipSuccess)
+            return (int)hipErrorOutOfMemory;
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreateWithFlags(&L.ev_h2d[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&L.ev_comp[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&L.ev_d2h[i], hipEventDisableTiming) != hipSuccess)
+                return (int)hipErrorOutOfMemory;
+    }
+    Lane::Block& b = L.blk[L.cur];
+    if (L.pend.empty()) b.used_tok = b.used_ref = b.used_out = 0; // a new group starts at the block's first column
     if (b.dev && b.used_tok + nt <= b.cap_tok && b.used_ref + nr <= b.cap_ref && b.used_out + nf2 <= b.cap_out) return AS_OK;
     if (!L.pend.empty()) return AS_ENOSPC;                        // (the caller sends the waiting group out first, then asks again)
     const auto grow_to = [](long need, int k_) { return (int)std::min<long>((long)INT_MAX / 64, (need * k_ * 5 + 3) / 4 + 64); };
@@ -552,10 +599,12 @@ static int block_fit(as_lanes* q, Lane& L, long nt, long nr, long nf2, int k)
     const int n_mels = q->cfg.n_mels;
     const size_t bytes = 2 * up256((size_t)ct * 4) + up256((size_t)cr * 4) + up256((size_t)10 * cr * 4) + up256((size_t)n_mels * cr * 4) +
                          up256((size_t)n_mels * co * 4);
-    AS_CHECK(hipStreamSynchronize(L.stream));                     // the previous group has left the old block
+    AS_CHECK(hipStreamSynchronize(L.stream));                     // the groups that used the old block have left it: kernels ...
+    AS_CHECK(hipStreamSynchronize(L.d2h));                        // ... and the copies of their results
     drop_graphs(L);                                               // (its graphs hold the old block's addresses)
     if (b.dev) q->retired.push_back(b.dev);                       // (not hipFree: it would stall the other lanes)
     b = Lane::Block();
+    L.blk_used[L.cur] = false;
     void* d = nullptr;
     if (hipMalloc(&d, bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -597,8 +646,11 @@ static int lanes_submit_host(as_lanes* q, const as_batch* batch, const as_host_i
             continue;
         }
         if (rc != AS_OK) return rc;
-        Lane::Block& b = L.blk;
-        hipStream_t s = L.stream;
+        Lane::Block& b = L.blk[L.cur];
+        hipStream_t s = L.h2d;
+        // the block's previous group (two groups back on this lane) has left it -- its kernels and the copies of its results -- before
+        // the first copy of this one lands
+        if (L.pend.empty() && L.blk_used[L.cur]) AS_CHECK(hipStreamWaitEvent(s, L.ev_d2h[L.cur], 0));
         AS_CHECK(hipMemcpyAsync(b.tokens + b.used_tok, h->tokens, (size_t)nt * 4, hipMemcpyHostToDevice, s));
         if (h->forced_dur) AS_CHECK(hipMemcpyAsync(b.forced + b.used_tok, h->forced_dur, (size_t)nt * 4, hipMemcpyHostToDevice, s));
         AS_CHECK(hipMemcpyAsync(b.f0 + b.used_ref, h->f0_raw, (size_t)nr * 4, hipMemcpyHostToDevice, s));

@@ -737,9 +737,10 @@ int as_lanes_set_debug(as_lanes* q, int on);
  * `synthesis` and the mel back), and under coalescing the device-buffer rule above is easy to get wrong -- so the lane can own the device
  * side.  as_lanes_submit_host copies the submission's inputs into the next free column range of the lane's own device block (one block per
  * lane: a group's submissions lie side by side in it, i.e. they are adjacent as as_lanes_set_coalesce wants them, with no gather), launches
- * the group when it is full (coalesce = 1: at once) and copies every submission's mel to ITS host array behind the launch -- copies and
- * kernels on the lane's stream in exactly that order, so a block is refilled only behind the kernels and copies of the group that used
- * it, by stream order, while the other lanes' kernels run beside the copies.  batch->frames must be given (forced durations, or known
+ * the group when it is full (coalesce = 1: at once) and copies every submission's mel to ITS host array behind the launch.  A lane keeps
+ * TWO such blocks and alternates between them from group to group, with a copy stream of its own for either direction: the copies of a
+ * lane's next group run under the kernels of its current one, and a block is refilled only behind the kernels AND the result copies of
+ * the group that used it last (events between the lane's three streams; nothing for the caller to keep).  batch->frames must be given (forced durations, or known
  * from an earlier pass).  Pointers are HOST pointers: pinned memory (hipHostMalloc) for copies that do not block the calling thread; the
  * input arrays must stay unchanged and the output array is valid after as_lanes_wait(q, lane) (lane = *lane_out) has returned.  A
  * submission that does not fit behind what waits on its lane's block (or follows a device submission there) sends that group out first. */
