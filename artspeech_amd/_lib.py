@@ -48,7 +48,7 @@ class ConvGemmArgs(ctypes.Structure):
                 ("in_slope", ctypes.c_float), ("act_slope", ctypes.c_float), ("acc_scale", ctypes.c_float),
                 ("n_groups", ctypes.c_int32), ("group_cols", ctypes.c_int32), ("range_probe", ctypes.c_int32), ("status", ctypes.c_void_p),
                 ("Xh2", ctypes.c_void_p), ("K2", ctypes.c_int32), ("src_col", ctypes.c_void_p), ("N_in", ctypes.c_int32), ("ileave_u", ctypes.c_int32),
-                ("slab_tr", ctypes.c_int32)]
+                ("slab_tr", ctypes.c_int32), ("n_valid", ctypes.c_void_p)]
 
 
 _SIGNATURES.update({
@@ -113,7 +113,8 @@ class LnArgs(ctypes.Structure):
 class AdainArgs(ctypes.Structure):
     _fields_ = [("x", c_p), ("ldx", ctypes.c_int32), ("C", ctypes.c_int32), ("gb", c_p), ("gb_off", c_p), ("ldgb", ctypes.c_int32),
                 ("gb_sc", ctypes.c_int32), ("col_off", c_p), ("src_off", c_p), ("U", ctypes.c_int32), ("N", ctypes.c_int32),
-                ("lrelu", ctypes.c_int32), ("yh", c_p), ("pool_w", c_p), ("pool_b", c_p), ("x_up", c_p), ("ld_up", ctypes.c_int32)]
+                ("lrelu", ctypes.c_int32), ("yh", c_p), ("pool_w", c_p), ("pool_b", c_p), ("x_up", c_p), ("ld_up", ctypes.c_int32),
+                ("col_w", c_p)]
 
 
 class DownArgs(ctypes.Structure):
@@ -251,7 +252,8 @@ AS_EDEVICE = -3
 STATUS_NAMES = ("clustered LSTM hand-over timed out", "MAS band hand-over timed out", "token id outside [0, n_token)",
                 "non-finite accumulator (an operand beyond fp16's range, or a non-finite input)",
                 "a layout the kernels cannot serve: an utterance wider than the column descriptors (AS_META_MAX_W) or than its caller said, "
-                "or (as_lanes debug mode) device buffers that changed while their submission was waiting for its group")
+                "or (as_lanes debug mode) device buffers that changed while their submission was waiting for its group",
+                "the predicted durations add up to more frames than the capacity the caller named (as_forward_io.frame_cap)")
 
 
 def device_status(clear=False):

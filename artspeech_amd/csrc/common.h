@@ -54,6 +54,36 @@ struct AsLdsOptIn {
 
 #define AS_WAVE 64
 
+// Capacity layouts of as_forward_test's second half (as_forward_io.frame_cap; csrc/model.hip "dynamic layouts", elementwise.hip): the
+// utterances' frame counts exist on the device only -- frame_off [B + 1], half rate, packed from column 0 -- and every table the kernels of
+// the second half read is derived from them by ONE launch.  Layout i of {0: half rate, 1: mel rate, 2: the batch three times at half rate
+// (group g from column g * cap1), 3: the same at mel rate}: widths w[i], first columns off[i] (one closing entry), column descriptors
+// meta[i], *nvalid[i] = the valid leading columns (of a group).  Any pointer may be NULL.
+struct AsDynGeo {
+    const int32_t* frame_off;
+    int32_t B, cap1, n_seg;
+    int32_t seg_first[17];            // segments = the submissions of a merged call: utterances [seg_first[s], seg_first[s + 1])
+    int32_t seg_cap[16];              // ... and the half-rate frames the segment's output slot holds
+    int32_t* seg_frame_off[16];       // optional: the segment's own frame offsets [its utterances + 1], from 0
+    int32_t* w[4];
+    int32_t* off[4];
+    unsigned long long* meta[4];
+    int32_t* nvalid[4];
+    int32_t* src3;                    // [3 B]: where utterance b of group g reads the shared half-rate input (= off[0][b])
+    int32_t* tof;                     // frame -> token map [cap1]: entries past the last frame are set to token 0
+    unsigned* status;
+};
+int as_dyn_geometry_launch(const AsDynGeo& g, hipStream_t stream);
+// mel [rows][ld_src] packed from column 0 -> every segment's columns to its own slot of dst: dst_s[r][i] = src[r][2 off[first_s] + i]
+struct AsSegScatter {
+    const float* src; int32_t ld_src, rows, n_seg;
+    const int32_t* frame_off;
+    int32_t seg_first[17];
+    int32_t seg_cap[16];
+    float* dst[16]; int32_t ld_dst[16];
+};
+int as_seg_scatter_launch(const AsSegScatter& a, hipStream_t stream);
+
 // kernel classes for the optional event profiler (prof.hip)
 enum { AS_CLS_GEMM = 0, AS_CLS_ADAIN = 1, AS_CLS_LN = 2, AS_CLS_ATTN = 3, AS_CLS_LSTM = 4, AS_CLS_MAS = 5, AS_CLS_OTHER = 6, AS_N_CLS = 7 };
 struct AsProfScope {

@@ -352,6 +352,8 @@ static __device__ __forceinline__ void as_reduce_epilogue(const ConvGemmArgs& a,
     const size_t total = (size_t)a.M * a.N;
     const float* slab = reinterpret_cast<const float*>(a.ws);
     const int grp = a.n_groups > 1 ? (j < a.N ? j : a.N - 1) / a.group_cols : 0;
+    // (capacity layouts: the slices stored nothing for the filler columns of a group, and nothing is made of what lies there)
+    if (a.n_valid && j < a.N && j - (a.n_groups > 1 ? grp * a.group_cols : 0) >= *a.n_valid) return;
     // the slabs first, eight loads (the thread's rows of one slab) in flight at a time and none of them behind a branch: with the
     // loads inside the per-row `if` every one of the 8 S waited for the one before (12.8 us per launch at batch 1, as long as the GEMM
     // it follows).  Same order of additions per element: s ascending.

@@ -103,6 +103,13 @@ conv_gemm_h3_kernel(const H3Multi mm)
         n0 = grp * a.group_cols + (tn - grp * tpg) * BN;
         n_end = min(a.N, (grp + 1) * a.group_cols);
     }
+    if (a.n_valid) {
+        // capacity layout: the group's leading *n_valid columns hold utterances, the rest is filler -- treated like the columns past
+        // the group's end (zero-column reads, no stores); a tile wholly inside it has nothing to do (tile 0 stays: it owns the zero
+        // column of the result image)
+        n_end = min(n_end, (a.n_groups > 1 ? grp * a.group_cols : 0) + __builtin_amdgcn_readfirstlane(*a.n_valid));
+        if (n0 >= n_end && n0 > 0) return;
+    }
     const int KB = a.Kp >> 4, KBx = (KB + 3) & ~3;
     const int NX = (a.src_col ? a.N_in : a.N) + 1;                       // columns of the activation image (the last one is zero)
 
@@ -633,7 +640,7 @@ adain_image_kernel(const AsAdainArgs a)
         xs[plane + a.N] = u32x4_t{0u, 0u, 0u, 0u};
         xs[plane + 2 * NX + a.N] = u32x4_t{0u, 0u, 0u, 0u};
     }
-    const int o0 = a.col_off[u], L = a.col_off[u + 1] - o0;
+    const int o0 = a.col_off[u], L = a.col_w ? a.col_w[u] : a.col_off[u + 1] - o0;
     if (L <= 0) return;
     const int s0 = a.src_off ? a.src_off[u] : o0;
     const size_t gbase = a.gb_off ? (size_t)a.gb_off[u] : (size_t)u * a.ldgb;

@@ -64,7 +64,6 @@ struct Lane {
     } blk[2];                                                     // two, alternating from group to group: the next group's copies run under this group's kernels
     int cur = 0;                                                  // the block the group that is being filled lives in
     bool blk_used[2] = {false, false};                            // a group has gone out from it (ev_d2h[i] has been recorded)
-    hipStream_t h2d = nullptr, d2h = nullptr;                     // copy streams of the host submissions (created with the first one)
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
     unsigned long long* dbg = nullptr;                            // debug mode: one device word for the checksum kernels
 };
@@ -113,6 +112,13 @@ struct as_lanes {
     int coalesce = 1;                                             // submissions of adjacent buffers launched as ONE as_forward_test call
     bool debug = false;                                           // as_lanes_set_debug / AS_DEBUG=1: a held-back submission's inputs are checksummed at submit and at its group's launch
     as_model_cfg cfg;
+    // copy streams of the host submissions, ONE pair for all lanes (created with the first host submission): HIP maps streams onto four
+    // hardware queues, and a copy stream per lane put lanes' copies behind other lanes' kernels (measured: + 7-10 % per step where the
+    // copies on the lane's own stream cost + 4.7 %)
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    bool copy_on_lane = false;                                    // AS_LANES_COPY_ON_LANE=1 (measurements): a lane's copies on its own stream
+    hipStream_t up(const Lane& L) const { return copy_on_lane ? L.stream : h2d; }
+    hipStream_t down(const Lane& L) const { return copy_on_lane ? L.stream : d2h; }
 };
 
 namespace {
@@ -152,9 +158,9 @@ extern "C" int as_lanes_destroy(as_lanes* q)
     }
     for (Lane& L : q->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        if (L.h2d) (void)hipStreamSynchronize(L.h2d);
-        if (L.d2h) (void)hipStreamSynchronize(L.d2h);
     }
+    if (q->h2d) (void)hipStreamSynchronize(q->h2d);
+    if (q->d2h) (void)hipStreamSynchronize(q->d2h);
     for (Lane& L : q->lanes) {
         for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
         if (L.wa) (void)hipFree(L.wa);
@@ -165,13 +171,13 @@ extern "C" int as_lanes_destroy(as_lanes* q)
             if (L.ev_comp[i]) (void)hipEventDestroy(L.ev_comp[i]);
             if (L.ev_d2h[i]) (void)hipEventDestroy(L.ev_d2h[i]);
         }
-        if (L.h2d) (void)hipStreamDestroy(L.h2d);
-        if (L.d2h) (void)hipStreamDestroy(L.d2h);
         if (L.dbg) (void)hipFree(L.dbg);
         if (L.plan) as_plan_destroy(L.plan);
         if (L.gplan) as_plan_destroy(L.gplan);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
+    if (q->h2d) (void)hipStreamDestroy(q->h2d);
+    if (q->d2h) (void)hipStreamDestroy(q->d2h);
     free_retired(q);
     delete q;
     return AS_OK;
@@ -188,6 +194,7 @@ static int lanes_create(const as_model* m, int n_lanes, as_lanes** out)
     if (as_model_get_cfg(m, &q->cfg) != AS_OK) { delete q; return AS_EINVAL; }
     const char* dbg = getenv("AS_DEBUG");
     q->debug = dbg && *dbg && *dbg != '0';
+    q->copy_on_lane = getenv("AS_LANES_COPY_ON_LANE") != nullptr;
     q->lanes.resize(n_lanes);
     for (Lane& L : q->lanes) {
         int rc = as_plan_create(m, &L.plan);
@@ -280,8 +287,9 @@ extern "C" int as_lanes_wait(as_lanes* q, int lane)
         if (lane < 0 || lane == i) {
             if (hipStreamSynchronize(q->lanes[i].stream) != hipSuccess) return (int)hipErrorUnknown;
             // (host submissions: their mel is at home when the lane's device -> host stream has drained)
-            if (q->lanes[i].d2h && hipStreamSynchronize(q->lanes[i].d2h) != hipSuccess) return (int)hipErrorUnknown;
-            if (q->lanes[i].h2d && hipStreamSynchronize(q->lanes[i].h2d) != hipSuccess) return (int)hipErrorUnknown;
+            const Lane& Lw = q->lanes[i];
+            for (int k = 0; k < 2; ++k)
+                if (Lw.blk_used[k] && hipEventSynchronize(Lw.ev_d2h[k]) != hipSuccess) return (int)hipErrorUnknown;
         }
     if (lane < 0) free_retired(q);                                // every lane is idle: a free's device synchronisation costs nothing now
     return as_device_status(0) ? AS_EDEVICE : AS_OK;
@@ -499,7 +507,7 @@ static int flush_lane(as_lanes* q, int lane)
     const bool host_group = !outs.empty();
     const int bi = L.cur;
     if (host_group) {                                             // the group's kernels start behind its host -> device copies
-        AS_CHECK(hipEventRecord(L.ev_h2d[bi], L.h2d));
+        AS_CHECK(hipEventRecord(L.ev_h2d[bi], q->up(L)));
         AS_CHECK(hipStreamWaitEvent(L.stream, L.ev_h2d[bi], 0));
         L.cur ^= 1;                                               // (the next group of this lane fills the other block)
         L.blk_used[bi] = true;
@@ -512,12 +520,12 @@ static int flush_lane(as_lanes* q, int lane)
         // ... and every submission's mel goes home behind them, on the lane's device -> host stream: the lane's next group computes meanwhile.
         // ev_d2h[bi] is what the block's NEXT group's copies wait for (recorded whatever happened: a block is never left without it)
         hipError_t e = hipEventRecord(L.ev_comp[bi], L.stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(L.d2h, L.ev_comp[bi], 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(q->down(L), L.ev_comp[bi], 0);
         for (const Out& o : outs)
             if (rc == AS_OK && e == hipSuccess && o.cols > 0)
                 e = hipMemcpy2DAsync(o.host, (size_t)o.ld * 4, o.dev, (size_t)io.ld_out * 4, (size_t)o.cols * 4, (size_t)q->cfg.n_mels,
-                                     hipMemcpyDeviceToHost, L.d2h);
-        const hipError_t e2 = hipEventRecord(L.ev_d2h[bi], L.d2h);
+                                     hipMemcpyDeviceToHost, q->down(L));
+        const hipError_t e2 = hipEventRecord(L.ev_d2h[bi], q->down(L));
         if (rc == AS_OK && (e != hipSuccess || e2 != hipSuccess)) return (int)(e != hipSuccess ? e : e2);
     }
     return rc;
@@ -571,9 +579,9 @@ extern "C" int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forw
 // the device side: one block per lane that holds the inputs of a group's submissions as ADJACENT column ranges (so that the group is one
 // batch as it lies) and the group's output.  A submission's inputs are copied into the block's next free columns when it is submitted, the
 // group's launch follows the last of them, and every submission's mel goes back to its own host array behind the launch.  TWO blocks per
-// lane, alternating from group to group, and a copy stream for either direction: host -> device copies of group g + 1 (stream h2d) run
-// under the kernels of group g (the lane's stream), whose results leave on stream d2h under the kernels of group g + 1.  Edges, all events
-// between streams of ONE lane: kernels(g) wait for h2d(g); d2h(g) waits for kernels(g); h2d(g + 2) -- the same block -- waits for d2h(g).
+// lane, alternating from group to group, and ONE copy stream for either direction shared by the lanes: host -> device copies of a lane's
+// group g + 1 (stream h2d) run under the kernels of its group g (the lane's stream), whose results leave on stream d2h under the kernels of
+// group g + 1.  Edges (events): kernels(g) wait for h2d(g); d2h(g) waits for kernels(g); h2d(g + 2) -- the same block -- waits for d2h(g).
 // (With copies and kernels on the one stream the copies of a lane cost it 0.17 ms per step of 3.69: measured first.)  This is the
 // buffer rule of as_lanes_set_coalesce kept by the library instead of the caller.
 static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -581,9 +589,9 @@ static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 // the block holds a group of `k` submissions like this one (with some slack); a block that has to grow is replaced while the lane is idle
 static int block_fit(as_lanes* q, Lane& L, long nt, long nr, long nf2, int k)
 {
-    if (!L.h2d) {                                                 // first host submission of this lane: its copy streams and events
-        if (hipStreamCreateWithFlags(&L.h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&L.d2h, hipStreamNonBlocking) != hipSuccess)
-            return (int)hipErrorOutOfMemory;
+    if (!q->h2d && (hipStreamCreateWithFlags(&q->h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&q->d2h, hipStreamNonBlocking) != hipSuccess))
+        return (int)hipErrorOutOfMemory;
+    if (!L.ev_h2d[0]) {                                           // first host submission of this lane: its events
         for (int i = 0; i < 2; ++i)
             if (hipEventCreateWithFlags(&L.ev_h2d[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&L.ev_comp[i], hipEventDisableTiming) != hipSuccess ||
@@ -600,7 +608,7 @@ static int block_fit(as_lanes* q, Lane& L, long nt, long nr, long nf2, int k)
     const size_t bytes = 2 * up256((size_t)ct * 4) + up256((size_t)cr * 4) + up256((size_t)10 * cr * 4) + up256((size_t)n_mels * cr * 4) +
                          up256((size_t)n_mels * co * 4);
     AS_CHECK(hipStreamSynchronize(L.stream));                     // the groups that used the old block have left it: kernels ...
-    AS_CHECK(hipStreamSynchronize(L.d2h));                        // ... and the copies of their results
+    AS_CHECK(hipStreamSynchronize(q->d2h));                       // ... and the copies of their results
     drop_graphs(L);                                               // (its graphs hold the old block's addresses)
     if (b.dev) q->retired.push_back(b.dev);                       // (not hipFree: it would stall the other lanes)
     b = Lane::Block();
@@ -647,7 +655,7 @@ static int lanes_submit_host(as_lanes* q, const as_batch* batch, const as_host_i
         }
         if (rc != AS_OK) return rc;
         Lane::Block& b = L.blk[L.cur];
-        hipStream_t s = L.h2d;
+        hipStream_t s = q->up(L);
         // the block's previous group (two groups back on this lane) has left it -- its kernels and the copies of its results -- before
         // the first copy of this one lands
         if (L.pend.empty() && L.blk_used[L.cur]) AS_CHECK(hipStreamWaitEvent(s, L.ev_d2h[L.cur], 0));

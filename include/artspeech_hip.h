@@ -47,12 +47,16 @@ int as_abi_version(void);
  *                               utterance wider than the post_max_w its caller named -- or, with one utterance, another column range
  *                               than [0, N) -- reached as_conv_gemm_multi_post_f32's reduction, or (as_lanes_set_debug) the device
  *                               buffers of a submission changed while it was waiting for its group
+ *   bit AS_STATUS_CAPACITY      the predicted durations of a batch (or of one submission of a merged call) add up to more frames than
+ *                               the capacity its caller named (as_forward_io.frame_cap): what was computed was cut at the capacity --
+ *                               nothing was written out of bounds, the mel is void; run it again with more room (the counterpart of
+ *                               AS_ENOSPC where no host read-back tells the host in time)
  * as_device_status returns the bits raised on the current HIP device since the last clear (0 = healthy) without synchronising; it is
  * final for work whose stream has been synchronised.  The module-level entry points (as_*_forward, as_forward_test*) return
  * AS_EDEVICE while any bit is set: results computed since it was raised are invalid; clear it to go on. */
 #define AS_EDEVICE (-3)
 enum { AS_STATUS_LSTM_TIMEOUT = 0, AS_STATUS_MAS_TIMEOUT = 1, AS_STATUS_BAD_TOKEN = 2, AS_STATUS_F16_RANGE = 3, AS_STATUS_BAD_LAYOUT = 4,
-       AS_STATUS_KINDS = 5 };
+       AS_STATUS_CAPACITY = 5, AS_STATUS_KINDS = 6 };
 int as_device_status(int clear);
 /* test hook: raise `kind` from a kernel on `stream`, exactly as a failing kernel would */
 int as_device_status_raise_for_test(int kind, as_stream_t stream);
@@ -208,6 +212,11 @@ typedef struct ConvGemmArgs {
     int32_t ileave_u;
     int32_t slab_tr;           /* library-owned (overwritten): the K slices' partial sums are stored time-major for a reduction that also
                                 * computes the channel LayerNorm behind the conv (as_conv_gemm_multi_post_f32) */
+    /* Capacity layouts (as_forward_io.frame_cap: the column count of a launch is a capacity, how many of the columns hold utterances is
+     * known on the device only): *n_valid (a DEVICE int) = the leading columns that are valid -- of every weight group's column range when
+     * the launch is grouped.  Columns behind them are filler: they read the zero column, nothing is stored for them, and a tile that lies
+     * wholly in the filler ends at once, so a launch costs what its valid columns cost.  NULL: every column is valid. */
+    const int32_t* n_valid;
 } ConvGemmArgs;
 #define AS_SLOPE_PATH 0.2f
 int as_conv_gemm_f32(const ConvGemmArgs* args_host, as_stream_t stream);
@@ -310,6 +319,8 @@ typedef struct AsAdainArgs {
     const float* pool_b;     /* [C] */
     float* x_up;             /* optional [C][ld_up]: nearest x2 copy of x */
     int32_t ld_up;
+    const int32_t* col_w;    /* optional [U]: utterance u has col_w[u] INPUT columns (times 2 out with the up-sampler) instead of col_off[u + 1] -
+                              * col_off[u] -- layouts whose utterances do not lie back to back (capacity layouts: filler between groups) */
 } AsAdainArgs;
 int as_adain_image_f32(const AsAdainArgs* args_host, as_stream_t stream);
 /* as_conv_gemm_multi_f32 for convolutions whose RESULT is (also) read through an AdaIN1d + LeakyReLU -- conv1 -> norm2 -> actv -> conv2

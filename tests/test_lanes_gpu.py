@@ -465,7 +465,7 @@ def test_lanes_submit_host_blocks_refilled_behind_groups_in_flight():
     torch.cuda.set_device(0)
     net = _net(dev)
     solo = _alone(net)
-    n_b, per = 12, 8
+    n_b, per = 16, 8
     pin = lambda a: torch.from_numpy(a).pin_memory()
     batches, wants = [], []
     for i in range(n_b):
