@@ -149,7 +149,7 @@ class ForwardIO(ctypes.Structure):
     _fields_ = [("tokens", c_p), ("mel", c_p), ("ld_mel", ctypes.c_int32), ("f0_raw", c_p), ("ema_raw", c_p), ("ld_ema", ctypes.c_int32),
                 ("forced_dur", c_p), ("mel_out", c_p), ("ld_out", ctypes.c_int32), ("duration", c_p), ("dur_i", c_p), ("frame_off", c_p),
                 ("style", c_p), ("feat12", c_p), ("ld_feat", ctypes.c_int32), ("t_en", c_p), ("a_en", c_p), ("ld_en", ctypes.c_int32),
-                ("F0", c_p), ("N", c_p), ("EMA", c_p), ("ld_pred", ctypes.c_int32)]
+                ("F0", c_p), ("N", c_p), ("EMA", c_p), ("ld_pred", ctypes.c_int32), ("frame_cap", ctypes.c_int32), ("segs", c_p)]
 
 
 class HostIO(ctypes.Structure):                 # as_host_io: HOST pointers (as_lanes_submit_host)
@@ -157,7 +157,7 @@ class HostIO(ctypes.Structure):                 # as_host_io: HOST pointers (as_
                 ("forced_dur", c_p), ("mel_out", c_p), ("ld_out", ctypes.c_int32)]
 
 
-AS_MOD_FORWARD_A, AS_MOD_FORWARD_B, AS_MOD_ENCODER, AS_MOD_STYLE, AS_MOD_DURATION, AS_MOD_ARTS, AS_MOD_DECODER = range(7)
+AS_MOD_FORWARD_A, AS_MOD_FORWARD_B, AS_MOD_ENCODER, AS_MOD_STYLE, AS_MOD_DURATION, AS_MOD_ARTS, AS_MOD_DECODER, AS_MOD_FORWARD_B_CAP = range(8)
 _pB, _pIO = ctypes.POINTER(Batch), ctypes.POINTER(ForwardIO)
 _SIGNATURES.update({
     "as_adain_image_f32": (c_i, [ctypes.POINTER(AdainArgs), c_p]),

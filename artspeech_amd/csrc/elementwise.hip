@@ -1231,3 +1231,90 @@ extern "C" int as_mean_pool_f32(const float* x, int ldx, const int32_t* col_off,
     AS_CHECK_LAUNCH();
     return AS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Capacity layouts (AsDynGeo, common.h): as_forward_test's second half when the frame counts exist on the device only
+// (as_forward_io.frame_cap; models.py:361-368 sizes everything from the PREDICTED durations).  One launch derives every table of the
+// half's four layouts from frame_off: blockIdx.z = 0 half rate, 1 mel rate, 2..4 the three groups of the tripled half-rate layout, 5..7
+// those of the tripled mel-rate one, 8 = the odd jobs (the frame -> token map's tail, the segments' own offsets); blockIdx.y = utterance.
+// Offsets are cut at the capacity (AS_STATUS_CAPACITY is raised): whatever the durations say, nothing is laid out past cap1 columns.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dyn_geometry_kernel(const AsDynGeo g)
+{
+    const int z = blockIdx.z, b = blockIdx.y, B = g.B, cap1 = g.cap1;
+    const int total_raw = g.frame_off[B];
+    if (z == 8) {
+        if (b == 0) {                                               // frames past the last one read token 0 (finite filler for the expansion)
+            if (g.tof)
+                for (int f = max(total_raw, 0) + (int)(blockIdx.x * blockDim.x + threadIdx.x); f < cap1; f += gridDim.x * blockDim.x) g.tof[f] = 0;
+            if (blockIdx.x == 0 && threadIdx.x == 0 && total_raw > cap1) as_status_raise(g.status, AS_STATUS_CAPACITY);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                  // the segment's own offsets (a merged call: every submission gets its own)
+            int s = 0;
+            while (s + 1 < g.n_seg && b >= g.seg_first[s + 1]) ++s;
+            const int first = g.seg_first[s], o_first = min(g.frame_off[first], cap1);
+            int32_t* fo = g.seg_frame_off[s];
+            if (fo) fo[b - first] = min(g.frame_off[b], cap1) - o_first;
+            if (b + 1 == g.seg_first[s + 1]) {
+                const int len = min(g.frame_off[b + 1], cap1) - o_first;
+                if (fo) fo[b + 1 - first] = len;
+                if (len > g.seg_cap[s]) as_status_raise(g.status, AS_STATUS_CAPACITY);   // (its slot of the output holds seg_cap frames)
+            }
+        }
+        return;
+    }
+    const int li = z == 0 ? 0 : (z == 1 ? 1 : (z < 5 ? 2 : 3));      // layout
+    const int grp = z < 2 ? 0 : (z < 5 ? z - 2 : z - 5);
+    const int sc = (li == 1 || li == 3) ? 2 : 1;
+    const int o = min(g.frame_off[b], cap1), e = min(g.frame_off[b + 1], cap1);
+    const int W = sc * (e - o), base = grp * sc * cap1 + sc * o, u = grp * B + b;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (g.w[li]) g.w[li][u] = W;
+        if (g.off[li]) {
+            g.off[li][u] = base;
+            // the closing entry: the end of the last utterance of the last group (AdaIN launches on tripled layouts take widths from w)
+            if (b == B - 1 && (li < 2 || grp == 2)) g.off[li][u + 1] = base + W;
+        }
+        if (li == 2 && g.src3) g.src3[u] = o;
+        if (b == 0 && grp == 0 && g.nvalid[li]) *g.nvalid[li] = sc * min(max(total_raw, 0), cap1);
+    }
+    unsigned long long* meta = g.meta[li];
+    if (!meta) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += gridDim.x * blockDim.x)
+        meta[base + i] = AS_META_PACK(0ull, (unsigned long long)i, 1ull, (unsigned long long)W);
+}
+
+int as_dyn_geometry_launch(const AsDynGeo& g, hipStream_t stream)
+{
+    if (!g.frame_off || g.B < 1 || g.B > 1024 || g.cap1 < 1 || g.n_seg < 1 || g.n_seg > 16) return AS_EINVAL;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, stream);
+    const int gx = std::min(64, std::max(1, as_cdiv(as_cdiv(2L * g.cap1, g.B), 256)));
+    hipLaunchKernelGGL(dyn_geometry_kernel, dim3(gx, g.B, 9), dim3(256), 0, stream, g);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+// every segment's columns of the packed mel to the segment's own slot (a merged call with predicted durations: a submission finds its
+// utterances from the first column of ITS output buffer on, whatever the submissions in front of it came to)
+__global__ void __launch_bounds__(256)
+seg_scatter_kernel(const AsSegScatter a)
+{
+    const int s = blockIdx.z, r = blockIdx.y;
+    const int first = a.seg_first[s], last = a.seg_first[s + 1];
+    const int o = 2 * a.frame_off[first], n = min(2 * (a.frame_off[last] - a.frame_off[first]), 2 * a.seg_cap[s]);
+    const float* src = a.src + (size_t)r * a.ld_src + o;
+    float* dst = a.dst[s] + (size_t)r * a.ld_dst[s];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int as_seg_scatter_launch(const AsSegScatter& a, hipStream_t stream)
+{
+    if (!a.src || !a.frame_off || a.rows < 1 || a.n_seg < 1 || a.n_seg > 16) return AS_EINVAL;
+    AsProfScope prof__(AS_FILE_CLS, 0, 0, stream);
+    int cap = 1;
+    for (int s = 0; s < a.n_seg; ++s) cap = std::max(cap, 2 * a.seg_cap[s]);
+    hipLaunchKernelGGL(seg_scatter_kernel, dim3(std::min(64, as_cdiv(cap, 256)), a.rows, a.n_seg), dim3(256), 0, stream, a);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}

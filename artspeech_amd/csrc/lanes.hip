@@ -98,6 +98,12 @@ std::string key_of(const as_batch* b, const as_forward_io* io)
     put(k, io->forced_dur); put(k, io->mel_out); put(k, io->ld_out); put(k, io->duration); put(k, io->dur_i); put(k, io->frame_off);
     put(k, io->style); put(k, io->feat12); put(k, io->ld_feat); put(k, io->t_en); put(k, io->a_en); put(k, io->ld_en);
     put(k, io->F0); put(k, io->N); put(k, io->EMA); put(k, io->ld_pred);
+    put(k, io->frame_cap);
+    if (io->segs) {
+        const as_segments& g = *io->segs;
+        put(k, g.n);
+        for (int i = 0; i < g.n && i < AS_MAX_SEGMENTS; ++i) { put(k, g.first[i]); put(k, g.cap[i]); put(k, g.mel_out[i]); put(k, g.ld_out[i]); put(k, g.frame_off[i]); }
+    }
     return k;
 }
 
@@ -308,20 +314,26 @@ static int lane_run(as_lanes* q, const as_batch* batch, const as_forward_io* io,
     // (sizes come from the eager plan: a count pass adds host-side layout entries, which that plan may flush; the graph plan stays small)
     const size_t na = as_module_workspace_bytes(q->m, L.plan, AS_MOD_FORWARD_A, batch);
     if (!na) return AS_EINVAL;
-    // workspace B depends on the frame counts: known (forced durations / a second pass), or sized for what the output buffer can hold
+    // workspace B depends on the frame counts: known (forced durations / a second pass), a capacity the caller named (frame_cap: the call
+    // then runs like one with known counts -- eager, captured, replayed), or sized for what the output buffer can hold
+    const bool cap_mode = !batch->frames && io->frame_cap > 0;
     std::vector<int32_t> cap;
     as_batch bb = *batch;
-    if (!batch->frames) {
+    if (cap_mode) {
+        cap.assign(batch->B, 0);
+        cap[0] = io->frame_cap;                                     // (AS_MOD_FORWARD_B_CAP: only the sum counts)
+        bb.frames = cap.data();
+    } else if (!batch->frames) {
         cap.assign(batch->B, std::max(1, io->ld_out / 2 / batch->B));
         bb.frames = cap.data();
     }
-    size_t nb = as_module_workspace_bytes(q->m, L.plan, AS_MOD_FORWARD_B, &bb);
+    size_t nb = as_module_workspace_bytes(q->m, L.plan, cap_mode ? AS_MOD_FORWARD_B_CAP : AS_MOD_FORWARD_B, &bb);
     if (!nb) return AS_EINVAL;
     if (na > L.na || nb > L.nb) drop_graphs(L);                   // the graphs hold the old workspaces' addresses
     if (!grow(q, &L.wa, &L.na, na) || !grow(q, &L.wb, &L.nb, nb)) return (int)hipErrorOutOfMemory;
     q->next = (lane + 1) % (int)q->lanes.size();
 
-    if (!batch->frames) {
+    if (!batch->frames && !cap_mode) {
         // predicted durations: the call synchronises once to read the frame counts; AS_ENOSPC = workspace B (sized for a capacity) is too
         // small for what came out -- frames_host_out says what is needed: size B for it and run again (the header's contract)
         std::vector<int32_t> fr(batch->B, 0);
@@ -343,7 +355,7 @@ static int lane_run(as_lanes* q, const as_batch* batch, const as_forward_io* io,
         }
         return rc;
     }
-    if (frames_host_out) memcpy(frames_host_out, batch->frames, sizeof(int32_t) * batch->B);
+    if (frames_host_out && batch->frames) memcpy(frames_host_out, batch->frames, sizeof(int32_t) * batch->B);
     const std::string key = key_of(batch, io);
     auto g = L.graphs.find(key);
     if (g != L.graphs.end()) {
@@ -406,17 +418,25 @@ static bool plain_io(const as_forward_io* io)                     // only the me
 {
     return !io->duration && !io->dur_i && !io->frame_off && !io->style && !io->feat12 && !io->t_en && !io->a_en && !io->F0 && !io->N && !io->EMA;
 }
-static bool adjacent(const Lane::Pending& p, const as_forward_io* io)
+static bool adjacent(const Lane::Pending& p, const as_forward_io* io, bool cap_mode)
 {
     long nt = 0, nr = 0, nf = 0;
     for (int32_t v : p.tok_lens) nt += v;
     for (int32_t v : p.ref_lens) nr += v;
     for (int32_t v : p.frames) nf += v;
     const as_forward_io& a = p.io;
-    return io->tokens == a.tokens + nt && io->mel == a.mel + nr && io->ld_mel == a.ld_mel && io->f0_raw == a.f0_raw + nr &&
-           io->ema_raw == a.ema_raw + nr && io->ld_ema == a.ld_ema &&
-           ((!io->forced_dur && !a.forced_dur) || (io->forced_dur && a.forced_dur && io->forced_dur == a.forced_dur + nt)) &&
+    if (cap_mode != (p.frames.empty() && a.frame_cap > 0)) return false;   // (a group is of one kind)
+    const bool in = io->tokens == a.tokens + nt && io->mel == a.mel + nr && io->ld_mel == a.ld_mel && io->f0_raw == a.f0_raw + nr &&
+                    io->ema_raw == a.ema_raw + nr && io->ld_ema == a.ld_ema;
+    // under a frame capacity every submission keeps its own output buffer (as_segments: the merged call's mel is dealt out to them)
+    if (cap_mode) return in && !io->forced_dur && !a.forced_dur;
+    return in && ((!io->forced_dur && !a.forced_dur) || (io->forced_dur && a.forced_dur && io->forced_dur == a.forced_dur + nt)) &&
            io->mel_out == a.mel_out + 2 * nf && io->ld_out == a.ld_out;
+}
+// (frame capacity: frame_off is the one optional output a submission of a merged call can have -- it is how the caller finds its utterances)
+static bool plain_cap_io(const as_forward_io* io)
+{
+    return !io->duration && !io->dur_i && !io->style && !io->feat12 && !io->t_en && !io->a_en && !io->F0 && !io->N && !io->EMA && !io->segs;
 }
 
 // ---- debug mode (as_lanes_set_debug, AS_DEBUG=1) -------------------------------------------------------------------------------------
@@ -492,7 +512,31 @@ static int flush_lane(as_lanes* q, int lane)
     as_batch b;
     b.B = (int32_t)tl.size();
     b.tok_lens = tl.data(); b.ref_lens = rl.data(); b.frames = fr.data();
-    const as_forward_io io = L.pend.front().io;
+    as_forward_io io = L.pend.front().io;
+    as_segments segs;
+    if (fr.empty()) {                                             // submissions under a frame capacity: the merged call deals its mel out to them
+        b.frames = nullptr;
+        if (L.pend.size() > 1) {
+            memset(&segs, 0, sizeof(segs));
+            segs.n = (int32_t)L.pend.size();
+            long cap = 0;
+            int32_t first = 0;
+            for (size_t i = 0; i < L.pend.size(); ++i) {
+                const Lane::Pending& p = L.pend[i];
+                segs.first[i] = first;
+                segs.cap[i] = p.io.frame_cap;
+                segs.mel_out[i] = p.io.mel_out;
+                segs.ld_out[i] = p.io.ld_out;
+                segs.frame_off[i] = p.io.frame_off;
+                first += (int32_t)p.tok_lens.size();
+                cap += p.io.frame_cap;
+            }
+            segs.first[segs.n] = first;
+            io.frame_cap = (int32_t)cap;
+            io.frame_off = nullptr;
+            io.segs = &segs;
+        }
+    }
     if (L.pend.size() > 1) ++L.n_merged;
     // (host submissions: where each one's mel goes once the group's kernels are enqueued)
     struct Out { float* host; int32_t ld; const float* dev; long cols; };
@@ -537,11 +581,13 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
     if (!q || !batch || !io || batch->B <= 0 || !batch->tok_lens || !batch->ref_lens) return AS_EINVAL;
     Lane& L = q->lanes[q->next];
     // (a host submission always joins the group of its lane's block -- a group of one when coalescing is off)
-    const bool can_wait = (q->coalesce > 1 || out_host) && batch->frames && plain_io(io);
+    const bool cap_mode = !batch->frames && io->frame_cap > 0;
+    const bool can_wait = (q->coalesce > 1 || out_host) && ((batch->frames && plain_io(io)) || (cap_mode && !out_host && plain_cap_io(io)));
     size_t waiting = 0;                                           // utterances of the group that waits here
     for (const Lane::Pending& p : L.pend) waiting += p.tok_lens.size();
-    // (a call takes at most 1024 utterances: as_durations_f32's one-workgroup scan)
-    if (!L.pend.empty() && !(can_wait && adjacent(L.pend.back(), io) && waiting + (size_t)batch->B <= 1024)) {
+    // (a call takes at most 1024 utterances: as_durations_f32's one-workgroup scan; at most AS_MAX_SEGMENTS submissions under a capacity)
+    if (!L.pend.empty() && !(can_wait && adjacent(L.pend.back(), io, cap_mode) && waiting + (size_t)batch->B <= 1024 &&
+                             (!cap_mode || L.pend.size() < (size_t)AS_MAX_SEGMENTS))) {
         const int rc = flush_lane(q, q->next);                    // not a neighbour of what waits here: that group goes out first (and the turn passes on)
         if (rc != AS_OK) return rc;
     }
@@ -551,7 +597,7 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
     Lane::Pending p;
     p.tok_lens.assign(batch->tok_lens, batch->tok_lens + batch->B);
     p.ref_lens.assign(batch->ref_lens, batch->ref_lens + batch->B);
-    p.frames.assign(batch->frames, batch->frames + batch->B);
+    if (batch->frames) p.frames.assign(batch->frames, batch->frames + batch->B);
     p.io = *io;
     p.out_host = out_host;
     p.ld_out_host = ld_out_host;
@@ -560,7 +606,7 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
         if (rc != AS_OK) return rc;
     }
     L2.pend.push_back(std::move(p));
-    if (frames_host_out) memcpy(frames_host_out, batch->frames, sizeof(int32_t) * batch->B);
+    if (frames_host_out && batch->frames) memcpy(frames_host_out, batch->frames, sizeof(int32_t) * batch->B);
     if ((int)L2.pend.size() >= q->coalesce) return flush_lane(q, q->next);
     return AS_OK;
 }

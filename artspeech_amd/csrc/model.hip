@@ -414,6 +414,12 @@ struct Lay {
     std::vector<int> w, off;
     int32_t *d_w = nullptr, *d_off = nullptr;
     uint64_t* d_meta = nullptr;
+    // a CAPACITY layout (as_forward_io.frame_cap): N columns are room, the utterances' widths exist on the device only -- w / off stay
+    // empty, d_w / d_off / d_meta / d_nvalid are rewritten by every call's as_dyn_geometry_launch (kind: AsDynGeo's layout index;
+    // dyn_B utterances per group, cap1 half-rate columns of room)
+    bool dyn = false;
+    int dyn_kind = 0, dyn_B = 0, cap1 = 0;
+    int32_t* d_nvalid = nullptr;
     std::map<std::string, int32_t*> tabs;      // further per-utterance device tables of launches on this layout
     int max_cols() const { return H * max_w; }
 };
@@ -622,9 +628,44 @@ struct Ctx {
         }
         return L;
     }
+    // capacity layout `kind` (AsDynGeo: 0 half rate, 1 mel rate, 2 / 3 the batch three times) of B utterances in cap1 half-rate columns
+    const Lay* dyn_lay(int kind, int B, int cap1)
+    {
+        if (kind < 0 || kind > 3 || B < 1 || cap1 < 1 || (double)cap1 * 6.0 > (double)AS_META_MAX_W) { fail(AS_EINVAL); return nullptr; }
+        auto key = std::make_pair(std::vector<int>{-1 - kind, B, cap1}, 1);
+        auto it = p.lays.find(key);
+        Lay* L;
+        if (it == p.lays.end()) {
+            auto u = std::make_unique<Lay>();
+            L = u.get();
+            L->dyn = true; L->dyn_kind = kind; L->dyn_B = B; L->cap1 = cap1;
+            L->B = kind < 2 ? B : 3 * B;
+            L->H = 1;
+            L->max_w = cap1 * ((kind & 1) ? 2 : 1);
+            L->N = L->max_w * (kind < 2 ? 1 : 3);
+            p.lays[key] = std::move(u);
+        } else {
+            L = it->second.get();
+        }
+        if (!count && launch && !L->d_off) {
+            L->d_w = static_cast<int32_t*>(p.pool.alloc((L->B + 1) * sizeof(int32_t)));
+            L->d_off = static_cast<int32_t*>(p.pool.alloc((L->B + 1) * sizeof(int32_t)));
+            L->d_meta = static_cast<uint64_t*>(p.pool.alloc((size_t)L->N * sizeof(uint64_t)));
+            L->d_nvalid = static_cast<int32_t*>(p.pool.alloc(sizeof(int32_t)));
+            int32_t* src3 = kind == 2 ? static_cast<int32_t*>(p.pool.alloc((size_t)L->B * sizeof(int32_t))) : nullptr;
+            if (!L->d_w || !L->d_off || !L->d_meta || !L->d_nvalid || (kind == 2 && !src3)) {
+                L->d_off = nullptr;
+                fail((int)hipErrorOutOfMemory);
+                return nullptr;
+            }
+            if (src3) L->tabs["src3"] = src3;
+        }
+        return L;
+    }
     const uint64_t* meta(const Lay* L)
     {
         if (!L || count || !launch) return nullptr;
+        if (L->dyn) return L->d_meta;                              // (written by the call's as_dyn_geometry_launch)
         Lay* M = const_cast<Lay*>(L);
         if (!M->d_meta) {
             M->d_meta = static_cast<uint64_t*>(p.pool.alloc((size_t)std::max(L->N, 1) * sizeof(uint64_t)));
@@ -664,6 +705,10 @@ struct Ctx {
     }
     const Lay* scaled(const Lay* L, int k)
     {
+        if (L->dyn) {
+            if (k != 2 || (L->dyn_kind & 1)) { fail(AS_EINVAL); return nullptr; }
+            return dyn_lay(L->dyn_kind + 1, L->dyn_B, L->cap1);
+        }
         std::vector<int> w(L->w);
         for (int& v : w) v *= k;
         return lay(w, L->H);
@@ -1150,6 +1195,7 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
     if (o.N_in && !o.src_col) { c.fail(AS_EINVAL); return; }
     a.meta = o.N_in ? o.src_meta : (pointwise ? nullptr : c.meta(lay));
     a.src_col = o.src_col;
+    a.n_valid = lay->dyn ? lay->d_nvalid : nullptr;                     // (a capacity layout: the columns behind the utterances are filler)
     AsAdainArgs post;
     memset(&post, 0, sizeof(post));
     int32_t post_mw = 0;
@@ -1157,7 +1203,8 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
         if (!o.post_n || !o.post_lay || o.post_lay->N != lay->N || !Y) { c.fail(AS_EINVAL); return; }
         post.gb = o.post_n->gb; post.gb_off = o.post_n->gb_off; post.ldgb = 1; post.gb_sc = o.post_n->gb_sc;
         post.col_off = o.post_lay->d_off; post.U = o.post_lay->B; post.lrelu = 1; post.yh = o.post_yh;
-        post_mw = o.post_lay->max_w;
+        post.col_w = o.post_lay->dyn ? o.post_lay->d_w : nullptr;
+        post_mw = o.post_lay->dyn ? (1 << 30) : o.post_lay->max_w;        // (widths unknown to the host: never the fused reduction)
     }
     if (o.ln.yh && (o.post_yh || !Y)) { c.fail(AS_EINVAL); return; }
     if (c.deferring() && !EXP_SKIP(as_conv_gemm_f32)) {                  // recorded: it may share its launch with other branches' convs
@@ -1251,6 +1298,7 @@ void adain_image(Ctx& c, const float* x, int ldx, int C, const Norm& n, const La
     a.x = x; a.ldx = ldx; a.C = C;
     a.gb = n.gb; a.gb_off = n.gb_off; a.ldgb = 1; a.gb_sc = n.gb_sc;
     a.col_off = lay->d_off; a.src_off = src_off; a.U = lay->B; a.N = N_out; a.lrelu = 1; a.yh = yh;
+    a.col_w = lay->dyn ? lay->d_w : nullptr;
     a.pool_w = pool_w; a.pool_b = pool_b; a.x_up = x_up; a.ld_up = ld_up;
     RUN(c, as_adain_image_f32(&a, c.s));
 }
@@ -1913,7 +1961,7 @@ void arts_predictor(Ctx& c, const float* a_en, int lda, const Lay* lay, const Fc
     // grouped layouts: the batch three times
     std::vector<int> w3;
     for (int g = 0; g < 3; ++g) w3.insert(w3.end(), lay->w.begin(), lay->w.end());
-    const Lay* layG1 = c.lay(w3);
+    const Lay* layG1 = lay->dyn ? c.dyn_lay(2, lay->dyn_B, lay->cap1) : c.lay(w3);
     const Lay* layG2 = layG1 ? c.scaled(layG1, 2) : nullptr;
     const Lay* lay2 = c.scaled(lay, 2);
     if (!layG1 || !layG2 || !lay2) return;
@@ -1957,6 +2005,7 @@ void arts_predictor(Ctx& c, const float* a_en, int lda, const Lay* lay, const Fc
             q.x = a.p; q.ldx = a.ld; q.C = C;
             q.gb = n1.gb; q.gb_off = n1.gb_off + g * B; q.ldgb = 1; q.gb_sc = n1.gb_sc;
             q.col_off = layG1->d_off + g * B; q.src_off = src_off + g * B; q.U = B; q.N = NG2; q.lrelu = 1; q.yh = xs;
+            q.col_w = layG1->dyn ? layG1->d_w + g * B : nullptr;
             q.pool_w = pw; q.pool_b = pb; q.x_up = up; q.ld_up = NG2;
             RUN(c, as_adain_image_f32(&q, c.s));
         }
@@ -2261,7 +2310,8 @@ PhaseA forward_a(Ctx& c, const as_batch* batch, const as_forward_io* io)
     if (c.go()) c.p.mark(2, c.s);
     // round half even -> clamp(min = 1) (or the forced durations), per-utterance frame offsets (models.py:361-366)
     // (with the frame counts given nobody reads this half's copy: the second half computes durations, offsets and the frame -> token map)
-    if (!batch->frames) RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, A.dur_i, A.frame_off, nullptr, 0, c.s));
+    // (... and so does a call under a frame capacity, as_forward_io.frame_cap)
+    if (!batch->frames && io->frame_cap <= 0) RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, A.dur_i, A.frame_off, nullptr, 0, c.s));
     (void)C;
     return A;
 }
@@ -2270,18 +2320,58 @@ void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_
 {
     const as_model& m = c.m;
     const int C = m.cfg.hidden_dim, B = batch->B, n_mels = m.cfg.n_mels;
-    const Lay* lay1 = c.lay(vec_of(batch->frames, B));
+    // frame counts from the host (forced durations / a second pass), or -- as_forward_io.frame_cap -- a capacity: the layouts are then
+    // room, and what lies where is derived on the device from the durations this half computes (no read-back, capturable)
+    const bool dyn = !batch->frames;
+    const as_segments* segs = dyn ? io->segs : nullptr;
+    const Lay* lay1 = dyn ? c.dyn_lay(0, B, io->frame_cap) : c.lay(vec_of(batch->frames, B));
     if (!lay1) return;
     const Lay* lay2 = c.scaled(lay1, 2);
     if (!lay2) return;
     const int N1 = lay1->N, N2 = lay2->N;
-    if (io->ld_out < N2 || (io->F0 && io->ld_pred < N2)) { c.fail(AS_ENOSPC); return; }
+    if (segs) {
+        long sum = 0;
+        if (segs->n < 1 || segs->n > AS_MAX_SEGMENTS || segs->first[0] != 0 || segs->first[segs->n] != B) { c.fail(AS_EINVAL); return; }
+        for (int i = 0; i < segs->n; ++i) {
+            if (segs->first[i + 1] <= segs->first[i] || segs->cap[i] < 1 || !segs->mel_out[i]) { c.fail(AS_EINVAL); return; }
+            if (segs->ld_out[i] < 2 * segs->cap[i]) { c.fail(AS_ENOSPC); return; }
+            sum += segs->cap[i];
+        }
+        if (sum != N1 || io->F0) { c.fail(AS_EINVAL); return; }         // (the predictions have no per-submission home)
+    } else if (io->ld_out < N2 || (io->F0 && io->ld_pred < N2)) { c.fail(AS_ENOSPC); return; }
     int32_t* tof = c.i32((size_t)std::max(N1, 1));
     int32_t* dur_i = c.i32((size_t)std::max(A.tok->N, 1));
     int32_t* frame_off = c.i32(B + 1);
+    float* mel_packed = dyn ? c.f32((size_t)n_mels * std::max(N2, 1)) : nullptr;   // (a merged call's mel before it goes to the submissions' slots)
     if (io->dur_i) dur_i = io->dur_i;
-    if (io->frame_off) frame_off = io->frame_off;
+    if (io->frame_off && !segs) frame_off = io->frame_off;
     RUN(c, as_durations_f32(A.duration, io->forced_dur, A.tok->d_off, B, dur_i, frame_off, tof, N1, c.s));
+    if (dyn) {
+        const Lay *lg1 = c.dyn_lay(2, B, io->frame_cap), *lg2 = lg1 ? c.scaled(lg1, 2) : nullptr;
+        if (!lg1 || !lg2) return;
+        if (c.go()) {
+            AsDynGeo g;
+            memset(&g, 0, sizeof(g));
+            g.frame_off = frame_off; g.B = B; g.cap1 = N1;
+            g.n_seg = segs ? segs->n : 1;
+            for (int i = 0; i < g.n_seg; ++i) {
+                g.seg_first[i] = segs ? segs->first[i] : 0;
+                g.seg_cap[i] = segs ? segs->cap[i] : N1;
+                g.seg_frame_off[i] = segs ? segs->frame_off[i] : nullptr;
+            }
+            g.seg_first[g.n_seg] = B;
+            const Lay* ls[4] = {lay1, lay2, lg1, lg2};
+            for (int i = 0; i < 4; ++i) {
+                g.w[i] = ls[i]->d_w; g.off[i] = ls[i]->d_off; g.nvalid[i] = ls[i]->d_nvalid;
+                g.meta[i] = reinterpret_cast<unsigned long long*>(ls[i]->d_meta);
+            }
+            auto t3 = lg1->tabs.find("src3");
+            g.src3 = t3 != lg1->tabs.end() ? t3->second : nullptr;
+            g.tof = tof;
+            g.status = as_status_words_device();
+            RUN(c, as_dyn_geometry_launch(g, c.s));
+        }
+    }
     float* a_ex = c.f32((size_t)C * std::max(N1, 1));
     float* fne = c.f32((size_t)12 * std::max(N2, 1));                    // rows: F0, N, EMA[10] (what the three branches predict)
     float* x0 = c.f32((size_t)(C + 128) * std::max(N2, 1));
@@ -2313,7 +2403,22 @@ void forward_b(Ctx& c, const PhaseA& A, const as_batch* batch, const as_forward_
         RUN(c, as_expand_f32(A.t_en, A.ld_en, C, tof, N1, 2, x0, N2, c.s));
         dp = decoder_pre(c, x0, lay2);
     }
-    decoder(c, dp, x0, lay2, fne, N2, fc, io->mel_out, io->ld_out);
+    if (segs) {
+        decoder(c, dp, x0, lay2, fne, N2, fc, mel_packed, N2);
+        if (c.go()) {
+            AsSegScatter sc;
+            memset(&sc, 0, sizeof(sc));
+            sc.src = mel_packed; sc.ld_src = N2; sc.rows = n_mels; sc.n_seg = segs->n; sc.frame_off = frame_off;
+            for (int i = 0; i < segs->n; ++i) {
+                sc.seg_first[i] = segs->first[i]; sc.seg_cap[i] = segs->cap[i];
+                sc.dst[i] = segs->mel_out[i]; sc.ld_dst[i] = segs->ld_out[i];
+            }
+            sc.seg_first[segs->n] = B;
+            RUN(c, as_seg_scatter_launch(sc, c.s));
+        }
+    } else {
+        decoder(c, dp, x0, lay2, fne, N2, fc, io->mel_out, io->ld_out);
+    }
     if (c.go()) c.p.mark(4, c.s);
     if (c.go()) {
         if (io->F0) copy_rows(c, io->F0, io->ld_pred, fne, N2, 1, N2);
@@ -2695,6 +2800,21 @@ size_t count_module(const as_model* m, as_plan* p, int module, const as_batch* b
         forward_b(c, A, batch, io);
         break;
     }
+    case AS_MOD_FORWARD_B_CAP: {                                         // batch->frames = capacities: their sum is the call's frame_cap
+        if (!batch_ok(batch, true, true, true)) return 0;
+        long cap = 0;
+        for (int b = 0; b < B; ++b) cap += std::max(batch->frames[b], 0);
+        if (cap < 1 || cap > (1 << 28)) return 0;
+        as_forward_io ioc = *io;
+        ioc.frame_cap = (int32_t)cap;
+        as_batch b2 = *batch;
+        b2.frames = nullptr;
+        Ctx ca(*m, *p, nullptr, nullptr, 0, false, true);
+        const PhaseA A = forward_a(ca, &b2, &ioc);
+        if (ca.rc || !A.tok) return 0;
+        forward_b(c, A, &b2, &ioc);
+        break;
+    }
     case AS_MOD_ENCODER: {
         if (!batch_ok(batch, true, false, false)) return 0;
         const Lay* lay = c.lay(vec_of(batch->tok_lens, B));
@@ -2945,6 +3065,17 @@ try {                                                                    // noth
     Call ka(m, p, ws_a, ws_a_bytes, stream);
     const PhaseA A = forward_a(ka.c, batch, io);
     if (ka.done() || !A.tok || !A.ref) return ka.done() ? ka.done() : AS_EINVAL;
+    if (!batch->frames && io->frame_cap > 0) {
+        // predicted durations under a frame capacity: the second half is sized by the capacity and finds the utterances' extents on the
+        // device -- no read-back, nothing here waits for the stream, the whole call is capturable
+        if (io->forced_dur) return AS_EINVAL;                               // (forced durations are host data: their sums are batch->frames)
+        outputs_a(ka.c, A, batch, io);
+        if (ka.done()) return ka.done();
+        Ctx cb(*m, *p, static_cast<hipStream_t>(stream), ws_b, ws_b_bytes, true, false);
+        if ((reinterpret_cast<uintptr_t>(ws_b) & 255) != 0) return AS_EINVAL;
+        forward_b(cb, A, batch, io);
+        return cb.rc ? cb.rc : m->err;
+    }
     as_batch b2 = *batch;
     if (!batch->frames) {                                                   // the one device -> host read of the path
         std::vector<int32_t> off(batch->B + 1);

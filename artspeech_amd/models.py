@@ -360,10 +360,15 @@ class ArtsSpeech(_Module):
             return mel, out
         return mel
 
-    def forward_packed(self, tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, forced=None, frames_hint=None, aux=False, out=None):
+    def forward_packed(self, tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, forced=None, frames_hint=None, aux=False, out=None, frame_cap=None):
         """The whole hot path on packed tensors (what bench.py times): one call of as_forward_test when the integer frame
         counts are known (forced durations), else as_forward_test_begin -> one device->host read of B + 1 integers ->
-        as_forward_test_finish.  `out`: the dict of a previous call with the same geometry (its tensors are reused)."""
+        as_forward_test_finish.  `out`: the dict of a previous call with the same geometry (its tensors are reused).
+        frame_cap (predicted durations only): the half-rate frames to make room for, all utterances together -- ONE as_forward_test call
+        with no read-back (capturable); the result's `frame_off` (device, [B + 1]) says where each utterance's frames lie in `mel`
+        [n_mels][2 frame_cap], `frames` is None; more frames than room raises the AS_STATUS_CAPACITY bit (as_device_status)."""
+        if frame_cap is not None:
+            return self._forward_packed_cap(tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, int(frame_cap), aux, out)
         rt, L = self.rt, _lib.lib()
         dev = rt.device
         tok_lens, ref_lens = [int(v) for v in tok_lens], [int(v) for v in ref_lens]
@@ -415,6 +420,46 @@ class ArtsSpeech(_Module):
         return res
 
 
+def _forward_packed_cap(self, tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, frame_cap, aux, out):
+    rt, L = self.rt, _lib.lib()
+    dev = rt.device
+    tok_lens, ref_lens = [int(v) for v in tok_lens], [int(v) for v in ref_lens]
+    B, Nt, Nr, C = len(tok_lens), sum(tok_lens), sum(ref_lens), rt.cfg.hidden_dim
+    with torch.cuda.device(dev):
+        io = _lib.ForwardIO()
+        io.tokens, io.mel, io.ld_mel = _p(tok), _p(mel_p), mel_p.stride(0)
+        io.f0_raw, io.ema_raw, io.ld_ema = _p(f0_p), _p(ema_p), ema_p.stride(0)
+        io.frame_cap = frame_cap
+        res = out if out is not None else {}
+
+        def new(key, shape, dtype=torch.float32):
+            t = res.get(key)
+            if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != dev:
+                t = res[key] = torch.empty(shape, dtype=dtype, device=dev)
+            return t
+        n2 = 2 * frame_cap
+        io.dur_i, io.frame_off = _p(new("dur_i", (max(Nt, 1),), torch.int32)), _p(new("frame_off", (B + 1,), torch.int32))
+        io.mel_out, io.ld_out = _p(new("mel", (rt.cfg.n_mels, n2))), n2
+        if aux:
+            io.duration = _p(new("duration", (1, max(Nt, 1))))
+            io.style = _p(new("style", (B, 2 * rt.cfg.style_dim)))
+            io.feat12, io.ld_feat = _p(new("feat12", (12, max(Nr, 1)))), max(Nr, 1)
+            io.t_en, io.a_en, io.ld_en = _p(new("t_en", (C, max(Nt, 1)))), _p(new("a_en", (C, max(Nt, 1)))), max(Nt, 1)
+            io.F0, io.N, io.EMA = _p(new("F0", (1, n2))), _p(new("N", (1, n2))), _p(new("EMA", (10, n2)))
+            io.ld_pred = n2
+        ba = rt.batch(tok_lens=tok_lens, ref_lens=ref_lens)
+        ws_a, na = rt.workspace("a", _lib.AS_MOD_FORWARD_A, ba)
+        bc = rt.batch(tok_lens=tok_lens, ref_lens=ref_lens, frames=[frame_cap] + [0] * (B - 1))     # (only the sum counts)
+        ws_b, nb = rt.workspace("b", _lib.AS_MOD_FORWARD_B_CAP, bc)
+        check(L.as_forward_test(rt.model, rt.plan, ctypes.byref(ba), ctypes.byref(io), _p(ws_a), na, _p(ws_b), nb, None, rt.stream()),
+              "as_forward_test")
+        res["frames"], res["frames2"], res["frame_cap"] = None, None, frame_cap
+    return res
+
+
+ArtsSpeech._forward_packed_cap = _forward_packed_cap
+
+
 class Lanes:
     """as_lanes (csrc/lanes.hip): n batches in flight on one model's weights, every batch one chain on a stream of its own -- the
     throughput arrangement (DESIGN.md section 5) as a piece of the library.  `submit` takes the packed tensors of `forward_packed`;
@@ -451,9 +496,11 @@ class Lanes:
     def merged_calls(self, lane):
         return int(_lib.lib().as_lanes_merged_calls(self.h, int(lane)))
 
-    def submit(self, tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, forced=None, frames=None, out=None, capacity=None):
+    def submit(self, tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, forced=None, frames=None, out=None, capacity=None, frame_cap=None):
         """-> (lane, dict with the output tensors).  frames (per-utterance half-rate frame counts) known: graph-replayed from the second
-        submit of the same tensors on a lane; None: predicted durations, `capacity` = the mel frames the output buffer is made for.
+        submit of the same tensors on a lane; None: predicted durations, `capacity` = the mel frames the output buffer is made for (eager,
+        one read-back per call) -- or frame_cap = the half-rate frames to make room for (as_forward_io.frame_cap: no read-back, replayed
+        from hipGraphs and coalesced like a submission with known counts; `frame_off` of the result says where the utterances lie).
         2-D tensors may be column ranges of a wider block (row stride = the block's width)."""
         def _p(t):                                                  # (rows of a wider block: only the last axis has to be dense)
             if t is None:
@@ -473,23 +520,30 @@ class Lanes:
             io.tokens, io.mel, io.ld_mel = _p(tok), _p(mel_p), mel_p.stride(0)
             io.f0_raw, io.ema_raw, io.ld_ema = _p(f0_p), _p(ema_p), ema_p.stride(0)
             io.forced_dur = _p(forced)
-            n2 = 2 * sum(int(f) for f in frames) if frames is not None else int(capacity)
+            n2 = 2 * sum(int(f) for f in frames) if frames is not None else (2 * int(frame_cap) if frame_cap is not None else int(capacity))
+            if frame_cap is not None:
+                if frames is not None or forced is not None:
+                    raise _lib.HipLibraryError("frame_cap goes with predicted durations (no frames, no forced durations)")
+                io.frame_cap = int(frame_cap)
             if "mel" not in res:
                 res["mel"] = torch.empty((rt.cfg.n_mels, max(n2, 1)), dtype=torch.float32, device=dev)
             # a submission that a lane may hold back for its group (frames known, coalescing on) has no per-submission home for the
             # optional outputs; every other one -- predicted durations above all, where frame_off is the only record of the split -- has
-            can_merge = self.coalesce > 1 and frames is not None
+            can_merge = self.coalesce > 1 and (frames is not None or frame_cap is not None)
             if not can_merge and "dur_i" not in res:
                 res["dur_i"] = torch.empty((max(Nt, 1),), dtype=torch.int32, device=dev)
+            if (not can_merge or frame_cap is not None) and "frame_off" not in res:
                 res["frame_off"] = torch.empty((B + 1,), dtype=torch.int32, device=dev)
             io.mel_out, io.ld_out = _p(res["mel"]), res["mel"].stride(0)
             if not can_merge:
-                io.dur_i, io.frame_off = _p(res["dur_i"]), _p(res["frame_off"])
+                io.dur_i = _p(res["dur_i"])
+            if not can_merge or frame_cap is not None:            # (under a capacity every submission of a merged call gets its own frame_off)
+                io.frame_off = _p(res["frame_off"])
             ba = rt.batch(tok_lens=tok_lens, ref_lens=ref_lens, frames=frames)
             fr = (ctypes.c_int32 * B)()
             lane = ctypes.c_int32(-1)
             check(L.as_lanes_submit(self.h, ctypes.byref(ba), ctypes.byref(io), fr, ctypes.byref(lane)), "as_lanes_submit")
-            res["frames"] = [int(v) for v in fr] if frames is None else [int(f) for f in frames]
+            res["frames"] = None if frame_cap is not None else ([int(v) for v in fr] if frames is None else [int(f) for f in frames])
             # (a lane's last group of submissions stays referenced: its launch may still be reading them)
             prev = self._keep[lane.value] or []
             self._keep[lane.value] = (prev + [(ba, io, tok, mel_p, f0_p, ema_p, forced, res)])[-2 * max(self.coalesce, 1):]

@@ -642,8 +642,9 @@ typedef struct as_batch {
 } as_batch;
 
 enum { AS_MOD_FORWARD_A = 0, AS_MOD_FORWARD_B = 1, AS_MOD_ENCODER = 2, AS_MOD_STYLE = 3, AS_MOD_DURATION = 4, AS_MOD_ARTS = 5,
-       AS_MOD_DECODER = 6 };
-/* workspace bytes of one module call for this geometry (AS_MOD_FORWARD_A / _B: the two workspaces of as_forward_test) */
+       AS_MOD_DECODER = 6, AS_MOD_FORWARD_B_CAP = 7 };
+/* workspace bytes of one module call for this geometry (AS_MOD_FORWARD_A / _B: the two workspaces of as_forward_test; AS_MOD_FORWARD_B_CAP:
+ * workspace B of a call with as_forward_io.frame_cap = the SUM of batch->frames, whose entries are then capacities, not counts) */
 size_t as_module_workspace_bytes(const as_model* m, as_plan* p, int module, const as_batch* batch);
 
 /* RelTransformerEncoder.forward (RelTransformerEnc.py:371-380).  which: 0 text_encoder, 1 arts_encoder, 2 the duration
@@ -691,7 +692,30 @@ typedef struct as_forward_io {
     float* feat12; int32_t ld_feat;      /* [12][ld_feat >= sum ref_lens] */
     float* t_en; float* a_en; int32_t ld_en;          /* [hidden_dim][ld_en >= sum tok_lens] */
     float* F0; float* N; float* EMA; int32_t ld_pred; /* [1] / [1] / [10] x [ld_pred >= 2 * sum frames] */
+    /* Predicted durations WITHOUT the host read-back (batch->frames == NULL and frame_cap > 0).  models.py:361-368 sizes the second half
+     * from the durations the first half predicts; frame_cap = the half-rate frames the caller makes ROOM for, all utterances together
+     * (ld_out >= 2 * frame_cap, ld_pred likewise; the workspace of AS_MOD_FORWARD_B_CAP).  Every launch of the second half is then sized by
+     * the capacity, the utterances' real extents are derived on the device (frame_off, optional output here, tells the caller where each
+     * utterance's frames lie: utterance b at columns [2 frame_off[b], 2 frame_off[b + 1]) of mel_out), columns behind them are filler that
+     * costs next to nothing (ConvGemmArgs.n_valid) -- and the call neither synchronises nor depends on values the host does not have: it
+     * can be captured into a hipGraph, and as_lanes replays and coalesces it.  More frames than room: AS_STATUS_CAPACITY (what was computed
+     * was cut at the capacity; nothing is written out of bounds; run again with more room).  frames_host_out is not written.
+     * Optional outputs in this mode: frame_off, dur_i, duration, style, feat12, t_en, a_en, F0 / N / EMA. */
+    int32_t frame_cap;
+    /* a merged call (as_lanes coalescing under frame_cap): the submissions it was made of.  Utterances [first[s], first[s + 1]) came with
+     * submission s, whose own output buffer mel_out[s] (row stride ld_out[s] >= 2 cap[s]) gets its utterances from its first column on and
+     * whose frame_off[s] (optional, [its utterances + 1]) counts from 0 -- every submission is served as if it had been alone.  NULL: the
+     * call is one submission (mel_out / frame_off above). */
+    const struct as_segments* segs;
 } as_forward_io;
+typedef struct as_segments {
+    int32_t n;                      /* 1 .. AS_MAX_SEGMENTS */
+    int32_t first[17];
+    int32_t cap[16];                /* half-rate frames of room of submission s; their sum = frame_cap */
+    float* mel_out[16]; int32_t ld_out[16];
+    int32_t* frame_off[16];
+} as_segments;
+#define AS_MAX_SEGMENTS 16
 int as_forward_test_begin(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,
                           as_stream_t stream);
 int as_forward_test_finish(const as_model* m, as_plan* p, const as_batch* batch, const as_forward_io* io, void* ws_a, size_t ws_a_bytes,

@@ -515,3 +515,83 @@ def test_lanes_submit_host_blocks_refilled_behind_groups_in_flight():
     assert float((b["out"] - wants[5]).abs().max()) <= 3e-5
     assert _lib.lib().as_device_status(0) == 0
     lanes.close()
+
+
+def test_lanes_predicted_durations_under_a_frame_capacity_graphs_and_coalescing():
+    """as_forward_io.frame_cap through as_lanes: submissions with PREDICTED durations are replayed from hipGraphs (nothing in the call
+    waits for the host) and coalesced like submissions with known counts -- two adjacent submissions of 16 ragged utterances go out as
+    ONE call whose mel is dealt out to the submissions' own output buffers (as_segments), each with its own frame_off from 0.  Every
+    utterance against the read-back path of its own submission run alone (<= 3e-5: another GEMM tile), frame offsets equal, replays bit
+    for bit; then uncoalesced (k = 1) submissions of the same kind: eager, captured, replayed."""
+    import bench
+    from artspeech_amd import _lib, models
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    net = _net(dev)
+    solo = _alone(net)
+    per, k, n_lanes = 16, 2, 2
+    blocks = []
+    for i in range(n_lanes):
+        host, g = bench.make_inputs(dev, per * k, 30, 70, 120, seed0=bench.DATA_SEED + 60 * i, vary=True)
+        subs, _ = bench.adjacent_submissions(g, per)
+        for j, sub in enumerate(subs):
+            gj = bench.pack_inputs(host, list(range(j * per, (j + 1) * per)), dev)
+            ref = solo.forward_packed(gj["tok"], gj["tok_lens"], gj["mel"], gj["f0"], gj["ema"], gj["ref_lens"])       # predicted, read-back path
+            sub["want_off"] = ref["frame_off"].cpu().numpy().copy()
+            sub["want_mel"] = ref["mel"].clone()
+            sub["cap"] = int(1.25 * int(sub["want_off"][-1])) + 5
+            sub["res"] = None
+        blocks.append(subs)
+    torch.cuda.synchronize()
+    lanes = models.Lanes(net, n_lanes)
+    lanes.set_coalesce(k)
+
+    def run_round():
+        for i, subs in enumerate(blocks):
+            got = []
+            for sub in subs:
+                lane, sub["res"] = lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"],
+                                                frame_cap=sub["cap"], out=sub["res"])
+                got.append(lane)
+            assert got == [i] * k
+        lanes.wait()
+    first = None
+    for r in range(5):                                             # eager, eager (graph plan), captured, replayed, replayed
+        for subs in blocks:
+            for sub in subs:
+                if sub["res"] is not None:
+                    sub["res"]["mel"].zero_()
+                    sub["res"]["frame_off"].zero_()
+        torch.cuda.synchronize()
+        run_round()
+        assert _lib.lib().as_device_status(0) == 0, _lib.device_status()
+        got = []
+        for subs in blocks:
+            for sub in subs:
+                off = sub["res"]["frame_off"].cpu().numpy()
+                assert np.array_equal(off, sub["want_off"]), (r, off, sub["want_off"])
+                n2 = 2 * int(off[-1])
+                assert sub["res"]["mel"].shape[1] == 2 * sub["cap"]
+                d = float((sub["res"]["mel"][:, :n2] - sub["want_mel"]).abs().max())
+                assert d <= 3e-5, (r, d)
+                got.append(sub["res"]["mel"][:, :n2].clone())
+        if r == 3:
+            first = got
+        if r == 4:
+            for a, b in zip(got, first):
+                assert torch.equal(a, b)
+    assert all(lanes.merged_calls(i) == 5 for i in range(n_lanes))
+    assert lanes.stats(0)["graph_launches"] >= 2 and lanes.stats(0)["eager_calls"] == 2
+    # one submission per call
+    lanes.set_coalesce(1)
+    sub = blocks[0][1]
+    res = None
+    for r in range(4):
+        lane, res = lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], frame_cap=sub["cap"], out=res)
+        lanes.wait(lane)
+        n2 = 2 * int(sub["want_off"][-1])
+        assert np.array_equal(res["frame_off"].cpu().numpy(), sub["want_off"])
+        assert np.array_equal(res["dur_i"].cpu().numpy().shape, (sum(sub["tok_lens"]),))
+        assert float((res["mel"][:, :n2] - sub["want_mel"]).abs().max()) <= 3e-5
+    assert _lib.lib().as_device_status(0) == 0
+    lanes.close()

@@ -368,6 +368,92 @@ def test_c3_full_config_ragged_batch_vs_oracle(cuda, arrangement):
     print(f"C3 ragged batch of 32, full config, {arrangement}: worst mel max-abs vs oracle", worst)
 
 
+@pytest.mark.parametrize("arrangement", ["side_streams", "merged_chain"])
+def test_c3_predicted_durations_under_a_frame_capacity_vs_oracle(cuda, arrangement):
+    """models.py:361-368 sizes the second half from the durations the first half PREDICTS.  as_forward_io.frame_cap: the same 32 ragged
+    utterances as one as_forward_test call that never reads anything back -- the second half is laid out for a capacity (here 1.3 x what
+    comes out, and once exactly what comes out), the utterances' extents are derived on the device.  Every utterance against the oracle's
+    batch-1 run (durations identical, mel <= 1e-4), frame_off against the read-back path's, the eager call and its replay from a hipGraph
+    bit for bit, the filler behind the last utterance is never mistaken for a non-finite mel, and a capacity that is too small raises
+    AS_STATUS_CAPACITY without writing out of bounds."""
+    from artspeech_amd import _lib
+    from artspeech_amd.ops import pack
+    from oracle import acoustic
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    hd, di, seed = 512, 64, 3407
+    net = get_model(hd, di, seed, cuda).replica()
+    if arrangement == "merged_chain":
+        net.rt.set_serial(True)
+    W = fold_state_dict(synth.synth_state_dict(hd, di, seed=seed))
+    dist = load_distribution(DEFAULT_STATS)
+    rng = np.random.default_rng(7)
+    Bn = 32
+    tl = [int(v) for v in rng.integers(24, 41, Bn)]
+    ml = [int(v) for v in rng.integers(120, 201, Bn)]
+    toks = [synth.synth_tokens(n, 500 + b) for b, n in enumerate(tl)]
+    feats = [raw_features(t, 500 + b) for b, t in enumerate(ml)]
+    with torch.cuda.device(cuda):
+        tok = torch.from_numpy(np.concatenate(toks).astype(np.int32)).to(cuda)
+        mel_p = torch.from_numpy(np.concatenate([f[0] for f in feats], 1)).to(cuda)
+        f0_p = torch.from_numpy(np.concatenate([f[1] for f in feats], 1)).to(cuda)
+        ema_p = torch.from_numpy(np.concatenate([f[2] for f in feats], 1)).to(cuda)
+    base = net.forward_packed(tok, tl, mel_p, f0_p, ema_p, ml)                   # the read-back path
+    off_ref = base["frame_off"].cpu().numpy()
+    total = int(off_ref[-1])
+    refs = [acoustic.forward_test(W, torch.from_numpy(toks[b]), *(torch.from_numpy(x) for x in feats[b]), dist) for b in range(Bn)]
+    for cap in (int(1.3 * total) + 7, total):
+        out = net.forward_packed(tok, tl, mel_p, f0_p, ema_p, ml, frame_cap=cap)
+        torch.cuda.synchronize()
+        assert _lib.lib().as_device_status(0) == 0, _lib.device_status()
+        assert out["mel"].shape == (80, 2 * cap)
+        off = out["frame_off"].cpu().numpy()
+        assert np.array_equal(off, off_ref)
+        assert np.array_equal(out["dur_i"].cpu().numpy(), base["dur_i"].cpu().numpy())
+        worst, o = 0.0, 0
+        for b in range(Bn):
+            assert np.array_equal(out["dur_i"].cpu().numpy()[o:o + tl[b]], refs[b]["pred_dur"].numpy().astype(np.int32)), (b, "durations")
+            o += tl[b]
+            a, e = 2 * int(off[b]), 2 * int(off[b + 1])
+            assert e - a == refs[b]["mel"].shape[1]
+            d = float((out["mel"][:, a:e].cpu() - refs[b]["mel"]).abs().max())
+            worst = max(worst, d)
+            assert d <= MEL_TOL, (cap, b, d)
+        assert float((out["mel"][:, : 2 * total] - base["mel"]).abs().max()) <= 3e-5
+        print(f"C3 ragged 32, predicted durations, frame_cap {cap} (needed {total}), {arrangement}: worst mel max-abs vs oracle", worst)
+    # the call as a hipGraph (nothing in it waits for the host): replays give the eager bits
+    cap = int(1.3 * total) + 7
+    eager = net.forward_packed(tok, tl, mel_p, f0_p, ema_p, ml, frame_cap=cap)
+    want = eager["mel"][:, : 2 * total].clone()
+    graph, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        net.forward_packed(tok, tl, mel_p, f0_p, ema_p, ml, frame_cap=cap, out=eager)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=st):
+            net.forward_packed(tok, tl, mel_p, f0_p, ema_p, ml, frame_cap=cap, out=eager)
+    for _ in range(2):
+        eager["mel"].zero_()
+        eager["frame_off"].zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(eager["mel"][:, : 2 * total], want)
+        assert np.array_equal(eager["frame_off"].cpu().numpy(), off_ref)
+    assert _lib.lib().as_device_status(0) == 0
+    # not enough room: loud, and nothing past the buffer is touched
+    small = total - 50
+    try:
+        cut = net.forward_packed(tok, tl, mel_p, f0_p, ema_p, ml, frame_cap=small)
+        torch.cuda.synchronize()
+        assert _lib.lib().as_device_status(0) & (1 << 5)                          # AS_STATUS_CAPACITY
+        assert int(cut["frame_off"].cpu().numpy()[-1]) == total                   # (the durations themselves are what they are)
+    finally:
+        _lib.lib().as_device_status(1)
+    out = net.forward_packed(tok, tl, mel_p, f0_p, ema_p, ml, frame_cap=cap)      # healthy again after the clear
+    torch.cuda.synchronize()
+    assert torch.equal(out["mel"][:, : 2 * total], want) and _lib.lib().as_device_status(0) == 0
+
+
 def test_f16_operand_mode_error_is_reported(cuda, golden_dir):
     """BASELINE config C2 names 16-bit operands ("error reported").  as_plan_set_operand_mode(plan, 1) runs every
     conv GEMM on the h parts only (plain fp16 operands, one matrix-core product, fp32 accumulate).  This mode is NOT held to the 1e-4
