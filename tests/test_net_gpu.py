@@ -377,7 +377,6 @@ def test_c3_predicted_durations_under_a_frame_capacity_vs_oracle(cuda, arrangeme
     bit for bit, the filler behind the last utterance is never mistaken for a non-finite mel, and a capacity that is too small raises
     AS_STATUS_CAPACITY without writing out of bounds."""
     from artspeech_amd import _lib
-    from artspeech_amd.ops import pack
     from oracle import acoustic
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     hd, di, seed = 512, 64, 3407
