@@ -750,6 +750,75 @@ def bench_coalesced(net, hosts, k, n_lanes, steps, warmup, barrier=lambda: None)
                 note="as_lanes_submit per 32-utterance batch; a lane launches its k adjacent batches as one as_forward_test call"), first
 
 
+def bench_predicted(net, hosts, k, n_lanes, steps, warmup, barrier=lambda: None):
+    """The same K submissions as `forward(step="test")` is actually called (/root/reference/models.py:361-368, test.py:113): durations
+    PREDICTED by the model, no forced durations, no frame counts from the host.  as_forward_io.frame_cap: every submission names the
+    half-rate frames it has room for (here 1.25 x what the predictor yields on these inputs, measured once through the read-back path),
+    the call is sized by that capacity and finds the utterances' extents on the device -- so the lanes replay it from hipGraphs and
+    coalesce k adjacent submissions into one call exactly as with known counts.  Every submission's mel and frame offsets are held
+    against the same submission run alone through the read-back path."""
+    from artspeech_amd import models
+    dev = net.rt.device
+    per = len(hosts[0]["frames"])
+    chain = net.replica()
+    chain.rt.set_serial(True)
+    order = []
+    for i in range(n_lanes):
+        hs = hosts[i * k:(i + 1) * k]
+        g = pack_inputs(merge_hosts(hs), list(range(per * k)), dev)
+        subs, _ = adjacent_submissions(g, per)
+        for h, sub in zip(hs, subs):
+            gj = pack_inputs(h, list(range(per)), dev)
+            ref = chain.forward_packed(gj["tok"], gj["tok_lens"], gj["mel"], gj["f0"], gj["ema"], gj["ref_lens"])   # predicted durations, read back
+            sub["want_off"] = ref["frame_off"].cpu()
+            sub["want_mel"] = ref["mel"].clone()
+            sub["total"] = int(sub["want_off"][-1])
+            sub["cap"] = int(1.25 * sub["total"]) + 8
+            sub["res"] = None
+            order.append(sub)
+    torch.cuda.synchronize()
+    lanes = models.Lanes(net, n_lanes)
+    lanes.set_coalesce(k)
+
+    def submit(i):
+        sub = order[i % len(order)]
+        _, sub["res"] = lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], frame_cap=sub["cap"],
+                                     out=sub["res"])
+    for i in range(max(warmup // len(order) + 1, 4) * len(order)):
+        submit(i)
+    lanes.wait()
+    els = []
+    for _ in range(REPEATS):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            submit(i)
+        lanes.wait()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        els.append(time.perf_counter() - t0)
+        for i in range(steps, (steps // len(order) + 1) * len(order)):
+            submit(i)
+        lanes.wait()
+    torch.cuda.synchronize()
+    worst = max(float((sub["res"]["mel"][:, : 2 * sub["total"]] - sub["want_mel"]).abs().max()) for sub in order)
+    offs_ok = all(torch.equal(sub["res"]["frame_off"].cpu(), sub["want_off"]) for sub in order)
+    st = lanes.stats(0)
+    merged = sum(lanes.merged_calls(i) for i in range(n_lanes))
+    lanes.close()
+    frames_step = 2.0 * sum(order[i % len(order)]["total"] for i in range(steps)) / steps            # mel frames of an average timed step
+    return dict(elapsed_s=els[0], ms_per_step=els[0] / steps * 1e3, ms_per_step_repeats=[e / steps * 1e3 for e in els], coalesce=k, lanes=n_lanes,
+                mel_frames_per_step=frames_step, frames_per_s=frames_step * steps / els[0],
+                frame_cap_per_submission=[sub["cap"] for sub in order], frames_predicted_per_submission=[sub["total"] for sub in order],
+                merged_calls=merged, graph_launches_lane0=st["graph_launches"], eager_calls_lane0=st["eager_calls"],
+                max_abs_vs_read_back_path=worst, frame_offsets_equal=bool(offs_ok), results_verified=bool(worst <= 3e-5 and offs_ok),
+                note="as_lanes_submit with as_forward_io.frame_cap: durations predicted on the device, no host read-back, hipGraph replay, "
+                     "k adjacent submissions per call (as_segments)")
+
+
 def c4_check(net, host, mel_mine, mine, world, rank, dev, dist, dump=None):
     """merge the ranks' shards on rank 0 and compare with rank 0 running the whole global batch alone; `dump`: an .npz that gets the
     merged mel of three utterances (shortest, median, longest) for the caller to hold against the oracle (tests/test_multirank_gpu.py)"""
@@ -967,6 +1036,14 @@ def main():
         if coal["adopted_as_value"]:
             elapsed_lanes32 = elapsed
             elapsed = coal["elapsed_s"]
+    predicted = None
+    if coal is not None and rank == 0:
+        try:
+            predicted = bench_predicted(net, hosts, kc, ncl, args.steps, args.warmup)
+            # per mel frame against the line's value (the predicted durations of these inputs do not add up to the forced 100 frames per utterance)
+            predicted["ms_per_mel_frame_vs_value"] = (predicted["ms_per_step"] / predicted["mel_frames_per_step"]) / (elapsed / args.steps * 1e3 / (frames_total / world))
+        except Exception as e:                               # (an extra: never costs the headline line)
+            predicted = {"error": repr(e)[:300]}
     native = None
     if n_fl > 1 and rank == 0 and not args.no_extras:
         native = bench_native_lanes(net, [r.g for r, _, _ in lanes], firsts, args.steps, args.warmup)
@@ -1072,6 +1149,7 @@ def main():
                                   (f"{n_fl} batches of 32 in flight, one hipGraph replay of one as_forward_test call each" if n_fl > 1 else "one batch at a time")},
         "ms_per_step_lanes_of_32": (elapsed_lanes32 / args.steps * 1e3) if elapsed_lanes32 else None,   # (the 4 x 32 arrangement, when `value` is the coalesced one's)
         "coalesced": coal,
+        "predicted": predicted,
         "ms_per_step_one_in_flight": single_ms,
         "ms_per_step_one_chain_alone": one_chain_ms,
         "chain_vs_side_streams_max_abs": chain_vs_side,
