@@ -762,11 +762,12 @@ def bench_predicted(net, hosts, k, n_lanes, steps, warmup, barrier=lambda: None)
     per = len(hosts[0]["frames"])
     chain = net.replica()
     chain.rt.set_serial(True)
-    order = []
+    order, known = [], []
     for i in range(n_lanes):
         hs = hosts[i * k:(i + 1) * k]
         g = pack_inputs(merge_hosts(hs), list(range(per * k)), dev)
         subs, _ = adjacent_submissions(g, per)
+        durs, frames = [], []
         for h, sub in zip(hs, subs):
             gj = pack_inputs(h, list(range(per)), dev)
             ref = chain.forward_packed(gj["tok"], gj["tok_lens"], gj["mel"], gj["f0"], gj["ema"], gj["ref_lens"])   # predicted durations, read back
@@ -776,6 +777,12 @@ def bench_predicted(net, hosts, k, n_lanes, steps, warmup, barrier=lambda: None)
             sub["cap"] = int(1.25 * sub["total"]) + 8
             sub["res"] = None
             order.append(sub)
+            durs.append(ref["dur_i"].clone())
+            frames += [int(sub["want_off"][b + 1] - sub["want_off"][b]) for b in range(per)]
+        # the SAME durations handed over as host-known counts (forced = what the predictor said): what the capacity mechanism itself costs
+        g2 = dict(g)
+        g2["forced"], g2["frames"] = torch.cat(durs).contiguous(), frames
+        known += adjacent_submissions(g2, per)[0]
     torch.cuda.synchronize()
     lanes = models.Lanes(net, n_lanes)
     lanes.set_coalesce(k)
@@ -810,7 +817,39 @@ def bench_predicted(net, hosts, k, n_lanes, steps, warmup, barrier=lambda: None)
     merged = sum(lanes.merged_calls(i) for i in range(n_lanes))
     lanes.close()
     frames_step = 2.0 * sum(order[i % len(order)]["total"] for i in range(steps)) / steps            # mel frames of an average timed step
-    return dict(elapsed_s=els[0], ms_per_step=els[0] / steps * 1e3, ms_per_step_repeats=[e / steps * 1e3 for e in els], coalesce=k, lanes=n_lanes,
+    # the same batches with the same durations as KNOWN counts through the same lanes (the headline's path on this ragged workload)
+    lanes = models.Lanes(net, n_lanes)
+    lanes.set_coalesce(k)
+
+    def submit_k(i):
+        sub = known[i % len(known)]
+        lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], forced=sub["forced"], frames=sub["frames"],
+                     out=sub["out"])
+    for i in range(max(warmup // len(known) + 1, 4) * len(known)):
+        submit_k(i)
+    lanes.wait()
+    els_k = []
+    for _ in range(REPEATS):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            submit_k(i)
+        lanes.wait()
+        torch.cuda.synchronize()
+        els_k.append(time.perf_counter() - t0)
+        for i in range(steps, (steps // len(known) + 1) * len(known)):
+            submit_k(i)
+        lanes.wait()
+    torch.cuda.synchronize()
+    worst_k = max(float((sk["out"]["mel"] - so["want_mel"]).abs().max()) for sk, so in zip(known, order))
+    lanes.close()
+    med = lambda v: sorted(v)[len(v) // 2]
+    return dict(known_counts_same_durations=dict(ms_per_step=els_k[0] / steps * 1e3, ms_per_step_repeats=[e / steps * 1e3 for e in els_k],
+                                                 max_abs_vs_read_back_path=worst_k,
+                                                 note="the same batches, the predictor's integer durations handed over as forced durations with "
+                                                      "host-known frame counts: the headline's path on this ragged workload"),
+                capacity_overhead=med(els) / med(els_k),
+                elapsed_s=els[0], ms_per_step=els[0] / steps * 1e3, ms_per_step_repeats=[e / steps * 1e3 for e in els], coalesce=k, lanes=n_lanes,
                 mel_frames_per_step=frames_step, frames_per_s=frames_step * steps / els[0],
                 frame_cap_per_submission=[sub["cap"] for sub in order], frames_predicted_per_submission=[sub["total"] for sub in order],
                 merged_calls=merged, graph_launches_lane0=st["graph_launches"], eager_calls_lane0=st["eager_calls"],
