@@ -10,6 +10,10 @@
 // host: launch the f16x3 kernel for tile `choice` (22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64, 14 = 64x256; 4 waves each) over the
 // tiles of `n` independent problems (1 <= n <= H3_MAXP), problem i in S[i] K slices; returns AS_OK or a hipError_t.  (conv_gemm_h3.hip)
 int as_conv_gemm_h3_launch(const ConvGemmArgs* const* a, const int* S, int n, int choice, hipStream_t stream);
+// host: ONE conv (no K slices, one weight set, f16x3) as one launch of two tile shapes: columns [0, col_split) on 128 x 128 tiles, listed
+// first, columns [col_split, N) on 128 x 64 tiles behind them -- the last round of a launch of 1.x rounds of the chip is then made of
+// half-size tiles (scripts/exp/records/riders_r06.txt).  col_split: a multiple of 128 inside (0, N).
+int as_conv_gemm_h3_launch_mix(const ConvGemmArgs* a, int col_split, hipStream_t stream);
 // host: the kernel that writes the split image of X (no profiling scope of its own)
 int as_split_f16x2_launch(const float* x, int ldx, int K, int N, int lrelu, float slope, uint16_t* xh, hipStream_t stream);
 
@@ -78,6 +82,8 @@ struct H3Prob {
     H3Taps tp;
     int32_t wg0, wgs;       // first workgroup, workgroups (a multiple of 8)
     int32_t tiles, S;       // output tiles, K slices: workgroup (tile, slice) = logical id % tiles, / tiles
+    int32_t col0, col1;     // the columns [col0, col1) of `a` this entry covers (0, N: all; a mixed-tile launch lists one conv twice)
+    int32_t small, pad_;    // mixed-tile launch: 1 = this entry's tiles are the launch's SMALL tile
 };
 struct H3Multi {
     int32_t n, pad_;

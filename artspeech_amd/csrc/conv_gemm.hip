@@ -655,6 +655,30 @@ static GemmPlan gemm_plan(const ConvGemmArgs& a)
     return p;
 }
 
+// A launch of 1.x rounds of the chip: 513 .. 1024 tiles of 128 x 128 on 512 workgroup slots (the six 1 024-row decoder convs at 64
+// utterances per call: 800 tiles).  Its second round leaves most CUs with one workgroup, at 0.71 of the paired rate.  The last sixth of
+// the columns on 128 x 64 tiles instead -- listed last, so they fill the slots the big tiles leave -- levels it: M1024 N12800 K1024 T3
+// 227 -> 200-203 us with 12-25 % of the columns small, K1216 270 -> 237-240 (scripts/exp/tilemix_bound.py, two free-running launches:
+// the bound; scripts/exp/records/riders_r06.txt).  Launches of one round or less lose (M1024 N6400 + 6 %, M512 N12800 + 4 %): not them.
+// Returns the first small column (a multiple of 128), or 0: no mixing.  Same products, and for the small tile's columns the order of
+// partial sums of the 128 x 64 tile (two K halves summed through LDS).
+// OFF unless AS_GEMM_MIX=1: inside the step the gain is not there -- two coalescing lanes, 40 steps, alternating runs on one box: 3.86-3.87
+// ms per step mixed against 3.82-3.84 unmixed (the conv class by events 0.387-0.389 against 0.384-0.386 of the ceiling: the launches are
+// a little faster, the step is not) -- like every tile experiment before it.  The kernel and the rule stay, tested.
+static int gemm_mix_split(const ConvGemmArgs& a, int choice, int S)
+{
+    const char* on = getenv("AS_GEMM_MIX");                                // (read per call: tests, A/B runs)
+    const bool off = !(on && *on == '1');
+    if (off || choice != 22 || S != 1 || a.n_prod != 3 || a.n_groups > 1 || a.M % 128 != 0 || a.slab_tr) return 0;
+    const int tn = as_cdiv(a.N, 128), tiles = (a.M / 128) * tn;
+    if (tiles <= 512 + 64 || tiles > 1024) return 0;
+    const char* fe = getenv("AS_GEMM_MIX_FRAC");
+    const double frac = fe ? atof(fe) : 0.17;
+    const int small_t = std::max(1, (int)(frac * tn + 0.5));
+    const int split = (tn - small_t) * 128;
+    return split > 0 && split < a.N ? split : 0;
+}
+
 static bool direct_cin1(const ConvGemmArgs& a)
 {
     return a.K == 1 && !a.K2 && a.W && a.X && (!a.Yh || a.T <= 9) && !a.res && !a.div_sqrt2 && !a.transpose_out && a.ileave_u <= 1 && a.M <= DIRECT_MAX_M && a.n_groups <= 1 &&
@@ -947,7 +971,8 @@ static int conv_gemm_one(const ConvGemmArgs* args_host, const AsAdainArgs* post_
     const ConvGemmArgs* one = &a;
     const bool fuse_ln = S > 1 && want_ln && ln_fusable(a, *ln_host);
     norm.slab_tr = fuse_ln ? 1 : 0;                                     // (the slices store time-major for the reduction that normalises columns)
-    const int rc = as_conv_gemm_h3_launch(&one, &S, 1, plan.choice, stream);
+    const int mix = gemm_mix_split(a, plan.choice, S);
+    const int rc = mix ? as_conv_gemm_h3_launch_mix(one, mix, stream) : as_conv_gemm_h3_launch(&one, &S, 1, plan.choice, stream);
     if (rc != AS_OK) return rc;
     if (fuse_ln) {
         const AsAdainArgs* np = nullptr;

@@ -67,25 +67,29 @@ struct H3Cfg {
 #ifndef H3_OCC
 #define H3_OCC 1
 #endif
+// which problem a workgroup belongs to (wave-uniform: scalar compares on the kernel arguments)
+static __device__ __forceinline__ int h3_problem_of(const H3Multi& mm)
+{
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < H3_MAXP; ++i) pi += (i < mm.n && (int)blockIdx.x >= mm.p[i].wg0) ? 1 : 0;
+    return pi;
+}
+
+// one workgroup's tile of problem `prob` (the whole kernel but for the problem look-up: conv_gemm_h3_kernel runs it for every
+// workgroup, conv_gemm_h3_mix_kernel runs one of two instantiations, by the problem's tile class)
 template <int WM, int WN, int WK, int KT, int NS, int NP, int TM = 2>
-__global__ void __launch_bounds__(64 * WM * WN * WK, H3_OCC)
-conv_gemm_h3_kernel(const H3Multi mm)
+static __device__ __forceinline__ void h3_tile(const H3Prob& prob, unsigned char* smem)
 {
     using C = H3Cfg<WM, WN, WK, KT, NS, NP, TM>;
     static_assert(NS >= 2 && NS <= 4, "stages");
     constexpr int BM = C::BM, BN = C::BN, ACH = C::ACH, BCH = C::BCH, NT = C::NT, QP = C::QP, KBS = C::KBS;
     static_assert(NT == 256 && ACH * NT == KBS * QP * BM && BCH * NT == KBS * QP * BN && ACH >= 1 && BCH >= 1, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn % WM, wn = wmn / WM;
     const int l31 = lane & 31, lk = lane >> 5;
-    // which problem this workgroup belongs to (wave-uniform: scalar compares on the kernel arguments), then its (tile, K slice)
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < H3_MAXP; ++i) pi += (i < mm.n && (int)blockIdx.x >= mm.p[i].wg0) ? 1 : 0;
-    const H3Prob& prob = mm.p[pi];
     const ConvGemmArgs& a = prob.a;
     const H3Taps& tp = prob.tp;
     const int lt = logical_of((int)blockIdx.x - prob.wg0, prob.wgs);
@@ -96,7 +100,7 @@ conv_gemm_h3_kernel(const H3Multi mm)
     const int m0 = (tile % tiles_m) * BM;
     // column tiles: per weight set when the launch is grouped (a group's columns are [grp * group_cols, (grp + 1) * group_cols);
     // its last tile is cut at the group's end, so group_cols needs no alignment)
-    int n0 = (tile / tiles_m) * BN, grp = 0, n_end = a.N;
+    int n0 = prob.col0 + (tile / tiles_m) * BN, grp = 0, n_end = prob.col1;
     if (a.n_groups > 1) {
         const int tpg = (a.group_cols + BN - 1) / BN, tn = tile / tiles_m;
         grp = tn / tpg;
@@ -402,6 +406,56 @@ conv_gemm_h3_kernel(const H3Multi mm)
 }
 
 template <int WM, int WN, int WK, int KT, int NS, int NP, int TM = 2>
+__global__ void __launch_bounds__(64 * WM * WN * WK, H3_OCC)
+conv_gemm_h3_kernel(const H3Multi mm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    h3_tile<WM, WN, WK, KT, NS, NP, TM>(mm.p[h3_problem_of(mm)], smem);
+}
+
+// ONE conv on two tile shapes (as_conv_gemm_h3_launch_mix): the entries listed first run the 128 x 128 tile, the ones flagged `small`
+// the 128 x 64 tile (four waves as two K halves of two 64 x 64 blocks).  A workgroup runs one of the two bodies; registers and LDS are
+// the larger of the two (the small tile stages two k-blocks per stage: 72 KB, two workgroups per CU as before).
+__global__ void __launch_bounds__(256, H3_OCC)
+conv_gemm_h3_mix_kernel(const H3Multi mm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // (two entries, constant indices: a dynamic index into the argument struct here made the compiler copy it to scratch)
+    if ((int)blockIdx.x >= mm.p[1].wg0) h3_tile<2, 1, 2, 1, 3, 3>(mm.p[1], smem);
+    else h3_tile<2, 2, 1, 1, 3, 3>(mm.p[0], smem);
+}
+
+int as_conv_gemm_h3_launch_mix(const ConvGemmArgs* a, int col_split, hipStream_t stream)
+{
+    using CB = H3Cfg<2, 2, 1, 1, 3, 3>;
+    using CS = H3Cfg<2, 1, 2, 1, 3, 3>;
+    constexpr int LDS = CB::LDS > CS::LDS ? CB::LDS : CS::LDS;
+    if (!a || a->n_prod != 3 || a->n_groups > 1 || col_split <= 0 || col_split >= a->N || col_split % CB::BN) return AS_EINVAL;
+    if ((double)as_kbx(a->K) * 4.0 * ((a->src_col ? a->N_in : a->N) + 1.0) * 16.0 >= 2147483648.0) return AS_EINVAL;
+    AS_LDS_OPT_IN((&conv_gemm_h3_mix_kernel), LDS);
+    H3Multi mm;
+    memset(&mm, 0, sizeof(mm));
+    mm.n = 2;
+    int wg = 0;
+    for (int i = 0; i < 2; ++i) {
+        H3Prob& p = mm.p[i];
+        p.a = *a;
+        if (h3_pack_taps(p.a, &p.tp) != AS_OK) return AS_EINVAL;
+        p.col0 = i == 0 ? 0 : col_split;
+        p.col1 = i == 0 ? col_split : a->N;
+        p.small = i;
+        p.tiles = as_cdiv(a->M, 128) * as_cdiv(p.col1 - p.col0, i == 0 ? CB::BN : CS::BN);
+        p.S = 1;
+        p.wg0 = wg;
+        p.wgs = (p.tiles + 7) & ~7;
+        wg += p.wgs;
+    }
+    hipLaunchKernelGGL(conv_gemm_h3_mix_kernel, dim3(wg), dim3(256), LDS, stream, mm);
+    AS_CHECK_LAUNCH();
+    return AS_OK;
+}
+
+template <int WM, int WN, int WK, int KT, int NS, int NP, int TM = 2>
 static int launch_h3(const ConvGemmArgs* const* a, const int* S, int n, hipStream_t stream)
 {
     using C = H3Cfg<WM, WN, WK, KT, NS, NP, TM>;
@@ -416,6 +470,8 @@ static int launch_h3(const ConvGemmArgs* const* a, const int* S, int n, hipStrea
         if (h3_pack_taps(p.a, &p.tp) != AS_OK) return AS_EINVAL;
         const int tiles_n = p.a.n_groups > 1 ? p.a.n_groups * as_cdiv(p.a.group_cols, C::BN) : as_cdiv(p.a.N, C::BN);
         p.tiles = as_cdiv(p.a.M, C::BM) * tiles_n;
+        p.col0 = 0;
+        p.col1 = p.a.N;
         p.S = S[i];
         p.wg0 = wg;
         p.wgs = (p.tiles * p.S + 7) & ~7;

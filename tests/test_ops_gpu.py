@@ -62,6 +62,56 @@ def test_conv1d_gemm(cuda, monkeypatch, impl, cin, cout, k, lens, tile):
     assert err <= 2e-5, err
 
 
+@pytest.mark.parametrize("M,K,K2,n_utt", [(1024, 48, 0, 48), (1024, 32, 80, 64), (512, 64, 0, 112), (1024, 48, 0, 33)])
+def test_conv_gemm_mixed_tiles(cuda, monkeypatch, M, K, K2, n_utt):
+    """AS_GEMM_MIX=1: a launch of between one and two rounds of the chip (513 .. 1024 tiles of 128 x 128 on 512 workgroup slots: the 1 024-row
+    decoder convs at 64 utterances per call) runs its last sixth of columns on 128 x 64 tiles in the SAME launch (as_conv_gemm_h3_launch_mix):
+    against float64 torch per utterance (walls between ragged utterances, bias, residual, folded shortcut, the result also as an operand
+    image), and against the unmixed launch -- the big tiles' columns bit for bit, the small tiles' within rounding (another order of the
+    partial sums).  The last case lies under the rule's threshold: mixed and unmixed are the same launch."""
+    g = torch.Generator().manual_seed(M + K + n_utt)
+    lens = [int(v) for v in torch.randint(150, 251, (n_utt,), generator=g)]
+    lay = Layout(lens, cuda)
+    w = torch.randn(M, K, 3, generator=g) / np.sqrt(3 * K + K2)
+    w2 = torch.randn(M, K2, generator=g) / np.sqrt(3 * K + K2) if K2 else None
+    b = torch.randn(M, generator=g)
+    xs = [torch.randn(K, L, generator=g) for L in lens]
+    x2 = [torch.randn(K2, L, generator=g) for L in lens] if K2 else None
+    res = [torch.randn(M, L, generator=g) for L in lens]
+    wt = ops.prep_weight(w, cuda, sc=w2) if K2 else ops.prep_weight(w, cuda)
+    X = packed(xs).to(cuda)
+    xh = ops.split_act(X, lay)
+    x2h = ops.split_act(packed(x2).to(cuda), lay) if K2 else None
+    R = packed(res).to(cuda)
+
+    def run():
+        yh = ops.new_image(M, lay.N, cuda)
+        y = ops.conv_gemm(wt, None, lay, lay.new(M), taps_1d(3), bias=b.to(cuda), res=None if K2 else R, div_sqrt2=True, xs=xh, K=K, x2s=x2h, K2=K2, yh=yh)
+        return y.clone(), yh.clone()
+    monkeypatch.setenv("AS_GEMM_MIX", "1")                                      # (off by default: no gain inside the step, conv_gemm.hip)
+    y_mix, yh_mix = run()
+    monkeypatch.delenv("AS_GEMM_MIX")
+    y_one, yh_one = run()
+    o, worst = 0, 0.0
+    for i, L in enumerate(lens):
+        want = F.conv1d(xs[i][None].double(), w.double(), b.double(), padding=1)[0]
+        want = want + (torch.einsum("mk,kl->ml", w2.double(), x2[i].double()) if K2 else res[i].double())
+        want = (want / np.sqrt(2)).float()
+        worst = max(worst, float((y_mix[:, o:o + L].cpu() - want).abs().max()))
+        o += L
+    assert worst <= 2e-5, worst
+    assert torch.equal(yh_mix, ops.split_act(y_mix, lay))                       # the image is the split of what was stored
+    tn = -(-lay.N // 128)
+    tiles = (M // 128) * tn
+    if 576 < tiles <= 1024:
+        split = (tn - max(1, int(0.17 * tn + 0.5))) * 128
+        assert torch.equal(y_mix[:, :split], y_one[:, :split])
+        assert not torch.equal(y_mix[:, split:], y_one[:, split:])             # (another tile: another order of partial sums)
+        assert float((y_mix - y_one).abs().max()) <= 1e-5
+    else:
+        assert torch.equal(y_mix, y_one) and torch.equal(yh_mix, yh_one)
+
+
 @pytest.mark.parametrize("cin,cout,cin2,k,lens,groups", [(64, 128, 64, 3, [50, 13, 1, 200], 1), (128, 64, 40, 9, [300], 1), (16, 512, 1216, 3, [128] * 8, 1),
                                                           (512, 256, 512, 3, [40] * 9, 3), (96, 80, 200, 1, [40, 41], 1)])
 @pytest.mark.parametrize("tile,ksplit", [("", ""), ("11", ""), ("21", "3"), ("22", ""), ("12", "2"), ("14", "")])
