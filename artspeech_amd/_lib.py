@@ -154,7 +154,7 @@ class ForwardIO(ctypes.Structure):
 
 class HostIO(ctypes.Structure):                 # as_host_io: HOST pointers (as_lanes_submit_host)
     _fields_ = [("tokens", c_p), ("mel", c_p), ("ld_mel", ctypes.c_int32), ("f0_raw", c_p), ("ema_raw", c_p), ("ld_ema", ctypes.c_int32),
-                ("forced_dur", c_p), ("mel_out", c_p), ("ld_out", ctypes.c_int32)]
+                ("forced_dur", c_p), ("mel_out", c_p), ("ld_out", ctypes.c_int32), ("frame_cap", ctypes.c_int32), ("frame_off", c_p)]
 
 
 AS_MOD_FORWARD_A, AS_MOD_FORWARD_B, AS_MOD_ENCODER, AS_MOD_STYLE, AS_MOD_DURATION, AS_MOD_ARTS, AS_MOD_DECODER, AS_MOD_FORWARD_B_CAP = range(8)

@@ -49,6 +49,7 @@ struct Lane {
         as_forward_io io;
         float* out_host = nullptr;                                // as_lanes_submit_host: where the submission's mel goes once its group is out
         int32_t ld_out_host = 0;
+        int32_t* foff_host = nullptr;                             // ... and, under a frame capacity, its frame offsets
         unsigned long long sum = 0;                               // debug mode: checksum of the device inputs as they were at submit
     };
     std::vector<Pending> pend;
@@ -57,9 +58,9 @@ struct Lane {
     struct Block {
         void* dev = nullptr;
         size_t bytes = 0;
-        int cap_tok = 0, cap_ref = 0, cap_out = 0;               // tokens / reference frames / mel frames (columns) the block holds
-        int used_tok = 0, used_ref = 0, used_out = 0;            // ... of which the group that is being filled has taken
-        int32_t *tokens = nullptr, *forced = nullptr;
+        int cap_tok = 0, cap_ref = 0, cap_out = 0, cap_utt = 0;  // tokens / reference frames / mel frames (columns) / utterances the block holds
+        int used_tok = 0, used_ref = 0, used_out = 0, used_utt = 0;   // ... of which the group that is being filled has taken
+        int32_t *tokens = nullptr, *forced = nullptr, *foff = nullptr;   // (foff: frame offsets of submissions under a frame capacity, [utterances + 1] each)
         float *f0 = nullptr, *ema = nullptr, *mel = nullptr, *out = nullptr;
     } blk[2];                                                     // two, alternating from group to group: the next group's copies run under this group's kernels
     int cur = 0;                                                  // the block the group that is being filled lives in
@@ -539,13 +540,15 @@ static int flush_lane(as_lanes* q, int lane)
     }
     if (L.pend.size() > 1) ++L.n_merged;
     // (host submissions: where each one's mel goes once the group's kernels are enqueued)
-    struct Out { float* host; int32_t ld; const float* dev; long cols; };
+    struct Out { float* host; int32_t ld; const float* dev; long cols; int32_t ld_dev; int32_t* foff_host; const int32_t* foff_dev; int n_foff; };
     std::vector<Out> outs;
     for (const Lane::Pending& p : L.pend)
         if (p.out_host) {
             long nf = 0;
             for (int32_t v : p.frames) nf += v;
-            outs.push_back({p.out_host, p.ld_out_host, p.io.mel_out, 2 * nf});
+            // (under a frame capacity the whole slot goes back: how much of it holds frames is known on the device only)
+            outs.push_back({p.out_host, p.ld_out_host, p.io.mel_out, p.frames.empty() ? 2L * p.io.frame_cap : 2 * nf, p.io.ld_out, p.foff_host,
+                            p.io.frame_off, (int)p.tok_lens.size() + 1});
         }
     L.pend.clear();
     const bool host_group = !outs.empty();
@@ -565,10 +568,13 @@ static int flush_lane(as_lanes* q, int lane)
         // ev_d2h[bi] is what the block's NEXT group's copies wait for (recorded whatever happened: a block is never left without it)
         hipError_t e = hipEventRecord(L.ev_comp[bi], L.stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(q->down(L), L.ev_comp[bi], 0);
-        for (const Out& o : outs)
+        for (const Out& o : outs) {
             if (rc == AS_OK && e == hipSuccess && o.cols > 0)
-                e = hipMemcpy2DAsync(o.host, (size_t)o.ld * 4, o.dev, (size_t)io.ld_out * 4, (size_t)o.cols * 4, (size_t)q->cfg.n_mels,
+                e = hipMemcpy2DAsync(o.host, (size_t)o.ld * 4, o.dev, (size_t)o.ld_dev * 4, (size_t)o.cols * 4, (size_t)q->cfg.n_mels,
                                      hipMemcpyDeviceToHost, q->down(L));
+            if (rc == AS_OK && e == hipSuccess && o.foff_host)
+                e = hipMemcpyAsync(o.foff_host, o.foff_dev, (size_t)o.n_foff * 4, hipMemcpyDeviceToHost, q->down(L));
+        }
         const hipError_t e2 = hipEventRecord(L.ev_d2h[bi], q->down(L));
         if (rc == AS_OK && (e != hipSuccess || e2 != hipSuccess)) return (int)(e != hipSuccess ? e : e2);
     }
@@ -576,13 +582,13 @@ static int flush_lane(as_lanes* q, int lane)
 }
 
 static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io* io, int32_t* frames_host_out, int32_t* lane_out,
-                        float* out_host = nullptr, int32_t ld_out_host = 0)
+                        float* out_host = nullptr, int32_t ld_out_host = 0, int32_t* foff_host = nullptr)
 {
     if (!q || !batch || !io || batch->B <= 0 || !batch->tok_lens || !batch->ref_lens) return AS_EINVAL;
     Lane& L = q->lanes[q->next];
     // (a host submission always joins the group of its lane's block -- a group of one when coalescing is off)
     const bool cap_mode = !batch->frames && io->frame_cap > 0;
-    const bool can_wait = (q->coalesce > 1 || out_host) && ((batch->frames && plain_io(io)) || (cap_mode && !out_host && plain_cap_io(io)));
+    const bool can_wait = (q->coalesce > 1 || out_host) && ((batch->frames && plain_io(io)) || (cap_mode && plain_cap_io(io)));
     size_t waiting = 0;                                           // utterances of the group that waits here
     for (const Lane::Pending& p : L.pend) waiting += p.tok_lens.size();
     // (a call takes at most 1024 utterances: as_durations_f32's one-workgroup scan; at most AS_MAX_SEGMENTS submissions under a capacity)
@@ -601,6 +607,7 @@ static int lanes_submit(as_lanes* q, const as_batch* batch, const as_forward_io*
     p.io = *io;
     p.out_host = out_host;
     p.ld_out_host = ld_out_host;
+    p.foff_host = foff_host;
     if (q->debug && !out_host) {                                  // (a host submission's device buffers are the library's own)
         const int rc = inputs_sum(q, L2, p.tok_lens, p.ref_lens, p.io, &p.sum);
         if (rc != AS_OK) return rc;
@@ -633,7 +640,7 @@ extern "C" int as_lanes_submit(as_lanes* q, const as_batch* batch, const as_forw
 static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 // the block holds a group of `k` submissions like this one (with some slack); a block that has to grow is replaced while the lane is idle
-static int block_fit(as_lanes* q, Lane& L, long nt, long nr, long nf2, int k)
+static int block_fit(as_lanes* q, Lane& L, long nt, long nr, long nf2, int n_utt, int k)
 {
     if (!q->h2d && (hipStreamCreateWithFlags(&q->h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&q->d2h, hipStreamNonBlocking) != hipSuccess))
         return (int)hipErrorOutOfMemory;
@@ -645,14 +652,17 @@ static int block_fit(as_lanes* q, Lane& L, long nt, long nr, long nf2, int k)
                 return (int)hipErrorOutOfMemory;
     }
     Lane::Block& b = L.blk[L.cur];
-    if (L.pend.empty()) b.used_tok = b.used_ref = b.used_out = 0; // a new group starts at the block's first column
-    if (b.dev && b.used_tok + nt <= b.cap_tok && b.used_ref + nr <= b.cap_ref && b.used_out + nf2 <= b.cap_out) return AS_OK;
+    if (L.pend.empty()) b.used_tok = b.used_ref = b.used_out = b.used_utt = 0;   // a new group starts at the block's first column
+    if (b.dev && b.used_tok + nt <= b.cap_tok && b.used_ref + nr <= b.cap_ref && b.used_out + nf2 <= b.cap_out &&
+        b.used_utt + n_utt + 1 <= b.cap_utt)
+        return AS_OK;
     if (!L.pend.empty()) return AS_ENOSPC;                        // (the caller sends the waiting group out first, then asks again)
     const auto grow_to = [](long need, int k_) { return (int)std::min<long>((long)INT_MAX / 64, (need * k_ * 5 + 3) / 4 + 64); };
     const int ct = std::max(b.cap_tok, grow_to(nt, k)), cr = std::max(b.cap_ref, grow_to(nr, k)), co = std::max(b.cap_out, grow_to(nf2, k));
+    const int cu = std::max(b.cap_utt, grow_to(n_utt + 1, k));
     const int n_mels = q->cfg.n_mels;
-    const size_t bytes = 2 * up256((size_t)ct * 4) + up256((size_t)cr * 4) + up256((size_t)10 * cr * 4) + up256((size_t)n_mels * cr * 4) +
-                         up256((size_t)n_mels * co * 4);
+    const size_t bytes = 2 * up256((size_t)ct * 4) + up256((size_t)cu * 4) + up256((size_t)cr * 4) + up256((size_t)10 * cr * 4) +
+                         up256((size_t)n_mels * cr * 4) + up256((size_t)n_mels * co * 4);
     AS_CHECK(hipStreamSynchronize(L.stream));                     // the groups that used the old block have left it: kernels ...
     AS_CHECK(hipStreamSynchronize(q->d2h));                       // ... and the copies of their results
     drop_graphs(L);                                               // (its graphs hold the old block's addresses)
@@ -665,9 +675,10 @@ static int block_fit(as_lanes* q, Lane& L, long nt, long nr, long nf2, int k)
         return (int)hipErrorOutOfMemory;
     }
     char* c = static_cast<char*>(d);
-    b.dev = d; b.bytes = bytes; b.cap_tok = ct; b.cap_ref = cr; b.cap_out = co;
+    b.dev = d; b.bytes = bytes; b.cap_tok = ct; b.cap_ref = cr; b.cap_out = co; b.cap_utt = cu;
     b.tokens = reinterpret_cast<int32_t*>(c); c += up256((size_t)ct * 4);
     b.forced = reinterpret_cast<int32_t*>(c); c += up256((size_t)ct * 4);
+    b.foff = reinterpret_cast<int32_t*>(c); c += up256((size_t)cu * 4);
     b.f0 = reinterpret_cast<float*>(c); c += up256((size_t)cr * 4);
     b.ema = reinterpret_cast<float*>(c); c += up256((size_t)10 * cr * 4);
     b.mel = reinterpret_cast<float*>(c); c += up256((size_t)n_mels * cr * 4);
@@ -677,13 +688,17 @@ static int block_fit(as_lanes* q, Lane& L, long nt, long nr, long nf2, int k)
 
 static int lanes_submit_host(as_lanes* q, const as_batch* batch, const as_host_io* h, int32_t* lane_out)
 {
-    if (!q || !batch || !h || batch->B <= 0 || !batch->tok_lens || !batch->ref_lens || !batch->frames) return AS_EINVAL;
+    if (!q || !batch || !h || batch->B <= 0 || !batch->tok_lens || !batch->ref_lens) return AS_EINVAL;
     if (!h->tokens || !h->mel || !h->f0_raw || !h->ema_raw || !h->mel_out) return AS_EINVAL;
+    // frame counts from the caller, or a capacity (durations predicted on the device: the frame offsets come back with the mel)
+    const bool cap_mode = !batch->frames;
+    if (cap_mode && (h->frame_cap < 1 || !h->frame_off || h->forced_dur)) return AS_EINVAL;
     long nt = 0, nr = 0, nf = 0;
     for (int b = 0; b < batch->B; ++b) {
-        if (batch->tok_lens[b] < 0 || batch->ref_lens[b] < 0 || batch->frames[b] < 0) return AS_EINVAL;
-        nt += batch->tok_lens[b]; nr += batch->ref_lens[b]; nf += batch->frames[b];
+        if (batch->tok_lens[b] < 0 || batch->ref_lens[b] < 0 || (!cap_mode && batch->frames[b] < 0)) return AS_EINVAL;
+        nt += batch->tok_lens[b]; nr += batch->ref_lens[b]; nf += cap_mode ? 0 : batch->frames[b];
     }
+    if (cap_mode) nf = h->frame_cap;
     if (h->ld_mel < nr || h->ld_ema < nr || h->ld_out < 2 * nf) return AS_EINVAL;
     const int n_mels = q->cfg.n_mels;
     for (int attempt = 0;; ++attempt) {
@@ -692,8 +707,9 @@ static int lanes_submit_host(as_lanes* q, const as_batch* batch, const as_host_i
         size_t waiting = 0;
         for (const Lane::Pending& p : L.pend) waiting += p.tok_lens.size();
         const bool foreign = !L.pend.empty() && (!L.pend.back().out_host || (L.pend.back().io.forced_dur != nullptr) != (h->forced_dur != nullptr) ||
-                                                 waiting + (size_t)batch->B > 1024);
-        int rc = foreign ? AS_ENOSPC : block_fit(q, L, nt, nr, 2 * nf, std::max(q->coalesce, 1));
+                                                 waiting + (size_t)batch->B > 1024 || L.pend.back().frames.empty() != cap_mode ||
+                                                 (cap_mode && L.pend.size() >= (size_t)AS_MAX_SEGMENTS));
+        int rc = foreign ? AS_ENOSPC : block_fit(q, L, nt, nr, 2 * nf, batch->B, std::max(q->coalesce, 1));
         if (rc == AS_ENOSPC && attempt <= (int)q->lanes.size()) {
             rc = flush_lane(q, q->next);                          // (the turn passes on: the submission opens the next lane's group)
             if (rc != AS_OK) return rc;
@@ -721,9 +737,13 @@ static int lanes_submit_host(as_lanes* q, const as_batch* batch, const as_host_i
         io.ema_raw = b.ema + b.used_ref; io.ld_ema = b.cap_ref;
         io.forced_dur = h->forced_dur ? b.forced + b.used_tok : nullptr;
         io.mel_out = b.out + b.used_out; io.ld_out = b.cap_out;
+        if (cap_mode) {
+            io.frame_cap = h->frame_cap;
+            io.frame_off = b.foff + b.used_utt;
+        }
         // (a group mixes forced and predicted-from-known-frames submissions only if all or none bring forced durations: `adjacent` says no otherwise)
-        b.used_tok += (int)nt; b.used_ref += (int)nr; b.used_out += (int)(2 * nf);
-        return lanes_submit(q, batch, &io, nullptr, lane_out, h->mel_out, h->ld_out);
+        b.used_tok += (int)nt; b.used_ref += (int)nr; b.used_out += (int)(2 * nf); b.used_utt += batch->B + 1;
+        return lanes_submit(q, batch, &io, nullptr, lane_out, h->mel_out, h->ld_out, cap_mode ? h->frame_off : nullptr);
     }
 }
 

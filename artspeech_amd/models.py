@@ -553,19 +553,23 @@ class Lanes:
         """as_lanes_set_debug: the device inputs of a held-back submission are checksummed at submit and at its group's launch"""
         check(_lib.lib().as_lanes_set_debug(self.h, int(bool(on))), "as_lanes_set_debug")
 
-    def submit_host(self, tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, forced, frames, out_mel):
+    def submit_host(self, tok, tok_lens, mel_p, f0_p, ema_p, ref_lens, forced, frames, out_mel, frame_cap=None, frame_off=None):
         """as_lanes_submit_host: HOST tensors in (pinned: `.pin_memory()`), the mel back into the host tensor `out_mel` [n_mels][>= 2 sum
         frames]; the lane owns the device side (its block, the copies, the group's launch).  -> lane.  Keep the tensors alive and unchanged
-        until `wait(lane)`; `out_mel` is valid after it."""
+        until `wait(lane)`; `out_mel` is valid after it.  Predicted durations: frames=None, forced=None, frame_cap = the half-rate frames
+        there is room for (out_mel [n_mels][>= 2 frame_cap]) and frame_off = a host int32 tensor [B + 1] that receives the offsets."""
         def _h(t):
             if t is None:
                 return None
             if t.is_cuda or t.stride(-1) != 1:
                 raise _lib.HipLibraryError("expected a host tensor whose rows are dense")
             return t.data_ptr()
-        tok_lens, ref_lens, frames = [int(v) for v in tok_lens], [int(v) for v in ref_lens], [int(v) for v in frames]
+        tok_lens, ref_lens = [int(v) for v in tok_lens], [int(v) for v in ref_lens]
+        frames = [int(v) for v in frames] if frames is not None else None
         with torch.cuda.device(self.rt.device):
             io = _lib.HostIO()
+            if frames is None:
+                io.frame_cap, io.frame_off = int(frame_cap), _h(frame_off)
             io.tokens, io.mel, io.ld_mel = _h(tok), _h(mel_p), mel_p.stride(0)
             io.f0_raw, io.ema_raw, io.ld_ema = _h(f0_p), _h(ema_p), ema_p.stride(0)
             io.forced_dur = _h(forced)
@@ -574,7 +578,7 @@ class Lanes:
             lane = ctypes.c_int32(-1)
             check(_lib.lib().as_lanes_submit_host(self.h, ctypes.byref(ba), ctypes.byref(io), ctypes.byref(lane)), "as_lanes_submit_host")
             prev = self._keep[lane.value] or []
-            self._keep[lane.value] = (prev + [(ba, io, tok, mel_p, f0_p, ema_p, forced, out_mel)])[-2 * max(self.coalesce, 1):]
+            self._keep[lane.value] = (prev + [(ba, io, tok, mel_p, f0_p, ema_p, forced, out_mel, frame_off)])[-2 * max(self.coalesce, 1):]
         return lane.value
 
     def wait(self, lane=-1):

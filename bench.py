@@ -843,12 +843,49 @@ def bench_predicted(net, hosts, k, n_lanes, steps, warmup, barrier=lambda: None)
     torch.cuda.synchronize()
     worst_k = max(float((sk["out"]["mel"] - so["want_mel"]).abs().max()) for sk, so in zip(known, order))
     lanes.close()
+    # ... and the boundary of the reference as it is called (/root/reference/test.py:96-113): HOST arrays in, durations predicted on the
+    # device, the mel and the frame offsets back on the host (as_lanes_submit_host with a frame capacity)
+    pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+    hb = []
+    for h, sub in zip(hosts, order):
+        cat = lambda key, ax: np.concatenate([h[key][b] for b in range(per)], ax)
+        hb.append(dict(tok=pin(cat("tokens", 0).astype(np.int32)), mel=pin(cat("mel", 1)), f0=pin(cat("f0", 1).reshape(-1)), ema=pin(cat("ema", 1)),
+                       tok_lens=h["tok_lens"], ref_lens=h["ref_lens"], cap=sub["cap"], off=torch.zeros(per + 1, dtype=torch.int32).pin_memory(),
+                       out=torch.zeros((net.rt.cfg.n_mels, 2 * sub["cap"]), dtype=torch.float32).pin_memory()))
+    lanes = models.Lanes(net, n_lanes)
+    lanes.set_coalesce(k)
+
+    def submit_h(i):
+        b = hb[i % len(hb)]
+        lanes.submit_host(b["tok"], b["tok_lens"], b["mel"], b["f0"], b["ema"], b["ref_lens"], None, None, b["out"], frame_cap=b["cap"], frame_off=b["off"])
+    for i in range(max(warmup // len(hb) + 1, 4) * len(hb)):
+        submit_h(i)
+    lanes.wait()
+    els_h = []
+    for _ in range(REPEATS):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            submit_h(i)
+        lanes.wait()
+        torch.cuda.synchronize()
+        els_h.append(time.perf_counter() - t0)
+        for i in range(steps, (steps // len(hb) + 1) * len(hb)):
+            submit_h(i)
+        lanes.wait()
+    host_ok = all(torch.equal(b["off"], sub["want_off"]) and
+                  torch.equal(b["out"][:, : 2 * sub["total"]], sub["res"]["mel"][:, : 2 * sub["total"]].cpu()) for b, sub in zip(hb, order))
+    lanes.close()
     med = lambda v: sorted(v)[len(v) // 2]
     return dict(known_counts_same_durations=dict(ms_per_step=els_k[0] / steps * 1e3, ms_per_step_repeats=[e / steps * 1e3 for e in els_k],
                                                  max_abs_vs_read_back_path=worst_k,
                                                  note="the same batches, the predictor's integer durations handed over as forced durations with "
                                                       "host-known frame counts: the headline's path on this ragged workload"),
                 capacity_overhead=med(els) / med(els_k),
+                host_boundary=dict(ms_per_step_including_transfers=els_h[0] / steps * 1e3, ms_per_step_repeats=[e / steps * 1e3 for e in els_h],
+                                   vs_resident_inputs=med(els_h) / med(els), copies_verified=bool(host_ok),
+                                   note="as_lanes_submit_host with a frame capacity: host arrays in, the whole capacity slot of the mel and the "
+                                        "frame offsets back; bitwise equal to the device-buffer submissions"),
                 elapsed_s=els[0], ms_per_step=els[0] / steps * 1e3, ms_per_step_repeats=[e / steps * 1e3 for e in els], coalesce=k, lanes=n_lanes,
                 mel_frames_per_step=frames_step, frames_per_s=frames_step * steps / els[0],
                 frame_cap_per_submission=[sub["cap"] for sub in order], frames_predicted_per_submission=[sub["total"] for sub in order],

@@ -786,6 +786,11 @@ typedef struct as_host_io {
     const float* ema_raw; int32_t ld_ema;  /* [10][ld_ema >= sum ref_lens] */
     const int32_t* forced_dur;             /* optional [sum tok_lens] */
     float* mel_out; int32_t ld_out;        /* [n_mels][ld_out >= 2 * sum frames] */
+    /* predicted durations (batch->frames == NULL; as_forward_io.frame_cap): the half-rate frames there is room for, and where the
+     * utterances' frame offsets [B + 1] go (HOST; required: it is how the caller finds its utterances in mel_out, whose row stride is then
+     * ld_out >= 2 * frame_cap and which is copied back whole) */
+    int32_t frame_cap;
+    int32_t* frame_off;
 } as_host_io;
 int as_lanes_submit_host(as_lanes* q, const as_batch* batch, const as_host_io* io, int32_t* lane_out);
 int64_t as_lanes_merged_calls(const as_lanes* q, int lane);   /* as_forward_test calls of this lane that held more than one submission */

@@ -514,6 +514,32 @@ def test_lanes_submit_host_blocks_refilled_behind_groups_in_flight():
     lanes.wait(lane)
     assert float((b["out"] - wants[5]).abs().max()) <= 3e-5
     assert _lib.lib().as_device_status(0) == 0
+    # predicted durations at the host boundary (test.py:96-113 as it is called): host arrays in, a frame capacity, the mel and the frame
+    # offsets back -- coalesced two at a time; against the read-back path of every batch run alone from device buffers
+    lanes.set_coalesce(2)
+    caps, offs, outs2, want2 = [], [], [], []
+    for i, b in enumerate(batches[:8]):
+        dv = lambda t: t.to(dev)
+        ref = solo.forward_packed(dv(b["tok"]), b["tok_lens"], dv(b["mel"]), dv(b["f0"]).reshape(1, -1), dv(b["ema"]), b["ref_lens"])
+        off = ref["frame_off"].cpu()
+        cap = int(1.2 * int(off[-1])) + 3
+        caps.append(cap)
+        want2.append((off, ref["mel"].cpu()))
+        offs.append(torch.zeros(per + 1, dtype=torch.int32).pin_memory())
+        outs2.append(torch.zeros((80, 2 * cap), dtype=torch.float32).pin_memory())
+    for r in range(4):
+        for o in outs2:
+            o.zero_()
+        for i, b in enumerate(batches[:8]):
+            lanes.submit_host(b["tok"], b["tok_lens"], b["mel"], b["f0"], b["ema"], b["ref_lens"], None, None, outs2[i], frame_cap=caps[i],
+                              frame_off=offs[i])
+        lanes.wait()
+        for i in range(8):
+            off, mel = want2[i]
+            assert torch.equal(offs[i], off), (r, i)
+            n2 = 2 * int(off[-1])
+            assert float((outs2[i][:, :n2] - mel).abs().max()) <= 3e-5, (r, i)
+    assert _lib.lib().as_device_status(0) == 0
     lanes.close()
 
 
