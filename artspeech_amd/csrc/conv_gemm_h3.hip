@@ -92,27 +92,52 @@ static __device__ __forceinline__ void h3_tile(const H3Prob& prob, unsigned char
     const int l31 = lane & 31, lk = lane >> 5;
     const ConvGemmArgs& a = prob.a;
     const H3Taps& tp = prob.tp;
-    const int lt = logical_of((int)blockIdx.x - prob.wg0, prob.wgs);
     const int S = prob.S;
-    if (lt >= prob.tiles * S) return;                                    // (the padding up to a multiple of 8; the whole workgroup)
-    const int slice = lt / prob.tiles, tile = lt - slice * prob.tiles;
     const int tiles_m = (a.M + BM - 1) / BM;
-    const int m0 = (tile % tiles_m) * BM;
-    // column tiles: per weight set when the launch is grouped (a group's columns are [grp * group_cols, (grp + 1) * group_cols);
-    // its last tile is cut at the group's end, so group_cols needs no alignment)
-    int n0 = prob.col0 + (tile / tiles_m) * BN, grp = 0, n_end = prob.col1;
-    if (a.n_groups > 1) {
-        const int tpg = (a.group_cols + BN - 1) / BN, tn = tile / tiles_m;
-        grp = tn / tpg;
-        n0 = grp * a.group_cols + (tn - grp * tpg) * BN;
-        n_end = min(a.N, (grp + 1) * a.group_cols);
-    }
-    if (a.n_valid) {
-        // capacity layout: the group's leading *n_valid columns hold utterances, the rest is filler -- treated like the columns past
-        // the group's end (zero-column reads, no stores); a tile wholly inside it has nothing to do (tile 0 stays: it owns the zero
-        // column of the result image)
-        n_end = min(n_end, (a.n_groups > 1 ? grp * a.group_cols : 0) + __builtin_amdgcn_readfirstlane(*a.n_valid));
-        if (n0 >= n_end && n0 > 0) return;
+    int lt, slice, tile, m0, n0, grp = 0, n_end = prob.col1;
+    if (a.n_valid && S == 1) {
+        // Capacity layout (ConvGemmArgs.n_valid): the launch is sized for room, the leading *n_valid columns of every group hold
+        // utterances, the rest is filler (zero-column reads, no stores, no work).  The VALID tiles are dealt out like the tiles of a
+        // launch that has no others: XCD x gets a contiguous run of them -- with the launch's own order the filler, which is the tail
+        // of the column range, would be whole XCDs' shares and the other XCDs would carry 8 / 6 of the work (measured: + 6 % per step
+        // at 25 % of room to spare).  Tiles are counted column tile by column tile ACROSS the groups (tn outer, group inner), so that
+        // the valid ones are a prefix.
+        const int nv = __builtin_amdgcn_readfirstlane(*a.n_valid);
+        const int G = a.n_groups > 1 ? a.n_groups : 1;
+        const int span = G > 1 ? a.group_cols : prob.col1 - prob.col0;
+        const int ctv = (min(max(nv, 1), span) + BN - 1) / BN;              // valid column tiles of a group (>= 1: tile 0 owns the image's zero column)
+        const int tiles_v = tiles_m * G * ctv, per = (tiles_v + 7) >> 3;
+        const int local = (int)blockIdx.x - prob.wg0;
+        if ((local >> 3) >= per) return;
+        lt = (local & 7) * per + (local >> 3);
+        if (lt >= tiles_v) return;
+        slice = 0;
+        tile = lt;
+        m0 = (lt % tiles_m) * BM;
+        const int q = lt / tiles_m, tn = q / G;
+        grp = q - tn * G;
+        const int base = G > 1 ? grp * a.group_cols : prob.col0;
+        n0 = base + tn * BN;
+        n_end = min(G > 1 ? min(a.N, (grp + 1) * a.group_cols) : prob.col1, base + nv);
+    } else {
+        lt = logical_of((int)blockIdx.x - prob.wg0, prob.wgs);
+        if (lt >= prob.tiles * S) return;                                // (the padding up to a multiple of 8; the whole workgroup)
+        slice = lt / prob.tiles;
+        tile = lt - slice * prob.tiles;
+        m0 = (tile % tiles_m) * BM;
+        // column tiles: per weight set when the launch is grouped (a group's columns are [grp * group_cols, (grp + 1) * group_cols);
+        // its last tile is cut at the group's end, so group_cols needs no alignment)
+        n0 = prob.col0 + (tile / tiles_m) * BN;
+        if (a.n_groups > 1) {
+            const int tpg = (a.group_cols + BN - 1) / BN, tn = tile / tiles_m;
+            grp = tn / tpg;
+            n0 = grp * a.group_cols + (tn - grp * tpg) * BN;
+            n_end = min(a.N, (grp + 1) * a.group_cols);
+        }
+        if (a.n_valid) {                                                 // (K-sliced launches under a capacity: small ones; the launch's own order)
+            n_end = min(n_end, (a.n_groups > 1 ? grp * a.group_cols : 0) + __builtin_amdgcn_readfirstlane(*a.n_valid));
+            if (n0 >= n_end && n0 > 0) return;
+        }
     }
     const int KB = a.Kp >> 4, KBx = (KB + 3) & ~3;
     const int NX = (a.src_col ? a.N_in : a.N) + 1;                       // columns of the activation image (the last one is zero)
