@@ -30,7 +30,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_pmc_fetch -o bench --outp
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_pmc_write -o bench --output-format csv -- python3 $R/bench.py $PARGS > $OUT/prof_pmc_write.log 2>&1
 # the library's own per-launch HIP-event log of the conv GEMM (class, shape / tile / split tag, ms, algorithmic flop and bytes)
 rm -f $OUT/gemm_launches_events.csv
-AS_PROF_CSV=$OUT/gemm_launches_events.csv python3 $R/bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-extras > $OUT/prof_events.log 2>&1   # (the instrumented steps: calls over two batches)
+# (--call-batches 2: every instrumented call is ONE as_forward_test over two batches of 32 -- the headline arrangement's call width, whatever arrangement a run adopts)
+AS_PROF_CSV=$OUT/gemm_launches_events.csv python3 $R/bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-extras --call-batches 2 > $OUT/prof_events.log 2>&1
 # the multi-rank launch path on this one-GPU box (two ranks on GPU 0, gloo for the barrier: AS_BENCH_TEST_ONE_GPU=1), weak scaling and C4
 cd $R
 for mode in weak c4; do
