@@ -36,7 +36,10 @@ Prints ONE JSON line (rank 0).  Beside the contract's keys:
   mas            monotonic alignment search (K1) at [32,40,100] and [8,1024,2000]: cells/s, us/column, GB/s, bit-exactness against the
                  reference-generated golden paths
   configs        C2 (batch 1, 150 frames: latency; also in the 16-bit-operand mode with its measured error) and C5 (long form)
-  transfers      host->device of tokens / reference features and device->host of the mel, and the step rate including them
+  predicted      the same K submissions with the durations PREDICTED on the device (models.py:361-368 as test.py:113 calls it): a frame capacity
+                 (as_forward_io.frame_cap), no read-back, hipGraph replay, coalesced; beside the same durations handed over as known counts
+  transfers      the headline arrangement with HOST buffers at the boundary (as_lanes_submit_host: the library's copies inside the timed
+                 region); `lanes_of_32`: copies around the replays of 32-utterance graphs on this script's own streams
   lanes_native   the same K steps through the library's own lanes (as_lanes_submit: plans, streams, workspaces, hipGraphs kept in C++)
   cpu_baseline   the oracle's CPU restatement timed on this box's host cores on a bounded sample of the same workload
 """
