@@ -12,9 +12,9 @@ batch of 32 synthetic utterances (config C3 of SURVEY.md section 8: N = 40 token
 summing to M = 100 => 200 mel frames per utterance, T_ref = 200; full-size model, seeded synthetic weights),
 as ONE call of the library's as_forward_test (csrc/model.hip) captured into a hipGraph and replayed.
 `value` is measured with the inputs resident in HBM when the timed region starts (the contract of this benchmark); the SAME K steps are
-then timed again with the host <-> device copies inside the region ("transfers": per lane one pinned H2D copy -> replay -> D2H of the mel
-on the lane's own stream, the reference's test.py:96-113 boundary) -- the two differ by a few per cent because a lane's copies overlap
-the other lane's kernels.
+then timed again with the host <-> device copies inside the region ("transfers": as_lanes_submit_host -- the library copies a submission's
+pinned host arrays into the lane's device block, launches the group and copies the mel back: the reference's test.py:96-113 boundary, in
+the arrangement `value` reports) -- the two differ by 2-3 per cent because the copies run beside the lanes' kernels.
 Consecutive steps are independent batches: by default FOUR are kept in flight per GPU (`--in-flight 4`: each lane its own plan +
 workspaces on the same weights, its own hipGraph and HIP stream; the K timed steps alternate between the lanes), so that one batch's tail
 rounds, launch gaps and latency-bound stretches are filled by the others' kernels; every lane has its own batch (other seeds) in its own
@@ -702,7 +702,8 @@ def bench_coalesced(net, hosts, k, n_lanes, steps, warmup, barrier=lambda: None)
     lanes.close()
     # The SAME K submissions with HOST buffers at the boundary (/root/reference/test.py:96-113 moves tokens / mel to the device
     # inside `synthesis`): as_lanes_submit_host -- per submission the pinned host -> device copies into the lane's own block, the group's
-    # launch, the device -> host copy of every submission's mel, all issued by the library on the lane's stream.  Same lanes, same coalescing,
+    # launch, the device -> host copy of every submission's mel, all issued by the library (the copies on its two copy streams, ordered against
+    # the lane's kernels by events; two device blocks per lane, alternating).  Same lanes, same coalescing,
     # same batches; the host results must be the BITS of the device-buffer run above (same groups, same graphs' kernels).
     pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
     hb = []
@@ -744,7 +745,8 @@ def bench_coalesced(net, hosts, k, n_lanes, steps, warmup, barrier=lambda: None)
                          arrangement="as the line's value",
                          note="as_lanes_submit_host: per 32-utterance submission five pinned host -> device copies (tokens, forced durations, f0, the EMA "
                               "and mel rows) into the lane's own device block, the group's launch, one device -> host copy of the submission's mel -- "
-                              "all issued by the library on the lane's stream; results bitwise equal to the device-buffer submissions")
+                              "all issued by the library (copies on its two copy streams, events against the lane's kernels); results bitwise equal to the "
+                              "device-buffer submissions")
     lanes.close()
     return dict(elapsed_s=el, ms_per_step=el / steps * 1e3, ms_per_step_repeats=[e / steps * 1e3 for e in els], coalesce=k, lanes=n_lanes,
                 utterances_per_call=per * k, merged_calls=merged,

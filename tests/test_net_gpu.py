@@ -453,6 +453,34 @@ def test_c3_predicted_durations_under_a_frame_capacity_vs_oracle(cuda, arrangeme
     assert torch.equal(out["mel"][:, : 2 * total], want) and _lib.lib().as_device_status(0) == 0
 
 
+@pytest.mark.parametrize("shape", ["one_utterance", "three_long", "merged_chain_pair"])
+def test_frame_capacity_at_batch_one_and_long_form(cuda, shape):
+    """as_forward_io.frame_cap where the launches are K-sliced (batch 1, BASELINE C2's shape: the slices store nothing for the filler and
+    the reductions skip it; no fused reduction + AdaIN under a capacity) and where utterances are hundreds of tokens long (the duration
+    predictor's recurrence on the side stream of a recording plan): frame offsets and durations equal to the read-back path's, mel within
+    3e-5 of it, with room to spare of one frame, of 2 x and of 5 x what comes out; status clean."""
+    import bench
+    net = get_model(512, 64, 3407, cuda).replica()
+    if shape == "one_utterance":
+        host, g = bench.make_inputs(cuda, 1, 30, 75, 150, seed0=41)
+    elif shape == "three_long":
+        host, g = bench.make_inputs(cuda, 3, 260, 300, 120, vary=True, seed0=77)
+    else:
+        net.rt.set_serial(True)
+        host, g = bench.make_inputs(cuda, 2, 220, 300, 100, vary=True, seed0=78)
+    base = net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"])
+    off = base["frame_off"].cpu()
+    total = int(off[-1])
+    for cap in (total + 1, 2 * total, 5 * total):
+        out = net.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], frame_cap=cap)
+        torch.cuda.synchronize()
+        assert _lib.lib().as_device_status(0) == 0, (cap, _lib.device_status())
+        assert torch.equal(out["frame_off"].cpu(), off) and torch.equal(out["dur_i"], base["dur_i"])
+        d = float((out["mel"][:, : 2 * total] - base["mel"]).abs().max())
+        assert d <= 3e-5, (shape, cap, d)
+        assert bool(torch.isfinite(out["mel"][:, : 2 * total]).all())
+
+
 def test_f16_operand_mode_error_is_reported(cuda, golden_dir):
     """BASELINE config C2 names 16-bit operands ("error reported").  as_plan_set_operand_mode(plan, 1) runs every
     conv GEMM on the h parts only (plain fp16 operands, one matrix-core product, fp32 accumulate).  This mode is NOT held to the 1e-4
