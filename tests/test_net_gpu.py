@@ -321,6 +321,25 @@ def test_c_abi_forward_on_full_goldens(cuda, golden_dir):
             d = float(np.abs(out[:, : 2 * frames[0]].cpu().numpy() - g["ref/mel"]).max())
             print(os.path.basename(f), "C ABI mel max-abs", d)
             assert d <= MEL_TOL, (f, d)
+            # the same utterance with NO read-back (as_forward_io.frame_cap; round 6): a capacity instead of a count, workspace B of
+            # AS_MOD_FORWARD_B_CAP, the call only enqueues -- the reference's durations and mel again, and the frame offsets on the device
+            out.zero_()
+            dur_i.zero_()
+            f_off = torch.zeros(2, dtype=torch.int32, device=cuda)
+            io.frame_cap, io.frame_off = cap // 2, f_off.data_ptr()
+            nb2 = L.as_module_workspace_bytes(model, plan, _lib.AS_MOD_FORWARD_B_CAP, ctypes.byref(b_cap))
+            assert nb2 > 0
+            ws_b2 = torch.empty(nb2, dtype=torch.uint8, device=cuda)
+            rc = L.as_forward_test(model, plan, ctypes.byref(b), ctypes.byref(io), ws_a.data_ptr(), na, ws_b2.data_ptr(), nb2, None,
+                                   torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+            assert L.as_device_status(0) == 0
+            assert f_off.cpu().tolist() == [0, int(g["ref/pred_dur"].sum())]
+            assert np.array_equal(dur_i.cpu().numpy(), g["ref/pred_dur"].astype(np.int32))
+            d2 = float(np.abs(out[:, : 2 * frames[0]].cpu().numpy() - g["ref/mel"]).max())
+            print(os.path.basename(f), "C ABI mel max-abs under a frame capacity", d2)
+            assert d2 <= MEL_TOL, (f, d2)
     finally:
         L.as_plan_destroy(plan)
         L.as_model_destroy(model)
