@@ -378,7 +378,8 @@ static __device__ __forceinline__ void reduce_adain(const ConvGemmArgs& a, int S
     // given are still read -- nothing waits for them until the end -- and an utterance that is NOT columns [0, N) is reported: the
     // two-launch form, as_adain_image_f32, honours col_off, and the two must never differ silently)
     int o0 = 0, L = a.N, c_lo = 0, c_hi = a.N;
-    if (n.U > 1) { o0 = n.col_off[u]; L = n.col_w ? n.col_w[u] : n.col_off[u + 1] - o0; }
+    // (explicit widths -- a capacity layout: the utterance is NOT all of the launch's columns even when it is the only one)
+    if (n.U > 1 || n.col_w) { o0 = n.col_off[u]; L = n.col_w ? n.col_w[u] : n.col_off[u + 1] - o0; }
     else if (n.col_off) { c_lo = n.col_off[0]; c_hi = n.col_off[1]; }
     if (L <= 0) return;
     if (L > 64 * NJ) {                                                   // the caller's post_max_w was not the widest utterance: say so, write nothing wrong silently

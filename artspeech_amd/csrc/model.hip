@@ -1204,7 +1204,7 @@ void conv_impl(Ctx& c, const GemmW* w, const float* X, int ldx, const uint16_t* 
         post.gb = o.post_n->gb; post.gb_off = o.post_n->gb_off; post.ldgb = 1; post.gb_sc = o.post_n->gb_sc;
         post.col_off = o.post_lay->d_off; post.U = o.post_lay->B; post.lrelu = 1; post.yh = o.post_yh;
         post.col_w = o.post_lay->dyn ? o.post_lay->d_w : nullptr;
-        post_mw = o.post_lay->dyn ? (1 << 30) : o.post_lay->max_w;        // (widths unknown to the host: never the fused reduction)
+        post_mw = o.post_lay->max_w;                                      // (a capacity layout: no utterance is wider than the room)
     }
     if (o.ln.yh && (o.post_yh || !Y)) { c.fail(AS_EINVAL); return; }
     if (c.deferring() && !EXP_SKIP(as_conv_gemm_f32)) {                  // recorded: it may share its launch with other branches' convs

@@ -376,6 +376,41 @@ def bench_config(net, dev, name, n_utt, n_tok, m_half, t_ref, steps, n_prod_mode
         firsts = [Runner(chain, b).step()["mel"].clone() for b in batches]
         rc = Runner(chain, g)
         res["ms_per_step_one_chain_alone"] = rc.timed(rc.capture(), steps, 3) / steps * 1e3
+        # the same batch with the durations PREDICTED on the device: one lane, a frame capacity (no read-back, hipGraph replay) -- and through
+        # the read-back path (as_forward_test_begin -> B + 1 integers to the host -> _finish), one at a time
+        try:
+            ref = chain.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"])
+            tot = int(ref["frame_off"][-1])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                chain.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], out=ref)
+            torch.cuda.synchronize()
+            rb_ms = (time.perf_counter() - t0) / steps * 1e3
+            cap = int(1.25 * tot) + 8
+            r1 = chain.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], frame_cap=cap)
+            graph, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                chain.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], frame_cap=cap, out=r1)
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=st):
+                    chain.forward_packed(g["tok"], g["tok_lens"], g["mel"], g["f0"], g["ema"], g["ref_lens"], frame_cap=cap, out=r1)
+                for _ in range(3):
+                    graph.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    graph.replay()
+                torch.cuda.synchronize()
+                cap_ms = (time.perf_counter() - t0) / steps * 1e3
+            ok = bool(torch.equal(r1["frame_off"], ref["frame_off"]) and float((r1["mel"][:, : 2 * tot] - ref["mel"]).abs().max()) <= 3e-5)
+            res["predicted_durations"] = dict(ms_per_step_frame_capacity_one_chain_alone=cap_ms, ms_per_step_read_back_path=rb_ms, mel_frames=2 * tot,
+                                              frame_cap=cap, results_verified=ok,
+                                              note="the durations PREDICTED on the device: as a replayed hipGraph under a frame capacity (one chain alone, like "
+                                                   "ms_per_step_one_chain_alone for forced durations) and eagerly through the read-back path")
+        except Exception as e:
+            res["predicted_durations"] = {"error": repr(e)[:200]}
         nl = bench_native_lanes(net, batches, firsts, 4 * steps, 0)
         res["in_flight"] = dict(lanes=lanes, ms_per_step=nl["ms_per_step"], ms_per_utt=nl["ms_per_step"] / n_utt,
                                 frames_per_s=2 * sum(g["frames"]) / (nl["ms_per_step"] * 1e-3), results_bitwise_equal=nl["results_bitwise_equal"],
