@@ -734,9 +734,10 @@ int as_forward_test(const as_model* m, as_plan* p, const as_batch* batch, const 
  * (forced durations, or a second pass) a (geometry, io) pair runs eagerly twice on a lane (first on the eager plan, then on the graph
  * plan, which uploads its tables), the third submit is captured into a hipGraph and later ones are one hipGraphLaunch; a lane keeps at
  * most as_lanes_set_graph_cap graphs (default 256) and drops them all -- with the graph plan's tables -- when one more is wanted.  With
- * frames == NULL (predicted durations) every submit runs as_forward_test eagerly, which synchronises that lane's stream once to read the
- * frame counts, and a workspace too small for them is re-sized and the call repeated (AS_ENOSPC only if io->ld_out itself is too small:
- * frames_host_out then says what is needed).  A workspace that is outgrown is kept until as_lanes_wait(q, -1) / as_lanes_destroy (freeing
+ * frames == NULL (predicted durations) and no frame capacity every submit runs as_forward_test eagerly, which synchronises that lane's stream
+ * once to read the frame counts, and a workspace too small for them is re-sized and the call repeated (AS_ENOSPC only if io->ld_out itself
+ * is too small: frames_host_out then says what is needed); with io->frame_cap > 0 (as_forward_io: the durations stay on the device) such a
+ * submission is eager, captured, replayed -- and coalesced -- like one with known counts.  A workspace that is outgrown is kept until as_lanes_wait(q, -1) / as_lanes_destroy (freeing
  * it would synchronise the device under the other lanes).  Not thread-safe: one host thread per as_lanes.  as_lanes_wait(q, lane):
  * lane < 0 = all; AS_EDEVICE if a kernel raised a status bit (as_device_status). */
 typedef struct as_lanes as_lanes;
@@ -750,7 +751,8 @@ int as_lanes_wait(as_lanes* q, int lane);
 /* Coalescing (k > 1; 1 = off, the default).  Every tensor of the path concatenates the utterances along its column axis, so submissions
  * whose buffers are ADJACENT views of one block -- the next one's tokens / mel / f0_raw / ema_raw / forced_dur / mel_out begin exactly where
  * the previous one's end, with the same leading dimensions -- are one batch as they lie: a lane holds such a submission back (frames given,
- * no optional outputs) until k neighbours have arrived and launches them as ONE as_forward_test call, without a copy (wider conv GEMM
+ * no optional outputs; or a frame capacity, io->frame_cap: then only the INPUTS have to be adjacent, every submission keeps its own mel_out
+ * and may ask for its own frame_off, as_segments) until k neighbours have arrived and launches them as ONE as_forward_test call, without a copy (wider conv GEMM
  * launches; one fetch of the weights for k batches).  A submission that is not the neighbour of what waits on its lane sends that group out
  * first; as_lanes_wait and as_lanes_flush launch whatever waits.  With k > 1 a submit may therefore return before anything of it is
  * enqueued, and the status of a group's launch is returned by the call that triggers it; the host arrays of as_batch are copied at
