@@ -621,3 +621,74 @@ def test_lanes_predicted_durations_under_a_frame_capacity_graphs_and_coalescing(
         assert float((res["mel"][:, :n2] - sub["want_mel"]).abs().max()) <= 3e-5
     assert _lib.lib().as_device_status(0) == 0
     lanes.close()
+
+
+def test_lanes_frame_capacity_three_unequal_submissions_and_one_too_small():
+    """Coalescing under a frame capacity with k = 3 and submissions of DIFFERENT sizes (8, 5 and 11 utterances: only the inputs have to be
+    adjacent, every submission has its own output buffer and frame offsets); a short last group sent out by as_lanes_wait; and one
+    submission whose capacity is too small for what the predictor says: AS_STATUS_CAPACITY (its slot is never written past), and after the
+    clear the lanes serve again."""
+    import bench
+    from artspeech_amd import _lib, models
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    net = _net(dev)
+    solo = _alone(net)
+    sizes = [8, 5, 11]
+    host, g = bench.make_inputs(dev, sum(sizes), 28, 66, 110, seed0=bench.DATA_SEED + 4242, vary=True)
+    subs, t0, r0, u0 = [], 0, 0, 0
+    for n in sizes:
+        nt, nr = sum(g["tok_lens"][u0:u0 + n]), sum(g["ref_lens"][u0:u0 + n])
+        sub = dict(tok=g["tok"][t0:t0 + nt], mel=g["mel"][:, r0:r0 + nr], f0=g["f0"][:, r0:r0 + nr], ema=g["ema"][:, r0:r0 + nr],
+                   tok_lens=g["tok_lens"][u0:u0 + n], ref_lens=g["ref_lens"][u0:u0 + n], res=None)
+        gj = bench.pack_inputs(host, list(range(u0, u0 + n)), dev)
+        ref = solo.forward_packed(gj["tok"], gj["tok_lens"], gj["mel"], gj["f0"], gj["ema"], gj["ref_lens"])
+        sub["want_off"], sub["want_mel"] = ref["frame_off"].cpu(), ref["mel"].clone()
+        sub["cap"] = int(1.2 * int(sub["want_off"][-1])) + 3
+        subs.append(sub)
+        t0, r0, u0 = t0 + nt, r0 + nr, u0 + n
+    torch.cuda.synchronize()
+    lanes = models.Lanes(net, 1)
+    lanes.set_coalesce(3)
+
+    def check(which):
+        for sub in which:
+            off = sub["res"]["frame_off"].cpu()
+            assert torch.equal(off, sub["want_off"])
+            n2 = 2 * int(off[-1])
+            assert float((sub["res"]["mel"][:, :n2] - sub["want_mel"]).abs().max()) <= 3e-5
+    for r in range(4):                                             # eager, eager, captured, replayed
+        for sub in subs:
+            _, sub["res"] = lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], frame_cap=sub["cap"], out=sub["res"])
+        lanes.wait()
+        check(subs)
+    assert lanes.merged_calls(0) == 4 and lanes.stats(0)["graph_launches"] >= 2
+    # a short group: two of the three, sent out by the wait
+    for sub in subs[:2]:
+        sub["res"]["mel"].zero_()
+    torch.cuda.synchronize()
+    for sub in subs[:2]:
+        lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], frame_cap=sub["cap"], out=sub["res"])
+    lanes.wait()
+    check(subs[:2])
+    assert lanes.merged_calls(0) == 5
+    # the middle submission without enough room: loud, and its neighbours' buffers end where they end
+    small = int(subs[1]["want_off"][-1]) - 20
+    guard = torch.full((80, 2 * small + 32), 7.0, device=dev)
+    res_small = {"mel": guard[:, : 2 * small]}
+    outs = [subs[0]["res"], res_small, subs[2]["res"]]
+    caps = [subs[0]["cap"], small, subs[2]["cap"]]
+    try:
+        for sub, o, c in zip(subs, outs, caps):
+            lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], frame_cap=c, out=o)
+        with pytest.raises(_lib.HipLibraryError):
+            lanes.wait()
+        assert _lib.lib().as_device_status(0) & (1 << 5)               # AS_STATUS_CAPACITY
+        assert float((guard[:, 2 * small:] - 7.0).abs().max()) == 0.0  # nothing past the slot
+    finally:
+        _lib.lib().as_device_status(1)
+    for sub in subs:
+        _, sub["res"] = lanes.submit(sub["tok"], sub["tok_lens"], sub["mel"], sub["f0"], sub["ema"], sub["ref_lens"], frame_cap=sub["cap"], out=sub["res"])
+    lanes.wait()
+    check(subs)
+    lanes.close()
