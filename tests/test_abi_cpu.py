@@ -34,6 +34,32 @@ def test_ctypes_table_matches_header():
     assert L.as_mas_workspace_bytes(2, 1 << 20, 100) == 0      # unsupported geometry -> 0, not a crash
 
 
+def test_ctypes_struct_layouts_match_the_header(tmp_path):
+    """Every struct that crosses the C ABI by value or by pointer has the SAME size and the same offset of its last field in the header
+    (compiled here with gcc, as a C host would) and in the ctypes binding (artspeech_amd/_lib.py): a field added on one side only -- the
+    way ConvGemmArgs.slab_tr, n_valid, AsAdainArgs.col_w, as_forward_io.frame_cap / segs and as_host_io came in -- fails here, on the CPU."""
+    import ctypes
+    pairs = [("ConvGemmArgs", _lib.ConvGemmArgs, "n_valid"), ("AsAdainArgs", _lib.AdainArgs, "col_w"), ("AsLnArgs", _lib.LnArgs, "yh"),
+             ("AsDownArgs", _lib.DownArgs, "n_out"), ("AsResPairArgs", _lib.ResPairArgs, None), ("as_model_cfg", _lib.ModelCfg, "stats"),
+             ("as_batch", _lib.Batch, "frames"), ("as_forward_io", _lib.ForwardIO, "segs"), ("as_host_io", _lib.HostIO, "frame_off"),
+             ("BiLstmJob", _lib.BiLstmJob, "ldo")]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "artspeech_hip.h"', 'int main(void) {']
+    for cname, _, last in pairs:
+        src.append(f'  printf("{cname} %zu %zu\\n", sizeof({cname}), {"offsetof(" + cname + ", " + last + ")" if last else "(size_t)0"});')
+    src.append('  printf("as_segments %zu %zu\\n", sizeof(as_segments), offsetof(as_segments, frame_off));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = {ln.split()[0]: (int(ln.split()[1]), int(ln.split()[2])) for ln in subprocess.check_output([str(exe)], text=True).splitlines()}
+    for cname, cls, last in pairs:
+        want = (ctypes.sizeof(cls), getattr(cls, last).offset if last else 0)
+        assert got[cname] == want, (cname, got[cname], want)
+    # as_segments (built by csrc/lanes.hip only; a C host may pass one): 4 + 17 * 4 + 16 * 4 ints, then pointers and ints
+    assert got["as_segments"][0] % 8 == 0 and got["as_segments"][1] > 0
+
+
 def test_invalid_arguments_are_rejected_without_a_gpu():
     L = _lib.lib()
     assert L.as_mas_f32(None, None, None, 1, 4, 4, 0, None, None, None, None, 0, None) == -1
